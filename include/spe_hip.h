@@ -1,0 +1,130 @@
+/*
+ * spe_hip.h - C ABI of libspe_hip.so: the MI355X (gfx950) kernels behind the SPE hot path.
+ *
+ * The reference (MingXiangL/SPE) has no native code: every "kernel" on its hot path is an
+ * implicit ATen/cuBLAS launch issued from Python.  Each entry point
+ * below therefore cites the reference *Python* site whose device work it replaces.  The
+ * Python host code in spe_amd/ binds these with ctypes (spe_amd/lib.py); INTEGRATION.md shows
+ * the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (the kernels never allocate);
+ *   - tensors are fp32, row-major, densely packed unless a leading dimension is passed;
+ *   - `stream` is the hipStream_t the work is enqueued on; calls are asynchronous;
+ *   - return value: 0 on success, a positive hipError_t on launch failure, a negative value
+ *     for an unsupported argument combination; no exception crosses the boundary;
+ *   - dropout masks are a pure function of (seed, offset, element index) - Philox4x32-10 -
+ *     so forward and backward regenerate the same mask and nothing is stored.
+ */
+#ifndef SPE_HIP_H
+#define SPE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* spe_stream_t; /* == hipStream_t */
+
+int spe_abi_version(void);
+
+/* ---- contraction ----------------------------------------------------------------------
+ * C[z] = act(alpha * opA(A[z]) @ opB(B[z]) + bias) for z = (z0, z1) in batch0 x batch1, each
+ * operand addressed as base + z0*s?0 + z1*s?1.  transA=0: A is [M,K] (lda); transA=1: A is
+ * [K,M].  transB=0: B is [K,N] (ldb); transB=1: B is [N,K] (nn.Linear weight layout).
+ * act: 0 none, 1 ReLU, 2 exact-erf GELU; C2 (optional) receives the pre-activation.
+ * splitk>1: K is split over workgroups and atomically accumulated into a PRE-ZEROED C
+ * (bias/act/C2 must be null/0).  precision: 0 = bf16 MFMA operands, fp32 accumulate;
+ * 1 = 3-term bf16 split (~fp32 accuracy).
+ * Replaces nn.Linear / torch.bmm / `@` at reference models/cait.py:376-390 (qkv, QK^T, PV, proj),
+ * :114-133 (class attention), timm Mlp fc1/fc2 (cait.py:409), Conv2d patch embed (cait.py:526),
+ * models/transformer.py:368-425 (decoder projections, FFN), models/attention.py:353,375,378,
+ * models/conditional_detr.py:104-110 (heads), and every one of their autograd backward GEMMs. */
+int spe_gemm_f32(const float* A, const float* B, float* C, const float* bias, float* C2,
+                 int M, int N, int K, long lda, long ldb, long ldc, int transA, int transB,
+                 int batch0, int batch1, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1,
+                 float alpha, int act, int splitk, int precision, spe_stream_t stream);
+
+/* ---- LayerNorm (nn.LayerNorm; reference models/cait.py:403,407 eps 1e-6,
+ * models/transformer.py:264-265,342-344 eps 1e-5).  C % 4 == 0, C <= 1024.
+ * bwd: dgamma/dbeta are ACCUMULATED into (pre-zeroed or running) buffers. */
+int spe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                      float* rstd, long R, int C, float eps, spe_stream_t stream);
+int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                      const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,
+                      spe_stream_t stream);
+
+/* ---- masked softmax over scores[B,H,Nq,ld] (Nk valid columns per row).
+ * mask[B,Nk] (1 = padded key, -inf) or null; P = softmax; Pd = dropout(P) written only when
+ * p_drop > 0.  Reference models/attention.py:363-373, models/cait.py:125-131 (class attention).
+ * bwd: dS = P*(dP - sum dP*P) with dP = dPd*keepscale; dS may alias dPd. */
+int spe_softmax_fwd(const float* S, const unsigned char* mask, float* P, float* Pd, int B, int H, int Nq,
+                    int Nk, long ld, float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
+int spe_softmax_bwd(const float* dPd, const float* P, float* dS, int B, int H, int Nq, int Nk, long ld,
+                    float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
+
+/* ---- talking-heads score transform (reference models/cait.py:379-387):
+ * S' = proj_l(S) over heads, P = softmax_k(S'), P' = proj_w(P), Pd = attn_drop(P').
+ * H in {4,6,8}.  P may alias S.  bwd consumes dPd, saved P and re-computed raw scores S and
+ * writes dS (may alias dPd) plus `nblocks` rows of partial [dWl | dbl | dWw | dbw] sums
+ * (row length 2*(H*H+H)) into ws; the caller column-sums ws (spe_colsum).  nblocks <= B*Nq. */
+int spe_talking_softmax_fwd(const float* S, const float* Wl, const float* bl, const float* Ww, const float* bw,
+                            float* P, float* Pd, int B, int H, int Nq, int Nk, long ld, float p_drop,
+                            uint64_t seed, uint64_t offset, spe_stream_t stream);
+int spe_talking_softmax_bwd(const float* dPd, const float* P, const float* S, const float* Wl, const float* Ww,
+                            float* dS, float* ws, int nblocks, int B, int H, int Nq, int Nk, long ld,
+                            float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
+
+/* ---- out[c] += sum_r in[r*ld + c] (bias gradients; autograd of nn.Linear bias). */
+int spe_colsum(const float* in, float* out, long R, int C, long ld, spe_stream_t stream);
+
+/* ---- LayerScale residual out = x + s_b*gamma*y (reference models/cait.py:413-416; s_b = the
+ * per-sample DropPath keep scale or null).  bwd: dy = s_b*gamma*dout, dgamma += sum s_b*dout*y. */
+int spe_layerscale_residual_fwd(const float* x, const float* y, const float* gamma, const float* sample_scale,
+                                float* out, long R, int C, long rows_per_sample, spe_stream_t stream);
+int spe_layerscale_residual_bwd(const float* dout, const float* y, const float* gamma, const float* sample_scale,
+                                float* dy, float* dgamma, long R, int C, long rows_per_sample, spe_stream_t stream);
+
+/* ---- activation backward: mode 1 ReLU (aux = forward output), mode 2 GELU (aux = pre-activation);
+ * autograd of F.relu (transformer.py:32,287,424) and nn.GELU (timm Mlp). n % 4 == 0. */
+int spe_act_bwd(const float* dy, const float* aux, float* dx, long n, int mode, spe_stream_t stream);
+
+/* ---- dropout y = x*keepscale (nn.Dropout at cait.py:387,391, transformer.py:266-288, timm Mlp);
+ * the backward is the same call on dy. */
+int spe_dropout(const float* x, float* y, long n, float p, uint64_t seed, uint64_t offset, spe_stream_t stream);
+
+/* ---- patch gather for the 16x16 stride-16 patch-embed conv (reference models/cait.py:518-528):
+ * img[B,Cin,Hi,Wi] -> cols[B*(Hi/P)*(Wi/P), Cin*P*P] in conv-weight column order. */
+int spe_patchify(const float* img, float* cols, int B, int Cin, int Hi, int Wi, int P, spe_stream_t stream);
+
+/* ---- out = a + b[(i mod period)] (adds the interpolated pos-embed table, cait.py:623-624). */
+int spe_add_rows(const float* a, const float* b, float* out, long n, long period, spe_stream_t stream);
+
+/* ---- Hungarian matcher cost (reference models/matcher.py:62-83 + util/box_ops.py:33-74):
+ * logits[L,B,Q,Kc], boxes[L,B,Q,4] (cxcywh), targets concatenated over images with prefix
+ * offsets toff[B+1].  cost[l] = packed concat over b of row-major [Q, M_b] blocks:
+ * w_bbox*L1 + w_class*(pos_focal-neg_focal)[label] - w_giou*GIoU.  *err is OR-ed with 1 if a
+ * degenerate box is seen (the reference's host assert, box_ops.py:64-65). */
+int spe_matcher_cost(const float* logits, const float* boxes, const int* tgt_ids, const float* tgt_boxes,
+                     const int* toff, int total_targets, float* cost, int* err, int L, int B, int Q, int Kc,
+                     float w_class, float w_bbox, float w_giou, spe_stream_t stream);
+
+/* ---- weighted sigmoid focal loss (reference models/conditional_detr.py:468-494, 504-535):
+ * logits[L*rows_per_l, Kc]; tclass[row] in [0,Kc] (Kc = no object); roww[row] row weight or
+ * null.  loss[l] += sum (pre-zeroed by caller); grad = d(sum)/d(logit); argmax = top-1 class. */
+int spe_focal_loss(const float* logits, const int* tclass, const float* roww, float* grad, float* loss,
+                   int* argmax, int L, long rows_per_l, int Kc, float alpha, float gamma, spe_stream_t stream);
+
+/* ---- matched-pair box losses (reference models/conditional_detr.py:300-319, 537-560):
+ * pair i = (row srow[i] of pred_boxes[*,4], tbox[i], weight w[i] or null, layer lidx[i]).
+ * sums[l][0] += w*L1, sums[l][1] += w*(1-GIoU) (pre-zeroed); g_l1/g_giou = d/d(pred cxcywh).
+ * bwd scatter-adds c1[l]*g_l1 + c2[l]*g_giou into dpred rows. */
+int spe_box_loss(const float* pred_boxes, const long* srow, const float* tbox, const float* w, const int* lidx,
+                 float* sums, float* g_l1, float* g_giou, long n, spe_stream_t stream);
+int spe_box_loss_bwd(const long* srow, const int* lidx, const float* g_l1, const float* g_giou, const float* c1,
+                     const float* c2, float* dpred, long n, spe_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPE_HIP_H */

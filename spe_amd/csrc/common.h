@@ -1,0 +1,85 @@
+// Shared device helpers for the SPE hot-path kernels (gfx950 / CDNA4 only).
+// Wave = 64 lanes everywhere in this tree.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SPE_WAVE 64
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+// fp32 -> bf16, round-to-nearest-even (inputs here are finite activations/weights).
+__device__ __forceinline__ unsigned short spe_f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float spe_bf2f(unsigned short h) {
+    return __uint_as_float(((uint32_t)h) << 16);
+}
+
+__device__ __forceinline__ float spe_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float spe_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide reductions for <=1024-thread blocks; `red` is >=16 floats of LDS.
+__device__ __forceinline__ float spe_block_sum(float v, float* red) {
+    v = spe_wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+__device__ __forceinline__ float spe_block_max(float v, float* red) {
+    v = spe_wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = -INFINITY;
+    for (int i = 0; i < nw; ++i) r = fmaxf(r, red[i]);
+    return r;
+}
+
+// Counter-based RNG for dropout: Philox4x32-10.  The mask for element `idx` of a
+// tensor is a pure function of (seed, offset, idx), so backward regenerates it.
+__device__ __forceinline__ void spe_philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// Uniform in [0,1) for linear element index idx (one Philox call serves 4 consecutive idx).
+__device__ __forceinline__ float spe_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
+    uint32_t o[4];
+    const uint64_t blk = idx >> 2;
+    spe_philox4((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)offset, (uint32_t)(offset >> 32),
+                (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    return (float)(o[idx & 3] >> 8) * (1.0f / 16777216.0f);
+}
+// keep-scale of element idx under dropout prob p: 0 (dropped) or 1/(1-p).
+__device__ __forceinline__ float spe_drop_scale(uint64_t seed, uint64_t offset, uint64_t idx, float p) {
+    return (spe_uniform(seed, offset, idx) >= p) ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+#define SPE_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -1,0 +1,263 @@
+// MFMA GEMM for every Linear / batched contraction on the SPE hot path (gfx950).
+//
+//   C[z][m][n] = act( alpha * sum_k opA(z)[m][k] * opB(z)[k][n] + bias[n] )
+//
+// fp32 tensors in HBM; operands are rounded to bf16 while they are staged into LDS and
+// multiplied with v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  `precision == 1` selects the
+// 3-term split (hi*hi + hi*lo + lo*hi) which recovers ~fp32 accuracy at 3x the MFMA work; it is
+// what the 1e-3 parity mode uses.  Replaces the implicit ATen GEMMs behind nn.Linear / torch.bmm
+// in reference models/cait.py:374-393, models/transformer.py:355-427, models/attention.py:353,375.
+//
+// Block = 256 threads = 4 waves (2x2); block tile 128x128x32; wave tile 64x64 = 4x4 MFMA tiles.
+// Register-staged double buffering: tile t+1 is in flight from HBM while tile t is multiplied.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define LDSLD 40  // bf16 per LDS row: 32 + 8 pad -> 80 B rows keep ds_read_b128 16-B aligned
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; float* C2; const float* bias;
+    int M, N, K;
+    long lda, ldb, ldc;
+    int nb1;
+    long sA0, sA1, sB0, sB1, sC0, sC1;
+    float alpha;
+    int act;       // 0 none, 1 relu, 2 gelu(erf)
+    int splitk;    // >1: partial sums are atomically added into pre-zeroed C (no bias/act)
+    int kt_per_split;
+    int vecA, vecB;
+};
+
+// ---- HBM -> registers -------------------------------------------------------------------
+// "KC": the contraction index is the contiguous one: X(r,k) = base[r*ld + k].
+// thread t loads rows r = (t>>3) + 32*i, k-quad (t&7).
+__device__ __forceinline__ void load_kc(const float* __restrict__ base, long ld, int row0, int nrows,
+                                        int k0, int kend, bool vec, float v[4][4]) {
+    const int t = threadIdx.x;
+    const int k = k0 + (t & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + (t >> 3) + 32 * i;
+        const float* p = base + (long)r * ld + k;
+        if (vec && r < nrows && k + 3 < kend) {
+            const float4 q = *reinterpret_cast<const float4*>(p);
+            v[i][0] = q.x; v[i][1] = q.y; v[i][2] = q.z; v[i][3] = q.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = (r < nrows && k + j < kend) ? p[j] : 0.f;
+        }
+    }
+}
+// "RC": the row (m or n) index is contiguous: X(r,k) = base[k*ld + r].
+// thread t loads k = (t&7)*4 + i, row-quad (t>>3); v[i][j] = X(row0 + 4*(t>>3) + j, k).
+__device__ __forceinline__ void load_rc(const float* __restrict__ base, long ld, int row0, int nrows,
+                                        int k0, int kend, bool vec, float v[4][4]) {
+    const int t = threadIdx.x;
+    const int r = row0 + (t >> 3) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + (t & 7) * 4 + i;
+        const float* p = base + (long)k * ld + r;
+        if (vec && k < kend && r + 3 < nrows) {
+            const float4 q = *reinterpret_cast<const float4*>(p);
+            v[i][0] = q.x; v[i][1] = q.y; v[i][2] = q.z; v[i][3] = q.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = (k < kend && r + j < nrows) ? p[j] : 0.f;
+        }
+    }
+}
+
+// ---- registers -> LDS (bf16, optionally hi/lo split) ---------------------------------------
+template <bool SPLIT>
+__device__ __forceinline__ void store4(unsigned short* hi, unsigned short* lo, int off,
+                                       float a, float b, float c, float d) {
+    u16x4_t h;
+    h[0] = spe_f2bf(a); h[1] = spe_f2bf(b); h[2] = spe_f2bf(c); h[3] = spe_f2bf(d);
+    *reinterpret_cast<u16x4_t*>(hi + off) = h;
+    if (SPLIT) {
+        u16x4_t l;
+        l[0] = spe_f2bf(a - spe_bf2f(h[0])); l[1] = spe_f2bf(b - spe_bf2f(h[1]));
+        l[2] = spe_f2bf(c - spe_bf2f(h[2])); l[3] = spe_f2bf(d - spe_bf2f(h[3]));
+        *reinterpret_cast<u16x4_t*>(lo + off) = l;
+    }
+}
+template <bool SPLIT>
+__device__ __forceinline__ void stage_kc(unsigned short* hi, unsigned short* lo, const float v[4][4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        store4<SPLIT>(hi, lo, ((t >> 3) + 32 * i) * LDSLD + (t & 7) * 4, v[i][0], v[i][1], v[i][2], v[i][3]);
+}
+template <bool SPLIT>
+__device__ __forceinline__ void stage_rc(unsigned short* hi, unsigned short* lo, const float v[4][4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        store4<SPLIT>(hi, lo, ((t >> 3) * 4 + j) * LDSLD + (t & 7) * 4, v[0][j], v[1][j], v[2][j], v[3][j]);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// TA: opA(m,k) = A[k*lda+m] (else A[m*lda+k]).  TB: opB(k,n) = B[n*ldb+k] (else B[k*ldb+n]).
+template <bool TA, bool TB, bool SPLIT>
+__global__ __launch_bounds__(256) void spe_gemm_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    constexpr int TILE = BM * LDSLD;           // elements per operand tile
+    constexpr int NPL = SPLIT ? 2 : 1;         // planes (hi, lo)
+    // layout: [buf][A hi, A lo, B hi, B lo]
+    auto sA = [&](int buf, int pl) { return smem + (buf * 2 * NPL + pl) * TILE; };
+    auto sB = [&](int buf, int pl) { return smem + (buf * 2 * NPL + NPL + pl) * TILE; };
+
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
+    const int zb = blockIdx.z / p.splitk, zs = blockIdx.z % p.splitk;
+    const int b0 = zb / p.nb1, b1 = zb % p.nb1;
+    const float* A = p.A + b0 * p.sA0 + b1 * p.sA1;
+    const float* B = p.B + b0 * p.sB0 + b1 * p.sB1;
+    float* C = p.C + b0 * p.sC0 + b1 * p.sC1;
+    float* C2 = p.C2 ? p.C2 + b0 * p.sC0 + b1 * p.sC1 : nullptr;
+
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int ktiles = (p.K + BK - 1) / BK;
+    const int kt_begin = zs * p.kt_per_split;
+    int kt_end = kt_begin + p.kt_per_split; if (kt_end > ktiles) kt_end = ktiles;
+    const int nt = kt_end - kt_begin;
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    float va[4][4], vb[4][4];
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+        if (TA) load_rc(A, p.lda, m0, p.M, k0, p.K, p.vecA, va); else load_kc(A, p.lda, m0, p.M, k0, p.K, p.vecA, va);
+        if (TB) load_kc(B, p.ldb, n0, p.N, k0, p.K, p.vecB, vb); else load_rc(B, p.ldb, n0, p.N, k0, p.K, p.vecB, vb);
+    };
+    auto stage = [&](int buf) {
+        if (TA) stage_rc<SPLIT>(sA(buf, 0), sA(buf, NPL - 1), va); else stage_kc<SPLIT>(sA(buf, 0), sA(buf, NPL - 1), va);
+        if (TB) stage_kc<SPLIT>(sB(buf, 0), sB(buf, NPL - 1), vb); else stage_rc<SPLIT>(sB(buf, 0), sB(buf, NPL - 1), vb);
+    };
+
+    if (nt > 0) {
+        gload(kt_begin);
+        stage(0);
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < nt) gload(kt_begin + t + 1);
+            bf16x8_t a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sA(buf, 0) + (wm * 64 + i * 16 + fr) * LDSLD + fk));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                b[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sB(buf, 0) + (wn * 64 + j * 16 + fr) * LDSLD + fk));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (SPLIT) {
+                bf16x8_t al[4], bl[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sA(buf, 1) + (wm * 64 + i * 16 + fr) * LDSLD + fk));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sB(buf, 1) + (wn * 64 + j * 16 + fr) * LDSLD + fk));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (t + 1 < nt) stage(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: acc[i][j][r] -> C[m0 + wm*64 + i*16 + (lane>>4)*4 + r][n0 + wn*64 + j*16 + (lane&15)]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + fr;
+        if (n >= p.N) continue;
+        const float bv = (p.bias && p.splitk == 1) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] * p.alpha;
+                const long off = (long)m * p.ldc + n;
+                if (p.splitk > 1) {
+                    if (nt > 0) atomicAdd(C + off, v);
+                } else {
+                    v += bv;
+                    if (C2) C2[off] = v;
+                    if (p.act == 1) v = fmaxf(v, 0.f);
+                    else if (p.act == 2) v = gelu_erf(v);
+                    C[off] = v;
+                }
+            }
+        }
+    }
+}
+
+template <bool TA, bool TB, bool SPLIT>
+static int launch_gemm(const GemmArgs& p, int nbatch, hipStream_t stream) {
+    constexpr int smem = 2 * 2 * (SPLIT ? 2 : 1) * BM * LDSLD * (int)sizeof(unsigned short);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spe_gemm_kernel<TA, TB, SPLIT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    dim3 grid(tiles, 1, nbatch * p.splitk);
+    hipLaunchKernelGGL((spe_gemm_kernel<TA, TB, SPLIT>), grid, dim3(256), smem, stream, p);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// C-ABI: see include/spe_hip.h (spe_gemm_f32).
+extern "C" int spe_gemm_f32(const float* A, const float* B, float* C, const float* bias, float* C2,
+                            int M, int N, int K, long lda, long ldb, long ldc, int transA, int transB,
+                            int batch0, int batch1, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1,
+                            float alpha, int act, int splitk, int precision, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || batch0 <= 0 || batch1 <= 0) return 0;
+    if (transA && transB) return -2;  // not needed on this path
+    GemmArgs p;
+    p.A = A; p.B = B; p.C = C; p.C2 = C2; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.nb1 = batch1; p.sA0 = sA0; p.sA1 = sA1; p.sB0 = sB0; p.sB1 = sB1; p.sC0 = sC0; p.sC1 = sC1;
+    p.alpha = alpha; p.act = act;
+    const int ktiles = (K + BK - 1) / BK;
+    if (splitk < 1) splitk = 1;
+    if (splitk > ktiles) splitk = ktiles > 0 ? ktiles : 1;
+    p.kt_per_split = (ktiles + splitk - 1) / splitk;
+    p.splitk = splitk;
+    if (splitk > 1 && (act != 0 || C2 != nullptr || bias != nullptr)) return -3;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    auto m4 = [](long v) { return (v & 3) == 0; };
+    // float4 loads need 16-B aligned rows; quads that straddle an edge fall back to scalars
+    p.vecA = al16(A) && m4(lda) && m4(sA0) && m4(sA1);
+    p.vecB = al16(B) && m4(ldb) && m4(sB0) && m4(sB1);
+    const int nbatch = batch0 * batch1;
+    const bool split = precision == 1;
+    if (!transA && transB)  return split ? launch_gemm<false, true, true>(p, nbatch, stream) : launch_gemm<false, true, false>(p, nbatch, stream);
+    if (!transA && !transB) return split ? launch_gemm<false, false, true>(p, nbatch, stream) : launch_gemm<false, false, false>(p, nbatch, stream);
+    return split ? launch_gemm<true, false, true>(p, nbatch, stream) : launch_gemm<true, false, false>(p, nbatch, stream);
+}

@@ -1,0 +1,198 @@
+// Matcher cost matrix + set-criterion losses (reference models/matcher.py:62-83,
+// util/box_ops.py:18-74, models/conditional_detr.py:237-265, 300-319, 468-494, 504-560).
+// All decoder layers (and any number of images) go through ONE launch per kernel; only the
+// block-diagonal (same-image) part of the cost matrix is ever computed.
+#include "common.h"
+
+struct Box { float x0, y0, x1, y1; };
+__device__ __forceinline__ Box to_xyxy(const float* b) {
+    Box r; r.x0 = b[0] - 0.5f * b[2]; r.y0 = b[1] - 0.5f * b[3]; r.x1 = b[0] + 0.5f * b[2]; r.y1 = b[1] + 0.5f * b[3];
+    return r;
+}
+__device__ __forceinline__ float giou_xyxy(const Box& a, const Box& b) {
+    const float area1 = (a.x1 - a.x0) * (a.y1 - a.y0), area2 = (b.x1 - b.x0) * (b.y1 - b.y0);
+    const float iw = fmaxf(fminf(a.x1, b.x1) - fmaxf(a.x0, b.x0), 0.f), ih = fmaxf(fminf(a.y1, b.y1) - fmaxf(a.y0, b.y0), 0.f);
+    const float inter = iw * ih, uni = area1 + area2 - inter, iou = inter / uni;
+    const float ew = fmaxf(fmaxf(a.x1, b.x1) - fminf(a.x0, b.x0), 0.f), eh = fmaxf(fmaxf(a.y1, b.y1) - fminf(a.y0, b.y0), 0.f);
+    const float ea = ew * eh;
+    return iou - (ea - uni) / ea;
+}
+
+// cost[l] = packed concat over images b of row-major [Q, M_b] blocks (block b starts at Q*toff[b]).
+//   C = w_bbox * L1(cxcywh) + w_class * (pos_focal - neg_focal)[label] - w_giou * GIoU
+// alpha = 0.25, gamma = 2, eps = 1e-8 are hard-coded in the reference (matcher.py:70-73).
+__global__ __launch_bounds__(256) void matcher_cost_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
+                                                           const int* __restrict__ tgt_ids, const float* __restrict__ tgt_boxes,
+                                                           const int* __restrict__ toff, float* __restrict__ cost,
+                                                           int* __restrict__ err, int L, int B, int Q, int Kc,
+                                                           float w_class, float w_bbox, float w_giou) {
+    const long total = (long)Q * toff[B];
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.y;
+    if (p >= total) return;
+    int b = 0;
+    while (b + 1 < B && p >= (long)Q * toff[b + 1]) ++b;
+    const int Mb = toff[b + 1] - toff[b];
+    const long rem = p - (long)Q * toff[b];
+    const int q = (int)(rem / Mb), j = (int)(rem % Mb);
+    const int t = toff[b] + j;
+    const long row = ((long)l * B + b) * Q + q;
+    const float x = logits[row * Kc + tgt_ids[t]];
+    const float pr = 1.f / (1.f + expf(-x));
+    const float neg = 0.75f * (pr * pr) * (-logf(1.f - pr + 1e-8f));
+    const float pos = 0.25f * ((1.f - pr) * (1.f - pr)) * (-logf(pr + 1e-8f));
+    const float* sb = boxes + row * 4;
+    const float* tb = tgt_boxes + (long)t * 4;
+    const float l1 = fabsf(sb[0] - tb[0]) + fabsf(sb[1] - tb[1]) + fabsf(sb[2] - tb[2]) + fabsf(sb[3] - tb[3]);
+    const Box a = to_xyxy(sb), c = to_xyxy(tb);
+    if (!(a.x1 >= a.x0 && a.y1 >= a.y0 && c.x1 >= c.x0 && c.y1 >= c.y0)) atomicOr(err, 1);  // box_ops.py:64-65 asserts
+    cost[(long)l * total + p] = w_bbox * l1 + w_class * (pos - neg) - w_giou * giou_xyxy(a, c);
+}
+
+extern "C" int spe_matcher_cost(const float* logits, const float* boxes, const int* tgt_ids, const float* tgt_boxes,
+                                const int* toff, int total_targets, float* cost, int* err, int L, int B, int Q, int Kc,
+                                float w_class, float w_bbox, float w_giou, hipStream_t st) {
+    const long total = (long)Q * total_targets;
+    if (total <= 0 || L <= 0) return 0;
+    hipLaunchKernelGGL(matcher_cost_kernel, dim3((unsigned)((total + 255) / 256), L), dim3(256), 0, st, logits, boxes, tgt_ids,
+                       tgt_boxes, toff, cost, err, L, B, Q, Kc, w_class, w_bbox, w_giou);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// Weighted sigmoid focal loss, forward value + d(sum)/d(logit) in one pass (one wave per
+// (l,b,q) row).  tclass[row] in [0,Kc] (Kc = no object -> all-zero one-hot), roww[row] = weight
+// of the row (nullptr = 1).  loss[l] += sum_row sum_c w * alpha_t * ce * (1-clamp(p_t))^gamma.
+// argmax[row] = top-1 class (for class_error / cardinality logging).
+__global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ logits, const int* __restrict__ tclass,
+                                                    const float* __restrict__ roww, float* __restrict__ grad,
+                                                    float* __restrict__ loss, int* __restrict__ argmax, long rows,
+                                                    long rows_per_l, int Kc, float alpha, float gamma) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int tc = tclass[row];
+    const float w = roww ? roww[row] : 1.f;
+    float acc = 0.f, best = -INFINITY; int bi = 0x7fffffff;
+    for (int c = lane; c < Kc; c += 64) {
+        const float x = logits[row * Kc + c];
+        const float t = (c == tc) ? 1.f : 0.f;
+        const float p = 1.f / (1.f + expf(-x));
+        const float ce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));   // BCE-with-logits, stable form
+        const float pt_raw = p * t + (1.f - p) * (1.f - t);
+        const float pt = fminf(fmaxf(pt_raw, 1e-5f), 1.f - 1e-5f);
+        const bool clamped = (pt_raw < 1e-5f) || (pt_raw > 1.f - 1e-5f);
+        const float om = 1.f - pt;
+        const float mod = powf(om, gamma);
+        const float at = alpha >= 0.f ? alpha * t + (1.f - alpha) * (1.f - t) : 1.f;
+        acc += w * at * ce * mod;
+        const float dpt = clamped ? 0.f : p * (1.f - p) * (2.f * t - 1.f);
+        const float dmod = -gamma * powf(om, gamma - 1.f) * dpt;
+        grad[row * Kc + c] = w * at * ((p - t) * mod + ce * dmod);
+        if (x > best) { best = x; bi = c; }
+    }
+    acc = spe_wave_sum(acc);
+    // argmax with lowest-index tie break
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { atomicAdd(loss + row / rows_per_l, acc); argmax[row] = bi; }
+}
+extern "C" int spe_focal_loss(const float* logits, const int* tclass, const float* roww, float* grad, float* loss,
+                              int* argmax, int L, long rows_per_l, int Kc, float alpha, float gamma, hipStream_t st) {
+    const long rows = (long)L * rows_per_l;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(focal_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, tclass, roww, grad, loss,
+                       argmax, rows, rows_per_l, Kc, alpha, gamma);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// Matched-pair box losses: for pair i (prediction row srow[i] of pred_boxes, target box tbox[i],
+// weight w[i] or 1, layer lidx[i]):  sums[l][0] += w*L1, sums[l][1] += w*(1-GIoU); the gradients
+// w.r.t. the predicted cxcywh box are written to g_l1[i][4], g_giou[i][4].
+__global__ __launch_bounds__(256) void box_loss_kernel(const float* __restrict__ pred_boxes, const long* __restrict__ srow,
+                                                       const float* __restrict__ tbox, const float* __restrict__ w,
+                                                       const int* __restrict__ lidx, float* __restrict__ sums,
+                                                       float* __restrict__ g_l1, float* __restrict__ g_giou, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* s = pred_boxes + srow[i] * 4;
+    const float* t = tbox + i * 4;
+    const float wt = w ? w[i] : 1.f;
+    float l1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float d = s[j] - t[j];
+        l1 += fabsf(d);
+        g_l1[i * 4 + j] = wt * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+    }
+    const Box a = to_xyxy(s), b = to_xyxy(t);
+    // value
+    const float bw = a.x1 - a.x0, bh = a.y1 - a.y0;
+    const float area1 = bw * bh, area2 = (b.x1 - b.x0) * (b.y1 - b.y0);
+    const float iwr = fminf(a.x1, b.x1) - fmaxf(a.x0, b.x0), ihr = fminf(a.y1, b.y1) - fmaxf(a.y0, b.y0);
+    const float iw = fmaxf(iwr, 0.f), ih = fmaxf(ihr, 0.f);
+    const float inter = iw * ih, uni = area1 + area2 - inter, iou = inter / uni;
+    const float ewr = fmaxf(a.x1, b.x1) - fminf(a.x0, b.x0), ehr = fmaxf(a.y1, b.y1) - fminf(a.y0, b.y0);
+    const float ew = fmaxf(ewr, 0.f), eh = fmaxf(ehr, 0.f);
+    const float ea = ew * eh;
+    const float giou = iou - (ea - uni) / ea;
+    // derivatives w.r.t. (x0,y0,x1,y1) of the predicted box; ties split 1/2 like torch.maximum/minimum
+    auto sel_lt = [](float u, float v) { return u < v ? 1.f : (u == v ? 0.5f : 0.f); };   // d min(u,v)/du
+    auto sel_gt = [](float u, float v) { return u > v ? 1.f : (u == v ? 0.5f : 0.f); };   // d max(u,v)/du
+    const float on_iw = iwr >= 0.f ? 1.f : 0.f, on_ih = ihr >= 0.f ? 1.f : 0.f;
+    const float on_ew = ewr >= 0.f ? 1.f : 0.f, on_eh = ehr >= 0.f ? 1.f : 0.f;
+    float d_area[4] = {-bh, -bw, bh, bw};
+    float d_iw[4] = {-on_iw * sel_gt(a.x0, b.x0), 0.f, on_iw * sel_lt(a.x1, b.x1), 0.f};
+    float d_ih[4] = {0.f, -on_ih * sel_gt(a.y0, b.y0), 0.f, on_ih * sel_lt(a.y1, b.y1)};
+    float d_ew[4] = {-on_ew * sel_lt(a.x0, b.x0), 0.f, on_ew * sel_gt(a.x1, b.x1), 0.f};
+    float d_eh[4] = {0.f, -on_eh * sel_lt(a.y0, b.y0), 0.f, on_eh * sel_gt(a.y1, b.y1)};
+    float dg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float d_inter = ih * d_iw[j] + iw * d_ih[j];
+        const float d_uni = d_area[j] - d_inter;
+        const float d_iou = (d_inter * uni - inter * d_uni) / (uni * uni);
+        const float d_ea = eh * d_ew[j] + ew * d_eh[j];
+        // giou = iou - (ea - uni)/ea  ->  d = d_iou - (d_ea - d_uni)/ea + (ea - uni) d_ea / ea^2
+        dg[j] = d_iou - (d_ea - d_uni) / ea + (ea - uni) * d_ea / (ea * ea);
+    }
+    // loss = w (1 - giou); chain to cxcywh
+    g_giou[i * 4 + 0] = -wt * (dg[0] + dg[2]);
+    g_giou[i * 4 + 1] = -wt * (dg[1] + dg[3]);
+    g_giou[i * 4 + 2] = -wt * 0.5f * (dg[2] - dg[0]);
+    g_giou[i * 4 + 3] = -wt * 0.5f * (dg[3] - dg[1]);
+    atomicAdd(sums + lidx[i] * 2 + 0, wt * l1);
+    atomicAdd(sums + lidx[i] * 2 + 1, wt * (1.f - giou));
+}
+extern "C" int spe_box_loss(const float* pred_boxes, const long* srow, const float* tbox, const float* w, const int* lidx,
+                            float* sums, float* g_l1, float* g_giou, long n, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(box_loss_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pred_boxes, srow, tbox, w, lidx,
+                       sums, g_l1, g_giou, n);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// dpred[srow[i]][:] += c1[lidx[i]] * g_l1[i][:] + c2[lidx[i]] * g_giou[i][:]   (scatter-add of the
+// matched-row gradients; c1/c2 = upstream grad / num_boxes per layer)
+__global__ __launch_bounds__(256) void box_loss_bwd_kernel(const long* __restrict__ srow, const int* __restrict__ lidx,
+                                                           const float* __restrict__ g_l1, const float* __restrict__ g_giou,
+                                                           const float* __restrict__ c1, const float* __restrict__ c2,
+                                                           float* __restrict__ dpred, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 4) return;
+    const long pi = i >> 2; const int j = (int)(i & 3);
+    atomicAdd(dpred + srow[pi] * 4 + j, c1[lidx[pi]] * g_l1[i] + c2[lidx[pi]] * g_giou[i]);
+}
+extern "C" int spe_box_loss_bwd(const long* srow, const int* lidx, const float* g_l1, const float* g_giou, const float* c1,
+                                const float* c2, float* dpred, long n, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(box_loss_bwd_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, st, srow, lidx, g_l1, g_giou, c1,
+                       c2, dpred, n);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}

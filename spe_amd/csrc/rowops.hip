@@ -1,0 +1,342 @@
+// Wavefront-reduced row kernels: LayerNorm fwd/bwd, masked softmax (+dropout) fwd/bwd,
+// column sums (bias / gamma gradients), LayerScale-residual, GELU/ReLU backward, dropout.
+// All tensors fp32, row-major, contiguous unless a stride is passed.  HBM-bound kernels:
+// every lane moves 16 B per access where the row length allows it.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm (reference: nn.LayerNorm at models/cait.py:403,407 eps=1e-6; transformer.py:264-265,
+// 342-344 eps=1e-5).  One wave per row; C % 4 == 0 and C <= 1024.
+// ------------------------------------------------------------------------------------------
+#define LN_MAXV 4  // float4 per lane -> C <= 1024
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     long R, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int C4 = C >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * C);
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C4) { v[i] = xr[c]; s += v[i].x + v[i].y + v[i].z + v[i].w; }
+    }
+    const float mu = spe_wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C4) {
+            const float a = v[i].x - mu, b = v[i].y - mu, d = v[i].z - mu, e = v[i].w - mu;
+            q += a * a + b * b + d * d + e * e;
+        }
+    }
+    const float rs = rsqrtf(spe_wave_sum(q) / (float)C + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    float4* yr = reinterpret_cast<float4*>(y + row * C);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C4) {
+            const float4 g = g4[c], b = b4[c];
+            float4 o;
+            o.x = (v[i].x - mu) * rs * g.x + b.x; o.y = (v[i].y - mu) * rs * g.y + b.y;
+            o.z = (v[i].z - mu) * rs * g.z + b.z; o.w = (v[i].w - mu) * rs * g.w + b.w;
+            yr[c] = o;
+        }
+    }
+}
+
+// dx per row; dgamma/dbeta accumulated per wave in registers over a grid-stride row loop,
+// combined through LDS, then one atomicAdd per column per block into pre-zeroed buffers.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     long R, int C) {
+    __shared__ float red[2][4][1024 + 4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int C4 = C >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    float4 ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
+    for (long row = (long)blockIdx.x * 4 + w; row < R; row += (long)gridDim.x * 4) {
+        const float4* xr = reinterpret_cast<const float4*>(x + row * C);
+        const float4* dr = reinterpret_cast<const float4*>(dy + row * C);
+        const float mu = mean[row], rs = rstd[row];
+        float4 xh[LN_MAXV], dg[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C4) {
+                const float4 xv = xr[c], dv = dr[c], g = g4[c];
+                xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs; xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
+                dg[i].x = dv.x * g.x; dg[i].y = dv.y * g.y; dg[i].z = dv.z * g.z; dg[i].w = dv.w * g.w;
+                s1 += dg[i].x + dg[i].y + dg[i].z + dg[i].w;
+                s2 += dg[i].x * xh[i].x + dg[i].y * xh[i].y + dg[i].z * xh[i].z + dg[i].w * xh[i].w;
+                ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
+                ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
+            }
+        }
+        s1 = spe_wave_sum(s1) / (float)C;
+        s2 = spe_wave_sum(s2) / (float)C;
+        float4* dxr = reinterpret_cast<float4*>(dx + row * C);
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C4) {
+                float4 o;
+                o.x = rs * (dg[i].x - s1 - xh[i].x * s2); o.y = rs * (dg[i].y - s1 - xh[i].y * s2);
+                o.z = rs * (dg[i].z - s1 - xh[i].z * s2); o.w = rs * (dg[i].w - s1 - xh[i].w * s2);
+                dxr[c] = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C4) {
+            red[0][w][4 * c + 0] = ag[i].x; red[0][w][4 * c + 1] = ag[i].y; red[0][w][4 * c + 2] = ag[i].z; red[0][w][4 * c + 3] = ag[i].w;
+            red[1][w][4 * c + 0] = ab[i].x; red[1][w][4 * c + 1] = ab[i].y; red[1][w][4 * c + 2] = ab[i].z; red[1][w][4 * c + 3] = ab[i].w;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+}
+
+extern "C" int spe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                 float* rstd, long R, int C, float eps, hipStream_t st) {
+    if (R <= 0) return 0;
+    if ((C & 3) || C > 256 * LN_MAXV) return -2;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, C, eps);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                 const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,
+                                 hipStream_t st) {
+    if (R <= 0) return 0;
+    if ((C & 3) || C > 256 * LN_MAXV) return -2;
+    long nb = (R + 3) / 4; if (nb > 512) nb = 512;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Masked softmax over the last axis of scores[B,H,Nq,ld] (Nk valid columns), one wave per row.
+// key-padding mask [B,Nk] (1 = padded key -> -inf), reference models/attention.py:363-371.
+// P = softmax(S) is written for backward; Pd = dropout(P) (reference :373) only when p_drop > 0.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, const unsigned char* __restrict__ mask,
+                                                          float* __restrict__ P, float* __restrict__ Pd,
+                                                          long rows, int rows_per_batch, int Nk, long ld,
+                                                          float p_drop, uint64_t seed, uint64_t offset) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* s = S + row * ld;
+    const unsigned char* mk = mask ? mask + (row / rows_per_batch) * (long)Nk : nullptr;
+    float m = -INFINITY, l = 0.f;
+    for (int k = lane; k < Nk; k += 64) {
+        float v = s[k];
+        if (mk && mk[k]) v = -INFINITY;
+        if (v > m) { l = l * __expf(m - v) + 1.f; m = v; }
+        else if (v > -INFINITY) l += __expf(v - m);
+    }
+    const float M = spe_wave_max(m);
+    l = (m > -INFINITY) ? l * __expf(m - M) : 0.f;
+    const float inv = 1.f / spe_wave_sum(l);
+    float* p = P + row * ld;
+    float* pd = Pd ? Pd + row * ld : nullptr;
+    for (int k = lane; k < Nk; k += 64) {
+        float v = s[k];
+        if (mk && mk[k]) v = -INFINITY;
+        const float pr = __expf(v - M) * inv;
+        p[k] = pr;
+        if (pd) pd[k] = pr * spe_drop_scale(seed, offset, (uint64_t)(row * (long)Nk + k), p_drop);
+    }
+}
+
+// dS = P * (dP - sum_k dP*P), dP = dPd * dropscale.  dS may alias dPd.
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dPd, const float* __restrict__ P,
+                                                          float* __restrict__ dS, long rows, int Nk, long ld,
+                                                          float p_drop, uint64_t seed, uint64_t offset) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* d = dPd + row * ld;
+    const float* p = P + row * ld;
+    float acc = 0.f;
+    for (int k = lane; k < Nk; k += 64) {
+        float g = d[k];
+        if (p_drop > 0.f) g *= spe_drop_scale(seed, offset, (uint64_t)(row * (long)Nk + k), p_drop);
+        acc += g * p[k];
+    }
+    acc = spe_wave_sum(acc);
+    float* o = dS + row * ld;
+    for (int k = lane; k < Nk; k += 64) {
+        float g = d[k];
+        if (p_drop > 0.f) g *= spe_drop_scale(seed, offset, (uint64_t)(row * (long)Nk + k), p_drop);
+        o[k] = p[k] * (g - acc);
+    }
+}
+
+extern "C" int spe_softmax_fwd(const float* S, const unsigned char* mask, float* P, float* Pd, int B, int H, int Nq,
+                               int Nk, long ld, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
+    const long rows = (long)B * H * Nq;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, mask, P,
+                       p_drop > 0.f ? Pd : nullptr, rows, H * Nq, Nk, ld, p_drop, seed, offset);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int spe_softmax_bwd(const float* dPd, const float* P, float* dS, int B, int H, int Nq, int Nk, long ld,
+                               float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
+    const long rows = (long)B * H * Nq;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, dPd, P, dS, rows, Nk, ld,
+                       p_drop, seed, offset);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Column sum: out[c] += sum_r in[r*ld + c]  (bias gradients).  out must be pre-zeroed / hold
+// the running gradient.  Block = 64 columns x 4 row-lanes; grid.y row chunks.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, long R, int C,
+                                                     long ld) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float acc = 0.f;
+    if (c < C)
+        for (long r = (long)blockIdx.y * 4 + rl; r < R; r += (long)gridDim.y * 4) acc += in[r * ld + c];
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+extern "C" int spe_colsum(const float* in, float* out, long R, int C, long ld, hipStream_t st) {
+    if (R <= 0 || C <= 0) return 0;
+    long ry = (R + 255) / 256; if (ry > 64) ry = 64; if (ry < 1) ry = 1;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, (unsigned)ry), dim3(256), 0, st, in, out, R, C, ld);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerScale residual  out = x + scale_b * gamma[c] * y   (reference models/cait.py:413-416;
+// scale_b = per-sample DropPath keep-scale, 1 when drop_path == 0).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lsres_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ y,
+                                                        const float4* __restrict__ gamma, const float* __restrict__ sample_scale,
+                                                        float4* __restrict__ out, long n4, int C4, long per_sample4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 g = gamma[i % C4], a = x[i], b = y[i];
+        const float sc = sample_scale ? sample_scale[i / per_sample4] : 1.f;
+        float4 o;
+        o.x = a.x + sc * g.x * b.x; o.y = a.y + sc * g.y * b.y; o.z = a.z + sc * g.z * b.z; o.w = a.w + sc * g.w * b.w;
+        out[i] = o;
+    }
+}
+// dy = scale_b*gamma*dout ; dgamma[c] += sum_rows scale_b*dout*y   (dx = dout is the caller's alias)
+__global__ __launch_bounds__(256) void lsres_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ sample_scale,
+                                                        float* __restrict__ dy, float* __restrict__ dgamma, long R, int C,
+                                                        long rows_per_sample) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float acc = 0.f;
+    if (c < C) {
+        const float g = gamma[c];
+        for (long r = (long)blockIdx.y * 4 + rl; r < R; r += (long)gridDim.y * 4) {
+            const float sc = sample_scale ? sample_scale[r / rows_per_sample] : 1.f;
+            const float d = dout[r * C + c] * sc;
+            acc += d * y[r * C + c];
+            dy[r * C + c] = d * g;
+        }
+    }
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) atomicAdd(dgamma + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+extern "C" int spe_layerscale_residual_fwd(const float* x, const float* y, const float* gamma, const float* sample_scale,
+                                           float* out, long R, int C, long rows_per_sample, hipStream_t st) {
+    if (R <= 0) return 0;
+    if (C & 3) return -2;
+    const long n4 = R * C / 4;
+    long nb = (n4 + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(lsres_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float4*)x, (const float4*)y,
+                       (const float4*)gamma, sample_scale, (float4*)out, n4, C / 4, rows_per_sample * C / 4);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int spe_layerscale_residual_bwd(const float* dout, const float* y, const float* gamma, const float* sample_scale,
+                                           float* dy, float* dgamma, long R, int C, long rows_per_sample, hipStream_t st) {
+    if (R <= 0) return 0;
+    long ry = (R + 127) / 128; if (ry > 128) ry = 128; if (ry < 1) ry = 1;
+    hipLaunchKernelGGL(lsres_bwd_kernel, dim3((C + 63) / 64, (unsigned)ry), dim3(256), 0, st, dout, y, gamma, sample_scale,
+                       dy, dgamma, R, C, rows_per_sample);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Activation backward + dropout (elementwise, grid-stride, 16 B per lane).
+// mode 1: dx = dy * (out > 0)            (ReLU, `aux` = forward output)
+// mode 2: dx = dy * gelu'(aux)           (exact-erf GELU, `aux` = pre-activation)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ aux,
+                                                      float4* __restrict__ dx, long n4, int mode) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 d = dy[i], a = aux[i];
+        float dv[4] = {d.x, d.y, d.z, d.w}, av[4] = {a.x, a.y, a.z, a.w}, o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (mode == 1) o[j] = av[j] > 0.f ? dv[j] : 0.f;
+            else {
+                const float h = av[j];
+                const float cdf = 0.5f * (1.f + erff(h * 0.70710678118654752f));
+                const float pdf = 0.3989422804014327f * __expf(-0.5f * h * h);
+                o[j] = dv[j] * (cdf + h * pdf);
+            }
+        }
+        dx[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+extern "C" int spe_act_bwd(const float* dy, const float* aux, float* dx, long n, int mode, hipStream_t st) {
+    if (n <= 0) return 0;
+    if (n & 3) return -2;
+    long nb = (n / 4 + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float4*)dy, (const float4*)aux, (float4*)dx, n / 4, mode);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// y = x * keepscale(idx); the same call with x := dy is the backward.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p,
+                                                      uint64_t seed, uint64_t offset) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        y[i] = x[i] * spe_drop_scale(seed, offset, (uint64_t)i, p);
+}
+extern "C" int spe_dropout(const float* x, float* y, long n, float p, uint64_t seed, uint64_t offset, hipStream_t st) {
+    if (n <= 0) return 0;
+    long nb = (n + 255) / 256; if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, y, n, p, seed, offset);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,260 @@
+"""Thin tensor-level wrappers over the C ABI (include/spe_hip.h).  No autograd here - see ops.py.
+
+Every function takes CUDA fp32 tensors, allocates its outputs with torch (device memory is
+PyTorch's job on this path) and enqueues the kernel on torch's current HIP stream.
+"""
+import ctypes
+
+import torch
+
+from . import lib
+
+# 0 = bf16 MFMA operands / fp32 accumulate (benchmark mode); 1 = 3-term bf16 split (~fp32, parity mode)
+_PRECISION = 0
+# Philox stream for dropout: (seed, running offset).  Each dropout site draws a fresh offset.
+_RNG = {"seed": 0x5EEDC0DE, "offset": 0}
+
+
+def set_precision(mode):
+    global _PRECISION
+    _PRECISION = {"bf16": 0, "bf16x3": 1, 0: 0, 1: 1}[mode]
+
+
+def get_precision():
+    return "bf16x3" if _PRECISION else "bf16"
+
+
+def manual_seed(seed):
+    _RNG["seed"] = int(seed) & 0xFFFFFFFFFFFFFFFF
+    _RNG["offset"] = 0
+
+
+def next_rng():
+    """-> (seed, offset) for one dropout site; offsets never repeat within a process."""
+    _RNG["offset"] += 1
+    return _RNG["seed"], _RNG["offset"]
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise lib.SpeLibraryError("spe_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback")
+        if t.dtype != torch.float32:
+            raise TypeError(f"expected float32, got {t.dtype}")
+
+
+def auto_splitk(M, N, K, batch):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
+    if tiles >= 128 or K < 512:
+        return 1
+    return max(1, min(512 // tiles, K // 256, 64))
+
+
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, C2=None,
+         batch0=1, batch1=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, act=0, splitk=1):
+    """Raw strided (batched) GEMM on already-allocated tensors; returns C."""
+    lib.call("spe_gemm_f32", _p(A), _p(B), _p(C), _p(bias), _p(C2), M, N, K, lda, ldb, ldc,
+             int(transA), int(transB), batch0, batch1, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
+             float(alpha), int(act), int(splitk), _PRECISION, _st())
+    return C
+
+
+# ---- nn.Linear ------------------------------------------------------------------------------
+def linear_fwd(x2, W, b, act=0, want_pre=False):
+    """y = act(x2 @ W.T + b); x2 [R,K] contiguous, W [N,K]."""
+    _chk(x2, W, b)
+    R, K = x2.shape
+    N = W.shape[0]
+    y = torch.empty((R, N), device=x2.device, dtype=torch.float32)
+    pre = torch.empty_like(y) if want_pre else None
+    gemm(x2, W, y, R, N, K, K, K, N, False, True, bias=b, C2=pre, act=act)
+    return (y, pre) if want_pre else y
+
+
+def linear_bwd(dy2, x2, W, need_dx=True, need_dw=True, need_db=True):
+    """dx = dy @ W ; dW = dy.T @ x ; db = colsum(dy)."""
+    _chk(dy2, x2, W)
+    R, N = dy2.shape
+    K = W.shape[1]
+    dx = dW = db = None
+    if need_dx:
+        dx = torch.empty((R, K), device=dy2.device, dtype=torch.float32)
+        gemm(dy2, W, dx, R, K, N, N, K, K, False, False)
+    if need_dw:
+        sk = auto_splitk(N, K, R, 1)
+        dW = (torch.zeros if sk > 1 else torch.empty)((N, K), device=dy2.device, dtype=torch.float32)
+        gemm(dy2, x2, dW, N, K, R, N, K, K, True, False, splitk=sk)
+    if need_db:
+        db = torch.zeros((N,), device=dy2.device, dtype=torch.float32)
+        lib.call("spe_colsum", _p(dy2), _p(db), R, N, N, _st())
+    return dx, dW, db
+
+
+def colsum(x2):
+    _chk(x2)
+    R, C = x2.shape
+    out = torch.zeros((C,), device=x2.device, dtype=torch.float32)
+    lib.call("spe_colsum", _p(x2), _p(out), R, C, x2.stride(0), _st())
+    return out
+
+
+def act_bwd(dy, aux, mode):
+    _chk(dy, aux)
+    dx = torch.empty_like(dy)
+    lib.call("spe_act_bwd", _p(dy), _p(aux), _p(dx), dy.numel(), mode, _st())
+    return dx
+
+
+# ---- LayerNorm ------------------------------------------------------------------------------
+def layernorm_fwd(x2, g, b, eps):
+    _chk(x2, g, b)
+    R, C = x2.shape
+    y = torch.empty_like(x2)
+    mean = torch.empty((R,), device=x2.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    lib.call("spe_layernorm_fwd", _p(x2), _p(g), _p(b), _p(y), _p(mean), _p(rstd), R, C, float(eps), _st())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy2, x2, g, mean, rstd):
+    _chk(dy2, x2, g)
+    R, C = x2.shape
+    dx = torch.empty_like(x2)
+    dg = torch.zeros((C,), device=x2.device, dtype=torch.float32)
+    db = torch.zeros_like(dg)
+    lib.call("spe_layernorm_bwd", _p(dy2), _p(x2), _p(g), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), R, C, _st())
+    return dx, dg, db
+
+
+# ---- LayerScale residual --------------------------------------------------------------------
+def layerscale_residual_fwd(x2, y2, gamma, sample_scale, rows_per_sample):
+    _chk(x2, y2, gamma, sample_scale)
+    R, C = x2.shape
+    out = torch.empty_like(x2)
+    lib.call("spe_layerscale_residual_fwd", _p(x2), _p(y2), _p(gamma), _p(sample_scale), _p(out), R, C,
+             rows_per_sample, _st())
+    return out
+
+
+def layerscale_residual_bwd(dout2, y2, gamma, sample_scale, rows_per_sample):
+    _chk(dout2, y2, gamma, sample_scale)
+    R, C = dout2.shape
+    dy = torch.empty_like(dout2)
+    dg = torch.zeros((C,), device=dout2.device, dtype=torch.float32)
+    lib.call("spe_layerscale_residual_bwd", _p(dout2), _p(y2), _p(gamma), _p(sample_scale), _p(dy), _p(dg), R, C,
+             rows_per_sample, _st())
+    return dy, dg
+
+
+# ---- dropout --------------------------------------------------------------------------------
+def dropout(x, p, seed, offset):
+    _chk(x)
+    y = torch.empty_like(x)
+    lib.call("spe_dropout", _p(x), _p(y), x.numel(), float(p), seed, offset, _st())
+    return y
+
+
+# ---- attention score transforms -------------------------------------------------------------
+def pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def softmax_fwd(S, mask_u8, B, H, Nq, Nk, ld, p_drop, seed, offset):
+    """S [B,H,Nq,ld] -> P (in place over S), Pd (or None)."""
+    Pd = torch.empty_like(S) if p_drop > 0 else None
+    lib.call("spe_softmax_fwd", _p(S), _p(mask_u8), _p(S), _p(Pd), B, H, Nq, Nk, ld, float(p_drop), seed, offset, _st())
+    return S, Pd
+
+
+def softmax_bwd(dPd, P, B, H, Nq, Nk, ld, p_drop, seed, offset):
+    lib.call("spe_softmax_bwd", _p(dPd), _p(P), _p(dPd), B, H, Nq, Nk, ld, float(p_drop), seed, offset, _st())
+    return dPd
+
+
+def talking_fwd(S, Wl, bl, Ww, bw, B, H, Nq, Nk, ld, p_drop, seed, offset):
+    """S [B,H,Nq,ld] raw scores -> P (in place over S), Pd (new)."""
+    Pd = torch.empty_like(S)
+    lib.call("spe_talking_softmax_fwd", _p(S), _p(Wl), _p(bl), _p(Ww), _p(bw), _p(S), _p(Pd), B, H, Nq, Nk, ld,
+             float(p_drop), seed, offset, _st())
+    return S, Pd
+
+
+def talking_bwd(dPd, P, S, Wl, Ww, B, H, Nq, Nk, ld, p_drop, seed, offset):
+    """-> dS (in place over dPd), dWl, dbl, dWw, dbw."""
+    nblocks = min(B * Nq, 1024)
+    nw = 2 * (H * H + H)
+    ws = torch.empty((nblocks, nw), device=dPd.device, dtype=torch.float32)
+    lib.call("spe_talking_softmax_bwd", _p(dPd), _p(P), _p(S), _p(Wl), _p(Ww), _p(dPd), _p(ws), nblocks, B, H, Nq, Nk, ld,
+             float(p_drop), seed, offset, _st())
+    g = colsum(ws)
+    hh = H * H
+    return dPd, g[:hh].view(H, H), g[hh:hh + H], g[hh + H:2 * hh + H].view(H, H), g[2 * hh + H:]
+
+
+# ---- misc -----------------------------------------------------------------------------------
+def patchify(img, P):
+    _chk(img)
+    B, Cin, Hi, Wi = img.shape
+    h, w = Hi // P, Wi // P
+    cols = torch.empty((B * h * w, Cin * P * P), device=img.device, dtype=torch.float32)
+    lib.call("spe_patchify", _p(img), _p(cols), B, Cin, Hi, Wi, P, _st())
+    return cols
+
+
+def add_rows(a, table):
+    """a [.., period] + table broadcast over leading rows (a.numel() % table.numel() == 0)."""
+    _chk(a, table)
+    out = torch.empty_like(a)
+    lib.call("spe_add_rows", _p(a), _p(table), _p(out), a.numel(), table.numel(), _st())
+    return out
+
+
+# ---- matcher / criterion --------------------------------------------------------------------
+def matcher_cost(logits, boxes, tgt_ids_i32, tgt_boxes, toff_i32, total_targets, w_class, w_bbox, w_giou):
+    """logits [L,B,Q,Kc], boxes [L,B,Q,4] -> cost [L, Q*total_targets] (packed per image), err flag tensor."""
+    _chk(logits, boxes, tgt_boxes)
+    L, B, Q, Kc = logits.shape
+    cost = torch.empty((L, Q * total_targets), device=logits.device, dtype=torch.float32)
+    err = torch.zeros((1,), device=logits.device, dtype=torch.int32)
+    lib.call("spe_matcher_cost", _p(logits), _p(boxes), _p(tgt_ids_i32), _p(tgt_boxes), _p(toff_i32), total_targets,
+             _p(cost), _p(err), L, B, Q, Kc, float(w_class), float(w_bbox), float(w_giou), _st())
+    return cost, err
+
+
+def focal_loss(logits, tclass_i32, roww, alpha, gamma):
+    """logits [L,R,Kc] -> loss_sum [L], grad [L,R,Kc], argmax [L,R]."""
+    _chk(logits, roww)
+    L, R, Kc = logits.shape
+    grad = torch.empty_like(logits)
+    loss = torch.zeros((L,), device=logits.device, dtype=torch.float32)
+    amax = torch.empty((L, R), device=logits.device, dtype=torch.int32)
+    lib.call("spe_focal_loss", _p(logits), _p(tclass_i32), _p(roww), _p(grad), _p(loss), _p(amax), L, R, Kc,
+             float(alpha), float(gamma), _st())
+    return loss, grad, amax
+
+
+def box_loss(pred_boxes, srow_i64, tbox, w, lidx_i32, L):
+    """-> sums [L,2], g_l1 [n,4], g_giou [n,4]."""
+    _chk(pred_boxes, tbox, w)
+    n = srow_i64.numel()
+    sums = torch.zeros((L, 2), device=pred_boxes.device, dtype=torch.float32)
+    g1 = torch.empty((n, 4), device=pred_boxes.device, dtype=torch.float32)
+    g2 = torch.empty_like(g1)
+    lib.call("spe_box_loss", _p(pred_boxes), _p(srow_i64), _p(tbox), _p(w), _p(lidx_i32), _p(sums), _p(g1), _p(g2), n, _st())
+    return sums, g1, g2
+
+
+def box_loss_bwd(srow_i64, lidx_i32, g1, g2, c1, c2, shape):
+    dpred = torch.zeros(shape, device=g1.device, dtype=torch.float32)
+    lib.call("spe_box_loss_bwd", _p(srow_i64), _p(lidx_i32), _p(g1), _p(g2), _p(c1), _p(c2), _p(dpred), srow_i64.numel(), _st())
+    return dpred

@@ -1,0 +1,311 @@
+"""Autograd operators of the SPE hot path.  Every forward AND backward is a sequence of
+libspe_hip.so kernel launches (spe_amd/kernels.py); torch only owns memory and the graph.
+
+Layout convention inside spe_amd: activations are batch-first [B, L, D] (the reference's
+transformer uses [L, B, D]; only the public outputs follow the reference's layout).
+"""
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+# ---------------------------------------------------------------------------------------------
+class _Linear(Function):
+    """y = act(x W^T + b)  (nn.Linear [+ F.relu / nn.GELU]); reference transformer.py:21-33,
+    cait.py:376,390, timm Mlp."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        Wc = W if W.is_contiguous() else W.contiguous()
+        aux = None
+        if act == ACT_GELU:
+            y, aux = K.linear_fwd(x2, Wc, b, act, want_pre=True)
+        else:
+            y = K.linear_fwd(x2, Wc, b, act)
+            if act == ACT_RELU:
+                aux = y
+        ctx.act = act
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x2, Wc, aux)
+        return y.view(*shp[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, aux = ctx.saved_tensors
+        dy2 = dy.reshape(-1, W.shape[0])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        if ctx.act != ACT_NONE:
+            dy2 = K.act_bwd(dy2, aux, ctx.act)
+        dx, dW, db = K.linear_bwd(dy2, x2, W, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                  ctx.has_bias and ctx.needs_input_grad[2])
+        if dx is not None:
+            dx = dx.view(*dy.shape[:-1], W.shape[1])
+        return dx, dW, db, None
+
+
+def linear(x, W, b=None, act=ACT_NONE):
+    return _Linear.apply(x, W, b, act)
+
+
+# ---------------------------------------------------------------------------------------------
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        y, mean, rstd = K.layernorm_fwd(x2, g, b, eps)
+        ctx.save_for_backward(x2, g, mean, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, mean, rstd = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx, dg, db = K.layernorm_bwd(dy2, x2, g, mean, rstd)
+        return dx.view(dy.shape), dg, db, None
+
+
+def layer_norm(x, g, b, eps):
+    return _LayerNorm.apply(x, g, b, eps)
+
+
+# ---------------------------------------------------------------------------------------------
+class _LayerScaleResidual(Function):
+    """out = x + s_b * gamma * y   (cait.py:413-416; s_b = DropPath keep-scale per sample)."""
+
+    @staticmethod
+    def forward(ctx, x, y, gamma, sample_scale):
+        B = x.shape[0]
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        y2 = y.reshape(-1, y.shape[-1]).contiguous()
+        rps = x2.shape[0] // B
+        out = K.layerscale_residual_fwd(x2, y2, gamma, sample_scale, rps)
+        ctx.rps = rps
+        ctx.save_for_backward(y2, gamma, sample_scale)
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        y2, gamma, ss = ctx.saved_tensors
+        d2 = dout.reshape(-1, dout.shape[-1]).contiguous()
+        dy, dg = K.layerscale_residual_bwd(d2, y2, gamma, ss, ctx.rps)
+        return dout, dy.view(dout.shape), dg, None
+
+
+def layerscale_residual(x, y, gamma, sample_scale=None):
+    return _LayerScaleResidual.apply(x, y, gamma, sample_scale)
+
+
+def drop_path_scale(B, p, training, device):
+    """Per-sample keep/(1-p) factors of timm DropPath (reference models/layers/drop.py:140-168)."""
+    if p <= 0.0 or not training:
+        return None
+    keep = 1.0 - p
+    return (torch.rand(B, device=device) < keep).to(torch.float32) / keep
+
+
+# ---------------------------------------------------------------------------------------------
+class _Dropout(Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        seed, off = K.next_rng()
+        ctx.p, ctx.seed, ctx.off = p, seed, off
+        return K.dropout(x.contiguous(), p, seed, off)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.dropout(dy.contiguous(), ctx.p, ctx.seed, ctx.off), None
+
+
+def dropout(x, p, training):
+    if p <= 0.0 or not training:
+        return x
+    return _Dropout.apply(x, p)
+
+
+# ---------------------------------------------------------------------------------------------
+class _TalkingHeadsAttention(Function):
+    """CaiT talking-heads self-attention core (reference models/cait.py:377-389): qkv [B,N,3C] ->
+    out [B,N,C].  Materialised-score implementation: QK^T GEMM -> fused head-mix/softmax/head-mix/
+    dropout row kernel -> PV GEMM; the saved tensors are P and Pd ([B,H,N,N] each)."""
+
+    @staticmethod
+    def forward(ctx, qkv, Wl, bl, Ww, bw, H, scale, p_drop):
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        dh = C // H
+        qkv = qkv.contiguous()
+        v5 = qkv.view(B, N, 3, H, dh)
+        q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
+        ld = K.pad4(N)
+        S = torch.empty((B, H, N, ld), device=qkv.device, dtype=torch.float32)
+        sq = (N * C3, dh)
+        sS = (H * N * ld, N * ld)
+        K.gemm(q, k, S, N, N, dh, C3, C3, ld, False, True, batch0=B, batch1=H, sA=sq, sB=sq, sC=sS, alpha=scale)
+        seed, off = K.next_rng() if p_drop > 0 else (0, 0)
+        P, Pd = K.talking_fwd(S, Wl, bl, Ww, bw, B, H, N, N, ld, p_drop, seed, off)
+        O = torch.empty((B, N, C), device=qkv.device, dtype=torch.float32)
+        K.gemm(Pd, v, O, N, dh, N, ld, C3, C, False, False, batch0=B, batch1=H, sA=sS, sB=sq, sC=(N * C, dh))
+        ctx.meta = (B, N, C, H, dh, ld, scale, p_drop, seed, off)
+        ctx.save_for_backward(qkv, P, Pd, Wl, Ww)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, P, Pd, Wl, Ww = ctx.saved_tensors
+        B, N, C, H, dh, ld, scale, p_drop, seed, off = ctx.meta
+        C3 = 3 * C
+        dO = dO.contiguous()
+        v5 = qkv.view(B, N, 3, H, dh)
+        q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
+        dqkv = torch.empty_like(qkv)
+        d5 = dqkv.view(B, N, 3, H, dh)
+        dq, dk, dv = d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]
+        sq, sS, sO = (N * C3, dh), (H * N * ld, N * ld), (N * C, dh)
+        # dPd = dO V^T ; dV = Pd^T dO
+        dPd = torch.empty((B, H, N, ld), device=qkv.device, dtype=torch.float32)
+        K.gemm(dO, v, dPd, N, N, dh, C, C3, ld, False, True, batch0=B, batch1=H, sA=sO, sB=sq, sC=sS)
+        K.gemm(Pd, dO, dv, N, dh, N, ld, C, C3, True, False, batch0=B, batch1=H, sA=sS, sB=sO, sC=sq)
+        # raw scores again (cheaper than keeping a third [B,H,N,N] tensor alive per block)
+        S = torch.empty((B, H, N, ld), device=qkv.device, dtype=torch.float32)
+        K.gemm(q, k, S, N, N, dh, C3, C3, ld, False, True, batch0=B, batch1=H, sA=sq, sB=sq, sC=sS, alpha=scale)
+        dS, dWl, dbl, dWw, dbw = K.talking_bwd(dPd, P, S, Wl, Ww, B, H, N, N, ld, p_drop, seed, off)
+        del S
+        # dQ = scale * dS K ; dK = scale * dS^T Q
+        K.gemm(dS, k, dq, N, dh, N, ld, C3, C3, False, False, batch0=B, batch1=H, sA=sS, sB=sq, sC=sq, alpha=scale)
+        K.gemm(dS, q, dk, N, dh, N, ld, C3, C3, True, False, batch0=B, batch1=H, sA=sS, sB=sq, sC=sq, alpha=scale)
+        return dqkv, dWl, dbl, dWw, dbw, None, None, None
+
+
+def talking_heads_attention(qkv, Wl, bl, Ww, bw, num_heads, scale, p_drop=0.0):
+    return _TalkingHeadsAttention.apply(qkv, Wl, bl, Ww, bw, num_heads, scale, p_drop)
+
+
+# ---------------------------------------------------------------------------------------------
+def _bh(t):
+    """(batch stride, head stride, row stride) of a [B,L,H,d] view with unit last stride."""
+    assert t.stride(3) == 1, "last dim must be contiguous"
+    return (t.stride(0), t.stride(2)), t.stride(1)
+
+
+class _Attention(Function):
+    """softmax(scale * q k^T + key_padding_mask) [dropout] v for q [B,Lq,H,dk], k [B,Lk,H,dk],
+    v [B,Lk,H,dv] -> [B,Lq,H*dv] (and optionally the softmax map [B,H,Lq,Lk], no grad).
+    Reference: models/attention.py:277-383 (decoder MHA; q/k head dim != v head dim),
+    nn.MultiheadAttention core (encoder, transformer.py:275-277), Multi_Class_Attention
+    (cait.py:120-131, map saved at :130)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask_u8, scale, p_drop, need_map):
+        B, Lq, H, dk = q.shape
+        Lk, dv = k.shape[1], v.shape[3]
+        sQ, ldq = _bh(q)
+        sK, ldk = _bh(k)
+        sV, ldv = _bh(v)
+        ld = K.pad4(Lk)
+        S = torch.empty((B, H, Lq, ld), device=q.device, dtype=torch.float32)
+        sS = (H * Lq * ld, Lq * ld)
+        K.gemm(q, k, S, Lq, Lk, dk, ldq, ldk, ld, False, True, batch0=B, batch1=H, sA=sQ, sB=sK, sC=sS, alpha=scale)
+        seed, off = K.next_rng() if p_drop > 0 else (0, 0)
+        P, Pd = K.softmax_fwd(S, mask_u8, B, H, Lq, Lk, ld, p_drop, seed, off)
+        O = torch.empty((B, Lq, H * dv), device=q.device, dtype=torch.float32)
+        K.gemm(Pd if Pd is not None else P, v, O, Lq, dv, Lk, ld, ldv, H * dv, False, False, batch0=B, batch1=H,
+               sA=sS, sB=sV, sC=(Lq * H * dv, dv))
+        ctx.meta = (B, Lq, Lk, H, dk, dv, ld, scale, p_drop, seed, off)
+        ctx.save_for_backward(q, k, v, P, Pd)
+        if need_map:
+            pmap = P[..., :Lk]
+            ctx.mark_non_differentiable(pmap)
+            return O, pmap
+        return O, None
+
+    @staticmethod
+    def backward(ctx, dO, _dmap):
+        q, k, v, P, Pd = ctx.saved_tensors
+        B, Lq, Lk, H, dk, dv, ld, scale, p_drop, seed, off = ctx.meta
+        dO = dO.contiguous()
+        sQ, ldq = _bh(q)
+        sK, ldk = _bh(k)
+        sV, ldv = _bh(v)
+        sS = (H * Lq * ld, Lq * ld)
+        sO = (Lq * H * dv, dv)
+        dq = torch.empty((B, Lq, H, dk), device=q.device, dtype=torch.float32)
+        dk_ = torch.empty((B, Lk, H, dk), device=q.device, dtype=torch.float32)
+        dv_ = torch.empty((B, Lk, H, dv), device=q.device, dtype=torch.float32)
+        dP = torch.empty((B, H, Lq, ld), device=q.device, dtype=torch.float32)
+        K.gemm(dO, v, dP, Lq, Lk, dv, H * dv, ldv, ld, False, True, batch0=B, batch1=H, sA=sO, sB=sV, sC=sS)
+        K.gemm(Pd if Pd is not None else P, dO, dv_, Lk, dv, Lq, ld, H * dv, H * dv, True, False, batch0=B, batch1=H,
+               sA=sS, sB=sO, sC=(Lk * H * dv, dv))
+        dS = K.softmax_bwd(dP, P, B, H, Lq, Lk, ld, p_drop, seed, off)
+        K.gemm(dS, k, dq, Lq, dk, Lk, ld, ldk, H * dk, False, False, batch0=B, batch1=H, sA=sS, sB=sK,
+               sC=(Lq * H * dk, dk), alpha=scale)
+        K.gemm(dS, q, dk_, Lk, dk, Lq, ld, ldq, H * dk, True, False, batch0=B, batch1=H, sA=sS, sB=sQ,
+               sC=(Lk * H * dk, dk), alpha=scale)
+        return dq, dk_, dv_, None, None, None, None
+
+
+def attention(q, k, v, key_padding_mask=None, scale=1.0, p_drop=0.0, need_map=False):
+    """key_padding_mask: bool/uint8 [B,Lk], True = padded key."""
+    m = None
+    if key_padding_mask is not None:
+        m = key_padding_mask.to(torch.uint8).contiguous()
+    return _Attention.apply(q, k, v, m, float(scale), float(p_drop), need_map)
+
+
+# ---------------------------------------------------------------------------------------------
+class _PatchEmbed(Function):
+    """Conv2d(3,C,16,16) patch embedding as gather + GEMM (reference cait.py:518-528)."""
+
+    @staticmethod
+    def forward(ctx, img, W, b, P):
+        B, Cin, Hi, Wi = img.shape
+        cols = K.patchify(img.contiguous(), P)
+        W2 = W.reshape(W.shape[0], -1)
+        y = K.linear_fwd(cols, W2, b)
+        ctx.save_for_backward(cols, W2)
+        ctx.wshape = W.shape
+        return y.view(B, (Hi // P) * (Wi // P), W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        cols, W2 = ctx.saved_tensors
+        dy2 = dy.reshape(-1, W2.shape[0]).contiguous()
+        _, dW, db = K.linear_bwd(dy2, cols, W2, need_dx=False)
+        return None, dW.view(ctx.wshape), db, None
+
+
+def patch_embed(img, W, b, P):
+    return _PatchEmbed.apply(img, W, b, P)
+
+
+class _AddRows(Function):
+    """x [B,N,C] + table [N,C] (pos-embed add, cait.py:623-624)."""
+
+    @staticmethod
+    def forward(ctx, x, table):
+        ctx.B = x.shape[0]
+        return K.add_rows(x.contiguous(), table.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dt = None
+        if ctx.needs_input_grad[1]:
+            n = dy.numel() // ctx.B
+            dt = K.colsum(dy.view(ctx.B, n)).view(dy.shape[1:])
+        return dy, dt
+
+
+def add_rows(x, table):
+    return _AddRows.apply(x, table)

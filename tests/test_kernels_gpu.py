@@ -1,0 +1,356 @@
+"""Kernel-level parity (GPU): every libspe_hip.so kernel against a plain fp32/fp64 torch
+restatement of the same arithmetic, on seeded asymmetric inputs.  Tolerances are stated per mode:
+`bf16x3` (3-term split) must sit at fp32 round-off; `bf16` is bounded by bf16 operand rounding
+(2^-9 per operand -> ~3e-3 relative per contraction)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+TOL = {"bf16": 6e-3, "bf16x3": 2e-5}
+
+
+@pytest.fixture(params=["bf16x3", "bf16"])
+def prec(request, dev):
+    from spe_amd import kernels as K
+    K.set_precision(request.param)
+    yield request.param
+    K.set_precision("bf16")
+
+
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 32), (200, 91, 48), (300, 384, 384), (77, 130, 4150), (1, 4, 384), (513, 257, 100)])
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
+def test_gemm_layouts(dev, prec, M, N, K_, layout):
+    from spe_amd import kernels as K
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K_)
+    A = torch.randn(M, K_, generator=g).to(dev)
+    B = torch.randn(K_, N, generator=g).to(dev)
+    ref = (A.double() @ B.double())
+    C = torch.full((M, N), float("nan"), device=dev)
+    if layout == "NT":
+        Bt = B.t().contiguous()
+        K.gemm(A, Bt, C, M, N, K_, K_, K_, N, False, True)
+    elif layout == "NN":
+        K.gemm(A, B, C, M, N, K_, K_, N, N, False, False)
+    else:
+        At = A.t().contiguous()
+        K.gemm(At, B, C, M, N, K_, M, N, N, True, False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(C).all()
+    assert rel(C, ref) < TOL[prec], (layout, rel(C, ref))
+
+
+def test_gemm_epilogue_splitk_batched(dev, prec):
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(333, 96, generator=g).to(dev)
+    W = torch.randn(200, 96, generator=g).to(dev)
+    b = torch.randn(200, generator=g).to(dev)
+    y, pre = K.linear_fwd(x, W, b, act=2, want_pre=True)
+    refpre = x.double() @ W.double().t() + b.double()
+    assert rel(pre, refpre) < TOL[prec]
+    assert rel(y, torch.nn.functional.gelu(refpre)) < TOL[prec]
+    y1 = K.linear_fwd(x, W, b, act=1)
+    assert rel(y1, torch.relu(refpre)) < TOL[prec]
+    # split-K (TN, long contraction)
+    dy = torch.randn(5000, 64, generator=g).to(dev)
+    xx = torch.randn(5000, 96, generator=g).to(dev)
+    dW = torch.zeros(64, 96, device=dev)
+    K.gemm(dy, xx, dW, 64, 96, 5000, 64, 96, 96, True, False, splitk=8)
+    assert rel(dW, dy.double().t() @ xx.double()) < TOL[prec]
+    # two-level batch with strides (the attention addressing): qkv [B,N,3,H,dh]
+    B_, N_, H_, dh = 2, 37, 4, 24
+    qkv = torch.randn(B_, N_, 3, H_, dh, generator=g).to(dev)
+    ld = K.pad4(N_)
+    S = torch.zeros(B_, H_, N_, ld, device=dev)
+    C3 = 3 * H_ * dh
+    K.gemm(qkv[:, :, 0], qkv[:, :, 1], S, N_, N_, dh, C3, C3, ld, False, True, batch0=B_, batch1=H_,
+           sA=(N_ * C3, dh), sB=(N_ * C3, dh), sC=(H_ * N_ * ld, N_ * ld), alpha=0.5)
+    ref = 0.5 * torch.einsum("bqhd,bkhd->bhqk", qkv[:, :, 0].double(), qkv[:, :, 1].double())
+    assert rel(S[..., :N_], ref) < TOL[prec]
+    assert (S[..., N_:] == 0).all()
+
+
+def test_linear_bwd(dev, prec):
+    from spe_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 50, 96, generator=g).to(dev).requires_grad_()
+    W = (torch.randn(130, 96, generator=g) * 0.1).to(dev).requires_grad_()
+    b = torch.randn(130, generator=g).to(dev).requires_grad_()
+    for act, f in [(0, lambda t: t), (1, torch.relu), (2, torch.nn.functional.gelu)]:
+        y = ops.linear(x, W, b, act)
+        go = torch.randn(y.shape, generator=g).to(dev)
+        gx, gW, gb = torch.autograd.grad(y, (x, W, b), go)
+        xd, Wd, bd = (t.detach().double().requires_grad_() for t in (x, W, b))
+        yr = f(xd @ Wd.t() + bd)
+        rx, rW, rb = torch.autograd.grad(yr, (xd, Wd, bd), go.double())
+        assert rel(y, yr) < TOL[prec]
+        # bf16 operand rounding flips the ReLU mask of pre-activations within ~3e-3 of zero
+        gt = 6e-2 if (act == 1 and prec == "bf16") else TOL[prec]
+        assert rel(gx, rx) < gt and rel(gW, rW) < gt and rel(gb, rb) < max(gt, 1e-5), (act, rel(gx, rx), rel(gW, rW), rel(gb, rb))
+
+
+@pytest.mark.parametrize("R,C", [(7, 192), (1000, 384), (33, 1024)])
+def test_layernorm(dev, R, C):
+    from spe_amd import ops
+    g = torch.Generator().manual_seed(R)
+    x = (torch.randn(R, C, generator=g) * 3 + 1).to(dev).requires_grad_()
+    w = torch.randn(C, generator=g).to(dev).requires_grad_()
+    b = torch.randn(C, generator=g).to(dev).requires_grad_()
+    y = ops.layer_norm(x, w, b, 1e-6)
+    go = torch.randn(R, C, generator=g).to(dev)
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), go)
+    xd, wd, bd = (t.detach().double().requires_grad_() for t in (x, w, b))
+    yr = torch.nn.functional.layer_norm(xd, (C,), wd, bd, 1e-6)
+    rx, rw, rb = torch.autograd.grad(yr, (xd, wd, bd), go.double())
+    assert rel(y, yr) < 1e-5 and rel(gx, rx) < 1e-5 and rel(gw, rw) < 1e-5 and rel(gb, rb) < 1e-5
+
+
+def test_softmax_mask_and_bwd(dev):
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    B, H, Nq, Nk = 2, 3, 5, 203
+    ld = K.pad4(Nk)
+    S = torch.zeros(B, H, Nq, ld, device=dev)
+    S[..., :Nk] = (torch.randn(B, H, Nq, Nk, generator=g) * 4).to(dev)
+    mask = torch.zeros(B, Nk, dtype=torch.bool)
+    mask[1, 150:] = True
+    mask[0, ::7] = True
+    Sd = S[..., :Nk].double().masked_fill(mask.to(dev)[:, None, None, :], float("-inf")).requires_grad_()
+    Pr = Sd.softmax(-1)
+    P, Pd = K.softmax_fwd(S.clone(), mask.to(torch.uint8).to(dev), B, H, Nq, Nk, ld, 0.0, 0, 0)
+    assert Pd is None and rel(P[..., :Nk], Pr) < 1e-5
+    go = torch.zeros(B, H, Nq, ld, device=dev)
+    go[..., :Nk] = torch.randn(B, H, Nq, Nk, generator=g).to(dev)
+    (rs,) = torch.autograd.grad(Pr, Sd, go[..., :Nk].double())
+    dS = K.softmax_bwd(go.clone(), P, B, H, Nq, Nk, ld, 0.0, 0, 0)
+    assert rel(dS[..., :Nk], rs) < 1e-5
+    # dropout: forward mask == backward mask, keep-rate ~ 1-p, scale 1/(1-p)
+    P2, Pd2 = K.softmax_fwd(S.clone(), None, B, H, Nq, Nk, ld, 0.25, 1234, 7)
+    ratio = Pd2[..., :Nk] / P2[..., :Nk]
+    kept = ratio > 0
+    assert abs(kept.float().mean().item() - 0.75) < 0.03
+    assert torch.allclose(ratio[kept], torch.full_like(ratio[kept], 1 / 0.75), rtol=1e-5)
+    ones = torch.zeros(B, H, Nq, ld, device=dev); ones[..., :Nk] = 1
+    # d(sum Pd)/dS through the same mask
+    Pdd = (P2[..., :Nk].double() * ratio.double())
+    Sd2 = S[..., :Nk].double().requires_grad_()
+    (r2,) = torch.autograd.grad((Sd2.softmax(-1) * ratio.double()).sum(), Sd2)
+    d2 = K.softmax_bwd(ones.clone(), P2, B, H, Nq, Nk, ld, 0.25, 1234, 7)
+    assert (d2[..., :Nk].double() - r2).abs().max().item() < 1e-5
+
+
+def _talking_ref(qkv, Wl, bl, Ww, bw, H, scale, keep=None):
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    q, k, v = qkv.reshape(B, N, 3, H, C // H).permute(2, 0, 3, 1, 4)
+    attn = (q * scale) @ k.transpose(-2, -1)
+    attn = torch.nn.functional.linear(attn.permute(0, 2, 3, 1), Wl, bl).permute(0, 3, 1, 2)
+    attn = attn.softmax(-1)
+    attn = torch.nn.functional.linear(attn.permute(0, 2, 3, 1), Ww, bw).permute(0, 3, 1, 2)
+    if keep is not None:
+        attn = attn * keep
+    return (attn @ v).transpose(1, 2).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("H,N,dh", [(4, 50, 48), (8, 131, 48), (6, 40, 32)])
+def test_talking_heads_attention(dev, prec, H, N, dh):
+    from spe_amd import ops
+    g = torch.Generator().manual_seed(H * N)
+    B, C = 2, H * dh
+    qkv = torch.randn(B, N, 3 * C, generator=g).to(dev).requires_grad_()
+    Wl = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g)).to(dev).requires_grad_()
+    Ww = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g)).to(dev).requires_grad_()
+    bl = (0.1 * torch.randn(H, generator=g)).to(dev).requires_grad_()
+    bw = (0.1 * torch.randn(H, generator=g)).to(dev).requires_grad_()
+    scale = dh ** -0.5
+    out = ops.talking_heads_attention(qkv, Wl, bl, Ww, bw, H, scale, 0.0)
+    go = torch.randn(out.shape, generator=g).to(dev)
+    grads = torch.autograd.grad(out, (qkv, Wl, bl, Ww, bw), go)
+    dd = [t.detach().double().requires_grad_() for t in (qkv, Wl, bl, Ww, bw)]
+    ref = _talking_ref(*dd, H, scale)
+    rg = torch.autograd.grad(ref, dd, go.double())
+    assert rel(out, ref) < TOL[prec]
+    for a, b, nm in zip(grads, rg, ["qkv", "Wl", "bl", "Ww", "bw"]):
+        if nm == "bl":   # softmax is shift invariant: the exact gradient is 0
+            assert a.abs().max().item() < 1e-3 * grads[1].abs().max().item()
+        else:
+            assert rel(a, b) < 2 * TOL[prec], (nm, rel(a, b))
+
+
+def test_talking_heads_dropout_consistency(dev):
+    """With attn_drop > 0 the backward must regenerate the forward mask: check d(out)/d(Ww) against
+    a reference that uses the mask recovered from the forward (Pd / P')."""
+    from spe_amd import kernels as K
+    K.set_precision("bf16x3")
+    g = torch.Generator().manual_seed(9)
+    B, H, N = 1, 4, 33
+    ld = K.pad4(N)
+    S = torch.zeros(B, H, N, ld, device=dev); S[..., :N] = torch.randn(B, H, N, N, generator=g).to(dev)
+    Wl = (torch.eye(H) + 0.2 * torch.randn(H, H, generator=g)).to(dev); bl = torch.zeros(H, device=dev)
+    Ww = (torch.eye(H) + 0.2 * torch.randn(H, H, generator=g)).to(dev); bw = (0.05 * torch.randn(H, generator=g)).to(dev)
+    S0 = S.clone()
+    P, Pd = K.talking_fwd(S, Wl, bl, Ww, bw, B, H, N, N, ld, 0.3, 99, 5)
+    Pm = torch.nn.functional.linear(P[..., :N].permute(0, 2, 3, 1), Ww, bw).permute(0, 3, 1, 2)
+    ratio = Pd[..., :N] / Pm
+    keep = ratio.abs() > 1e-6
+    assert abs(keep.float().mean().item() - 0.7) < 0.05
+    go = torch.zeros(B, H, N, ld, device=dev); go[..., :N] = torch.randn(B, H, N, N, generator=g).to(dev)
+    Sd = S0[..., :N].double().requires_grad_()
+    Wld, Wwd = Wl.double().requires_grad_(), Ww.double().requires_grad_()
+    a = torch.nn.functional.linear(Sd.permute(0, 2, 3, 1), Wld, bl.double()).permute(0, 3, 1, 2).softmax(-1)
+    a = torch.nn.functional.linear(a.permute(0, 2, 3, 1), Wwd, bw.double()).permute(0, 3, 1, 2) * (keep.double() / 0.7)
+    rS, rWl, rWw = torch.autograd.grad(a, (Sd, Wld, Wwd), go[..., :N].double())
+    dS, dWl, dbl, dWw, dbw = K.talking_bwd(go.clone(), P, S0, Wl, Ww, B, H, N, N, ld, 0.3, 99, 5)
+    assert rel(dS[..., :N], rS) < 1e-4 and rel(dWl, rWl) < 1e-4 and rel(dWw, rWw) < 1e-4
+    K.set_precision("bf16")
+
+
+def test_attention_generic(dev, prec):
+    from spe_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, Lq, Lk, H, dk, dv = 2, 10, 77, 4, 48, 24
+    q = torch.randn(B, Lq, H, dk, generator=g).to(dev).requires_grad_()
+    k = torch.randn(B, Lk, H, dk, generator=g).to(dev).requires_grad_()
+    v = torch.randn(B, Lk, H, dv, generator=g).to(dev).requires_grad_()
+    mask = torch.zeros(B, Lk, dtype=torch.bool); mask[1, 60:] = True
+    out, pmap = ops.attention(q, k, v, mask.to(dev), scale=dk ** -0.5, p_drop=0.0, need_map=True)
+    go = torch.randn(out.shape, generator=g).to(dev)
+    gq, gk, gv = torch.autograd.grad(out, (q, k, v), go)
+    qd, kd, vd = (t.detach().double().requires_grad_() for t in (q, k, v))
+    s = torch.einsum("bqhd,bkhd->bhqk", qd * dk ** -0.5, kd).masked_fill(mask.to(dev)[:, None, None], float("-inf"))
+    p = s.softmax(-1)
+    ref = torch.einsum("bhqk,bkhd->bqhd", p, vd).reshape(B, Lq, H * dv)
+    rq, rk, rv = torch.autograd.grad(ref, (qd, kd, vd), go.double())
+    assert rel(out, ref) < TOL[prec] and rel(pmap, p) < TOL[prec]
+    assert rel(gq, rq) < 2 * TOL[prec] and rel(gk, rk) < 2 * TOL[prec] and rel(gv, rv) < 2 * TOL[prec]
+
+
+def test_elementwise(dev):
+    from spe_amd import kernels as K, ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 50, 192, generator=g).to(dev).requires_grad_()
+    y = torch.randn(2, 50, 192, generator=g).to(dev).requires_grad_()
+    gam = torch.randn(192, generator=g).to(dev).requires_grad_()
+    ss = torch.tensor([0.0, 1.25], device=dev)
+    for s in (None, ss):
+        out = ops.layerscale_residual(x, y, gam, s)
+        go = torch.randn(out.shape, generator=g).to(dev)
+        gx, gy, gg = torch.autograd.grad(out, (x, y, gam), go)
+        xd, yd, gd = (t.detach().double().requires_grad_() for t in (x, y, gam))
+        sc = 1.0 if s is None else s.double()[:, None, None]
+        ref = xd + sc * gd * yd
+        rx, ry, rg = torch.autograd.grad(ref, (xd, yd, gd), go.double())
+        assert rel(out, ref) < 1e-6 and rel(gx, rx) < 1e-6 and rel(gy, ry) < 1e-6 and rel(gg, rg) < 1e-5
+    h = torch.randn(1000, 64, generator=g).to(dev)
+    d = torch.randn(1000, 64, generator=g).to(dev)
+    hd = h.double().requires_grad_()
+    (r,) = torch.autograd.grad(torch.nn.functional.gelu(hd), hd, d.double())
+    assert rel(K.act_bwd(d, h, 2), r) < 1e-5
+    assert rel(K.colsum(h), h.double().sum(0)) < 1e-5
+    dr = K.dropout(h, 0.1, 42, 1)
+    kept = dr != 0
+    assert abs(kept.float().mean().item() - 0.9) < 0.02
+    assert torch.equal(K.dropout(h, 0.1, 42, 1), dr) and not torch.equal(K.dropout(h, 0.1, 42, 2), dr)
+    img = torch.randn(2, 3, 64, 96, generator=g).to(dev)
+    W = torch.randn(32, 3, 16, 16, generator=g).to(dev).requires_grad_()
+    b = torch.randn(32, generator=g).to(dev).requires_grad_()
+    K.set_precision("bf16x3")
+    pe = ops.patch_embed(img, W, b, 16)
+    ref = torch.nn.functional.conv2d(img.double(), W.double(), b.double(), stride=16).flatten(2).transpose(1, 2)
+    assert rel(pe, ref) < 2e-5
+    K.set_precision("bf16")
+    t = torch.randn(50, 192, generator=g).to(dev).requires_grad_()
+    o = ops.add_rows(x, t)
+    assert rel(o, x + t) < 1e-7
+    (gt,) = torch.autograd.grad(o, t, torch.ones_like(o))
+    assert rel(gt, torch.full_like(t, 2.0)) < 1e-6
+
+
+def _giou(a, b):
+    def xyxy(x):
+        cx, cy, w, h = x.unbind(-1)
+        return torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], -1)
+    a, b = xyxy(a), xyxy(b)
+    a1 = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]); a2 = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = torch.max(a[:, None, :2], b[:, :2]); rb = torch.min(a[:, None, 2:], b[:, 2:])
+    wh = (rb - lt).clamp(min=0); inter = wh[..., 0] * wh[..., 1]
+    union = a1[:, None] + a2 - inter; iou = inter / union
+    lt = torch.min(a[:, None, :2], b[:, :2]); rb = torch.max(a[:, None, 2:], b[:, 2:])
+    wh = (rb - lt).clamp(min=0); area = wh[..., 0] * wh[..., 1]
+    return iou - (area - union) / area
+
+
+def _rand_boxes(n, g):
+    c = torch.rand(n, 2, generator=g) * 0.6 + 0.2
+    wh = torch.rand(n, 2, generator=g) * 0.35 + 0.05
+    return torch.cat([c, wh], 1)
+
+
+def test_matcher_cost_and_losses(dev):
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(17)
+    L, B, Q, Kc = 3, 2, 20, 21
+    logits = (torch.randn(L, B, Q, Kc, generator=g) * 2).to(dev)
+    boxes = torch.stack([torch.stack([_rand_boxes(Q, g) for _ in range(B)]) for _ in range(L)]).to(dev)
+    sizes = [5, 0] if False else [5, 9]
+    tgt_ids = torch.randint(1, Kc, (sum(sizes),), generator=g)
+    tgt_boxes = _rand_boxes(sum(sizes), g)
+    toff = torch.tensor([0, sizes[0], sum(sizes)], dtype=torch.int32)
+    cost, err = K.matcher_cost(logits, boxes, tgt_ids.int().to(dev), tgt_boxes.to(dev), toff.to(dev), sum(sizes), 2.0, 5.0, 2.0)
+    assert err.item() == 0
+    for l in range(L):
+        for b in range(B):
+            p = logits[l, b].double().sigmoid().cpu()
+            ids = tgt_ids[toff[b]:toff[b + 1]]
+            tb = tgt_boxes[toff[b]:toff[b + 1]].double()
+            neg = 0.75 * p ** 2 * (-(1 - p + 1e-8).log()); pos = 0.25 * (1 - p) ** 2 * (-(p + 1e-8).log())
+            ref = 5.0 * torch.cdist(boxes[l, b].double().cpu(), tb, p=1) + 2.0 * (pos[:, ids] - neg[:, ids]) \
+                - 2.0 * _giou(boxes[l, b].double().cpu(), tb)
+            got = cost[l, Q * toff[b]:Q * toff[b + 1]].view(Q, sizes[b])
+            assert (got.double().cpu() - ref).abs().max().item() < 2e-5
+    # focal loss + gradient
+    tcls = torch.randint(0, Kc + 1, (L, B * Q), generator=g)
+    roww = torch.rand(L, B * Q, generator=g)
+    for gamma in (2.0, 0.5):
+        for rw in (None, roww):
+            lg = logits.view(L, B * Q, Kc)
+            loss, grad, amax = K.focal_loss(lg, tcls.int().to(dev), None if rw is None else rw.to(dev), 0.25, gamma)
+            x = lg.double().cpu().requires_grad_()
+            t = torch.nn.functional.one_hot(tcls, Kc + 1)[..., :Kc].double()
+            prob = x.sigmoid()
+            ce = torch.nn.functional.binary_cross_entropy_with_logits(x, t, reduction="none")
+            pt = (prob * t + (1 - prob) * (1 - t)).clamp(1e-5, 1 - 1e-5)
+            w = 1.0 if rw is None else rw.double()[..., None]
+            le = (0.25 * t + 0.75 * (1 - t)) * w * ce * (1 - pt) ** gamma
+            ref = le.sum((1, 2))
+            (rg,) = torch.autograd.grad(ref.sum(), x)
+            assert rel(loss, ref) < 1e-5 and rel(grad, rg) < 1e-4
+            assert torch.equal(amax.cpu().long(), lg.cpu().argmax(-1))
+    # box losses + gradient
+    n = 40
+    pb = boxes.reshape(-1, 4)
+    srow = torch.randint(0, pb.shape[0], (n,), generator=g)
+    tb = _rand_boxes(n, g)
+    w = torch.rand(n, generator=g)
+    lidx = (srow // (B * Q)).int()
+    sums, g1, g2 = K.box_loss(pb, srow.to(dev), tb.to(dev), w.to(dev), lidx.to(dev), L)
+    s = pb.double().cpu()[srow].requires_grad_()
+    l1 = ((s - tb.double()).abs().sum(1) * w.double())
+    gi = (1 - torch.diag(_giou(s, tb.double()))) * w.double()
+    (r1,) = torch.autograd.grad(l1.sum(), s, retain_graph=True)
+    (r2,) = torch.autograd.grad(gi.sum(), s)
+    ref_sums = torch.zeros(L, 2, dtype=torch.double)
+    ref_sums.index_add_(0, lidx.long(), torch.stack([l1, gi], 1).detach())
+    assert rel(sums, ref_sums) < 1e-5 and rel(g1, r1) < 1e-6 and rel(g2, r2) < 1e-4
+    c1 = torch.tensor([1.0, 2.0, 3.0], device=dev); c2 = torch.tensor([0.5, 0.25, 2.0], device=dev)
+    dp = K.box_loss_bwd(srow.to(dev), lidx.to(dev), g1, g2, c1, c2, pb.shape)
+    refd = torch.zeros(pb.shape, dtype=torch.double)
+    refd.index_add_(0, srow, c1.cpu().double()[lidx.long()][:, None] * r1 + c2.cpu().double()[lidx.long()][:, None] * r2)
+    assert rel(dp, refd) < 1e-4
