@@ -1,0 +1,49 @@
+"""Parameter containers with the reference's (torch.nn) names and initialisation whose forward is
+a libspe_hip.so launch.  Same state_dict keys as nn.Linear / nn.LayerNorm."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class Linear(nn.Linear):
+    """nn.Linear parameters; forward = MFMA GEMM with fused bias (+ReLU/GELU)."""
+
+    def forward(self, x, act=ops.ACT_NONE):
+        return ops.linear(x, self.weight, self.bias, act)
+
+
+class LayerNorm(nn.LayerNorm):
+    def forward(self, x):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+
+class Dropout(nn.Module):
+    """nn.Dropout semantics with a counter-based (Philox) mask regenerated in backward."""
+
+    def __init__(self, p=0.0):
+        super().__init__()
+        self.p = float(p)
+
+    def forward(self, x):
+        return ops.dropout(x, self.p, self.training)
+
+
+class MLP(nn.Module):
+    """Reference models/transformer.py:21-33 / conditional_detr.py:626-638: Linear stack, ReLU between."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = layer(x, ops.ACT_RELU if i < self.num_layers - 1 else ops.ACT_NONE)
+        return x
+
+
+def trunc_normal_(tensor, mean=0.0, std=1.0, a=-2.0, b=2.0):
+    """timm trunc_normal_ (reference models/layers/weight_init.py:6-60)."""
+    return torch.nn.init.trunc_normal_(tensor, mean=mean, std=std, a=a, b=b)

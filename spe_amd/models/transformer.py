@@ -1,0 +1,234 @@
+"""Conditional-DETR transformer on libspe_hip.so kernels (mirror of reference
+models/transformer.py: Transformer.forward_refine 122-160, TransformerEncoderLayer.forward_post
+275-288, TransformerDecoder.forward 206-250, TransformerDecoderLayer.forward_post 355-427,
+gen_sineembed_for_position 35-49).  Same parameter names; activations are batch-first [B, L, d].
+
+MI355X-first differences from the reference's execution (results identical):
+  * the memory-side projections of every decoder layer (ca_kcontent_proj, ca_v_proj, ca_kpos_proj
+    and the per-head [content | pos] key concat) do not depend on the queries, so they are computed
+    once per layer and shared by the 1+num_refines decoder passes (the reference recomputes them);
+  * attention never forms head-averaged weights (the reference computes and discards them).
+"""
+import copy
+import math
+
+import torch
+from torch import nn
+
+from .. import ops
+from .attention import MultiheadAttention
+from .layers import MLP, Dropout, LayerNorm, Linear
+
+
+def gen_sineembed_for_position(pos_tensor, d_model=256):
+    """[.., 2] normalised (x, y) -> [.., d_model] sine embedding.  The exponent divisor is the
+    reference's hard-coded 128 (transformer.py:41), NOT d_model/2.  Tiny [B,Q,d] tensor ops."""
+    n_steps = d_model // 2
+    scale = 2 * math.pi
+    dim_t = torch.arange(n_steps, dtype=torch.float32, device=pos_tensor.device)
+    dim_t = 10000 ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / 128)
+    pos_x = pos_tensor[..., 0, None] * scale / dim_t
+    pos_y = pos_tensor[..., 1, None] * scale / dim_t
+    pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=-1).flatten(-2)
+    pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=-1).flatten(-2)
+    return torch.cat((pos_y, pos_x), dim=-1)
+
+
+class PackedSelfAttention(nn.Module):
+    """Parameter layout of torch nn.MultiheadAttention (in_proj_weight [3d,d], in_proj_bias, out_proj)
+    used by the reference's encoder layer (transformer.py:258)."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, float(dropout)
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = Linear(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+    def forward(self, qk_in, v_in, key_padding_mask):
+        B, S, d = qk_in.shape
+        H = self.num_heads
+        qk = ops.linear(qk_in, self.in_proj_weight[:2 * d], self.in_proj_bias[:2 * d]).view(B, S, 2, H, d // H)
+        v = ops.linear(v_in, self.in_proj_weight[2 * d:], self.in_proj_bias[2 * d:]).view(B, S, H, d // H)
+        o, _ = ops.attention(qk[:, :, 0], qk[:, :, 1], v, key_padding_mask, float(d // H) ** -0.5,
+                             self.dropout if self.training else 0.0)
+        return self.out_proj(o)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False):
+        super().__init__()
+        if normalize_before:
+            raise NotImplementedError("pre-norm is not reachable in the reference (transformer.py:461-462)")
+        self.self_attn = PackedSelfAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = Linear(d_model, dim_feedforward)
+        self.dropout = Dropout(dropout)
+        self.linear2 = Linear(dim_feedforward, d_model)
+        self.norm1 = LayerNorm(d_model)
+        self.norm2 = LayerNorm(d_model)
+        self.dropout1 = Dropout(dropout)
+        self.dropout2 = Dropout(dropout)
+
+    def forward(self, src, src_key_padding_mask=None, pos=None):
+        qk = src if pos is None else ops.add(src, pos)
+        src2 = self.self_attn(qk, src, src_key_padding_mask)
+        src = self.norm1(ops.add(src, self.dropout1(src2)))
+        src2 = self.linear2(self.dropout(self.linear1(src, ops.ACT_RELU)))
+        return self.norm2(ops.add(src, self.dropout2(src2)))
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers, norm=None):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer if num_layers != 0 else nn.Identity(), max(num_layers, 1))
+        self.num_layers = num_layers
+        self.norm = norm
+
+    def forward(self, src, src_key_padding_mask=None, pos=None):
+        out = src
+        if self.num_layers:
+            for layer in self.layers:
+                out = layer(out, src_key_padding_mask=src_key_padding_mask, pos=pos)
+        return out if self.norm is None else self.norm(out)
+
+
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False):
+        super().__init__()
+        self.sa_qcontent_proj = Linear(d_model, d_model)
+        self.sa_qpos_proj = Linear(d_model, d_model)
+        self.sa_kcontent_proj = Linear(d_model, d_model)
+        self.sa_kpos_proj = Linear(d_model, d_model)
+        self.sa_v_proj = Linear(d_model, d_model)
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout, vdim=d_model)
+        self.ca_qcontent_proj = Linear(d_model, d_model)
+        self.ca_qpos_proj = Linear(d_model, d_model)
+        self.ca_kcontent_proj = Linear(d_model, d_model)
+        self.ca_kpos_proj = Linear(d_model, d_model)
+        self.ca_v_proj = Linear(d_model, d_model)
+        self.ca_qpos_sine_proj = Linear(d_model, d_model)
+        self.cross_attn = MultiheadAttention(d_model * 2, nhead, dropout=dropout, vdim=d_model)
+        self.nhead = nhead
+        self.linear1 = Linear(d_model, dim_feedforward)
+        self.dropout = Dropout(dropout)
+        self.linear2 = Linear(dim_feedforward, d_model)
+        self.norm1 = LayerNorm(d_model)
+        self.norm2 = LayerNorm(d_model)
+        self.norm3 = LayerNorm(d_model)
+        self.dropout1 = Dropout(dropout)
+        self.dropout2 = Dropout(dropout)
+        self.dropout3 = Dropout(dropout)
+
+    def memory_side(self, memory, pos, is_first):
+        """Query-independent half of the cross attention: per-head [k_content(+k_pos) | k_pos] keys
+        [B,S,H,2*dh] and values [B,S,d] (transformer.py:390-419)."""
+        B, S, d = memory.shape
+        H, dh = self.nhead, d // self.nhead
+        k_content = self.ca_kcontent_proj(memory)
+        v = self.ca_v_proj(memory)
+        k_pos = self.ca_kpos_proj(pos)
+        k = ops.add(k_content, k_pos) if is_first else k_content
+        k = torch.cat([k.view(B, S, H, dh), k_pos.view(B, S, H, dh)], dim=3)
+        return k.view(B, S, 2 * d), v
+
+    def forward(self, tgt, mem_kv, memory_key_padding_mask, query_pos, query_sine_embed, is_first):
+        B, Q, d = tgt.shape
+        H, dh = self.nhead, d // self.nhead
+        # ---- self attention over the queries
+        q = self.sa_qcontent_proj(tgt) + self.sa_qpos_proj(query_pos)
+        k = self.sa_kcontent_proj(tgt) + self.sa_kpos_proj(query_pos)
+        v = self.sa_v_proj(tgt)
+        tgt2 = self.self_attn(q, k, v)[0]
+        tgt = self.norm1(tgt + self.dropout1(tgt2))
+        # ---- conditional cross attention
+        q = self.ca_qcontent_proj(tgt)
+        if is_first:
+            q = q + self.ca_qpos_proj(query_pos)
+        qs = self.ca_qpos_sine_proj(query_sine_embed)
+        q = torch.cat([q.view(B, Q, H, dh), qs.view(B, Q, H, dh)], dim=3).view(B, Q, 2 * d)
+        k, v = mem_kv
+        tgt2 = self.cross_attn(q, k, v, key_padding_mask=memory_key_padding_mask)[0]
+        tgt = self.norm2(tgt + self.dropout2(tgt2))
+        # ---- FFN
+        tgt2 = self.linear2(self.dropout(self.linear1(tgt, ops.ACT_RELU)))
+        return self.norm3(tgt + self.dropout3(tgt2))
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False, d_model=256):
+        super().__init__()
+        self.layers = _get_clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+        self.return_intermediate = return_intermediate
+        self.d_model = d_model
+        self.query_scale = MLP(d_model, d_model, d_model, 2)
+        self.ref_point_head = MLP(d_model, d_model, 2, 2)
+        for layer_id in range(num_layers - 1):
+            self.layers[layer_id + 1].ca_qpos_proj = None      # only the first layer adds query_pos (transformer.py:203-204)
+
+    def forward(self, tgt, memory, memory_key_padding_mask, pos, query_pos, mem_cache=None):
+        """tgt/query_pos [B,Q,d]; memory/pos [B,S,d].  -> (hs [L,B,Q,d], reference_points [B,Q,2])."""
+        mem_cache = {} if mem_cache is None else mem_cache
+        output = tgt
+        reference_points = self.ref_point_head(query_pos).sigmoid()            # [B,Q,2]
+        intermediate = []
+        for layer_id, layer in enumerate(self.layers):
+            if layer_id not in mem_cache:
+                mem_cache[layer_id] = layer.memory_side(memory, pos, layer_id == 0)
+            sine = gen_sineembed_for_position(reference_points[..., :2], self.d_model)
+            if layer_id > 0:
+                sine = sine * self.query_scale(output)
+            output = layer(output, mem_cache[layer_id], memory_key_padding_mask, query_pos, sine, layer_id == 0)
+            intermediate.append(self.norm(output))
+        return torch.stack(intermediate), reference_points
+
+
+class Transformer(nn.Module):
+    def __init__(self, d_model=512, nhead=8, num_queries=300, num_encoder_layers=6, num_decoder_layers=6,
+                 dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False,
+                 return_intermediate_dec=False, args=None, num_refines=1, drloc=False):
+        super().__init__()
+        enc_layer = TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, normalize_before)
+        self.encoder = TransformerEncoder(enc_layer, num_encoder_layers, None)
+        dec_layer = TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout, activation, normalize_before)
+        self.decoder = TransformerDecoder(dec_layer, num_decoder_layers, LayerNorm(d_model),
+                                          return_intermediate=return_intermediate_dec, d_model=d_model)
+        self.H = self.W = None
+        self._reset_parameters()
+        self.d_model, self.nhead = d_model, nhead
+        self.dec_layers, self.num_queries, self.num_refines = num_decoder_layers, num_queries, num_refines
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, src, mask, query_embed, pos_embed, queries_embed_refine=None):
+        """src/pos_embed [B,d,h,w] (views of [B,hw,d] buffers), mask [B,h,w], query_embed [Q,d].
+        -> (list of hs [L,B,Q,d], list of reference points [B,Q,2]), one entry per decoder pass."""
+        B = src.shape[0]
+        memory = src.flatten(2).transpose(1, 2).contiguous()       # no copy when src is the backbone's view
+        pos = pos_embed.flatten(2).transpose(1, 2).contiguous()
+        mask = mask.flatten(1)
+        memory = self.encoder(memory, src_key_padding_mask=mask, pos=pos)
+        queries = [query_embed] + [qe.weight for qe in (queries_embed_refine or [])]
+        hs, refs, cache = [], [], {}
+        for qw in queries:
+            query_pos = qw.unsqueeze(0).expand(B, -1, -1).contiguous()
+            h, r = self.decoder(torch.zeros_like(query_pos), memory, mask, pos, query_pos, mem_cache=cache)
+            hs.append(h)
+            refs.append(r)
+        return hs, refs
+
+
+def _get_clones(module, n):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+def build_transformer(args):
+    return Transformer(d_model=args.hidden_dim, dropout=args.dropout, nhead=args.nheads, num_queries=args.num_queries,
+                       dim_feedforward=args.dim_feedforward, num_encoder_layers=args.enc_layers,
+                       num_decoder_layers=args.dec_layers, normalize_before=args.pre_norm, return_intermediate_dec=True)

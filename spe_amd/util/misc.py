@@ -1,0 +1,59 @@
+"""Host-side helpers the hot path shares with its callers (mirror of reference util/misc.py:
+NestedTensor 291-311, nested_tensor_from_tensor_list 314-336, inverse_sigmoid 477-481,
+dist helpers 385-396).  Pure plumbing: no device arithmetic beyond padding copies."""
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+class NestedTensor(object):
+    def __init__(self, tensors, mask: Optional[Tensor]):
+        self.tensors = tensors
+        self.mask = mask
+
+    def to(self, device):
+        return NestedTensor(self.tensors.to(device), None if self.mask is None else self.mask.to(device))
+
+    def decompose(self):
+        return self.tensors, self.mask
+
+    def __repr__(self):
+        return str(self.tensors)
+
+
+def nested_tensor_from_tensor_list(tensor_list: List[Tensor]):
+    """Zero-pad a list of [C,H,W] images to the batch maximum; mask is True on padding."""
+    if isinstance(tensor_list, Tensor) and tensor_list.ndim == 4:
+        tensor_list = list(tensor_list.unbind(0))
+    if tensor_list[0].ndim != 3:
+        raise ValueError("not supported")
+    c = tensor_list[0].shape[0]
+    h = max(img.shape[1] for img in tensor_list)
+    w = max(img.shape[2] for img in tensor_list)
+    b = len(tensor_list)
+    dtype, device = tensor_list[0].dtype, tensor_list[0].device
+    tensor = torch.zeros((b, c, h, w), dtype=dtype, device=device)
+    mask = torch.ones((b, h, w), dtype=torch.bool, device=device)
+    for img, pad_img, m in zip(tensor_list, tensor, mask):
+        pad_img[: img.shape[0], : img.shape[1], : img.shape[2]].copy_(img)
+        m[: img.shape[1], : img.shape[2]] = False
+    return NestedTensor(tensor, mask)
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def is_dist_avail_and_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return dist.get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if is_dist_avail_and_initialized() else 0
