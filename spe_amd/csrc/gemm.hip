@@ -31,22 +31,37 @@ struct GemmArgs {
 };
 
 // ---- HBM -> registers -------------------------------------------------------------------
+// All loads are UNCONDITIONAL on clamped addresses and masked afterwards: a branch around a load
+// makes hipcc serialise it behind an s_waitcnt vmcnt(0) (one round trip per element).
+// `vec` (wave-uniform): rows are 16-B aligned and padded to a multiple of 4 floats, so a float4
+// at any 4-aligned in-row offset is inside the allocation even when it straddles the logical edge.
+//
 // "KC": the contraction index is the contiguous one: X(r,k) = base[r*ld + k].
 // thread t loads rows r = (t>>3) + 32*i, k-quad (t&7).
 __device__ __forceinline__ void load_kc(const float* __restrict__ base, long ld, int row0, int nrows,
                                         int k0, int kend, bool vec, float v[4][4]) {
     const int t = threadIdx.x;
     const int k = k0 + (t & 7) * 4;
+    const int kq = min(k, (kend - 1) & ~3);            // clamped quad start (>= 0 since kend >= 1)
+    if (vec) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = row0 + (t >> 3) + 32 * i;
-        const float* p = base + (long)r * ld + k;
-        if (vec && r < nrows && k + 3 < kend) {
-            const float4 q = *reinterpret_cast<const float4*>(p);
-            v[i][0] = q.x; v[i][1] = q.y; v[i][2] = q.z; v[i][3] = q.w;
-        } else {
+        for (int i = 0; i < 4; ++i) {
+            const int r = row0 + (t >> 3) + 32 * i;
+            const float4 q = *reinterpret_cast<const float4*>(base + (long)min(r, nrows - 1) * ld + kq);
+            const bool rv = r < nrows;
+            v[i][0] = (rv && k + 0 < kend) ? q.x : 0.f; v[i][1] = (rv && k + 1 < kend) ? q.y : 0.f;
+            v[i][2] = (rv && k + 2 < kend) ? q.z : 0.f; v[i][3] = (rv && k + 3 < kend) ? q.w : 0.f;
+        }
+    } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[i][j] = (r < nrows && k + j < kend) ? p[j] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int r = row0 + (t >> 3) + 32 * i;
+            const float* p = base + (long)min(r, nrows - 1) * ld;
+            float q[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[j] = p[min(k + j, kend - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = (r < nrows && k + j < kend) ? q[j] : 0.f;
         }
     }
 }
@@ -56,32 +71,43 @@ __device__ __forceinline__ void load_rc(const float* __restrict__ base, long ld,
                                         int k0, int kend, bool vec, float v[4][4]) {
     const int t = threadIdx.x;
     const int r = row0 + (t >> 3) * 4;
+    const int rq = min(r, (nrows - 1) & ~3);
+    if (vec) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = k0 + (t & 7) * 4 + i;
-        const float* p = base + (long)k * ld + r;
-        if (vec && k < kend && r + 3 < nrows) {
-            const float4 q = *reinterpret_cast<const float4*>(p);
-            v[i][0] = q.x; v[i][1] = q.y; v[i][2] = q.z; v[i][3] = q.w;
-        } else {
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + (t & 7) * 4 + i;
+            const float4 q = *reinterpret_cast<const float4*>(base + (long)min(k, kend - 1) * ld + rq);
+            const bool kv = k < kend;
+            v[i][0] = (kv && r + 0 < nrows) ? q.x : 0.f; v[i][1] = (kv && r + 1 < nrows) ? q.y : 0.f;
+            v[i][2] = (kv && r + 2 < nrows) ? q.z : 0.f; v[i][3] = (kv && r + 3 < nrows) ? q.w : 0.f;
+        }
+    } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[i][j] = (k < kend && r + j < nrows) ? p[j] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + (t & 7) * 4 + i;
+            const float* p = base + (long)min(k, kend - 1) * ld;
+            float q[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[j] = p[min(r + j, nrows - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = (k < kend && r + j < nrows) ? q[j] : 0.f;
         }
     }
 }
 
-// ---- registers -> LDS (bf16, optionally hi/lo split) ---------------------------------------
+// ---- registers -> LDS (bf16 via v_cvt_pk_bf16_f32, optionally hi/lo split) -------------------
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 template <bool SPLIT>
 __device__ __forceinline__ void store4(unsigned short* hi, unsigned short* lo, int off,
                                        float a, float b, float c, float d) {
-    u16x4_t h;
-    h[0] = spe_f2bf(a); h[1] = spe_f2bf(b); h[2] = spe_f2bf(c); h[3] = spe_f2bf(d);
-    *reinterpret_cast<u16x4_t*>(hi + off) = h;
+    bf16x4_t h;
+    h[0] = (__bf16)a; h[1] = (__bf16)b; h[2] = (__bf16)c; h[3] = (__bf16)d;
+    *reinterpret_cast<bf16x4_t*>(hi + off) = h;
     if (SPLIT) {
-        u16x4_t l;
-        l[0] = spe_f2bf(a - spe_bf2f(h[0])); l[1] = spe_f2bf(b - spe_bf2f(h[1]));
-        l[2] = spe_f2bf(c - spe_bf2f(h[2])); l[3] = spe_f2bf(d - spe_bf2f(h[3]));
-        *reinterpret_cast<u16x4_t*>(lo + off) = l;
+        bf16x4_t l;
+        l[0] = (__bf16)(a - (float)h[0]); l[1] = (__bf16)(b - (float)h[1]);
+        l[2] = (__bf16)(c - (float)h[2]); l[3] = (__bf16)(d - (float)h[3]);
+        *reinterpret_cast<bf16x4_t*>(lo + off) = l;
     }
 }
 template <bool SPLIT>
@@ -165,7 +191,7 @@ __global__ __launch_bounds__(256) void spe_gemm_kernel(GemmArgs p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
             if (SPLIT) {
                 bf16x8_t al[4], bl[4];
 #pragma unroll
@@ -178,8 +204,8 @@ __global__ __launch_bounds__(256) void spe_gemm_kernel(GemmArgs p) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], a[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], al[i], acc[i][j], 0, 0, 0);
                     }
             }
             if (t + 1 < nt) stage(buf ^ 1);
@@ -187,29 +213,56 @@ __global__ __launch_bounds__(256) void spe_gemm_kernel(GemmArgs p) {
         }
     }
 
-    // ---- epilogue: acc[i][j][r] -> C[m0 + wm*64 + i*16 + (lane>>4)*4 + r][n0 + wn*64 + j*16 + (lane&15)]
+    // ---- epilogue.  The MFMAs were issued as (B-frag, A-frag), i.e. they produced C^T tiles, so
+    // acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane&15)][n0 + wn*64 + j*16 + (lane>>4)*4 + r]:
+    // every lane owns 4 consecutive columns of one row -> one 16-B store per tile.
+    const bool vst = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                     (!C2 || (reinterpret_cast<uintptr_t>(C2) & 15) == 0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + fr;
+        const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
         if (n >= p.N) continue;
-        const float bv = (p.bias && p.splitk == 1) ? p.bias[n] : 0.f;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && p.splitk == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = p.bias[min(n + r, p.N - 1)];
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + fr;
+            if (m >= p.M) continue;
+            const long off = (long)m * p.ldc + n;
+            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] * p.alpha;
-                const long off = (long)m * p.ldc + n;
-                if (p.splitk > 1) {
-                    if (nt > 0) atomicAdd(C + off, v);
-                } else {
-                    v += bv;
-                    if (C2) C2[off] = v;
-                    if (p.act == 1) v = fmaxf(v, 0.f);
-                    else if (p.act == 2) v = gelu_erf(v);
-                    C[off] = v;
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+            if (p.splitk > 1) {
+                if (nt > 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) atomicAdd(C + off + r, v[r]);
                 }
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bv[r];
+            const bool full = vst && (n + 3 < p.N);
+            if (C2) {
+                if (full) *reinterpret_cast<float4*>(C2 + off) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) C2[off + r] = v[r];
+                }
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (full) *reinterpret_cast<float4*>(C + off) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) C[off + r] = v[r];
             }
         }
     }
@@ -237,7 +290,7 @@ extern "C" int spe_gemm_f32(const float* A, const float* B, float* C, const floa
                             int M, int N, int K, long lda, long ldb, long ldc, int transA, int transB,
                             int batch0, int batch1, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1,
                             float alpha, int act, int splitk, int precision, hipStream_t stream) {
-    if (M <= 0 || N <= 0 || batch0 <= 0 || batch1 <= 0) return 0;
+    if (M <= 0 || N <= 0 || K <= 0 || batch0 <= 0 || batch1 <= 0) return K <= 0 && M > 0 && N > 0 ? -4 : 0;
     if (transA && transB) return -2;  // not needed on this path
     GemmArgs p;
     p.A = A; p.B = B; p.C = C; p.C2 = C2; p.bias = bias;

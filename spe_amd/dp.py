@@ -1,0 +1,96 @@
+"""Data-parallel gradient exchange: bucketed all-reduce overlapped with backward.
+
+Replaces DistributedDataParallel(find_unused_parameters=True) at reference main.py:172 (SURVEY.md
+section 2.3, C1).  One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm and
+runs its collectives on its own HIP stream, so a bucket's all-reduce overlaps the backward kernels
+still being enqueued on the compute stream.  Design for xGMI (7 point-to-point links per GPU):
+few large buckets (default 64 MB) in reverse-registration order; gradients live INSIDE the flat
+bucket buffers (param.grad is a view), so there is no pack/unpack copy and the collective moves
+exactly the gradient bytes once.
+
+Parameters that never receive a gradient (e.g. the unused `backbone.0.body.head.*`, the reason the
+reference needs find_unused_parameters=True) cannot hang anything: buckets that did not fill during
+backward are reduced by `finish()`.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradAllReducer:
+    def __init__(self, params, bucket_bytes=64 << 20, average=True, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.average = average
+        self.buckets = []          # dicts: flat, params, pending, work
+        self._bucket_of = {}
+        self._views = {}
+        cur, cur_bytes = [], 0
+        for p in reversed(self.params):                     # ~ order in which autograd finishes them
+            cur.append(p)
+            cur_bytes += p.numel() * p.element_size()
+            if cur_bytes >= bucket_bytes:
+                self._make_bucket(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            self._make_bucket(cur)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.reset()
+
+    def _make_bucket(self, plist):
+        dev, dt = plist[0].device, plist[0].dtype
+        n = sum(p.numel() for p in plist)
+        flat = torch.zeros(n, device=dev, dtype=dt)
+        off = 0
+        for p in plist:
+            v = flat[off:off + p.numel()].view_as(p)
+            p.grad = v                                       # gradient accumulates in place into the bucket
+            self._views[p] = v
+            off += p.numel()
+            self._bucket_of[p] = len(self.buckets)
+        self.buckets.append({"flat": flat, "params": list(plist), "pending": 0, "work": None})
+
+    def reset(self):
+        """Call before every backward (after the optimizer consumed the gradients): zero the buckets."""
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["pending"] = len(b["params"])
+            b["work"] = None
+        self._next = 0
+
+    def zero_grad(self):
+        self.reset()
+
+    def _launch(self, b):
+        if self.world > 1:
+            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            b["work"] = "local"
+
+    def _on_grad(self, p):
+        b = self.buckets[self._bucket_of[p]]
+        view = self._views[p]
+        if p.grad.data_ptr() != view.data_ptr():
+            # someone replaced .grad (e.g. zero_grad(set_to_none=True)); move it back into the bucket
+            view.copy_(p.grad)
+            p.grad = view
+        b["pending"] -= 1
+        # collectives are issued strictly in bucket order so every rank enqueues the same sequence
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
+
+    def finish(self):
+        """Reduce buckets that never filled (unused parameters), wait for every collective, average."""
+        while self._next < len(self.buckets):
+            self._launch(self.buckets[self._next])
+            self._next += 1
+        for b in self.buckets:
+            if b["work"] not in (None, "local"):
+                b["work"].wait()
+            if self.average and self.world > 1:
+                b["flat"].div_(self.world)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()

@@ -35,6 +35,33 @@ def next_rng():
     return _RNG["seed"], _RNG["offset"]
 
 
+# Optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg).
+_TIMED = {}
+
+
+def enable_timing(names):
+    """Record a (start, stop) event pair around every launch of the named entry points."""
+    _TIMED.clear()
+    for n in names:
+        _TIMED[n] = []
+
+
+def timing_results():
+    """-> {name: (launches, mean_ms)}; call after torch.cuda.synchronize()."""
+    return {n: (len(ev), (sum(a.elapsed_time(b) for a, b in ev) / len(ev)) if ev else 0.0) for n, ev in _TIMED.items()}
+
+
+def _call(name, *args):
+    ev = _TIMED.get(name)
+    if ev is None:
+        return lib.call(name, *args)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    lib.call(name, *args)
+    b.record()
+    ev.append((a, b))
+
+
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -63,7 +90,7 @@ def auto_splitk(M, N, K, batch):
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, C2=None,
          batch0=1, batch1=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, act=0, splitk=1):
     """Raw strided (batched) GEMM on already-allocated tensors; returns C."""
-    lib.call("spe_gemm_f32", _p(A), _p(B), _p(C), _p(bias), _p(C2), M, N, K, lda, ldb, ldc,
+    _call("spe_gemm_f32", _p(A), _p(B), _p(C), _p(bias), _p(C2), M, N, K, lda, ldb, ldc,
              int(transA), int(transB), batch0, batch1, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
              float(alpha), int(act), int(splitk), _PRECISION, _st())
     return C
@@ -96,7 +123,7 @@ def linear_bwd(dy2, x2, W, need_dx=True, need_dw=True, need_db=True):
         gemm(dy2, x2, dW, N, K, R, N, K, K, True, False, splitk=sk)
     if need_db:
         db = torch.zeros((N,), device=dy2.device, dtype=torch.float32)
-        lib.call("spe_colsum", _p(dy2), _p(db), R, N, N, _st())
+        _call("spe_colsum", _p(dy2), _p(db), R, N, N, _st())
     return dx, dW, db
 
 
@@ -104,14 +131,14 @@ def colsum(x2):
     _chk(x2)
     R, C = x2.shape
     out = torch.zeros((C,), device=x2.device, dtype=torch.float32)
-    lib.call("spe_colsum", _p(x2), _p(out), R, C, x2.stride(0), _st())
+    _call("spe_colsum", _p(x2), _p(out), R, C, x2.stride(0), _st())
     return out
 
 
 def act_bwd(dy, aux, mode):
     _chk(dy, aux)
     dx = torch.empty_like(dy)
-    lib.call("spe_act_bwd", _p(dy), _p(aux), _p(dx), dy.numel(), mode, _st())
+    _call("spe_act_bwd", _p(dy), _p(aux), _p(dx), dy.numel(), mode, _st())
     return dx
 
 
@@ -122,7 +149,7 @@ def layernorm_fwd(x2, g, b, eps):
     y = torch.empty_like(x2)
     mean = torch.empty((R,), device=x2.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
-    lib.call("spe_layernorm_fwd", _p(x2), _p(g), _p(b), _p(y), _p(mean), _p(rstd), R, C, float(eps), _st())
+    _call("spe_layernorm_fwd", _p(x2), _p(g), _p(b), _p(y), _p(mean), _p(rstd), R, C, float(eps), _st())
     return y, mean, rstd
 
 
@@ -132,7 +159,7 @@ def layernorm_bwd(dy2, x2, g, mean, rstd):
     dx = torch.empty_like(x2)
     dg = torch.zeros((C,), device=x2.device, dtype=torch.float32)
     db = torch.zeros_like(dg)
-    lib.call("spe_layernorm_bwd", _p(dy2), _p(x2), _p(g), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), R, C, _st())
+    _call("spe_layernorm_bwd", _p(dy2), _p(x2), _p(g), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), R, C, _st())
     return dx, dg, db
 
 
@@ -141,7 +168,7 @@ def layerscale_residual_fwd(x2, y2, gamma, sample_scale, rows_per_sample):
     _chk(x2, y2, gamma, sample_scale)
     R, C = x2.shape
     out = torch.empty_like(x2)
-    lib.call("spe_layerscale_residual_fwd", _p(x2), _p(y2), _p(gamma), _p(sample_scale), _p(out), R, C,
+    _call("spe_layerscale_residual_fwd", _p(x2), _p(y2), _p(gamma), _p(sample_scale), _p(out), R, C,
              rows_per_sample, _st())
     return out
 
@@ -151,7 +178,7 @@ def layerscale_residual_bwd(dout2, y2, gamma, sample_scale, rows_per_sample):
     R, C = dout2.shape
     dy = torch.empty_like(dout2)
     dg = torch.zeros((C,), device=dout2.device, dtype=torch.float32)
-    lib.call("spe_layerscale_residual_bwd", _p(dout2), _p(y2), _p(gamma), _p(sample_scale), _p(dy), _p(dg), R, C,
+    _call("spe_layerscale_residual_bwd", _p(dout2), _p(y2), _p(gamma), _p(sample_scale), _p(dy), _p(dg), R, C,
              rows_per_sample, _st())
     return dy, dg
 
@@ -160,7 +187,7 @@ def layerscale_residual_bwd(dout2, y2, gamma, sample_scale, rows_per_sample):
 def dropout(x, p, seed, offset):
     _chk(x)
     y = torch.empty_like(x)
-    lib.call("spe_dropout", _p(x), _p(y), x.numel(), float(p), seed, offset, _st())
+    _call("spe_dropout", _p(x), _p(y), x.numel(), float(p), seed, offset, _st())
     return y
 
 
@@ -172,19 +199,19 @@ def pad4(n):
 def softmax_fwd(S, mask_u8, B, H, Nq, Nk, ld, p_drop, seed, offset):
     """S [B,H,Nq,ld] -> P (in place over S), Pd (or None)."""
     Pd = torch.empty_like(S) if p_drop > 0 else None
-    lib.call("spe_softmax_fwd", _p(S), _p(mask_u8), _p(S), _p(Pd), B, H, Nq, Nk, ld, float(p_drop), seed, offset, _st())
+    _call("spe_softmax_fwd", _p(S), _p(mask_u8), _p(S), _p(Pd), B, H, Nq, Nk, ld, float(p_drop), seed, offset, _st())
     return S, Pd
 
 
 def softmax_bwd(dPd, P, B, H, Nq, Nk, ld, p_drop, seed, offset):
-    lib.call("spe_softmax_bwd", _p(dPd), _p(P), _p(dPd), B, H, Nq, Nk, ld, float(p_drop), seed, offset, _st())
+    _call("spe_softmax_bwd", _p(dPd), _p(P), _p(dPd), B, H, Nq, Nk, ld, float(p_drop), seed, offset, _st())
     return dPd
 
 
 def talking_fwd(S, Wl, bl, Ww, bw, B, H, Nq, Nk, ld, p_drop, seed, offset):
     """S [B,H,Nq,ld] raw scores -> P (in place over S), Pd (new)."""
     Pd = torch.empty_like(S)
-    lib.call("spe_talking_softmax_fwd", _p(S), _p(Wl), _p(bl), _p(Ww), _p(bw), _p(S), _p(Pd), B, H, Nq, Nk, ld,
+    _call("spe_talking_softmax_fwd", _p(S), _p(Wl), _p(bl), _p(Ww), _p(bw), _p(S), _p(Pd), B, H, Nq, Nk, ld,
              float(p_drop), seed, offset, _st())
     return S, Pd
 
@@ -194,7 +221,7 @@ def talking_bwd(dPd, P, S, Wl, Ww, B, H, Nq, Nk, ld, p_drop, seed, offset):
     nblocks = min(B * Nq, 1024)
     nw = 2 * (H * H + H)
     ws = torch.empty((nblocks, nw), device=dPd.device, dtype=torch.float32)
-    lib.call("spe_talking_softmax_bwd", _p(dPd), _p(P), _p(S), _p(Wl), _p(Ww), _p(dPd), _p(ws), nblocks, B, H, Nq, Nk, ld,
+    _call("spe_talking_softmax_bwd", _p(dPd), _p(P), _p(S), _p(Wl), _p(Ww), _p(dPd), _p(ws), nblocks, B, H, Nq, Nk, ld,
              float(p_drop), seed, offset, _st())
     g = colsum(ws)
     hh = H * H
@@ -207,7 +234,7 @@ def patchify(img, P):
     B, Cin, Hi, Wi = img.shape
     h, w = Hi // P, Wi // P
     cols = torch.empty((B * h * w, Cin * P * P), device=img.device, dtype=torch.float32)
-    lib.call("spe_patchify", _p(img), _p(cols), B, Cin, Hi, Wi, P, _st())
+    _call("spe_patchify", _p(img), _p(cols), B, Cin, Hi, Wi, P, _st())
     return cols
 
 
@@ -215,7 +242,7 @@ def add_rows(a, table):
     """a [.., period] + table broadcast over leading rows (a.numel() % table.numel() == 0)."""
     _chk(a, table)
     out = torch.empty_like(a)
-    lib.call("spe_add_rows", _p(a), _p(table), _p(out), a.numel(), table.numel(), _st())
+    _call("spe_add_rows", _p(a), _p(table), _p(out), a.numel(), table.numel(), _st())
     return out
 
 
@@ -226,7 +253,7 @@ def matcher_cost(logits, boxes, tgt_ids_i32, tgt_boxes, toff_i32, total_targets,
     L, B, Q, Kc = logits.shape
     cost = torch.empty((L, Q * total_targets), device=logits.device, dtype=torch.float32)
     err = torch.zeros((1,), device=logits.device, dtype=torch.int32)
-    lib.call("spe_matcher_cost", _p(logits), _p(boxes), _p(tgt_ids_i32), _p(tgt_boxes), _p(toff_i32), total_targets,
+    _call("spe_matcher_cost", _p(logits), _p(boxes), _p(tgt_ids_i32), _p(tgt_boxes), _p(toff_i32), total_targets,
              _p(cost), _p(err), L, B, Q, Kc, float(w_class), float(w_bbox), float(w_giou), _st())
     return cost, err
 
@@ -238,7 +265,7 @@ def focal_loss(logits, tclass_i32, roww, alpha, gamma):
     grad = torch.empty_like(logits)
     loss = torch.zeros((L,), device=logits.device, dtype=torch.float32)
     amax = torch.empty((L, R), device=logits.device, dtype=torch.int32)
-    lib.call("spe_focal_loss", _p(logits), _p(tclass_i32), _p(roww), _p(grad), _p(loss), _p(amax), L, R, Kc,
+    _call("spe_focal_loss", _p(logits), _p(tclass_i32), _p(roww), _p(grad), _p(loss), _p(amax), L, R, Kc,
              float(alpha), float(gamma), _st())
     return loss, grad, amax
 
@@ -250,11 +277,11 @@ def box_loss(pred_boxes, srow_i64, tbox, w, lidx_i32, L):
     sums = torch.zeros((L, 2), device=pred_boxes.device, dtype=torch.float32)
     g1 = torch.empty((n, 4), device=pred_boxes.device, dtype=torch.float32)
     g2 = torch.empty_like(g1)
-    lib.call("spe_box_loss", _p(pred_boxes), _p(srow_i64), _p(tbox), _p(w), _p(lidx_i32), _p(sums), _p(g1), _p(g2), n, _st())
+    _call("spe_box_loss", _p(pred_boxes), _p(srow_i64), _p(tbox), _p(w), _p(lidx_i32), _p(sums), _p(g1), _p(g2), n, _st())
     return sums, g1, g2
 
 
 def box_loss_bwd(srow_i64, lidx_i32, g1, g2, c1, c2, shape):
     dpred = torch.zeros(shape, device=g1.device, dtype=torch.float32)
-    lib.call("spe_box_loss_bwd", _p(srow_i64), _p(lidx_i32), _p(g1), _p(g2), _p(c1), _p(c2), _p(dpred), srow_i64.numel(), _st())
+    _call("spe_box_loss_bwd", _p(srow_i64), _p(lidx_i32), _p(g1), _p(g2), _p(c1), _p(c2), _p(dpred), srow_i64.numel(), _st())
     return dpred

@@ -50,6 +50,9 @@ def load():
     if not os.path.exists(LIBPATH):
         raise SpeLibraryError(
             f"{LIBPATH} is missing - build it with `python -m spe_amd.build` (there is no CPU fallback)")
+    # torch bundles its own libamdhip64.so.7; it must be the HIP runtime of this process BEFORE our library
+    # resolves the same SONAME, otherwise two runtimes coexist and our launches see no device (hipErrorNoDevice).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIBPATH)
     for name, sig in PROTOS.items():
         try:

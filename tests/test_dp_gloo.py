@@ -1,0 +1,72 @@
+"""Data-parallel gradient exchange (spe_amd/dp.py) on CPU with gloo, world_size 2."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spe_amd.dp import GradAllReducer
+    torch.manual_seed(0)                                    # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    unused = torch.nn.Linear(3, 3)                          # never receives a gradient (cf. backbone.0.body.head)
+    params = list(net.parameters()) + list(unused.parameters())
+    red = GradAllReducer(params, bucket_bytes=64)           # several small buckets
+    assert len(red.buckets) > 2
+    g = torch.Generator().manual_seed(100 + rank)           # different data per rank
+    results = []
+    for it in range(2):                                     # two iterations: reset() must clear the buckets
+        x = torch.randn(5, 8, generator=g)
+        red.reset()
+        y = net(x)
+        # the first layer is used twice in the graph (like the decoder weights over two passes)
+        loss = y.pow(2).sum() + net[0](x).sum()
+        loss.backward()
+        red.finish()
+        results.append([p.grad.clone() for p in params])
+        # local reference gradient of this rank
+        ref = torch.autograd.grad(net(x).pow(2).sum() + net[0](x).sum(), list(net.parameters()))
+        gathered = [torch.zeros_like(torch.cat([r.flatten() for r in ref])) for _ in range(world)]
+        dist.all_gather(gathered, torch.cat([r.flatten() for r in ref]))
+        mean = sum(gathered) / world
+        got = torch.cat([p.grad.flatten() for p in net.parameters()])
+        assert torch.allclose(got, mean, atol=1e-6), (rank, it)
+        assert all(float(p.grad.abs().max()) == 0.0 for p in unused.parameters())
+    # scalar collective used by SetCriterion (num_boxes, conditional_detr.py:436-440)
+    nb = torch.tensor([float(3 + 4 * rank)])
+    dist.all_reduce(nb)
+    assert float(torch.clamp(nb / world, min=1)) == 5.0
+    out[rank] = True
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_allreducer_gloo_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
+def test_single_process_passthrough():
+    from spe_amd.dp import GradAllReducer
+    net = torch.nn.Linear(4, 2)
+    red = GradAllReducer(net.parameters())
+    red.reset()
+    net(torch.ones(3, 4)).sum().backward()
+    red.finish()
+    assert torch.allclose(net.weight.grad, torch.full((2, 4), 3.0))

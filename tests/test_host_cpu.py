@@ -1,0 +1,127 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol of include/spe_hip.h,
+the product's parameter names/shapes equal the reference's, host logic of the boundary, and the
+product FAILS LOUDLY instead of computing on the CPU."""
+import argparse
+import ctypes
+import os
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_header_symbol():
+    from spe_amd import lib
+    protos = lib.parse_header()
+    assert len(protos) >= 19
+    l = lib.load()
+    for name, sig in protos.items():
+        fn = getattr(l, name)            # AttributeError == missing export
+        assert fn.restype is ctypes.c_int and len(fn.argtypes) == len(sig)
+    assert l.spe_abi_version() == 1
+
+
+def test_header_cites_reference_sites():
+    text = open(os.path.join(ROOT, "include", "spe_hip.h")).read()
+    for ref in ("models/cait.py", "models/matcher.py", "models/conditional_detr.py", "models/attention.py",
+                "models/transformer.py", "util/box_ops.py"):
+        assert ref in text, ref
+
+
+def _build(blob):
+    from spe_amd.models import build_model
+    args = argparse.Namespace(**blob["args"])
+    args.device = "cpu"
+    return build_model(args), args
+
+
+@pytest.mark.parametrize("name", ["e2e_single", "e2e_two_branch"])
+def test_state_dict_matches_reference(name):
+    """Checkpoint compatibility (--resume does a strict load, reference main.py:229)."""
+    blob = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    (model, crit, crit_r, pp, rpp), args = _build(blob)
+    ref = blob["state_dict"]
+    own = model.state_dict()
+    assert list(own.keys()) != [] and set(own) == set(ref)
+    for k in ref:
+        assert own[k].shape == ref[k].shape, k
+    model.load_state_dict(ref, strict=True)
+    assert args.hidden_dim == 32                                   # Backbone overwrites --hidden_dim (cait_backbone.py:85)
+    assert model.backbone[0].body.patch_size == 16                 # read by ConditionalDETR_Refine.forward
+    names = [n for n, _ in model.named_parameters()]
+    assert any("backbone" in n for n in names) and any("blocks_token_only" in n for n in names)   # LR groups, main.py:177-188
+    assert set(crit.weight_dict) == set(blob["train"]["weight_dict"])
+    assert crit.losses == ["labels", "boxes", "cardinality", "image_label"] and crit_r.losses == ["labels", "boxes", "cardinality"]
+    assert set(pp) == {"bbox"} and set(rpp) == {"bbox"}
+    crit.update_hung_match_ratio(3)
+    assert crit.matcher.match_ratio == 3 and crit.hung_match_ratio == 3
+
+
+def test_no_cpu_fallback():
+    """The product path must not compute on the CPU (and must not reach for the oracle)."""
+    from spe_amd import lib, ops
+    blob = torch.load(os.path.join(GOLD, "e2e_single.pt"), weights_only=False)
+    (model, *_), _ = _build(blob)
+    from spe_amd.util.misc import NestedTensor
+    with pytest.raises(lib.SpeLibraryError):
+        model(NestedTensor(blob["tensors"], blob["mask"]))
+    with pytest.raises(lib.SpeLibraryError):
+        ops.linear(torch.randn(4, 8), torch.randn(3, 8), None)
+    import spe_amd
+    src = ""
+    for dp, _, fs in os.walk(os.path.dirname(spe_amd.__file__)):
+        for f in fs:
+            if f.endswith(".py"):
+                src += open(os.path.join(dp, f)).read()
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_nested_tensor_and_mask_downsample():
+    from spe_amd.util.misc import nested_tensor_from_tensor_list
+    a, b = torch.ones(3, 32, 48), torch.ones(3, 16, 64)
+    nt = nested_tensor_from_tensor_list([a, b])
+    assert nt.tensors.shape == (2, 3, 32, 64) and nt.mask.shape == (2, 32, 64)
+    assert not nt.mask[0, :, :48].any() and nt.mask[0, :, 48:].all() and nt.mask[1, 16:].all() and not nt.mask[1, :16].any()
+    assert float(nt.tensors[0, :, :, 48:].abs().sum()) == 0
+
+
+def test_postprocess_refine_matches_reference_golden():
+    """PostProcessRefine / PostProcess are host-side tensor plumbing: check them on the golden outputs."""
+    from spe_amd.models.conditional_detr import PostProcess, PostProcessRefine
+    blob = torch.load(os.path.join(GOLD, "e2e_single.pt"), weights_only=False)
+    ev = blob["eval"]
+    orig = torch.stack([t["orig_size"] for t in blob["targets"]])
+    res = PostProcessRefine()(ev["out0"], orig, blob["targets"])
+    for p, r in zip(res, ev["pseudo"]):
+        assert torch.equal(p["labels"], r["labels"])
+        assert torch.allclose(p["scores"], r["scores"]) and torch.allclose(p["boxes"], r["boxes"])
+    post = PostProcess()(ev["out0"], orig, 10)
+    for p, r in zip(post, ev["postprocess"]):
+        assert torch.equal(p["labels"], r["labels"]) and torch.allclose(p["scores"], r["scores"]) and torch.allclose(p["boxes"], r["boxes"])
+
+
+def test_jitter_targets_semantics():
+    """One-to-many targets (conditional_detr.py:409-431): ratio rows per GT, jittered copies first (IoU>0.7),
+    original last, labels/scores repeated - same contract as the oracle's restatement."""
+    from oracle import spe_oracle as O
+    from spe_amd.models.conditional_detr import jitter_targets
+    torch.manual_seed(0)
+    t = [{"boxes": torch.tensor([[0.5, 0.5, 0.2, 0.3], [0.3, 0.6, 0.1, 0.1]]), "labels": torch.tensor([3, 7]),
+          "scores": torch.tensor([0.9, 0.4])}, {"boxes": torch.zeros(0, 4), "labels": torch.zeros(0, dtype=torch.int64)}]
+    o = jitter_targets(t, 5, 0.1)
+    assert o[0]["boxes"].shape == (10, 4) and o[0]["labels"].tolist() == [3] * 5 + [7] * 5
+    assert torch.equal(o[0]["boxes"][4], t[0]["boxes"][0]) and torch.equal(o[0]["boxes"][9], t[0]["boxes"][1])
+    for g in range(2):
+        iou, _ = O.box_iou(O.box_cxcywh_to_xyxy(o[0]["boxes"][5 * g:5 * g + 4]), O.box_cxcywh_to_xyxy(t[0]["boxes"][g:g + 1]))
+        assert (iou > 0.7).all()
+        assert (o[0]["boxes"][5 * g:5 * g + 4] != t[0]["boxes"][g]).any()
+    assert o[1]["labels"].numel() == 0 and o[1]["boxes"].shape == (0, 4)
+    assert t[0]["boxes"].shape == (2, 4)           # input untouched (deepcopy)
+
+
+def test_registry_has_baseline_backbones():
+    from spe_amd.models.cait import _REGISTRY
+    for n in ("TSCAM_cait_XXS24", "TSCAM_cait_XXS36", "TSCAM_cait_XXS36_Two_Branch", "TSCAM_cait_S24", "TSCAM_cait_S36"):
+        assert n in _REGISTRY

@@ -1,0 +1,56 @@
+"""Micro-benchmark of spe_gemm_f32 on the shapes of the cfg2 hot path (run on the GPU box)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from spe_amd import kernels as K
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e-3
+
+
+def run(name, M, N, Kd, tA, tB, batch=(1, 1), splitk=1):
+    b0, b1 = batch
+    nb = b0 * b1
+    A = torch.randn(nb, (Kd * M), device=dev)
+    B = torch.randn(nb, (Kd * N), device=dev)
+    C = torch.zeros(nb, M * N, device=dev)
+    lda = M if tA else Kd
+    ldb = Kd if tB else N
+    f = lambda: K.gemm(A, B, C, M, N, Kd, lda, ldb, N, tA, tB, batch0=b0, batch1=b1, sA=(b1 * Kd * M, Kd * M),
+                       sB=(b1 * Kd * N, Kd * N), sC=(b1 * M * N, M * N), splitk=splitk)
+    t = timeit(f)
+    fl = 2.0 * M * N * Kd * nb
+    by = 4.0 * nb * (M * Kd + N * Kd + M * N)
+    print(f"{name:34s} M={M:5d} N={N:5d} K={Kd:5d} b={nb:3d} sk={splitk:2d} {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.0f} GB/s")
+
+
+for prec in (["bf16", "bf16x3"] if len(sys.argv) < 2 else [sys.argv[1]]):
+    K.set_precision(prec)
+    print("precision", prec)
+    R = 8300
+    run("qkv fwd NT", R, 1152, 384, False, True)
+    run("fc1 fwd NT", R, 1536, 384, False, True)
+    run("fc2 fwd NT", R, 384, 1536, False, True)
+    run("proj fwd NT", R, 384, 384, False, True)
+    run("fc1 dx NN", R, 384, 1536, False, False)
+    run("fc2 dx NN", R, 1536, 384, False, False)
+    run("fc1 dW TN", 1536, 384, R, True, False, splitk=K.auto_splitk(1536, 384, R, 1))
+    run("fc2 dW TN", 384, 1536, R, True, False, splitk=K.auto_splitk(384, 1536, R, 1))
+    run("qkv dW TN", 1152, 384, R, True, False, splitk=K.auto_splitk(1152, 384, R, 1))
+    run("QK^T NT batched", 4150, 4150, 48, False, True, batch=(2, 8))
+    run("PV NN batched", 4150, 48, 4150, False, False, batch=(2, 8))
+    run("dV TN batched", 4150, 48, 4150, True, False, batch=(2, 8))
+    run("square 4096 NT", 4096, 4096, 4096, False, True)
+    run("dec proj NT", 200, 384, 384, False, True)
