@@ -71,6 +71,23 @@ def weighted_total(l0, l1, wd):
     return sum(l0[k] * wd[k] for k in l0 if k in wd) + sum(l1[k] * wd[k] for k in l1 if k in wd)
 
 
+def host_cores():
+    """Usable host cores: os.cpu_count() capped by the cgroup CPU quota (the GPU box reports 256 logical
+    CPUs under a 16-CPU quota; oversubscribing it throttles the process by >50x)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(enc_layers):
     """The oracle (CPU fp32 restatement, parity-pinned to the reference) timed on this box's host cores on a
     bounded sample of the same workload: ONE 3x800x1333 image, S24 dims, forward + both criteria + backward,
@@ -78,7 +95,8 @@ def cpu_baseline(enc_layers):
     from oracle import spe_oracle as O
     from spe_amd.models import build_model
     from spe_amd.models.cait import TSCAM_cait, _make, register_model
-    torch.set_num_threads(os.cpu_count())
+    cores = host_cores()
+    torch.set_num_threads(cores)
     times = {}
     for depth in (1, 3):
         name = f"TSCAM_cait_S24_depth{depth}"
@@ -104,7 +122,7 @@ def cpu_baseline(enc_layers):
     per_block = max((times[3] - times[1]) / 2.0, 1e-9)
     rest = max(times[1] - per_block, 0.0)
     t_img = rest + 24 * per_block
-    return {"value": 1.0 / t_img, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+    return {"value": 1.0 / t_img, "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": (f"oracle fwd+criteria+bwd, 1 image 3x800x1333, S24 dims; timed with 1 and 3 backbone blocks "
                        f"({times[1]:.1f}s, {times[3]:.1f}s), per-block {per_block:.2f}s scaled to 24 blocks + rest {rest:.1f}s")}
 
@@ -222,7 +240,7 @@ def main():
             try:
                 res["cpu_baseline"] = cpu_baseline(a.enc_layers)
             except Exception as e:      # the CPU leg must never take the GPU number down with it
-                res["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+                res["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": host_cores(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(res), flush=True)
     if world > 1:

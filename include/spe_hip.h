@@ -45,6 +45,14 @@ int spe_gemm_f32(const float* A, const float* B, float* C, const float* bias, fl
                  int batch0, int batch1, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1,
                  float alpha, int act, int splitk, int precision, spe_stream_t stream);
 
+/* Same contraction with the A operand stored as bf16 when a_bf16 = 1 (lda and sA0/sA1 count bf16
+ * elements): consumes the transposed score tensors written by spe_talking_fused for the PV / dV /
+ * dQ / dK products of reference models/cait.py:389 and its autograd. */
+int spe_gemm_ex(const void* A, int a_bf16, const float* B, float* C, const float* bias, float* C2,
+                int M, int N, int K, long lda, long ldb, long ldc, int transA, int transB,
+                int batch0, int batch1, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1,
+                float alpha, int act, int splitk, int precision, spe_stream_t stream);
+
 /* ---- LayerNorm (nn.LayerNorm; reference models/cait.py:403,407 eps 1e-6,
  * models/transformer.py:264-265,342-344 eps 1e-5).  C % 4 == 0, C <= 1024.
  * bwd: dgamma/dbeta are ACCUMULATED into (pre-zeroed or running) buffers. */
@@ -74,6 +82,29 @@ int spe_talking_softmax_fwd(const float* S, const float* Wl, const float* bl, co
 int spe_talking_softmax_bwd(const float* dPd, const float* P, const float* S, const float* Wl, const float* Ww,
                             float* dS, float* ws, int nblocks, int B, int H, int Nq, int Nk, long ld,
                             float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
+
+/* ---- fused talking-heads attention scores (reference models/cait.py:377-389 + autograd): no fp32
+ * N x N tensor in HBM.  spe_attn_pack writes bf16 "row fragment" operands
+ *   out[b][h][tile][dstep][lane][8] = scale * x[b, tile*16 + (lane&15), h, dstep*32 + (lane>>4)*8 + i]
+ * from x[b][n][h][d] (element strides sb, sn, sh).  spe_talking_fused(mode):
+ *   0: partial softmax statistics of S' = proj_l(scale q k^T) per (b,g,q)        -> ws_stats
+ *   1: P'd[b][g][q][key] = bf16(attn_drop(proj_w(softmax(S')))) (row stride ldq)   -> outT
+ *   2: backward pass 1: dP' = (dO V^T)*keepscale, dWw/dbw partials -> ws_w, D = sum_k dP.P partials -> ws_stats
+ *   3: backward pass 2: dS' = P(dP - D), dWl/dbl partials -> ws_w, dS[b][h][q][key] = bf16(proj_l^T dS') -> outT
+ * spe_attn_merge reduces ws_stats to M/IL (mode 0: row max, 1/row sum) or D (mode 2).
+ * ws_stats: B*nt*8*H*32 floats (nt = ceil(N/16)); ws_w: nwg_used rows of 2*(H*H+H) = [dWl|dbl|dWw|dbw]
+ * (column-sum them with spe_colsum); outT: [B,H,nt*16,ldq] bf16, ldq >= nt*16.
+ * Supported: H in {4,8}, head dim <= 64.  Returns -2 otherwise (use the materialised path). */
+int spe_attn_pack(const float* x, long sb, long sn, long sh, int B, int N, int H, int dh, float scale,
+                  void* out, spe_stream_t stream);
+int spe_talking_fused_plan(int B, int N, int nwg, int* steps_per_wg, int* nwg_used);
+int spe_talking_fused(int mode, const void* Qf, const void* Kf, const void* Vf, const void* dOf,
+                      const float* Wl, const float* bl, const float* Ww, const float* bw,
+                      const float* M, const float* IL, const float* D, float* ws_stats, float* ws_w, void* outT,
+                      int B, int H, int N, int dh, long ldq, int nwg, float p_drop, uint64_t seed, uint64_t offset,
+                      spe_stream_t stream);
+int spe_attn_merge(const float* ws, float* out0, float* out1, int B, int H, int N, int steps_per_wg, int mode,
+                   spe_stream_t stream);
 
 /* ---- out[c] += sum_r in[r*ld + c] (bias gradients; autograd of nn.Linear bias). */
 int spe_colsum(const float* in, float* out, long R, int C, long ld, spe_stream_t stream);

@@ -28,6 +28,7 @@ struct GemmArgs {
     int splitk;    // >1: partial sums are atomically added into pre-zeroed C (no bias/act)
     int kt_per_split;
     int vecA, vecB;
+    int a_bf16;    // A operand is stored as bf16 (the transposed score tensors of attn_fused.hip)
 };
 
 // ---- HBM -> registers -------------------------------------------------------------------
@@ -95,6 +96,51 @@ __device__ __forceinline__ void load_rc(const float* __restrict__ base, long ld,
     }
 }
 
+// bf16-stored A operand (same thread mapping; 8-B vector loads of 4 elements).
+__device__ __forceinline__ float bfbits(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ void load_kc_bf16(const unsigned short* __restrict__ base, long ld, int row0, int nrows,
+                                             int k0, int kend, bool vec, float v[4][4]) {
+    const int t = threadIdx.x;
+    const int k = k0 + (t & 7) * 4;
+    const int kq = min(k, (kend - 1) & ~3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + (t >> 3) + 32 * i;
+        const unsigned short* p = base + (long)min(r, nrows - 1) * ld;
+        unsigned short q[4];
+        if (vec) {
+            const uint2 u = *reinterpret_cast<const uint2*>(p + kq);
+            q[0] = u.x & 0xffff; q[1] = u.x >> 16; q[2] = u.y & 0xffff; q[3] = u.y >> 16;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[j] = p[min(k + j, kend - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] = (r < nrows && k + j < kend) ? bfbits(q[j]) : 0.f;
+    }
+}
+__device__ __forceinline__ void load_rc_bf16(const unsigned short* __restrict__ base, long ld, int row0, int nrows,
+                                             int k0, int kend, bool vec, float v[4][4]) {
+    const int t = threadIdx.x;
+    const int r = row0 + (t >> 3) * 4;
+    const int rq = min(r, (nrows - 1) & ~3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + (t & 7) * 4 + i;
+        const unsigned short* p = base + (long)min(k, kend - 1) * ld;
+        unsigned short q[4];
+        if (vec) {
+            const uint2 u = *reinterpret_cast<const uint2*>(p + rq);
+            q[0] = u.x & 0xffff; q[1] = u.x >> 16; q[2] = u.y & 0xffff; q[3] = u.y >> 16;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[j] = p[min(r + j, nrows - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] = (k < kend && r + j < nrows) ? bfbits(q[j]) : 0.f;
+    }
+}
+
 // ---- registers -> LDS (bf16 via v_cvt_pk_bf16_f32, optionally hi/lo split) -------------------
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 template <bool SPLIT>
@@ -141,7 +187,8 @@ __global__ __launch_bounds__(256) void spe_gemm_kernel(GemmArgs p) {
     const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
     const int zb = blockIdx.z / p.splitk, zs = blockIdx.z % p.splitk;
     const int b0 = zb / p.nb1, b1 = zb % p.nb1;
-    const float* A = p.A + b0 * p.sA0 + b1 * p.sA1;
+    const float* A = p.a_bf16 ? nullptr : p.A + b0 * p.sA0 + b1 * p.sA1;
+    const unsigned short* A16 = p.a_bf16 ? reinterpret_cast<const unsigned short*>(p.A) + b0 * p.sA0 + b1 * p.sA1 : nullptr;
     const float* B = p.B + b0 * p.sB0 + b1 * p.sB1;
     float* C = p.C + b0 * p.sC0 + b1 * p.sC1;
     float* C2 = p.C2 ? p.C2 + b0 * p.sC0 + b1 * p.sC1 : nullptr;
@@ -165,7 +212,11 @@ __global__ __launch_bounds__(256) void spe_gemm_kernel(GemmArgs p) {
     float va[4][4], vb[4][4];
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
-        if (TA) load_rc(A, p.lda, m0, p.M, k0, p.K, p.vecA, va); else load_kc(A, p.lda, m0, p.M, k0, p.K, p.vecA, va);
+        if (p.a_bf16) {
+            if (TA) load_rc_bf16(A16, p.lda, m0, p.M, k0, p.K, p.vecA, va); else load_kc_bf16(A16, p.lda, m0, p.M, k0, p.K, p.vecA, va);
+        } else {
+            if (TA) load_rc(A, p.lda, m0, p.M, k0, p.K, p.vecA, va); else load_kc(A, p.lda, m0, p.M, k0, p.K, p.vecA, va);
+        }
         if (TB) load_kc(B, p.ldb, n0, p.N, k0, p.K, p.vecB, vb); else load_rc(B, p.ldb, n0, p.N, k0, p.K, p.vecB, vb);
     };
     auto stage = [&](int buf) {
@@ -285,15 +336,29 @@ static int launch_gemm(const GemmArgs& p, int nbatch, hipStream_t stream) {
     return 0;
 }
 
+extern "C" int spe_gemm_ex(const void* A, int a_bf16, const float* B, float* C, const float* bias, float* C2,
+                           int M, int N, int K, long lda, long ldb, long ldc, int transA, int transB,
+                           int batch0, int batch1, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1,
+                           float alpha, int act, int splitk, int precision, hipStream_t stream);
+
 // C-ABI: see include/spe_hip.h (spe_gemm_f32).
 extern "C" int spe_gemm_f32(const float* A, const float* B, float* C, const float* bias, float* C2,
                             int M, int N, int K, long lda, long ldb, long ldc, int transA, int transB,
                             int batch0, int batch1, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1,
                             float alpha, int act, int splitk, int precision, hipStream_t stream) {
+    return spe_gemm_ex(A, 0, B, C, bias, C2, M, N, K, lda, ldb, ldc, transA, transB, batch0, batch1, sA0, sA1, sB0, sB1, sC0, sC1,
+                       alpha, act, splitk, precision, stream);
+}
+
+// Same contraction with the A operand optionally stored as bf16 (a_bf16 = 1; lda / sA* in elements).
+extern "C" int spe_gemm_ex(const void* A, int a_bf16, const float* B, float* C, const float* bias, float* C2,
+                           int M, int N, int K, long lda, long ldb, long ldc, int transA, int transB,
+                           int batch0, int batch1, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1,
+                           float alpha, int act, int splitk, int precision, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0 || batch0 <= 0 || batch1 <= 0) return K <= 0 && M > 0 && N > 0 ? -4 : 0;
     if (transA && transB) return -2;  // not needed on this path
     GemmArgs p;
-    p.A = A; p.B = B; p.C = C; p.C2 = C2; p.bias = bias;
+    p.A = reinterpret_cast<const float*>(A); p.a_bf16 = a_bf16; p.B = B; p.C = C; p.C2 = C2; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.nb1 = batch1; p.sA0 = sA0; p.sA1 = sA1; p.sB0 = sB0; p.sB1 = sB1; p.sC0 = sC0; p.sC1 = sC1;
     p.alpha = alpha; p.act = act;
@@ -306,7 +371,7 @@ extern "C" int spe_gemm_f32(const float* A, const float* B, float* C, const floa
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     auto m4 = [](long v) { return (v & 3) == 0; };
     // float4 loads need 16-B aligned rows; quads that straddle an edge fall back to scalars
-    p.vecA = al16(A) && m4(lda) && m4(sA0) && m4(sA1);
+    p.vecA = (a_bf16 ? ((reinterpret_cast<uintptr_t>(A) & 7) == 0) : al16(A)) && m4(lda) && m4(sA0) && m4(sA1);
     p.vecB = al16(B) && m4(ldb) && m4(sB0) && m4(sB1);
     const int nbatch = batch0 * batch1;
     const bool split = precision == 1;

@@ -285,3 +285,46 @@ def box_loss_bwd(srow_i64, lidx_i32, g1, g2, c1, c2, shape):
     dpred = torch.zeros(shape, device=g1.device, dtype=torch.float32)
     _call("spe_box_loss_bwd", _p(srow_i64), _p(lidx_i32), _p(g1), _p(g2), _p(c1), _p(c2), _p(dpred), srow_i64.numel(), _st())
     return dpred
+
+
+# ---- fused talking-heads attention (bf16 mode) ----------------------------------------------
+FUSED_NWG = 512          # two workgroups per CU
+
+
+def fused_supported(H, dh):
+    return H in (4, 8) and dh <= 64
+
+
+def attn_pack(x4, scale=1.0):
+    """x4 [B,N,H,dh] view (unit last stride) -> bf16 row-fragment array (int32 storage)."""
+    _chk(x4)
+    B, N, H, dh = x4.shape
+    nt, ds = (N + 15) // 16, (dh + 31) // 32
+    out = torch.empty((B * H * nt * ds * 64 * 4,), device=x4.device, dtype=torch.int32)
+    _call("spe_attn_pack", _p(x4), x4.stride(0), x4.stride(1), x4.stride(2), B, N, H, dh, float(scale), _p(out), _st())
+    return out
+
+
+def fused_plan(B, N):
+    spw, nwg = ctypes.c_int(0), ctypes.c_int(0)
+    lib.call("spe_talking_fused_plan", B, N, FUSED_NWG, ctypes.byref(spw), ctypes.byref(nwg))
+    return spw.value, nwg.value
+
+
+def talking_fused(mode, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, ws_stats, ws_w, outT, B, H, N, dh, ldq, p_drop, seed, offset):
+    _call("spe_talking_fused", mode, _p(Qf), _p(Kf), _p(Vf), _p(dOf), _p(Wl), _p(bl), _p(Ww), _p(bw), _p(M), _p(IL), _p(D),
+          _p(ws_stats), _p(ws_w), _p(outT), B, H, N, dh, ldq, FUSED_NWG, float(p_drop), seed, offset, _st())
+
+
+def attn_merge(ws_stats, B, H, N, spw, mode):
+    out0 = torch.empty((B, H, N), device=ws_stats.device, dtype=torch.float32)
+    out1 = torch.empty_like(out0) if mode == 0 else None
+    _call("spe_attn_merge", _p(ws_stats), _p(out0), _p(out1), B, H, N, spw, mode, _st())
+    return out0, out1
+
+
+def gemm_bf16a(A16, B, C, M, N, K, lda, ldb, ldc, transA, transB, batch0, batch1, sA, sB, sC, alpha=1.0):
+    """GEMM whose A operand is a bf16 tensor (element strides)."""
+    _call("spe_gemm_ex", _p(A16), 1, _p(B), _p(C), None, None, M, N, K, lda, ldb, ldc, int(transA), int(transB), batch0, batch1,
+          sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], float(alpha), 0, 1, 0, _st())
+    return C

@@ -354,3 +354,38 @@ def test_matcher_cost_and_losses(dev):
     refd = torch.zeros(pb.shape, dtype=torch.double)
     refd.index_add_(0, srow, c1.cpu().double()[lidx.long()][:, None] * r1 + c2.cpu().double()[lidx.long()][:, None] * r2)
     assert rel(dp, refd) < 1e-4
+
+
+@pytest.mark.parametrize("H,N,dh,B", [(4, 50, 8, 2), (8, 131, 48, 2), (4, 200, 48, 1), (8, 330, 48, 1)])
+def test_talking_heads_attention_fused(dev, H, N, dh, B):
+    """Fused score kernels (bf16 operands, bf16 P'd/dS storage) vs the fp64 restatement; tail tiles, several
+    segments per workgroup and several workgroups per q-tile are all exercised by these shapes."""
+    from spe_amd import kernels as K, ops
+    K.set_precision("bf16")
+    g = torch.Generator().manual_seed(H * N + 1)
+    C = H * dh
+    qkv = torch.randn(B, N, 3 * C, generator=g).to(dev).requires_grad_()
+    Wl = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g)).to(dev).requires_grad_()
+    Ww = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g)).to(dev).requires_grad_()
+    bl = (0.1 * torch.randn(H, generator=g)).to(dev).requires_grad_()
+    bw = (0.1 * torch.randn(H, generator=g)).to(dev).requires_grad_()
+    scale = dh ** -0.5
+    out = ops.talking_heads_attention(qkv, Wl, bl, Ww, bw, H, scale, 0.0, fused=True)
+    go = torch.randn(out.shape, generator=g).to(dev)
+    grads = torch.autograd.grad(out, (qkv, Wl, bl, Ww, bw), go)
+    dd = [t.detach().double().requires_grad_() for t in (qkv, Wl, bl, Ww, bw)]
+    ref = _talking_ref(*dd, H, scale)
+    rg = torch.autograd.grad(ref, dd, go.double())
+    assert torch.isfinite(out).all()
+    assert rel(out, ref) < 1e-2, rel(out, ref)
+    for a, b, nm in zip(grads, rg, ["qkv", "Wl", "bl", "Ww", "bw"]):
+        assert torch.isfinite(a).all(), nm
+        if nm == "bl":
+            assert a.abs().max().item() < 2e-2 * grads[1].abs().max().item()
+        else:
+            assert rel(a, b) < 2e-2, (nm, rel(a, b))
+    # and against the materialised bf16 path (same operand rounding): tighter
+    out2 = ops.talking_heads_attention(qkv, Wl, bl, Ww, bw, H, scale, 0.0, fused=False)
+    g2 = torch.autograd.grad(out2, (qkv, Wl, Ww), go)
+    assert rel(out, out2) < 8e-3
+    assert rel(grads[0], g2[0]) < 1.5e-2 and rel(grads[1], g2[1]) < 1.5e-2 and rel(grads[3], g2[2]) < 1.5e-2

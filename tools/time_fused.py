@@ -1,0 +1,41 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from spe_amd import kernels as K
+dev = torch.device("cuda:0")
+H, N, dh, B = 8, 4150, 48, 2
+g = torch.Generator().manual_seed(1)
+C = H * dh
+qkv = torch.randn(B, N, 3 * C, generator=g).to(dev)
+Wl = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g)).to(dev); bl = (0.1 * torch.randn(H, generator=g)).to(dev)
+Ww = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g)).to(dev); bw = (0.1 * torch.randn(H, generator=g)).to(dev)
+dO = torch.randn(B, N, C, generator=g).to(dev)
+scale = dh ** -0.5
+v5 = qkv.view(B, N, 3, H, dh)
+q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
+nt = (N + 15) // 16; ldq = nt * 16
+spw, nwg = K.fused_plan(B, N)
+Qf, Kf, Vf, dOf = K.attn_pack(q, scale), K.attn_pack(k), K.attn_pack(v), K.attn_pack(dO.view(B, N, H, dh))
+ws = torch.zeros(B * nt * 8 * H * 32, device=dev)
+ws_w = torch.zeros(nwg, 2 * (H * H + H), device=dev)
+PT = torch.empty(B, H, ldq, ldq, device=dev, dtype=torch.bfloat16)
+dST = torch.empty(B, H, ldq, ldq, device=dev, dtype=torch.bfloat16)
+O = torch.empty(B, N, C, device=dev)
+K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws, None, None, B, H, N, dh, ldq, 0.0, 0, 0)
+M, IL = K.attn_merge(ws, B, H, N, spw, 0)
+D = torch.zeros(B, H, N, device=dev)
+def t(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+f = lambda mode, out=None: K.talking_fused(mode, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, ws, ws_w, out, B, H, N, dh, ldq, 0.0, 0, 0)
+print("pack q", t(lambda: K.attn_pack(q, scale)))
+for mode, out in ((0, None), (1, PT), (2, None), (3, dST)):
+    print("mode", mode, "%.3f ms" % t(lambda: f(mode, out)))
+sP, sq, sO = (H * ldq * ldq, ldq * ldq), (N * 3 * C, dh), (N * C, dh)
+print("PV  gemm bf16A^T %.3f ms" % t(lambda: K.gemm_bf16a(PT, v, O, N, dh, N, ldq, 3 * C, C, False, False, B, H, sP, sq, sO)))
+dq = torch.empty_like(qkv)
+print("dV  gemm bf16A   %.3f ms" % t(lambda: K.gemm_bf16a(PT, dO, dq.view(B, N, 3, H, dh)[:, :, 2], N, dh, N, ldq, C, 3 * C, True, False, B, H, sP, sO, sq)))
