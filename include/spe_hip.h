@@ -53,6 +53,9 @@ int spe_gemm_ex(const void* A, int a_bf16, const float* B, float* C, const float
                 int batch0, int batch1, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1,
                 float alpha, int act, int splitk, int precision, spe_stream_t stream);
 
+/* Tile edge (128 or 64) spe_gemm_* will use for an (M, N, batch) problem; callers use it to choose split-K. */
+int spe_gemm_tile(int M, int N, int nbatch);
+
 /* ---- LayerNorm (nn.LayerNorm; reference models/cait.py:403,407 eps 1e-6,
  * models/transformer.py:264-265,342-344 eps 1e-5).  C % 4 == 0, C <= 1024.
  * bwd: dgamma/dbeta are ACCUMULATED into (pre-zeroed or running) buffers. */

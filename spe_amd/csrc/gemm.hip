@@ -11,9 +11,8 @@
 // Block = 256 threads = 4 waves (2x2); block tile 128x128x32; wave tile 64x64 = 4x4 MFMA tiles.
 // Register-staged double buffering: tile t+1 is in flight from HBM while tile t is multiplied.
 #include "common.h"
+#include <stdlib.h>
 
-#define BM 128
-#define BN 128
 #define BK 32
 #define LDSLD 40  // bf16 per LDS row: 32 + 8 pad -> 80 B rows keep ds_read_b128 16-B aligned
 
@@ -39,14 +38,24 @@ struct GemmArgs {
 //
 // "KC": the contraction index is the contiguous one: X(r,k) = base[r*ld + k].
 // thread t loads rows r = (t>>3) + 32*i, k-quad (t&7).
+template <int R, bool MASK>
 __device__ __forceinline__ void load_kc(const float* __restrict__ base, long ld, int row0, int nrows,
                                         int k0, int kend, bool vec, float v[4][4]) {
     const int t = threadIdx.x;
     const int k = k0 + (t & 7) * 4;
+    if (!MASK) {   // interior tile, 16-B aligned rows: no clamps, no selects (the staging VALU work bounds this kernel)
+        const float* p0 = base + (long)(row0 + (t >> 3)) * ld + k;
+#pragma unroll
+        for (int i = 0; i < R / 32; ++i) {
+            const float4 q = *reinterpret_cast<const float4*>(p0 + (long)(32 * i) * ld);
+            v[i][0] = q.x; v[i][1] = q.y; v[i][2] = q.z; v[i][3] = q.w;
+        }
+        return;
+    }
     const int kq = min(k, (kend - 1) & ~3);            // clamped quad start (>= 0 since kend >= 1)
     if (vec) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < R / 32; ++i) {
             const int r = row0 + (t >> 3) + 32 * i;
             const float4 q = *reinterpret_cast<const float4*>(base + (long)min(r, nrows - 1) * ld + kq);
             const bool rv = r < nrows;
@@ -55,7 +64,7 @@ __device__ __forceinline__ void load_kc(const float* __restrict__ base, long ld,
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < R / 32; ++i) {
             const int r = row0 + (t >> 3) + 32 * i;
             const float* p = base + (long)min(r, nrows - 1) * ld;
             float q[4];
@@ -67,16 +76,29 @@ __device__ __forceinline__ void load_kc(const float* __restrict__ base, long ld,
     }
 }
 // "RC": the row (m or n) index is contiguous: X(r,k) = base[k*ld + r].
-// thread t loads k = (t&7)*4 + i, row-quad (t>>3); v[i][j] = X(row0 + 4*(t>>3) + j, k).
+// R = 128: thread t loads k = (t&7)*4 + i (i < 4), row-quad (t>>3); v[i][j] = X(row0 + 4*(t>>3) + j, k).
+// R =  64: row-quad (t>>3)&15, k = (t&7)*4 + 2*(t>>7) + i (i < 2).
+template <int R, bool MASK>
 __device__ __forceinline__ void load_rc(const float* __restrict__ base, long ld, int row0, int nrows,
                                         int k0, int kend, bool vec, float v[4][4]) {
     const int t = threadIdx.x;
-    const int r = row0 + (t >> 3) * 4;
+    constexpr int NI = R / 32;
+    const int r = row0 + ((R == 128) ? (t >> 3) : ((t >> 3) & 15)) * 4;
+    const int kb = k0 + (t & 7) * 4 + ((R == 128) ? 0 : 2 * (t >> 7));
+    if (!MASK) {
+        const float* p0 = base + (long)kb * ld + r;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float4 q = *reinterpret_cast<const float4*>(p0 + (long)i * ld);
+            v[i][0] = q.x; v[i][1] = q.y; v[i][2] = q.z; v[i][3] = q.w;
+        }
+        return;
+    }
     const int rq = min(r, (nrows - 1) & ~3);
     if (vec) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = k0 + (t & 7) * 4 + i;
+        for (int i = 0; i < NI; ++i) {
+            const int k = kb + i;
             const float4 q = *reinterpret_cast<const float4*>(base + (long)min(k, kend - 1) * ld + rq);
             const bool kv = k < kend;
             v[i][0] = (kv && r + 0 < nrows) ? q.x : 0.f; v[i][1] = (kv && r + 1 < nrows) ? q.y : 0.f;
@@ -84,8 +106,8 @@ __device__ __forceinline__ void load_rc(const float* __restrict__ base, long ld,
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = k0 + (t & 7) * 4 + i;
+        for (int i = 0; i < NI; ++i) {
+            const int k = kb + i;
             const float* p = base + (long)min(k, kend - 1) * ld;
             float q[4];
 #pragma unroll
@@ -98,13 +120,24 @@ __device__ __forceinline__ void load_rc(const float* __restrict__ base, long ld,
 
 // bf16-stored A operand (same thread mapping; 8-B vector loads of 4 elements).
 __device__ __forceinline__ float bfbits(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+template <int R, bool MASK>
 __device__ __forceinline__ void load_kc_bf16(const unsigned short* __restrict__ base, long ld, int row0, int nrows,
                                              int k0, int kend, bool vec, float v[4][4]) {
     const int t = threadIdx.x;
     const int k = k0 + (t & 7) * 4;
+    if (!MASK) {
+        const unsigned short* p0 = base + (long)(row0 + (t >> 3)) * ld + k;
+#pragma unroll
+        for (int i = 0; i < R / 32; ++i) {
+            const uint2 u = *reinterpret_cast<const uint2*>(p0 + (long)(32 * i) * ld);
+            v[i][0] = __uint_as_float(u.x << 16); v[i][1] = __uint_as_float(u.x & 0xffff0000u);
+            v[i][2] = __uint_as_float(u.y << 16); v[i][3] = __uint_as_float(u.y & 0xffff0000u);
+        }
+        return;
+    }
     const int kq = min(k, (kend - 1) & ~3);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < R / 32; ++i) {
         const int r = row0 + (t >> 3) + 32 * i;
         const unsigned short* p = base + (long)min(r, nrows - 1) * ld;
         unsigned short q[4];
@@ -119,14 +152,26 @@ __device__ __forceinline__ void load_kc_bf16(const unsigned short* __restrict__ 
         for (int j = 0; j < 4; ++j) v[i][j] = (r < nrows && k + j < kend) ? bfbits(q[j]) : 0.f;
     }
 }
+template <int R, bool MASK>
 __device__ __forceinline__ void load_rc_bf16(const unsigned short* __restrict__ base, long ld, int row0, int nrows,
                                              int k0, int kend, bool vec, float v[4][4]) {
     const int t = threadIdx.x;
-    const int r = row0 + (t >> 3) * 4;
+    const int r = row0 + ((R == 128) ? (t >> 3) : ((t >> 3) & 15)) * 4;
+    const int kb = k0 + (t & 7) * 4 + ((R == 128) ? 0 : 2 * (t >> 7));
+    if (!MASK) {
+        const unsigned short* p0 = base + (long)kb * ld + r;
+#pragma unroll
+        for (int i = 0; i < R / 32; ++i) {
+            const uint2 u = *reinterpret_cast<const uint2*>(p0 + (long)i * ld);
+            v[i][0] = __uint_as_float(u.x << 16); v[i][1] = __uint_as_float(u.x & 0xffff0000u);
+            v[i][2] = __uint_as_float(u.y << 16); v[i][3] = __uint_as_float(u.y & 0xffff0000u);
+        }
+        return;
+    }
     const int rq = min(r, (nrows - 1) & ~3);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = k0 + (t & 7) * 4 + i;
+    for (int i = 0; i < R / 32; ++i) {
+        const int k = kb + i;
         const unsigned short* p = base + (long)min(k, kend - 1) * ld;
         unsigned short q[4];
         if (vec) {
@@ -156,34 +201,54 @@ __device__ __forceinline__ void store4(unsigned short* hi, unsigned short* lo, i
         *reinterpret_cast<bf16x4_t*>(lo + off) = l;
     }
 }
-template <bool SPLIT>
+template <int R, bool SPLIT>
 __device__ __forceinline__ void stage_kc(unsigned short* hi, unsigned short* lo, const float v[4][4]) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < R / 32; ++i)
         store4<SPLIT>(hi, lo, ((t >> 3) + 32 * i) * LDSLD + (t & 7) * 4, v[i][0], v[i][1], v[i][2], v[i][3]);
 }
 template <bool SPLIT>
+__device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, int off, float a, float b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t h;
+    h[0] = (__bf16)a; h[1] = (__bf16)b;
+    *reinterpret_cast<bf16x2_t*>(hi + off) = h;
+    if (SPLIT) {
+        bf16x2_t l;
+        l[0] = (__bf16)(a - (float)h[0]); l[1] = (__bf16)(b - (float)h[1]);
+        *reinterpret_cast<bf16x2_t*>(lo + off) = l;
+    }
+}
+template <int R, bool SPLIT>
 __device__ __forceinline__ void stage_rc(unsigned short* hi, unsigned short* lo, const float v[4][4]) {
     const int t = threadIdx.x;
+    if (R == 128) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        store4<SPLIT>(hi, lo, ((t >> 3) * 4 + j) * LDSLD + (t & 7) * 4, v[0][j], v[1][j], v[2][j], v[3][j]);
+        for (int j = 0; j < 4; ++j)
+            store4<SPLIT>(hi, lo, ((t >> 3) * 4 + j) * LDSLD + (t & 7) * 4, v[0][j], v[1][j], v[2][j], v[3][j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            store2<SPLIT>(hi, lo, (((t >> 3) & 15) * 4 + j) * LDSLD + (t & 7) * 4 + 2 * (t >> 7), v[0][j], v[1][j]);
+    }
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 // TA: opA(m,k) = A[k*lda+m] (else A[m*lda+k]).  TB: opB(k,n) = B[n*ldb+k] (else B[k*ldb+n]).
-template <bool TA, bool TB, bool SPLIT>
+template <int T, bool TA, bool TB, bool SPLIT>
 __global__ __launch_bounds__(256) void spe_gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    constexpr int TILE = BM * LDSLD;           // elements per operand tile
+    constexpr int TILE = T * LDSLD;            // elements per operand tile
+    constexpr int NF = T / 32;                 // 16x16 MFMA tiles per wave in each direction (wave tile = T/2)
+    constexpr int WT = T / 2;
     constexpr int NPL = SPLIT ? 2 : 1;         // planes (hi, lo)
     // layout: [buf][A hi, A lo, B hi, B lo]
     auto sA = [&](int buf, int pl) { return smem + (buf * 2 * NPL + pl) * TILE; };
     auto sB = [&](int buf, int pl) { return smem + (buf * 2 * NPL + NPL + pl) * TILE; };
 
-    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_m = (p.M + T - 1) / T;
     const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
     const int zb = blockIdx.z / p.splitk, zs = blockIdx.z % p.splitk;
     const int b0 = zb / p.nb1, b1 = zb % p.nb1;
@@ -193,7 +258,7 @@ __global__ __launch_bounds__(256) void spe_gemm_kernel(GemmArgs p) {
     float* C = p.C + b0 * p.sC0 + b1 * p.sC1;
     float* C2 = p.C2 ? p.C2 + b0 * p.sC0 + b1 * p.sC1 : nullptr;
 
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * T, n0 = tn * T;
     const int ktiles = (p.K + BK - 1) / BK;
     const int kt_begin = zs * p.kt_per_split;
     int kt_end = kt_begin + p.kt_per_split; if (kt_end > ktiles) kt_end = ktiles;
@@ -203,25 +268,31 @@ __global__ __launch_bounds__(256) void spe_gemm_kernel(GemmArgs p) {
     const int wm = w >> 1, wn = w & 1;
     const int fr = lane & 15, fk = (lane >> 4) * 8;
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[NF][NF];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NF; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     float va[4][4], vb[4][4];
+    // interior fast path: the whole operand tile is in bounds and rows are vector-aligned -> unmasked loads
+    const bool rowsA_in = p.vecA && (m0 + T <= p.M), rowsB_in = p.vecB && (n0 + T <= p.N);
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
-        if (p.a_bf16) {
-            if (TA) load_rc_bf16(A16, p.lda, m0, p.M, k0, p.K, p.vecA, va); else load_kc_bf16(A16, p.lda, m0, p.M, k0, p.K, p.vecA, va);
+        const bool k_in = k0 + BK <= p.K;
+        if (rowsA_in && k_in) {
+            if (p.a_bf16) { if (TA) load_rc_bf16<T, false>(A16, p.lda, m0, p.M, k0, p.K, true, va); else load_kc_bf16<T, false>(A16, p.lda, m0, p.M, k0, p.K, true, va); }
+            else          { if (TA) load_rc<T, false>(A, p.lda, m0, p.M, k0, p.K, true, va); else load_kc<T, false>(A, p.lda, m0, p.M, k0, p.K, true, va); }
         } else {
-            if (TA) load_rc(A, p.lda, m0, p.M, k0, p.K, p.vecA, va); else load_kc(A, p.lda, m0, p.M, k0, p.K, p.vecA, va);
+            if (p.a_bf16) { if (TA) load_rc_bf16<T, true>(A16, p.lda, m0, p.M, k0, p.K, p.vecA, va); else load_kc_bf16<T, true>(A16, p.lda, m0, p.M, k0, p.K, p.vecA, va); }
+            else          { if (TA) load_rc<T, true>(A, p.lda, m0, p.M, k0, p.K, p.vecA, va); else load_kc<T, true>(A, p.lda, m0, p.M, k0, p.K, p.vecA, va); }
         }
-        if (TB) load_kc(B, p.ldb, n0, p.N, k0, p.K, p.vecB, vb); else load_rc(B, p.ldb, n0, p.N, k0, p.K, p.vecB, vb);
+        if (rowsB_in && k_in) { if (TB) load_kc<T, false>(B, p.ldb, n0, p.N, k0, p.K, true, vb); else load_rc<T, false>(B, p.ldb, n0, p.N, k0, p.K, true, vb); }
+        else                  { if (TB) load_kc<T, true>(B, p.ldb, n0, p.N, k0, p.K, p.vecB, vb); else load_rc<T, true>(B, p.ldb, n0, p.N, k0, p.K, p.vecB, vb); }
     };
     auto stage = [&](int buf) {
-        if (TA) stage_rc<SPLIT>(sA(buf, 0), sA(buf, NPL - 1), va); else stage_kc<SPLIT>(sA(buf, 0), sA(buf, NPL - 1), va);
-        if (TB) stage_kc<SPLIT>(sB(buf, 0), sB(buf, NPL - 1), vb); else stage_rc<SPLIT>(sB(buf, 0), sB(buf, NPL - 1), vb);
+        if (TA) stage_rc<T, SPLIT>(sA(buf, 0), sA(buf, NPL - 1), va); else stage_kc<T, SPLIT>(sA(buf, 0), sA(buf, NPL - 1), va);
+        if (TB) stage_kc<T, SPLIT>(sB(buf, 0), sB(buf, NPL - 1), vb); else stage_rc<T, SPLIT>(sB(buf, 0), sB(buf, NPL - 1), vb);
     };
 
     if (nt > 0) {
@@ -231,30 +302,30 @@ __global__ __launch_bounds__(256) void spe_gemm_kernel(GemmArgs p) {
         for (int t = 0; t < nt; ++t) {
             const int buf = t & 1;
             if (t + 1 < nt) gload(kt_begin + t + 1);
-            bf16x8_t a[4], b[4];
+            bf16x8_t a[NF], b[NF];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sA(buf, 0) + (wm * 64 + i * 16 + fr) * LDSLD + fk));
+            for (int i = 0; i < NF; ++i)
+                a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sA(buf, 0) + (wm * WT + i * 16 + fr) * LDSLD + fk));
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                b[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sB(buf, 0) + (wn * 64 + j * 16 + fr) * LDSLD + fk));
+            for (int j = 0; j < NF; ++j)
+                b[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sB(buf, 0) + (wn * WT + j * 16 + fr) * LDSLD + fk));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NF; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NF; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
             if (SPLIT) {
-                bf16x8_t al[4], bl[4];
+                bf16x8_t al[NF], bl[NF];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sA(buf, 1) + (wm * 64 + i * 16 + fr) * LDSLD + fk));
+                for (int i = 0; i < NF; ++i)
+                    al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sA(buf, 1) + (wm * WT + i * 16 + fr) * LDSLD + fk));
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sB(buf, 1) + (wn * 64 + j * 16 + fr) * LDSLD + fk));
+                for (int j = 0; j < NF; ++j)
+                    bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sB(buf, 1) + (wn * WT + j * 16 + fr) * LDSLD + fk));
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NF; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < NF; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], a[i], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], al[i], acc[i][j], 0, 0, 0);
                     }
@@ -265,13 +336,13 @@ __global__ __launch_bounds__(256) void spe_gemm_kernel(GemmArgs p) {
     }
 
     // ---- epilogue.  The MFMAs were issued as (B-frag, A-frag), i.e. they produced C^T tiles, so
-    // acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane&15)][n0 + wn*64 + j*16 + (lane>>4)*4 + r]:
+    // acc[i][j][r] = C[m0 + wm*T/2 + i*16 + (lane&15)][n0 + wn*T/2 + j*16 + (lane>>4)*4 + r]:
     // every lane owns 4 consecutive columns of one row -> one 16-B store per tile.
     const bool vst = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                      (!C2 || (reinterpret_cast<uintptr_t>(C2) & 15) == 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+    for (int j = 0; j < NF; ++j) {
+        const int n = n0 + wn * WT + j * 16 + (lane >> 4) * 4;
         if (n >= p.N) continue;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (p.bias && p.splitk == 1) {
@@ -279,8 +350,8 @@ __global__ __launch_bounds__(256) void spe_gemm_kernel(GemmArgs p) {
             for (int r = 0; r < 4; ++r) bv[r] = p.bias[min(n + r, p.N - 1)];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + fr;
+        for (int i = 0; i < NF; ++i) {
+            const int m = m0 + wm * WT + i * 16 + fr;
             if (m >= p.M) continue;
             const long off = (long)m * p.ldc + n;
             float v[4];
@@ -319,21 +390,38 @@ __global__ __launch_bounds__(256) void spe_gemm_kernel(GemmArgs p) {
     }
 }
 
-template <bool TA, bool TB, bool SPLIT>
-static int launch_gemm(const GemmArgs& p, int nbatch, hipStream_t stream) {
-    constexpr int smem = 2 * 2 * (SPLIT ? 2 : 1) * BM * LDSLD * (int)sizeof(unsigned short);
+template <int T, bool TA, bool TB, bool SPLIT>
+static int launch_gemm_t(const GemmArgs& p, int nbatch, hipStream_t stream) {
+    constexpr int smem = 2 * 2 * (SPLIT ? 2 : 1) * T * LDSLD * (int)sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spe_gemm_kernel<TA, TB, SPLIT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spe_gemm_kernel<T, TA, TB, SPLIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int tiles = ((p.M + T - 1) / T) * ((p.N + T - 1) / T);
     dim3 grid(tiles, 1, nbatch * p.splitk);
-    hipLaunchKernelGGL((spe_gemm_kernel<TA, TB, SPLIT>), grid, dim3(256), smem, stream, p);
+    hipLaunchKernelGGL((spe_gemm_kernel<T, TA, TB, SPLIT>), grid, dim3(256), smem, stream, p);
     SPE_CHECK_LAUNCH();
     return 0;
+}
+
+// Tile choice: every GEMM of this model is HBM/latency bound, so what matters is enough workgroups in flight.
+// 128x128 tiles when they already give >= 2 workgroups per CU, 64x64 tiles (4x the workgroups, half the
+// registers) otherwise and for skinny outputs (N <= 64: the per-head attention contractions).
+extern "C" int spe_gemm_tile(int M, int N, int nbatch) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("SPE_GEMM_TILE"); forced = e ? atoi(e) : 0; }
+    if (forced == 64 || forced == 128) return forced;
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nbatch;
+    return (t128 >= 512 && N > 64 && M > 64) ? 128 : 64;
+}
+
+template <bool TA, bool TB, bool SPLIT>
+static int launch_gemm(const GemmArgs& p, int nbatch, hipStream_t stream) {
+    if (spe_gemm_tile(p.M, p.N, nbatch) == 128) return launch_gemm_t<128, TA, TB, SPLIT>(p, nbatch, stream);
+    return launch_gemm_t<64, TA, TB, SPLIT>(p, nbatch, stream);
 }
 
 extern "C" int spe_gemm_ex(const void* A, int a_bf16, const float* B, float* C, const float* bias, float* C2,

@@ -81,10 +81,13 @@ def _chk(*ts):
 
 
 def auto_splitk(M, N, K, batch):
-    tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
-    if tiles >= 128 or K < 512:
+    """Split-K factor for long contractions with few output tiles (the dW GEMMs): enough workgroups to fill
+    256 CUs twice, but few splits - the partial sums are combined with atomics."""
+    tile = lib.load().spe_gemm_tile(M, N, batch)
+    tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile) * batch
+    if tiles >= 256 or K < 1024:
         return 1
-    return max(1, min(512 // tiles, K // 256, 64))
+    return max(1, min(512 // tiles, K // 512, 8))
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, C2=None,

@@ -36,21 +36,26 @@ def run(name, M, N, Kd, tA, tB, batch=(1, 1), splitk=1):
     print(f"{name:34s} M={M:5d} N={N:5d} K={Kd:5d} b={nb:3d} sk={splitk:2d} {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.0f} GB/s")
 
 
-for prec in (["bf16", "bf16x3"] if len(sys.argv) < 2 else [sys.argv[1]]):
-    K.set_precision(prec)
-    print("precision", prec)
-    R = 8300
-    run("qkv fwd NT", R, 1152, 384, False, True)
-    run("fc1 fwd NT", R, 1536, 384, False, True)
-    run("fc2 fwd NT", R, 384, 1536, False, True)
-    run("proj fwd NT", R, 384, 384, False, True)
-    run("fc1 dx NN", R, 384, 1536, False, False)
-    run("fc2 dx NN", R, 1536, 384, False, False)
-    run("fc1 dW TN", 1536, 384, R, True, False, splitk=K.auto_splitk(1536, 384, R, 1))
-    run("fc2 dW TN", 384, 1536, R, True, False, splitk=K.auto_splitk(384, 1536, R, 1))
-    run("qkv dW TN", 1152, 384, R, True, False, splitk=K.auto_splitk(1152, 384, R, 1))
-    run("QK^T NT batched", 4150, 4150, 48, False, True, batch=(2, 8))
-    run("PV NN batched", 4150, 48, 4150, False, False, batch=(2, 8))
-    run("dV TN batched", 4150, 48, 4150, True, False, batch=(2, 8))
-    run("square 4096 NT", 4096, 4096, 4096, False, True)
-    run("dec proj NT", 200, 384, 384, False, True)
+def main():
+  for prec in (["bf16", "bf16x3"] if len(sys.argv) < 2 else [sys.argv[1]]):
+      K.set_precision(prec)
+      print("precision", prec)
+      R = 8300
+      run("qkv fwd NT", R, 1152, 384, False, True)
+      run("fc1 fwd NT", R, 1536, 384, False, True)
+      run("fc2 fwd NT", R, 384, 1536, False, True)
+      run("proj fwd NT", R, 384, 384, False, True)
+      run("fc1 dx NN", R, 384, 1536, False, False)
+      run("fc2 dx NN", R, 1536, 384, False, False)
+      run("fc1 dW TN", 1536, 384, R, True, False, splitk=K.auto_splitk(1536, 384, R, 1))
+      run("fc2 dW TN", 384, 1536, R, True, False, splitk=K.auto_splitk(384, 1536, R, 1))
+      run("qkv dW TN", 1152, 384, R, True, False, splitk=K.auto_splitk(1152, 384, R, 1))
+      run("QK^T NT batched", 4150, 4150, 48, False, True, batch=(2, 8))
+      run("PV NN batched", 4150, 48, 4150, False, False, batch=(2, 8))
+      run("dV TN batched", 4150, 48, 4150, True, False, batch=(2, 8))
+      run("square 4096 NT", 4096, 4096, 4096, False, True)
+      run("dec proj NT", 200, 384, 384, False, True)
+
+
+if __name__ == "__main__":
+    main()
