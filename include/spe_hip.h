@@ -34,7 +34,8 @@ int spe_abi_version(void);
  * [K,M].  transB=0: B is [K,N] (ldb); transB=1: B is [N,K] (nn.Linear weight layout).
  * act: 0 none, 1 ReLU, 2 exact-erf GELU; C2 (optional) receives the pre-activation.
  * splitk>1: K is split over workgroups and atomically accumulated into a PRE-ZEROED C
- * (bias/act/C2 must be null/0).  precision: 0 = bf16 MFMA operands, fp32 accumulate;
+ * (bias/act/C2 must be null/0).  splitk<-1: |splitk| splits, split z stores its partial result into the
+ * private slab C + z*M*ldc (no atomics); the caller sums the slabs (spe_colsum over |splitk| rows of M*ldc).  precision: 0 = bf16 MFMA operands, fp32 accumulate;
  * 1 = 3-term bf16 split (~fp32 accuracy).
  * Replaces nn.Linear / torch.bmm / `@` at reference models/cait.py:376-390 (qkv, QK^T, PV, proj),
  * :114-133 (class attention), timm Mlp fc1/fc2 (cait.py:409), Conv2d patch embed (cait.py:526),
@@ -133,6 +134,11 @@ int spe_patchify(const float* img, float* cols, int B, int Cin, int Hi, int Wi, 
 
 /* ---- out = a + b[(i mod period)] (adds the interpolated pos-embed table, cait.py:623-624). */
 int spe_add_rows(const float* a, const float* b, float* out, long n, long period, spe_stream_t stream);
+
+/* ---- bicubic (A=-0.75, align_corners=false) resize of the learned position grid, token-major:
+ * forward: src[gh*gw][C] -> dst[h*w][C]; backward=1: src = d(out)[h*w][C], dst = d(in)[gh*gw][C] PRE-ZEROED.
+ * Reference models/cait.py:598-613 (F.interpolate(mode='bicubic')). */
+int spe_bicubic(const float* src, float* dst, int gh, int gw, int h, int w, int C, int backward, spe_stream_t stream);
 
 /* ---- Hungarian matcher cost (reference models/matcher.py:62-83 + util/box_ops.py:33-74):
  * logits[L,B,Q,Kc], boxes[L,B,Q,4] (cxcywh), targets concatenated over images with prefix

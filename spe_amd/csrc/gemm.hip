@@ -24,9 +24,11 @@ struct GemmArgs {
     long sA0, sA1, sB0, sB1, sC0, sC1;
     float alpha;
     int act;       // 0 none, 1 relu, 2 gelu(erf)
-    int splitk;    // >1: partial sums are atomically added into pre-zeroed C (no bias/act)
+    int splitk;    // >1: K split over workgroups (no bias/act): atomically added into pre-zeroed C, or, when
+    long slab;     //     slab != 0, split z stores its partial tile into C + z*slab (reduced by the caller)
     int kt_per_split;
     int vecA, vecB;
+    int xcd_bind;  // 0: plain tile order, 1: M-panels bound to XCDs, 2: N-panels bound to XCDs
     int a_bf16;    // A operand is stored as bf16 (the transposed score tensors of attn_fused.hip)
 };
 
@@ -248,14 +250,25 @@ __global__ __launch_bounds__(256) void spe_gemm_kernel(GemmArgs p) {
     auto sA = [&](int buf, int pl) { return smem + (buf * 2 * NPL + pl) * TILE; };
     auto sB = [&](int buf, int pl) { return smem + (buf * 2 * NPL + NPL + pl) * TILE; };
 
-    const int tiles_m = (p.M + T - 1) / T;
-    const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
+    // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (8 private L2s).  The panels of the LARGER operand
+    // are bound to XCDs (all tiles that read one such panel run on the same XCD), so that operand is fetched
+    // into one L2 only; the smaller operand is re-fetched by each XCD.
+    const int tiles_m = (p.M + T - 1) / T, tiles_n = (p.N + T - 1) / T;
+    int tm, tn;
+    if (p.xcd_bind == 0) { tm = blockIdx.x % tiles_m; tn = blockIdx.x / tiles_m; }
+    else {
+        const int no = (p.xcd_bind == 1) ? tiles_n : tiles_m;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int tb = xcd + 8 * (idx / no), to = idx % no;
+        tm = (p.xcd_bind == 1) ? tb : to; tn = (p.xcd_bind == 1) ? to : tb;
+        if (tm >= tiles_m || tn >= tiles_n) return;
+    }
     const int zb = blockIdx.z / p.splitk, zs = blockIdx.z % p.splitk;
     const int b0 = zb / p.nb1, b1 = zb % p.nb1;
     const float* A = p.a_bf16 ? nullptr : p.A + b0 * p.sA0 + b1 * p.sA1;
     const unsigned short* A16 = p.a_bf16 ? reinterpret_cast<const unsigned short*>(p.A) + b0 * p.sA0 + b1 * p.sA1 : nullptr;
     const float* B = p.B + b0 * p.sB0 + b1 * p.sB1;
-    float* C = p.C + b0 * p.sC0 + b1 * p.sC1;
+    float* C = p.C + b0 * p.sC0 + b1 * p.sC1 + (long)zs * p.slab;
     float* C2 = p.C2 ? p.C2 + b0 * p.sC0 + b1 * p.sC1 : nullptr;
 
     const int m0 = tm * T, n0 = tn * T;
@@ -358,7 +371,13 @@ __global__ __launch_bounds__(256) void spe_gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
             if (p.splitk > 1) {
-                if (nt > 0) {
+                if (p.slab != 0) {      // private slab of this split: plain (vector) stores, zeros if the split was empty
+                    if (vst && n + 3 < p.N) *reinterpret_cast<float4*>(C + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) C[off + r] = v[r];
+                    }
+                } else if (nt > 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (n + r < p.N) atomicAdd(C + off + r, v[r]);
                 }
@@ -400,9 +419,19 @@ static int launch_gemm_t(const GemmArgs& p, int nbatch, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int tiles = ((p.M + T - 1) / T) * ((p.N + T - 1) / T);
+    const int tiles_m = (p.M + T - 1) / T, tiles_n = (p.N + T - 1) / T;
+    GemmArgs q = p;
+    // bind the operand with more bytes (same K: more rows) if it has enough panels to balance 8 XCDs
+    q.xcd_bind = 0;
+    if (p.M >= p.N && tiles_m >= 16) q.xcd_bind = 1;
+    else if (p.N > p.M && tiles_n >= 16) q.xcd_bind = 2;
+    else if (tiles_m >= 16) q.xcd_bind = 1;
+    else if (tiles_n >= 16) q.xcd_bind = 2;
+    int tiles = tiles_m * tiles_n;
+    if (q.xcd_bind == 1) tiles = 8 * ((tiles_m + 7) / 8) * tiles_n;
+    if (q.xcd_bind == 2) tiles = 8 * ((tiles_n + 7) / 8) * tiles_m;
     dim3 grid(tiles, 1, nbatch * p.splitk);
-    hipLaunchKernelGGL((spe_gemm_kernel<T, TA, TB, SPLIT>), grid, dim3(256), smem, stream, p);
+    hipLaunchKernelGGL((spe_gemm_kernel<T, TA, TB, SPLIT>), grid, dim3(256), smem, stream, q);
     SPE_CHECK_LAUNCH();
     return 0;
 }
@@ -449,8 +478,12 @@ extern "C" int spe_gemm_ex(const void* A, int a_bf16, const float* B, float* C, 
     p.A = reinterpret_cast<const float*>(A); p.a_bf16 = a_bf16; p.B = B; p.C = C; p.C2 = C2; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.nb1 = batch1; p.sA0 = sA0; p.sA1 = sA1; p.sB0 = sB0; p.sB1 = sB1; p.sC0 = sC0; p.sC1 = sC1;
-    p.alpha = alpha; p.act = act;
+    p.alpha = alpha; p.act = act; p.slab = 0;
     const int ktiles = (K + BK - 1) / BK;
+    if (splitk < 0) {           // slab mode: C must hold |splitk| slabs of M*ldc floats
+        splitk = -splitk; p.slab = (long)M * ldc;
+        if (splitk > ktiles) return -5;
+    }
     if (splitk < 1) splitk = 1;
     if (splitk > ktiles) splitk = ktiles > 0 ? ktiles : 1;
     p.kt_per_split = (ktiles + splitk - 1) / splitk;

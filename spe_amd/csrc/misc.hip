@@ -52,4 +52,69 @@ extern "C" int spe_add_rows(const float* a, const float* b, float* out, long n, 
     return 0;
 }
 
+// Bicubic (A = -0.75, align_corners = false) resize of the learned position-embedding grid, token-major:
+// in[gh*gw][C] -> out[h*w][C]  (reference models/cait.py:598-613, F.interpolate(mode='bicubic')).
+__device__ __forceinline__ void cubic_w(float t, float w[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x3 = 2.f - t, x2 = 1.f - t;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+template <bool BWD>
+__global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ src, float* __restrict__ dst, int gh, int gw, int h,
+                                                      int w, int C) {
+    const int C4 = C >> 2;
+    const long total = (long)h * w * C4;
+    const float sy = (float)gh / (float)h, sx = (float)gw / (float)w;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % C4); const int o = (int)(i / C4);
+        const int oy = o / w, ox = o % w;
+        const float fy = sy * (oy + 0.5f) - 0.5f, fx = sx * (ox + 0.5f) - 0.5f;
+        const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+        float wy[4], wx[4];
+        cubic_w(fy - iy, wy); cubic_w(fx - ix, wx);
+        if (!BWD) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int yy = min(max(iy - 1 + a, 0), gh - 1);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int xx = min(max(ix - 1 + b, 0), gw - 1);
+                    const float4 v = reinterpret_cast<const float4*>(src + ((long)yy * gw + xx) * C)[c4];
+                    const float wt = wy[a] * wx[b];
+                    acc.x += wt * v.x; acc.y += wt * v.y; acc.z += wt * v.z; acc.w += wt * v.w;
+                }
+            }
+            reinterpret_cast<float4*>(dst + (long)o * C)[c4] = acc;
+        } else {      // dst = d(in) (pre-zeroed), src = d(out)
+            const float4 g = reinterpret_cast<const float4*>(src + (long)o * C)[c4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int yy = min(max(iy - 1 + a, 0), gh - 1);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int xx = min(max(ix - 1 + b, 0), gw - 1);
+                    const float wt = wy[a] * wx[b];
+                    if (wt == 0.f) continue;
+                    float* d = dst + ((long)yy * gw + xx) * C + c4 * 4;
+                    atomicAdd(d + 0, wt * g.x); atomicAdd(d + 1, wt * g.y); atomicAdd(d + 2, wt * g.z); atomicAdd(d + 3, wt * g.w);
+                }
+            }
+        }
+    }
+}
+extern "C" int spe_bicubic(const float* src, float* dst, int gh, int gw, int h, int w, int C, int backward, hipStream_t st) {
+    if (C & 3) return -2;
+    const long total = (long)h * w * (C / 4);
+    if (total <= 0) return 0;
+    long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
+    if (backward) hipLaunchKernelGGL(bicubic_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, src, dst, gh, gw, h, w, C);
+    else hipLaunchKernelGGL(bicubic_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, src, dst, gh, gw, h, w, C);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int spe_abi_version(void) { return 1; }

@@ -81,13 +81,13 @@ def _chk(*ts):
 
 
 def auto_splitk(M, N, K, batch):
-    """Split-K factor for long contractions with few output tiles (the dW GEMMs): enough workgroups to fill
-    256 CUs twice, but few splits - the partial sums are combined with atomics."""
+    """Split-K factor for long contractions with few output tiles (the dW GEMMs): enough workgroups to keep
+    ~8 per CU in flight (the kernel is latency bound per workgroup).  Partial results go to private slabs."""
     tile = lib.load().spe_gemm_tile(M, N, batch)
     tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile) * batch
-    if tiles >= 256 or K < 1024:
+    if tiles >= 512 or K < 1024:
         return 1
-    return max(1, min(512 // tiles, K // 512, 8))
+    return max(1, min(2048 // tiles, K // 256, 32))
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, C2=None,
@@ -122,8 +122,13 @@ def linear_bwd(dy2, x2, W, need_dx=True, need_dw=True, need_db=True):
         gemm(dy2, W, dx, R, K, N, N, K, K, False, False)
     if need_dw:
         sk = auto_splitk(N, K, R, 1)
-        dW = (torch.zeros if sk > 1 else torch.empty)((N, K), device=dy2.device, dtype=torch.float32)
-        gemm(dy2, x2, dW, N, K, R, N, K, K, True, False, splitk=sk)
+        if sk > 1:       # slab split-K: no atomics; the slabs are summed by one column-sum launch
+            ws = torch.empty((sk, N * K), device=dy2.device, dtype=torch.float32)
+            gemm(dy2, x2, ws, N, K, R, N, K, K, True, False, splitk=-sk)
+            dW = colsum(ws).view(N, K)
+        else:
+            dW = torch.empty((N, K), device=dy2.device, dtype=torch.float32)
+            gemm(dy2, x2, dW, N, K, R, N, K, K, True, False)
     if need_db:
         db = torch.zeros((N,), device=dy2.device, dtype=torch.float32)
         _call("spe_colsum", _p(dy2), _p(db), R, N, N, _st())
@@ -331,3 +336,15 @@ def gemm_bf16a(A16, B, C, M, N, K, lda, ldb, ldc, transA, transB, batch0, batch1
     _call("spe_gemm_ex", _p(A16), 1, _p(B), _p(C), None, None, M, N, K, lda, ldb, ldc, int(transA), int(transB), batch0, batch1,
           sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], float(alpha), 0, 1, 0, _st())
     return C
+
+
+def bicubic(src, gh, gw, h, w, backward=False):
+    """Token-major bicubic resize of a [gh*gw, C] grid to [h*w, C] (or its adjoint when backward)."""
+    _chk(src)
+    C = src.shape[-1]
+    if backward:
+        out = torch.zeros((gh * gw, C), device=src.device, dtype=torch.float32)
+    else:
+        out = torch.empty((h * w, C), device=src.device, dtype=torch.float32)
+    _call("spe_bicubic", _p(src), _p(out), gh, gw, h, w, C, int(backward), _st())
+    return out

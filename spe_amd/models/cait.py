@@ -213,8 +213,10 @@ class _TSCAMBase(nn.Module):
         """Bicubic (align_corners=False) resize of the learned grid (cait.py:572-613)."""
         B, Q, E = pos_embed.shape
         gh, gw = self.img_size[0] // self.patch_size, self.img_size[1] // self.patch_size
+        if pos_embed.is_cuda:
+            return ops.bicubic_grid(pos_embed, gh, gw, size_hw[0], size_hw[1])
+        # construction-time only (finetune_det runs on the CPU before the model is moved): parameter re-gridding
         pe = pos_embed.transpose(1, 2).reshape(B, E, gh, gw)
-        # TODO(hip): tiny [1,C,gh,gw] resample; still an ATen op (negligible time, has grad into pos_embed)
         pe = F.interpolate(pe, size=size_hw, mode="bicubic", align_corners=False)
         return pe.flatten(2).transpose(1, 2)
 

@@ -396,3 +396,21 @@ class _Add(Function):
 def add(a, b):
     assert a.shape == b.shape
     return _Add.apply(a, b)
+
+
+class _BicubicGrid(Function):
+    """pos_embed [1, gh*gw, C] -> [1, h*w, C] (cait.py:598-613)."""
+
+    @staticmethod
+    def forward(ctx, pe, gh, gw, h, w):
+        ctx.g = (gh, gw, h, w)
+        return K.bicubic(pe[0].contiguous(), gh, gw, h, w).unsqueeze(0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        gh, gw, h, w = ctx.g
+        return K.bicubic(dy[0].contiguous(), gh, gw, h, w, backward=True).unsqueeze(0), None, None, None, None
+
+
+def bicubic_grid(pe, gh, gw, h, w):
+    return _BicubicGrid.apply(pe, gh, gw, h, w)

@@ -64,6 +64,9 @@ def test_gemm_epilogue_splitk_batched(dev, prec):
     dW = torch.zeros(64, 96, device=dev)
     K.gemm(dy, xx, dW, 64, 96, 5000, 64, 96, 96, True, False, splitk=8)
     assert rel(dW, dy.double().t() @ xx.double()) < TOL[prec]
+    slabs = torch.full((11, 64 * 96), float("nan"), device=dev)           # slab split-K: no atomics, summed afterwards
+    K.gemm(dy, xx, slabs, 64, 96, 5000, 64, 96, 96, True, False, splitk=-11)
+    assert rel(slabs.sum(0).view(64, 96), dy.double().t() @ xx.double()) < TOL[prec]
     # two-level batch with strides (the attention addressing): qkv [B,N,3,H,dh]
     B_, N_, H_, dh = 2, 37, 4, 24
     qkv = torch.randn(B_, N_, 3, H_, dh, generator=g).to(dev)
@@ -271,6 +274,17 @@ def test_elementwise(dev):
     assert rel(o, x + t) < 1e-7
     (gt,) = torch.autograd.grad(o, t, torch.ones_like(o))
     assert rel(gt, torch.full_like(t, 2.0)) < 1e-6
+    # bicubic grid resize (+ adjoint) vs F.interpolate
+    for (gh, gw, hh, ww) in ((24, 24, 14, 14), (50, 84, 50, 83), (5, 7, 9, 4)):
+        pe = torch.randn(1, gh * gw, 32, generator=g).to(dev).requires_grad_()
+        out = ops.bicubic_grid(pe, gh, gw, hh, ww)
+        ped = pe.detach().double().requires_grad_()
+        ref = torch.nn.functional.interpolate(ped.transpose(1, 2).reshape(1, 32, gh, gw), size=(hh, ww), mode="bicubic",
+                                              align_corners=False).flatten(2).transpose(1, 2)
+        go = torch.randn(out.shape, generator=g).to(dev)
+        (gp,) = torch.autograd.grad(out, pe, go)
+        (rp,) = torch.autograd.grad(ref, ped, go.double())
+        assert rel(out, ref) < 1e-5 and rel(gp, rp) < 1e-5, (gh, gw, hh, ww, rel(out, ref), rel(gp, rp))
 
 
 def _giou(a, b):
