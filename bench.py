@@ -91,14 +91,14 @@ def host_cores():
 def cpu_baseline(enc_layers):
     """The oracle (CPU fp32 restatement, parity-pinned to the reference) timed on this box's host cores on a
     bounded sample of the same workload: ONE 3x800x1333 image, S24 dims, forward + both criteria + backward,
-    with 1 and 3 of the 24 backbone blocks; the per-block time (their difference / 2) is scaled to 24 blocks."""
+    with 2 and 6 of the 24 backbone blocks; the per-block time (their difference / 4) is scaled to 24 blocks."""
     from oracle import spe_oracle as O
     from spe_amd.models import build_model
     from spe_amd.models.cait import TSCAM_cait, _make, register_model
     cores = host_cores()
     torch.set_num_threads(cores)
     times = {}
-    for depth in (1, 3):
+    for depth in (2, 6):
         name = f"TSCAM_cait_S24_depth{depth}"
 
         def fac(pretrained=False, _d=depth, **kw):
@@ -119,12 +119,12 @@ def cpu_baseline(enc_layers):
         tot.backward()
         times[depth] = time.perf_counter() - t0
         del model, sd, tot
-    per_block = max((times[3] - times[1]) / 2.0, 1e-9)
-    rest = max(times[1] - per_block, 0.0)
+    per_block = max((times[6] - times[2]) / 4.0, 1e-9)
+    rest = max(times[2] - 2 * per_block, 0.0)
     t_img = rest + 24 * per_block
     return {"value": 1.0 / t_img, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": (f"oracle fwd+criteria+bwd, 1 image 3x800x1333, S24 dims; timed with 1 and 3 backbone blocks "
-                       f"({times[1]:.1f}s, {times[3]:.1f}s), per-block {per_block:.2f}s scaled to 24 blocks + rest {rest:.1f}s")}
+            "sample": (f"oracle fwd+criteria+bwd, 1 image 3x800x1333, S24 dims; timed with 2 and 6 backbone blocks "
+                       f"({times[2]:.1f}s, {times[6]:.1f}s), per-block {per_block:.2f}s scaled to 24 blocks + rest {rest:.1f}s")}
 
 
 def main():
@@ -198,8 +198,9 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    # dominant kernel timed live with HIP events on the launch stream
-    DOM = "spe_talking_softmax_bwd"
+    # dominant kernel (largest single-shape kernel of the step: backward pass 2 of the fused talking-heads
+    # attention) timed live with HIP events on the launch stream
+    DOM = "spe_talking_fused"
     K.enable_timing([DOM])
     sync()
     t0 = time.perf_counter()
@@ -219,10 +220,15 @@ def main():
         imgs = a.batch * world * a.steps
         N = (a.height // 16) * (a.width // 16)
         Hh = 8
-        launches, mean_ms = K_res[DOM]
-        # materialised talking-heads backward: reads dP', P, S and writes dS, each [B,H,N,N] fp32
-        alg_bytes = 4 * a.batch * Hh * N * N * 4
-        ach = alg_bytes / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0
+        # K.timing_results() keys fused launches by mode: "spe_talking_fused:3" = backward pass 2
+        launches, mean_ms = K_res.get(DOM + ":3", (0, 0.0))
+        # algorithmic MFMA work of one launch: S = QK^T and dP' = dO V^T for all heads, 2*N*N*dh FLOP each
+        alg_flop = 2 * (2.0 * N * N * 48) * Hh * a.batch
+        ach = alg_flop / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
+        # the kernel's real limiter is the fp32 head-mix VALU work (3 mixes + the dWl outer product, 2*H FLOP each
+        # per score and head): reported alongside against the 157.3 TFLOP/s vector peak
+        valu_flop = 4 * (2.0 * Hh * Hh) * N * N * a.batch
+        valu = valu_flop / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
         res = {
             "metric": "images/sec (whole node) at 3x800x1333 bs=2/GPU", "value": imgs / dt, "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -233,8 +239,11 @@ def main():
                                    f"{a.batch}x3x{a.height}x{a.width} per GPU (N={N} tokens), fwd + SetCriterion + "
                                    f"SetCriterionRefine + bwd + grad all-reduce + clip + AdamW",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": loss_val},
-            "roofline": {"bound": "hbm", "kernel": DOM, "launches": launches, "avg_ms": mean_ms, "achieved": ach,
-                         "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None},
+            "roofline": {"bound": "mfma", "kernel": "talking_fused_kernel<8,2,3> (attention backward pass 2)", "launches": launches,
+                         "avg_ms": mean_ms, "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
+                         "traffic": 2.59e9,   # bytes/launch, profiles/r01_pmc_fetch_write.txt (2*FETCH_SIZE + WRITE_SIZE)
+                         "note": "VALU-bound: fp32 head mixes have no MFMA form", "valu_achieved": valu, "valu_peak": 157.3,
+                         "valu_frac": valu / 157.3},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:
