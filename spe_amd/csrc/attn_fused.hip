@@ -63,7 +63,7 @@ __device__ __forceinline__ void load_w(float wv, float (&w)[H][H]) {
 
 #define FUSED_MAXSLOT 8
 
-template <int H, int DSTEPS, int MODE, bool DROP, bool GW>
+template <int H, int DSTEPS, int MODE, bool DROP, int KT>
 __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
     constexpr int NFR = H * DSTEPS;                        // fragments (16 B per lane) per q-tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -121,62 +121,79 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
             if (MODE == 3) rD[g] = a.D[((long)b * H + g) * N + (qv ? q : 0)];
         }
 
-        for (int kt = kt0 + wave; kt < kt0 + seg; kt += 4) {
-            // ---- raw scores of all heads acc[h] = K_tile(h).Q_tile(h)^T (and acc2[g] = V_tile(g).dO_tile(g)^T),
-            // software-pipelined over the head "jobs": the operand fragments of job j+1 are in flight while the
-            // MFMAs of job j issue (bounds the staging registers to 2*DSTEPS fragments).
-            constexpr int NJ = (MODE >= 2) ? 2 * H : H;
-            f32x4_t acc[H];
-            f32x4_t acc2[(MODE >= 2) ? H : 1];
-            u32x4_t cur[DSTEPS], nxt[DSTEPS];
+        // A wave's unit of work is a macro step of KT consecutive 16-key tiles against the 16 queries of the
+        // q-tile: the mixing weights (SGPR reload), the Q / dO fragments (LDS) and the loop overhead are paid once
+        // per macro step.  Waves take macro steps round-robin.
+        for (int km = wave; km * KT < seg; km += 4) {
+            const int kt_first = kt0 + km * KT;
+            // ---- raw scores of all heads acc[j][h] = K_tile(h).Q_tile(h)^T (and acc2[j][g] = V_tile(g).dO_tile(g)^T),
+            // software-pipelined: the operand fragments of the next (head, tile) job are in flight while the MFMAs of
+            // the current job issue (bounds the staging registers to 2*DSTEPS fragments).
+            constexpr int NH = (MODE >= 2) ? 2 * H : H;
+            constexpr int NJ = NH * KT;
+            f32x4_t acc[KT][H];
+            f32x4_t acc2[(MODE >= 2) ? KT : 1][(MODE >= 2) ? H : 1];
+            u32x4_t cur[DSTEPS], nxt[DSTEPS], qf[DSTEPS];
+            {
+                const int ktl = min(kt_first, nt - 1);
 #pragma unroll
-            for (int st = 0; st < DSTEPS; ++st) cur[st] = a.Kf[((((long)b * H + 0) * nt + kt) * DSTEPS + st) * 64 + lane];
+                for (int st = 0; st < DSTEPS; ++st) cur[st] = a.Kf[((((long)b * H + 0) * nt + ktl) * DSTEPS + st) * 64 + lane];
+            }
 #pragma unroll
             for (int jb = 0; jb < NJ; ++jb) {
+                const int hj = jb / KT, tj = jb % KT;                 // head job (0..NH-1), tile within the macro step
                 if (jb + 1 < NJ) {
-                    const int hn = (jb + 1) % H;
-                    const u32x4_t* srcp = (jb + 1 < H) ? a.Kf : a.Vf;
+                    const int hn = ((jb + 1) / KT) % H, tn = (jb + 1) % KT;
+                    const u32x4_t* srcp = ((jb + 1) / KT < H) ? a.Kf : a.Vf;
+                    const int ktl = min(kt_first + tn, nt - 1);
 #pragma unroll
-                    for (int st = 0; st < DSTEPS; ++st) nxt[st] = srcp[((((long)b * H + hn) * nt + kt) * DSTEPS + st) * 64 + lane];
+                    for (int st = 0; st < DSTEPS; ++st) nxt[st] = srcp[((((long)b * H + hn) * nt + ktl) * DSTEPS + st) * 64 + lane];
                 }
-                const int hh = jb % H;
-                const u32x4_t* lds = (jb < H) ? sQ : sdO;
+                const int hh = hj % H;
+                if (tj == 0) {
+                    const u32x4_t* lds = (hj < H) ? sQ : sdO;
+#pragma unroll
+                    for (int st = 0; st < DSTEPS; ++st) qf[st] = lds[(hh * DSTEPS + st) * 64 + lane];
+                }
                 f32x4_t c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int st = 0; st < DSTEPS; ++st) {
-                    const u32x4_t qf = lds[(hh * DSTEPS + st) * 64 + lane];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, cur[st]), __builtin_bit_cast(bf16x8_t, qf), c, 0, 0, 0);
-                }
-                if (jb < H) acc[hh] = c; else acc2[(MODE >= 2) ? hh : 0] = c;
+                for (int st = 0; st < DSTEPS; ++st)
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, cur[st]), __builtin_bit_cast(bf16x8_t, qf[st]), c, 0, 0, 0);
+                if (hj < H) acc[tj][hh] = c; else acc2[(MODE >= 2) ? tj : 0][(MODE >= 2) ? hh : 0] = c;
 #pragma unroll
                 for (int st = 0; st < DSTEPS; ++st) cur[st] = nxt[st];
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const int kbase = kt * 16 + 4 * (lane >> 4);      // this lane's 4 consecutive keys: kbase + r
+            // this lane's 4 consecutive keys of tile j: kb(j) + r ; tiles past the segment end belong to another workgroup
+#define KB(j) ((kt_first + (j)) * 16 + 4 * (lane >> 4))
+#define TV(j) (kt_first + (j) < kt0 + seg)
 
             // Every mode runs as two register phases that each use ONE mixing matrix, so that the 64 weights
             // of a phase stay in SGPRs (both matrices together do not fit the scalar file).
             if (MODE == 0) {
-                // phase A (Wl): S' in place + tile max ; then one rescale + 16 exps per head
+                // phase A (Wl): S' in place + macro-step max ; then one rescale + 4*KT exps per head
                 float wl[H][H];
                 load_w<H>(wlv, wl);
                 float tmax[H];
 #pragma unroll
                 for (int g = 0; g < H; ++g) tmax[g] = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool kv = kbase + r < N;
-                    float sv[H];
+                for (int j = 0; j < KT; ++j) {
 #pragma unroll
-                    for (int h = 0; h < H; ++h) sv[h] = acc[h][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const bool kv = TV(j) && KB(j) + r < N;
+                        float sv[H];
 #pragma unroll
-                    for (int g = 0; g < H; ++g) {
-                        float v = vbl[g];
+                        for (int h = 0; h < H; ++h) sv[h] = acc[j][h][r];
 #pragma unroll
-                        for (int h = 0; h < H; ++h) v = fmaf(wl[g][h], sv[h], v);
-                        v = kv ? v : -INFINITY;
-                        acc[g][r] = v;
-                        tmax[g] = fmaxf(tmax[g], v);
+                        for (int g = 0; g < H; ++g) {
+                            float v = vbl[g];
+#pragma unroll
+                            for (int h = 0; h < H; ++h) v = fmaf(wl[g][h], sv[h], v);
+                            v = kv ? v : -INFINITY;
+                            acc[j][g][r] = v;
+                            tmax[g] = fmaxf(tmax[g], v);
+                        }
                     }
                 }
 #pragma unroll
@@ -185,7 +202,9 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                     float sum = 0.f;
                     if (mn > -INFINITY) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) sum += __expf(acc[g][r] - mn);
+                        for (int j = 0; j < KT; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) sum += __expf(acc[j][g][r] - mn);
                         rl[g] = rl[g] * __expf(rm[g] - mn) + sum;
                         rm[g] = mn;
                     }
@@ -196,19 +215,22 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                 float wl[H][H];
                 load_w<H>(wlv, wl);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool kv = kbase + r < N;
-                    float sv[H];
+                for (int j = 0; j < KT; ++j) {
 #pragma unroll
-                    for (int h = 0; h < H; ++h) sv[h] = acc[h][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const bool kv = TV(j) && KB(j) + r < N;
+                        float sv[H];
 #pragma unroll
-                    for (int g = 0; g < H; ++g) {
-                        float v = vbl[g];
+                        for (int h = 0; h < H; ++h) sv[h] = acc[j][h][r];
 #pragma unroll
-                        for (int h = 0; h < H; ++h) v = fmaf(wl[g][h], sv[h], v);
-                        acc[g][r] = kv ? __expf(v - rm[g]) * rl[g] : 0.f;
+                        for (int g = 0; g < H; ++g) {
+                            float v = vbl[g];
+#pragma unroll
+                            for (int h = 0; h < H; ++h) v = fmaf(wl[g][h], sv[h], v);
+                            acc[j][g][r] = kv ? __expf(v - rm[g]) * rl[g] : 0.f;
+                        }
+                        if (MODE == 2) __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (MODE == 2) __builtin_amdgcn_sched_barrier(0);
                 }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -216,50 +238,54 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                 float ww[H][H];
                 load_w<H>(wwv, ww);
                 if (MODE == 1) {
-                    float o4[H][4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kbase + r;
-                        float pv[H];
+                    for (int j = 0; j < KT; ++j) {
+                        float o4[H][4];
 #pragma unroll
-                        for (int h = 0; h < H; ++h) pv[h] = acc[h][r];
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = KB(j) + r;
+                            float pv[H];
 #pragma unroll
-                        for (int g = 0; g < H; ++g) {
-                            float v = vbw[g];
+                            for (int h = 0; h < H; ++h) pv[h] = acc[j][h][r];
 #pragma unroll
-                            for (int h = 0; h < H; ++h) v = fmaf(ww[g][h], pv[h], v);
-                            if (DROP) v *= spe_drop_scale(a.seed, a.offset, (uint64_t)((((long)b * H + g) * N + q) * (long)N + key), a.p_drop);
-                            o4[g][r] = v;
+                            for (int g = 0; g < H; ++g) {
+                                float v = vbw[g];
+#pragma unroll
+                                for (int h = 0; h < H; ++h) v = fmaf(ww[g][h], pv[h], v);
+                                if (DROP) v *= spe_drop_scale(a.seed, a.offset, (uint64_t)((((long)b * H + g) * N + q) * (long)N + key), a.p_drop);
+                                o4[g][r] = v;
+                            }
                         }
-                    }
-                    // lane owns 4 consecutive keys of row q: one 8-B store per head
+                        // lane owns 4 consecutive keys of row q: one 8-B store per head
+                        if (TV(j)) {
 #pragma unroll
-                    for (int g = 0; g < H; ++g) {
-                        bf16x4_t o;
-                        o[0] = (__bf16)o4[g][0]; o[1] = (__bf16)o4[g][1]; o[2] = (__bf16)o4[g][2]; o[3] = (__bf16)o4[g][3];
-                        *reinterpret_cast<bf16x4_t*>(a.outT + (((long)b * H + g) * (nt * 16) + q) * a.ldq + kbase) = o;
+                            for (int g = 0; g < H; ++g) {
+                                bf16x4_t o;
+                                o[0] = (__bf16)o4[g][0]; o[1] = (__bf16)o4[g][1]; o[2] = (__bf16)o4[g][2]; o[3] = (__bf16)o4[g][3];
+                                *reinterpret_cast<bf16x4_t*>(a.outT + (((long)b * H + g) * (nt * 16) + q) * a.ldq + KB(j)) = o;
+                            }
+                        }
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kbase + r;
-                        float pv[H];
+                    for (int j = 0; j < KT; ++j) {
 #pragma unroll
-                        for (int h = 0; h < H; ++h) pv[h] = acc[h][r];
-                        const bool ev = qv && key < N;
-                        float dpp[H];
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = KB(j) + r;
+                            float pv[H];
 #pragma unroll
-                        for (int g = 0; g < H; ++g) {
-                            float v = ev ? acc2[g][r] : 0.f;
-                            if (DROP) v *= spe_drop_scale(a.seed, a.offset, (uint64_t)((((long)b * H + g) * N + q) * (long)N + key), a.p_drop);
-                            dpp[g] = v;
-                            {
+                            for (int h = 0; h < H; ++h) pv[h] = acc[j][h][r];
+                            const bool ev = qv && TV(j) && key < N;
+                            float dpp[H];
+#pragma unroll
+                            for (int g = 0; g < H; ++g) {
+                                float v = ev ? acc2[j][g][r] : 0.f;
+                                if (DROP) v *= spe_drop_scale(a.seed, a.offset, (uint64_t)((((long)b * H + g) * N + q) * (long)N + key), a.p_drop);
+                                dpp[g] = v;
                                 gb[g] += v;
 #pragma unroll
                                 for (int h = 0; h < H; ++h) gW[g][h] = fmaf(v, pv[h], gW[g][h]);
                             }
-                        }
-                        {
 #pragma unroll
                             for (int h = 0; h < H; ++h) {
                                 float v = 0.f;
@@ -276,64 +302,74 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                 float ww[H][H];
                 load_w<H>(wwv, ww);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kbase + r;
-                    float dpp[H];
+                for (int j = 0; j < KT; ++j) {
 #pragma unroll
-                    for (int g = 0; g < H; ++g) {
-                        float v = acc2[g][r];
-                        if (DROP) v *= spe_drop_scale(a.seed, a.offset, (uint64_t)((((long)b * H + g) * N + q) * (long)N + key), a.p_drop);
-                        dpp[g] = v;
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = KB(j) + r;
+                        float dpp[H];
+#pragma unroll
+                        for (int g = 0; g < H; ++g) {
+                            float v = acc2[j][g][r];
+                            if (DROP) v *= spe_drop_scale(a.seed, a.offset, (uint64_t)((((long)b * H + g) * N + q) * (long)N + key), a.p_drop);
+                            dpp[g] = v;
+                        }
+#pragma unroll
+                        for (int h = 0; h < H; ++h) {
+                            float v = 0.f;
+#pragma unroll
+                            for (int g = 0; g < H; ++g) v = fmaf(ww[g][h], dpp[g], v);
+                            acc2[j][h][r] = v;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-#pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        float v = 0.f;
-#pragma unroll
-                        for (int g = 0; g < H; ++g) v = fmaf(ww[g][h], dpp[g], v);
-                        acc2[h][r] = v;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 float wl[H][H];
                 load_w<H>(wlv, wl);
                 // phase B (Wl both ways): P from raw S, dS' = P (dP - D), dWl += dS' S^T, dS = Wl^T dS'
-                float o4[H][4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kbase + r;
-                    const bool ev = qv && key < N;
-                    float sv[H], ds1[H];
+                for (int j = 0; j < KT; ++j) {
+                    float o4[H][4];
 #pragma unroll
-                    for (int h = 0; h < H; ++h) sv[h] = acc[h][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = KB(j) + r;
+                        const bool ev = qv && TV(j) && key < N;
+                        float sv[H], ds1[H];
 #pragma unroll
-                    for (int g = 0; g < H; ++g) {
-                        float v = vbl[g];
+                        for (int h = 0; h < H; ++h) sv[h] = acc[j][h][r];
 #pragma unroll
-                        for (int h = 0; h < H; ++h) v = fmaf(wl[g][h], sv[h], v);
-                        const float pg = __expf(v - rm[g]) * rl[g];
-                        const float d = ev ? pg * (acc2[g][r] - rD[g]) : 0.f;
-                        ds1[g] = d;
-                        gb[g] += d;
+                        for (int g = 0; g < H; ++g) {
+                            float v = vbl[g];
 #pragma unroll
-                        for (int h = 0; h < H; ++h) gW[g][h] = fmaf(d, sv[h], gW[g][h]);
+                            for (int h = 0; h < H; ++h) v = fmaf(wl[g][h], sv[h], v);
+                            const float pg = __expf(v - rm[g]) * rl[g];
+                            const float d = ev ? pg * (acc2[j][g][r] - rD[g]) : 0.f;
+                            ds1[g] = d;
+                            gb[g] += d;
+#pragma unroll
+                            for (int h = 0; h < H; ++h) gW[g][h] = fmaf(d, sv[h], gW[g][h]);
+                        }
+#pragma unroll
+                        for (int h = 0; h < H; ++h) {
+                            float v = 0.f;
+#pragma unroll
+                            for (int g = 0; g < H; ++g) v = fmaf(wl[g][h], ds1[g], v);
+                            o4[h][r] = v;
+                        }
                     }
+                    if (TV(j)) {
 #pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        float v = 0.f;
-#pragma unroll
-                        for (int g = 0; g < H; ++g) v = fmaf(wl[g][h], ds1[g], v);
-                        o4[h][r] = v;
+                        for (int h = 0; h < H; ++h) {
+                            bf16x4_t o;
+                            o[0] = (__bf16)o4[h][0]; o[1] = (__bf16)o4[h][1]; o[2] = (__bf16)o4[h][2]; o[3] = (__bf16)o4[h][3];
+                            *reinterpret_cast<bf16x4_t*>(a.outT + (((long)b * H + h) * (nt * 16) + q) * a.ldq + KB(j)) = o;
+                        }
                     }
-                }
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    bf16x4_t o;
-                    o[0] = (__bf16)o4[h][0]; o[1] = (__bf16)o4[h][1]; o[2] = (__bf16)o4[h][2]; o[3] = (__bf16)o4[h][3];
-                    *reinterpret_cast<bf16x4_t*>(a.outT + (((long)b * H + h) * (nt * 16) + q) * a.ldq + kbase) = o;
                 }
             }
+#undef KB
+#undef TV
         }
 
         // ---- segment end: combine the row statistics of the 4 lane groups (same q, different keys) and 4 waves
@@ -481,29 +517,39 @@ static int plan_spw(long total, int nt, int nwg) {
     return (int)spw;
 }
 
-template <int H, int DSTEPS, int MODE, bool DROP, bool GW>
+template <int H, int DSTEPS, int MODE, bool DROP, int KT>
 static int launch_fused(const FusedArgs& a, int nwg, hipStream_t st) {
     constexpr int NFR = H * DSTEPS;
     constexpr int smem = NFR * 64 * 16 * ((MODE >= 2) ? 2 : 1) + 4 * (H * 16 * 2 > (H * H + H) ? H * 16 * 2 : (H * H + H)) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&talking_fused_kernel<H, DSTEPS, MODE, DROP, GW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&talking_fused_kernel<H, DSTEPS, MODE, DROP, KT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((talking_fused_kernel<H, DSTEPS, MODE, DROP, GW>), dim3(nwg), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((talking_fused_kernel<H, DSTEPS, MODE, DROP, KT>), dim3(nwg), dim3(256), smem, st, a);
     SPE_CHECK_LAUNCH();
     return 0;
 }
 
+// macro-step sizes (measured at cfg2): 4 tiles for the statistics pass (0.26 -> 0.235 ms), 1 tile for the write
+// pass (4 tiles: 0.43 -> 0.48 ms, occupancy loss) and for the backward passes (H*H weight-gradient accumulators +
+// the second accumulator set)
+#ifndef SPE_FUSED_KTF
+#define SPE_FUSED_KTF 4
+#endif
+#ifndef SPE_FUSED_KTB
+#define SPE_FUSED_KTB 1
+#endif
 template <int H, int DSTEPS>
 static int dispatch_mode(const FusedArgs& a, int mode, bool drop, int nwg, hipStream_t st) {
+    constexpr int KF = SPE_FUSED_KTF, KB_ = SPE_FUSED_KTB;
     switch (mode) {
-        case 0: return launch_fused<H, DSTEPS, 0, false, false>(a, nwg, st);
-        case 1: return drop ? launch_fused<H, DSTEPS, 1, true, false>(a, nwg, st) : launch_fused<H, DSTEPS, 1, false, false>(a, nwg, st);
-        case 2: return drop ? launch_fused<H, DSTEPS, 2, true, true>(a, nwg, st) : launch_fused<H, DSTEPS, 2, false, true>(a, nwg, st);
-        case 3: return drop ? launch_fused<H, DSTEPS, 3, true, true>(a, nwg, st) : launch_fused<H, DSTEPS, 3, false, true>(a, nwg, st);
+        case 0: return launch_fused<H, DSTEPS, 0, false, KF>(a, nwg, st);
+        case 1: return drop ? launch_fused<H, DSTEPS, 1, true, KB_>(a, nwg, st) : launch_fused<H, DSTEPS, 1, false, KB_>(a, nwg, st);
+        case 2: return drop ? launch_fused<H, DSTEPS, 2, true, KB_>(a, nwg, st) : launch_fused<H, DSTEPS, 2, false, KB_>(a, nwg, st);
+        case 3: return drop ? launch_fused<H, DSTEPS, 3, true, KB_>(a, nwg, st) : launch_fused<H, DSTEPS, 3, false, KB_>(a, nwg, st);
     }
     return -2;
 }
