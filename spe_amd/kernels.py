@@ -64,6 +64,27 @@ def _call(name, *args):
     ev.append((a, b))
 
 
+# Small accumulate-into buffers (bias / gamma / weight-gradient sums) are carved out of a pre-zeroed arena: one
+# memset per 16 MB instead of one fill launch per buffer (~600 launches per training step).  A carved view is
+# handed out exactly once; when the arena is exhausted a fresh one is allocated (the old one lives as long as any
+# view of it does).
+_ZPOOL = {"buf": None, "off": 0}
+_ZPOOL_FLOATS = 4 << 20
+
+
+def zeros_small(n, device):
+    if n > (1 << 18):
+        return torch.zeros((n,), device=device, dtype=torch.float32)
+    na = (n + 63) & ~63
+    z = _ZPOOL
+    if z["buf"] is None or z["buf"].device != device or z["off"] + na > z["buf"].numel():
+        z["buf"] = torch.zeros((_ZPOOL_FLOATS,), device=device, dtype=torch.float32)
+        z["off"] = 0
+    out = z["buf"][z["off"]:z["off"] + n]
+    z["off"] += na
+    return out
+
+
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -132,7 +153,7 @@ def linear_bwd(dy2, x2, W, need_dx=True, need_dw=True, need_db=True):
             dW = torch.empty((N, K), device=dy2.device, dtype=torch.float32)
             gemm(dy2, x2, dW, N, K, R, N, K, K, True, False)
     if need_db:
-        db = torch.zeros((N,), device=dy2.device, dtype=torch.float32)
+        db = zeros_small(N, dy2.device)
         _call("spe_colsum", _p(dy2), _p(db), R, N, N, _st())
     return dx, dW, db
 
@@ -140,7 +161,7 @@ def linear_bwd(dy2, x2, W, need_dx=True, need_dw=True, need_db=True):
 def colsum(x2):
     _chk(x2)
     R, C = x2.shape
-    out = torch.zeros((C,), device=x2.device, dtype=torch.float32)
+    out = zeros_small(C, x2.device)
     _call("spe_colsum", _p(x2), _p(out), R, C, x2.stride(0), _st())
     return out
 
@@ -167,8 +188,8 @@ def layernorm_bwd(dy2, x2, g, mean, rstd):
     _chk(dy2, x2, g)
     R, C = x2.shape
     dx = torch.empty_like(x2)
-    dg = torch.zeros((C,), device=x2.device, dtype=torch.float32)
-    db = torch.zeros_like(dg)
+    dg = zeros_small(C, x2.device)
+    db = zeros_small(C, x2.device)
     _call("spe_layernorm_bwd", _p(dy2), _p(x2), _p(g), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), R, C, _st())
     return dx, dg, db
 
@@ -187,7 +208,7 @@ def layerscale_residual_bwd(dout2, y2, gamma, sample_scale, rows_per_sample):
     _chk(dout2, y2, gamma, sample_scale)
     R, C = dout2.shape
     dy = torch.empty_like(dout2)
-    dg = torch.zeros((C,), device=dout2.device, dtype=torch.float32)
+    dg = zeros_small(C, dout2.device)
     _call("spe_layerscale_residual_bwd", _p(dout2), _p(y2), _p(gamma), _p(sample_scale), _p(dy), _p(dg), R, C,
              rows_per_sample, _st())
     return dy, dg

@@ -4,9 +4,9 @@ models/transformer.py: Transformer.forward_refine 122-160, TransformerEncoderLay
 gen_sineembed_for_position 35-49).  Same parameter names; activations are batch-first [B, L, d].
 
 MI355X-first differences from the reference's execution (results identical):
-  * the memory-side projections of every decoder layer (ca_kcontent_proj, ca_v_proj, ca_kpos_proj
-    and the per-head [content | pos] key concat) do not depend on the queries, so they are computed
-    once per layer and shared by the 1+num_refines decoder passes (the reference recomputes them);
+  * the 1+num_refines proposal stages share the decoder weights and the memory, so they run through the
+    decoder in ONE pass, stacked along the query axis (the reference runs the decoder once per stage and
+    recomputes the query-independent memory-side projections each time);
   * attention never forms head-averaged weights (the reference computes and discards them).
 """
 import copy
@@ -133,21 +133,26 @@ class TransformerDecoderLayer(nn.Module):
         k = torch.cat([k.view(B, S, H, dh), k_pos.view(B, S, H, dh)], dim=3)
         return k.view(B, S, 2 * d), v
 
-    def forward(self, tgt, mem_kv, memory_key_padding_mask, query_pos, query_sine_embed, is_first):
-        B, Q, d = tgt.shape
+    def forward(self, tgt, mem_kv, memory_key_padding_mask, query_pos, query_sine_embed, is_first, n_stages=1):
+        """tgt [B, R*Q, d]: the R proposal stages are stacked along the query axis.  Cross attention, projections,
+        FFN and LayerNorms are per-query, so they run once on all R*Q rows; only the query self-attention must not
+        mix stages - it sees the same buffer as [B*R, Q, d]."""
+        B, RQ, d = tgt.shape
         H, dh = self.nhead, d // self.nhead
-        # ---- self attention over the queries
+        Q = RQ // n_stages
+        # ---- self attention over the queries of each stage
         q = self.sa_qcontent_proj(tgt) + self.sa_qpos_proj(query_pos)
         k = self.sa_kcontent_proj(tgt) + self.sa_kpos_proj(query_pos)
         v = self.sa_v_proj(tgt)
-        tgt2 = self.self_attn(q, k, v)[0]
+        sa = lambda t: t.view(B * n_stages, Q, d)
+        tgt2 = self.self_attn(sa(q), sa(k), sa(v))[0].view(B, RQ, d)
         tgt = self.norm1(tgt + self.dropout1(tgt2))
         # ---- conditional cross attention
         q = self.ca_qcontent_proj(tgt)
         if is_first:
             q = q + self.ca_qpos_proj(query_pos)
         qs = self.ca_qpos_sine_proj(query_sine_embed)
-        q = torch.cat([q.view(B, Q, H, dh), qs.view(B, Q, H, dh)], dim=3).view(B, Q, 2 * d)
+        q = torch.cat([q.view(B, RQ, H, dh), qs.view(B, RQ, H, dh)], dim=3).view(B, RQ, 2 * d)
         k, v = mem_kv
         tgt2 = self.cross_attn(q, k, v, key_padding_mask=memory_key_padding_mask)[0]
         tgt = self.norm2(tgt + self.dropout2(tgt2))
@@ -169,11 +174,12 @@ class TransformerDecoder(nn.Module):
         for layer_id in range(num_layers - 1):
             self.layers[layer_id + 1].ca_qpos_proj = None      # only the first layer adds query_pos (transformer.py:203-204)
 
-    def forward(self, tgt, memory, memory_key_padding_mask, pos, query_pos, mem_cache=None):
-        """tgt/query_pos [B,Q,d]; memory/pos [B,S,d].  -> (hs [L,B,Q,d], reference_points [B,Q,2])."""
+    def forward(self, tgt, memory, memory_key_padding_mask, pos, query_pos, mem_cache=None, n_stages=1):
+        """tgt/query_pos [B, R*Q, d] (R stages stacked along the query axis); memory/pos [B,S,d].
+        -> (hs [L,B,R*Q,d], reference_points [B,R*Q,2])."""
         mem_cache = {} if mem_cache is None else mem_cache
         output = tgt
-        reference_points = self.ref_point_head(query_pos).sigmoid()            # [B,Q,2]
+        reference_points = self.ref_point_head(query_pos).sigmoid()            # [B,RQ,2]
         intermediate = []
         for layer_id, layer in enumerate(self.layers):
             if layer_id not in mem_cache:
@@ -181,7 +187,8 @@ class TransformerDecoder(nn.Module):
             sine = gen_sineembed_for_position(reference_points[..., :2], self.d_model)
             if layer_id > 0:
                 sine = sine * self.query_scale(output)
-            output = layer(output, mem_cache[layer_id], memory_key_padding_mask, query_pos, sine, layer_id == 0)
+            output = layer(output, mem_cache[layer_id], memory_key_padding_mask, query_pos, sine, layer_id == 0,
+                           n_stages=n_stages)
             intermediate.append(self.norm(output))
         return torch.stack(intermediate), reference_points
 
@@ -214,13 +221,16 @@ class Transformer(nn.Module):
         pos = pos_embed.flatten(2).transpose(1, 2).contiguous()
         mask = mask.flatten(1)
         memory = self.encoder(memory, src_key_padding_mask=mask, pos=pos)
+        # All proposal stages go through the decoder in ONE pass: the stages share the decoder weights and the
+        # memory, and differ only in their query embeddings (reference transformer.py:147-155 runs the decoder
+        # 1 + num_refines times).  Stacking the stages along the query axis is exact - every decoder op is per
+        # query except the query self-attention, which is evaluated per stage - and halves the kernel launches.
         queries = [query_embed] + [qe.weight for qe in (queries_embed_refine or [])]
-        hs, refs, cache = [], [], {}
-        for qw in queries:
-            query_pos = qw.unsqueeze(0).expand(B, -1, -1).contiguous()
-            h, r = self.decoder(torch.zeros_like(query_pos), memory, mask, pos, query_pos, mem_cache=cache)
-            hs.append(h)
-            refs.append(r)
+        R, Q = len(queries), query_embed.shape[0]
+        query_pos = torch.stack(queries).reshape(1, R * Q, -1).expand(B, -1, -1).contiguous()
+        h, r = self.decoder(torch.zeros_like(query_pos), memory, mask, pos, query_pos, n_stages=R)
+        hs = [h[:, :, i * Q:(i + 1) * Q] for i in range(R)]
+        refs = [r[:, i * Q:(i + 1) * Q] for i in range(R)]
         return hs, refs
 
 
