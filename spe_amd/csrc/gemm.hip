@@ -437,19 +437,19 @@ static int launch_gemm_t(const GemmArgs& p, int nbatch, hipStream_t stream) {
 }
 
 // Tile choice: every GEMM of this model is HBM/latency bound, so what matters is enough workgroups in flight.
-// 128x128 tiles when they already give >= 2 workgroups per CU, 64x64 tiles (4x the workgroups, half the
-// registers) otherwise and for skinny outputs (N <= 64: the per-head attention contractions).
+// 128x128 tiles when they already give >= 1 workgroup per CU (split-K slices count), 64x64 tiles (4x the
+// workgroups, half the registers, twice the L2 re-reads) otherwise and for skinny outputs (N <= 64: the per-head attention contractions).
 extern "C" int spe_gemm_tile(int M, int N, int nbatch) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("SPE_GEMM_TILE"); forced = e ? atoi(e) : 0; }
     if (forced == 64 || forced == 128) return forced;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nbatch;
-    return (t128 >= 512 && N > 64 && M > 64) ? 128 : 64;
+    return (t128 >= 256 && N > 64 && M > 64) ? 128 : 64;
 }
 
 template <bool TA, bool TB, bool SPLIT>
 static int launch_gemm(const GemmArgs& p, int nbatch, hipStream_t stream) {
-    if (spe_gemm_tile(p.M, p.N, nbatch) == 128) return launch_gemm_t<128, TA, TB, SPLIT>(p, nbatch, stream);
+    if (spe_gemm_tile(p.M, p.N, nbatch * p.splitk) == 128) return launch_gemm_t<128, TA, TB, SPLIT>(p, nbatch, stream);
     return launch_gemm_t<64, TA, TB, SPLIT>(p, nbatch, stream);
 }
 

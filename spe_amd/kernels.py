@@ -104,13 +104,13 @@ def _chk(*ts):
 
 
 def auto_splitk(M, N, K, batch):
-    """Split-K factor for long contractions with few output tiles (the dW GEMMs): enough workgroups to keep
-    ~8 per CU in flight (the kernel is latency bound per workgroup).  Partial results go to private slabs."""
-    tile = lib.load().spe_gemm_tile(M, N, batch)
-    tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile) * batch
-    if tiles >= 512 or K < 1024:
+    """Split-K factor for long contractions with few output tiles (the dW GEMMs).  Sized for 128x128 tiles
+    (half the L2 re-reads of 64x64: 45 vs 74 us for fc1's dW) and ~2 workgroups per CU; the partial results go to
+    private slabs that one column-sum launch adds up."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
+    if tiles >= 256 or K < 1024:
         return 1
-    return max(1, min(2048 // tiles, K // 256, 32))
+    return max(1, min((512 + tiles - 1) // tiles, K // 512, 16))
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, C2=None,
