@@ -92,12 +92,14 @@ int spe_talking_softmax_bwd(const float* dPd, const float* P, const float* S, co
  *   out[b][h][tile][dstep][lane][8] = scale * x[b, tile*16 + (lane&15), h, dstep*32 + (lane>>4)*8 + i]
  * from x[b][n][h][d] (element strides sb, sn, sh).  spe_talking_fused(mode):
  *   0: partial softmax statistics of S' = proj_l(scale q k^T) per (b,g,q)        -> ws_stats
- *   1: P'd[b][g][q][key] = bf16(attn_drop(proj_w(softmax(S')))) (row stride ldq)   -> outT
+ *   1: P'd = bf16(attn_drop(proj_w(softmax(S'))))                                  -> outT (blocks)
  *   2: backward pass 1: dP' = (dO V^T)*keepscale, dWw/dbw partials -> ws_w, D = sum_k dP.P partials -> ws_stats
- *   3: backward pass 2: dS' = P(dP - D), dWl/dbl partials -> ws_w, dS[b][h][q][key] = bf16(proj_l^T dS') -> outT
+ *   3: backward pass 2: dS' = P(dP - D), dWl/dbl partials -> ws_w, dS = bf16(proj_l^T dS') -> outT (blocks)
  * spe_attn_merge reduces ws_stats to M/IL (mode 0: row max, 1/row sum) or D (mode 2).
  * ws_stats: B*nt*8*H*32 floats (nt = ceil(N/16)); ws_w: nwg_used rows of 2*(H*H+H) = [dWl|dbl|dWw|dbw]
- * (column-sum them with spe_colsum); outT: [B,H,nt*16,ldq] bf16, ldq >= nt*16.
+ * (column-sum them with spe_colsum); outT: bf16 16x16 blocks [B,H,nt,nt][64][4], lane l of block (qt,kt) =
+ * query qt*16+(l&15), keys kt*16+4*(l>>4)+i.  The Q fragments must be packed with scale*log2(e) (the kernels
+ * work in the log2 domain; M is the log2-domain row max).
  * Supported: H in {4,8}, head dim <= 64.  Returns -2 otherwise (use the materialised path). */
 int spe_attn_pack(const float* x, long sb, long sn, long sh, int B, int N, int H, int dh, float scale,
                   void* out, spe_stream_t stream);
@@ -105,10 +107,20 @@ int spe_talking_fused_plan(int B, int N, int nwg, int* steps_per_wg, int* nwg_us
 int spe_talking_fused(int mode, const void* Qf, const void* Kf, const void* Vf, const void* dOf,
                       const float* Wl, const float* bl, const float* Ww, const float* bw,
                       const float* M, const float* IL, const float* D, float* ws_stats, float* ws_w, void* outT,
-                      int B, int H, int N, int dh, long ldq, int nwg, float p_drop, uint64_t seed, uint64_t offset,
+                      int B, int H, int N, int dh, int nwg, float p_drop, uint64_t seed, uint64_t offset,
                       spe_stream_t stream);
 int spe_attn_merge(const float* ws, float* out0, float* out1, int B, int H, int N, int steps_per_wg, int mode,
                    spe_stream_t stream);
+
+/* ---- streaming contractions of a blocked bf16 score tensor T (written by spe_talking_fused modes 1/3):
+ *   trans = 0: out[b, q, h, :]   = alpha * sum_key T[b,h][q,key] x[b, key, h, :]   (`attn @ v`, cait.py:388; dQ)
+ *   trans = 1: out[b, key, h, :] = alpha * sum_q   T[b,h][q,key] x[b, q, h, :]     (dV, dK of the same autograd)
+ * X16 = spe_attn_pack16(x): bf16 [B,H,nt,ceil(dh/16)][64][4] = x[b, tile*16+4*(lane>>4)+i, h, dtile*16+(lane&15)]
+ * (x element strides sb, sn, sh; 0 outside).  out element strides ob (batch), on (row), oh (head), unit d stride.
+ * Head dim <= 64, returns -2 otherwise. */
+int spe_attn_pack16(const float* x, long sb, long sn, long sh, int B, int N, int H, int dh, void* out, spe_stream_t stream);
+int spe_attn_contract(const void* T, const void* X16, float* out, long ob, long on, long oh, int B, int H, int N, int dh,
+                      int trans, float alpha, spe_stream_t stream);
 
 /* ---- out[c] += sum_r in[r*ld + c] (bias gradients; autograd of nn.Linear bias). */
 int spe_colsum(const float* in, float* out, long R, int C, long ld, spe_stream_t stream);

@@ -1,0 +1,192 @@
+// Streaming contractions of the bf16 score tensors written by the fused talking-heads kernels
+// (attn_fused.hip modes 1 and 3) with a [N, dh] operand:
+//   trans = 0 :  out[q, :]   = alpha * sum_key T[q, key] X[key, :]     (O = P'd V ; dQ = scale dS K)
+//   trans = 1 :  out[key, :] = alpha * sum_q   T[q, key] X[q, :]       (dV = P'd^T dO ; dK = scale dS^T Q)
+// Reference: the `attn @ v` of models/cait.py:388 and the autograd of cait.py:377-388.
+//
+// T is stored in 16 x 16 blocks, T[b][h][qt][kt][lane][4]: lane l of a block holds query qt*16 + (l&15) and the
+// 4 consecutive keys kt*16 + 4*(l>>4) + i - exactly the accumulator layout of the producer AND the A/B operand
+// layout of v_mfma_f32_16x16x16_bf16, so a block is written with one fully coalesced 512-B wave store and read
+// back straight into an MFMA operand (8 B per lane, no LDS, no shuffles):
+//   trans = 0 : the block is the B operand  B[k = key][n = q]                        -> C[m = d][n = q]
+//   trans = 1 : the block is the A operand  A[m = q][k = key] of an MFMA against the identity; the product
+//               C[m = q][n = key] has lane = (key, 4 queries), i.e. it IS the B operand B[k = q][n = key] of the
+//               real contraction (one extra matrix instruction transposes the lane ownership; exact in bf16).
+// The other operand comes packed by spe_attn_pack16 as A[m = d][k = row]: X16[b][h][rowtile][dtile][lane][4] =
+// x[row = rowtile*16 + 4*(lane>>4) + i][d = dtile*16 + (lane&15)].  The output tile C[m = d][n = row] gives every
+// lane 4 consecutive d of one output row: 16-B stores.
+//
+// This path is HBM-streaming (2 B per score element, read once).  A workgroup owns R = 4 consecutive output
+// tiles of one (b, h) (so the X fragments of a step are loaded once for 4 blocks), its 4 waves take the
+// contraction steps round-robin and the partial tiles are summed through LDS.
+#include "common.h"
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4c_t __attribute__((ext_vector_type(4)));
+
+#define CONTRACT_R 4
+
+template <int DT, bool TRANS>
+__global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restrict__ T, const uint2* __restrict__ X,
+                                                            float* __restrict__ out, long ob, long on, long oh,
+                                                            int H, int N, int nt, int dh, int ngrp, float alpha) {
+    constexpr int R = CONTRACT_R;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem_raw);          // [2 waves][R][DT][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = blockIdx.x % ngrp, bh = blockIdx.x / ngrp;
+    const int t0 = grp * R;
+    const uint2* Tb = T + (long)bh * nt * nt * 64;
+    const uint2* Xb = X + (long)bh * nt * DT * 64;
+
+    f32x4_t acc[R][DT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) acc[r][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    s16x4_t ident;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ident[i] = ((lane & 15) == 4 * (lane >> 4) + i) ? (short)0x3F80 : (short)0;
+
+    // tile indices of the R output tiles, clamped (a clamped duplicate is computed and never stored)
+    int tr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) tr[r] = min(t0 + r, nt - 1);
+
+    uint2 tb[R], xf[DT], tb_n[R], xf_n[DT];
+    // loads are unconditional with clamped indices (a branch around a load costs a full vmcnt(0) drain)
+#define LOAD_STEP(c_, tb_, xf_)                                                                         \
+    {                                                                                                   \
+        const int cc = min((c_), nt - 1);                                                               \
+        _Pragma("unroll") for (int d = 0; d < DT; ++d) xf_[d] = Xb[((long)cc * DT + d) * 64 + lane];    \
+        _Pragma("unroll") for (int r = 0; r < R; ++r)                                                   \
+            tb_[r] = TRANS ? Tb[((long)cc * nt + tr[r]) * 64 + lane] : Tb[((long)tr[r] * nt + cc) * 64 + lane]; \
+    }
+    LOAD_STEP(wave, tb, xf);
+    for (int c = wave; c < nt; c += 4) {
+        LOAD_STEP(c + 4, tb_n, xf_n);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            s16x4_t bt;
+            if (TRANS) {
+                const f32x4_t t = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, tb[r]), ident,
+                                                                              (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                bf16x4c_t tv;
+                tv[0] = (__bf16)t[0]; tv[1] = (__bf16)t[1]; tv[2] = (__bf16)t[2]; tv[3] = (__bf16)t[3];
+                bt = __builtin_bit_cast(s16x4_t, tv);
+            } else {
+                bt = __builtin_bit_cast(s16x4_t, tb[r]);
+            }
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+                acc[r][d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, xf[d]), bt, acc[r][d], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) tb[r] = tb_n[r];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) xf[d] = xf_n[d];
+    }
+#undef LOAD_STEP
+
+    // ---- sum the 4 waves' partial tiles: (2,3) -> LDS -> (0,1) ; then 1 -> LDS -> 0
+    if (wave >= 2) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int d = 0; d < DT; ++d) red[(((wave - 2) * R + r) * DT + d) * 64 + lane] = acc[r][d];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int d = 0; d < DT; ++d) acc[r][d] += red[((wave * R + r) * DT + d) * 64 + lane];
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int d = 0; d < DT; ++d) red[(r * DT + d) * 64 + lane] = acc[r][d];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int b = bh / H, h = bh % H;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = (t0 + r) * 16 + (lane & 15);
+            if (t0 + r < nt && row < N) {
+                float* dst = out + b * ob + (long)row * on + h * oh;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    f32x4_t v = acc[r][d] + red[(r * DT + d) * 64 + lane];
+                    v *= alpha;
+                    const int dc = d * 16 + 4 * (lane >> 4);
+                    if (dc + 3 < dh && ((((uintptr_t)(dst + dc)) & 15) == 0)) {
+                        *reinterpret_cast<f32x4_t*>(dst + dc) = v;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (dc + i < dh) dst[dc + i] = v[i];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// X16[b][h][rowtile][dtile][lane][4] = bf16(x[b, rowtile*16 + 4*(lane>>4) + i, h, dtile*16 + (lane&15)])  (0 outside)
+__global__ __launch_bounds__(256) void attn_pack16_kernel(const float* __restrict__ x, long sb, long sn, long sh, int B, int N, int H,
+                                                          int dh, int nt, int DT, uint2* __restrict__ out) {
+    const long total = (long)B * H * nt * DT * 64;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ln = (int)(i & 63); long t = i >> 6;
+        const int dt = (int)(t % DT); t /= DT;
+        const int tile = (int)(t % nt); t /= nt;
+        const int h = (int)(t % H); const int b = (int)(t / H);
+        const int d = dt * 16 + (ln & 15), r0 = tile * 16 + 4 * (ln >> 4);
+        bf16x4c_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = r0 + j;
+            const float f = x[b * sb + (long)min(row, N - 1) * sn + h * sh + min(d, dh - 1)];
+            o[j] = (__bf16)((row < N && d < dh) ? f : 0.f);
+        }
+        out[i] = __builtin_bit_cast(uint2, o);
+    }
+}
+
+extern "C" int spe_attn_pack16(const float* x, long sb, long sn, long sh, int B, int N, int H, int dh, void* out, hipStream_t st) {
+    const int nt = (N + 15) / 16, DT = (dh + 15) / 16;
+    const long total = (long)B * H * nt * DT * 64;
+    if (total <= 0) return 0;
+    long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(attn_pack16_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, sb, sn, sh, B, N, H, dh, nt, DT,
+                       reinterpret_cast<uint2*>(out));
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int DT, bool TRANS>
+static int launch_contract(const void* T, const void* X, float* out, long ob, long on, long oh, int B, int H, int N, int nt, int dh,
+                           float alpha, hipStream_t st) {
+    const int ngrp = (nt + CONTRACT_R - 1) / CONTRACT_R;
+    const int smem = 2 * CONTRACT_R * DT * 64 * 16;
+    hipLaunchKernelGGL((attn_contract_kernel<DT, TRANS>), dim3((unsigned)((long)B * H * ngrp)), dim3(256), smem, st,
+                       reinterpret_cast<const uint2*>(T), reinterpret_cast<const uint2*>(X), out, ob, on, oh, H, N, nt, dh, ngrp, alpha);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// C-ABI: see include/spe_hip.h (spe_attn_contract).  Returns -2 for head dims above 64.
+extern "C" int spe_attn_contract(const void* T, const void* X16, float* out, long ob, long on, long oh, int B, int H, int N, int dh,
+                                 int trans, float alpha, hipStream_t st) {
+    const int nt = (N + 15) / 16, DT = (dh + 15) / 16;
+    if (B <= 0 || H <= 0 || N <= 0) return 0;
+    switch (DT) {
+        case 1: return trans ? launch_contract<1, true>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st) : launch_contract<1, false>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st);
+        case 2: return trans ? launch_contract<2, true>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st) : launch_contract<2, false>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st);
+        case 3: return trans ? launch_contract<3, true>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st) : launch_contract<3, false>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st);
+        case 4: return trans ? launch_contract<4, true>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st) : launch_contract<4, false>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st);
+    }
+    return -2;
+}

@@ -18,10 +18,11 @@
 //
 // Modes (one template, same skeleton):
 //   0  forward statistics : partial (max, sum) of softmax_k(S'_g) per (b, g, q)
-//   1  forward write      : P'd[b][g][q][key] = bf16( dropout( Ww . softmax(S') + bw ) )
+//   1  forward write      : P'd = bf16( dropout( Ww . softmax(S') + bw ) )   (16x16 blocks, see attn_contract.hip)
 //   2  backward pass 1    : dP' = (dO.V^T) * keepscale ; dWw, dbw ; D_h[q] = sum_k dP_h P_h
-//   3  backward pass 2    : dS' = P (dP - D) ; dWl, dbl ; dS[b][h][q][key] = bf16( Wl^T dS' )
-// The bf16 tensors feed the PV / dV / dQ / dK contractions (spe_gemm_ex with a bf16 A operand).
+//   3  backward pass 2    : dS' = P (dP - D) ; dWl, dbl ; dS = bf16( Wl^T dS' )   (same block layout)
+// The bf16 tensors are written as whole 512-B blocks (one coalesced wave store per head and tile; row-major
+// 8-B pieces cost 0.2 ms per pass at cfg2) and feed the PV / dV / dQ / dK contractions of attn_contract.hip.
 //
 // Work partition: the (b, q-tile, k-tile) steps are flattened q-major and split evenly over the
 // workgroups (two per CU, 4 waves each); a workgroup's range covers 1-3 q-tiles ("segments"), its 4 waves
@@ -39,9 +40,8 @@ struct FusedArgs {
     const float* M; const float* IL; const float* D;      // final row stats [B,H,N] (modes 1-3), D (mode 3)
     float* ws_stats;                                      // partial row stats [B*nt][MAXSLOT][H][16][2] (modes 0, 2)
     float* ws_w;                                          // weight-gradient partials [nwg][2*(H*H+H)] (modes 2, 3)
-    unsigned short* outT;                                 // bf16 [B,H,nt*16,ldq] (modes 1, 3), row = q, column = key
+    unsigned short* outT;                                 // bf16 16x16 blocks [B,H,nt,nt][64 lanes][4] (modes 1, 3): lane = (q, 4 keys)
     int B, N, nt;                                         // nt = ceil(N/16) tiles per axis
-    long ldq;
     int steps_per_wg; long total_steps;
     float p_drop; uint64_t seed, offset;
 };
@@ -63,9 +63,39 @@ __device__ __forceinline__ void load_w(float wv, float (&w)[H][H]) {
 
 #define FUSED_MAXSLOT 8
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#define PLO(v) __builtin_shufflevector(v, v, 0, 1)
+#define PHI(v) __builtin_shufflevector(v, v, 2, 3)
+#define PCAT(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3)
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
+#define SPE_LOG2E 1.4426950408889634f
+#define SPE_LN2 0.6931471805599453f
+__device__ __forceinline__ f32x2_t fma2(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2_t splat2(float x) { return (f32x2_t){x, x}; }
+
+// out[g] = c[g] + sum_h w[g][h] * s[h] for a lane's 4 keys, as two key pairs (lo = keys 0,1 ; hi = keys 2,3):
+// H*H v_pk_fma_f32 with the weight broadcast from one SGPR.
+template <int H>
+__device__ __forceinline__ void mix_rows(const f32x4_t (&s)[H], const float (&w)[H][H], const float (&c)[H], f32x2_t (&lo)[H], f32x2_t (&hi)[H]) {
+#pragma unroll
+    for (int g = 0; g < H; ++g) { lo[g] = splat2(c[g]); hi[g] = lo[g]; }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const f32x2_t sl = PLO(s[h]), sh = PHI(s[h]);
+#pragma unroll
+        for (int g = 0; g < H; ++g) { lo[g] = fma2(sl, splat2(w[g][h]), lo[g]); hi[g] = fma2(sh, splat2(w[g][h]), hi[g]); }
+    }
+}
+
 template <int H, int DSTEPS, int MODE, bool DROP, int KT>
 __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
     constexpr int NFR = H * DSTEPS;                        // fragments (16 B per lane) per q-tile
+    constexpr int JB = (MODE >= 2) ? ((H >= 4) ? 4 : H) : H;  // MFMA jobs per operand-fragment batch
+    // request the next macro step's first batch before the VALU phases (its registers stay live through them)
+#ifndef SPE_FUSED_PREF1
+#define SPE_FUSED_PREF1 1
+#endif
+    constexpr bool PREF = (MODE == 0) || (MODE == 1 && SPE_FUSED_PREF1) || (MODE == 2 && !DROP);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4_t* sQ = reinterpret_cast<u32x4_t*>(smem_raw);    // [NFR][64]
     u32x4_t* sdO = sQ + NFR * 64;                          // [NFR][64]   (modes 2, 3)
@@ -78,18 +108,27 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
 
     // The mixing matrices are (re)loaded into SGPRs at the start of each register phase (see load_w): both
     // together (2*H*H+2H values) do not fit the scalar file next to the addressing state.
-    float vbl[H], vbw[H];
+    // Scores arrive in the log2 domain (spe_attn_pack folds scale * log2(e) into the Q fragments): Wl S + bl*log2(e)
+    // is log2(e) * S', so every exponential is a bare v_exp_f32.
+    float vbl2[H], vbw[H];
 #pragma unroll
-    for (int g = 0; g < H; ++g) { vbl[g] = a.bl[g]; vbw[g] = a.bw[g]; }
+    for (int g = 0; g < H; ++g) { vbl2[g] = a.bl[g] * SPE_LOG2E; vbw[g] = a.bw[g]; }
     const float wlv = a.Wl[(threadIdx.x & 63) < H * H ? (threadIdx.x & 63) : 0];   // lane i holds Wl[i / H][i % H]
     const float wwv = a.Ww[(threadIdx.x & 63) < H * H ? (threadIdx.x & 63) : 0];
     // weight-gradient accumulators (whole workgroup range)
-    float gW[(MODE >= 2) ? H : 1][(MODE >= 2) ? H : 1], gb[(MODE >= 2) ? H : 1];
+    // as head pairs: mode 2 gWp[g*(H/2)+hp] = (dWw[g][2hp], dWw[g][2hp+1]) ; mode 3 gWp[gp*H+h] = (dWl[2gp][h], dWl[2gp+1][h])
+    f32x2_t gWp[(MODE >= 2) ? H * H / 2 : 1], gb2[(MODE == 3) ? H / 2 : 1];
+    float gb[(MODE == 2) ? H : 1];
     if (MODE >= 2) {
 #pragma unroll
-        for (int g = 0; g < H; ++g) { gb[g] = 0.f;
+        for (int i = 0; i < H * H / 2; ++i) gWp[i] = splat2(0.f);
+        if (MODE == 2) {
 #pragma unroll
-            for (int h = 0; h < H; ++h) gW[g][h] = 0.f; }
+            for (int g = 0; g < H; ++g) gb[g] = 0.f;
+        } else {
+#pragma unroll
+            for (int g = 0; g < H / 2; ++g) gb2[g] = splat2(0.f);
+        }
     }
 
     long s = s_begin;
@@ -109,69 +148,86 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
         }
         __syncthreads();
         // ---- per-lane row state
-        float rm[H], rl[H], rD[H];
+        float rm[(MODE == 0) ? H : 1], rl[(MODE == 0) ? H : 1], c0[(MODE >= 1) ? H : 1];
+        f32x2_t rD2[(MODE >= 2) ? H / 2 : 1];
 #pragma unroll
         for (int g = 0; g < H; ++g) {
             if (MODE == 0) { rm[g] = -INFINITY; rl[g] = 0.f; }
             else {
+                // P = exp2(S' + c0), c0 = bl - m + log2(1/l): max subtraction and normalisation folded into the mix's addend
                 const long si = ((long)b * H + g) * N + (qv ? q : 0);
-                rm[g] = a.M[si]; rl[g] = a.IL[si];
+                c0[g] = vbl2[g] - a.M[si] + __builtin_amdgcn_logf(a.IL[si]);
             }
-            if (MODE == 2) rD[g] = 0.f;
-            if (MODE == 3) rD[g] = a.D[((long)b * H + g) * N + (qv ? q : 0)];
+            if (MODE == 2) rD2[g / 2][g & 1] = 0.f;
+            if (MODE == 3) rD2[g / 2][g & 1] = qv ? a.D[((long)b * H + g) * N + q] : 0.f;
         }
 
         // A wave's unit of work is a macro step of KT consecutive 16-key tiles against the 16 queries of the
         // q-tile: the mixing weights (SGPR reload), the Q / dO fragments (LDS) and the loop overhead are paid once
         // per macro step.  Waves take macro steps round-robin.
+        // operand-fragment staging registers for one batch of jobs, and the batch loader: job jb of a macro step is
+        // (tile jb / NH, head job jb % NH); head jobs >= H read the V fragments
+        u32x4_t fr[JB * DSTEPS];
+        auto load_batch = [&](int bi, int kt_first_) {
+            constexpr int NH_ = (MODE >= 2) ? 2 * H : H;
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) {
+                const int jb = bi * JB + jj;
+                const int hj = jb % NH_, tj = jb / NH_;
+                const u32x4_t* srcp = (hj < H) ? a.Kf : a.Vf;
+                const int ktl = min(kt_first_ + tj, nt - 1);
+#pragma unroll
+                for (int st = 0; st < DSTEPS; ++st) fr[jj * DSTEPS + st] = srcp[((((long)b * H + (hj % H)) * nt + ktl) * DSTEPS + st) * 64 + lane];
+            }
+        };
         for (int km = wave; km * KT < seg; km += 4) {
             const int kt_first = kt0 + km * KT;
-            // ---- raw scores of all heads acc[j][h] = K_tile(h).Q_tile(h)^T (and acc2[j][g] = V_tile(g).dO_tile(g)^T),
-            // software-pipelined: the operand fragments of the next (head, tile) job are in flight while the MFMAs of
-            // the current job issue (bounds the staging registers to 2*DSTEPS fragments).
+            // ---- raw scores of all heads acc[j][h] = K_tile(h).Q_tile(h)^T (and acc2[j][g] = V_tile(g).dO_tile(g)^T).
+            // The (operand, tile, head) jobs are issued in batches of JB: the JB*DSTEPS operand fragments of a batch
+            // are requested together (one L2 round trip per batch instead of one per head - the kernel was ~55 %
+            // s_waitcnt-bound), and the first batch of the NEXT macro step is requested right after the last MFMA of
+            // this one, so it lands during the VALU phases.
             constexpr int NH = (MODE >= 2) ? 2 * H : H;
             constexpr int NJ = NH * KT;
+            constexpr int NB = NJ / JB;
             f32x4_t acc[KT][H];
             f32x4_t acc2[(MODE >= 2) ? KT : 1][(MODE >= 2) ? H : 1];
-            u32x4_t cur[DSTEPS], nxt[DSTEPS], qf[DSTEPS];
-            {
-                const int ktl = min(kt_first, nt - 1);
+            u32x4_t qf[DSTEPS];
+            if (!PREF || km == wave) load_batch(0, kt_first);   // first macro step of the segment: nothing prefetched yet
 #pragma unroll
-                for (int st = 0; st < DSTEPS; ++st) cur[st] = a.Kf[((((long)b * H + 0) * nt + ktl) * DSTEPS + st) * 64 + lane];
-            }
+            for (int bi = 0; bi < NB; ++bi) {
 #pragma unroll
-            for (int jb = 0; jb < NJ; ++jb) {
-                const int hj = jb / KT, tj = jb % KT;                 // head job (0..NH-1), tile within the macro step
-                if (jb + 1 < NJ) {
-                    const int hn = ((jb + 1) / KT) % H, tn = (jb + 1) % KT;
-                    const u32x4_t* srcp = ((jb + 1) / KT < H) ? a.Kf : a.Vf;
-                    const int ktl = min(kt_first + tn, nt - 1);
-#pragma unroll
-                    for (int st = 0; st < DSTEPS; ++st) nxt[st] = srcp[((((long)b * H + hn) * nt + ktl) * DSTEPS + st) * 64 + lane];
-                }
-                const int hh = hj % H;
-                if (tj == 0) {
+                for (int jj = 0; jj < JB; ++jj) {
+                    const int jb = bi * JB + jj;
+                    const int hj = jb % NH, tj = jb / NH;           // head job (0..NH-1; >= H: V/dO), tile within the macro step
+                    const int hh = hj % H;
                     const u32x4_t* lds = (hj < H) ? sQ : sdO;
 #pragma unroll
                     for (int st = 0; st < DSTEPS; ++st) qf[st] = lds[(hh * DSTEPS + st) * 64 + lane];
+                    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int st = 0; st < DSTEPS; ++st)
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fr[jj * DSTEPS + st]), __builtin_bit_cast(bf16x8_t, qf[st]), c, 0, 0, 0);
+                    if (hj < H) acc[tj][hh] = c; else acc2[(MODE >= 2) ? tj : 0][(MODE >= 2) ? hh : 0] = c;
                 }
-                f32x4_t c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int st = 0; st < DSTEPS; ++st)
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, cur[st]), __builtin_bit_cast(bf16x8_t, qf[st]), c, 0, 0, 0);
-                if (hj < H) acc[tj][hh] = c; else acc2[(MODE >= 2) ? tj : 0][(MODE >= 2) ? hh : 0] = c;
-#pragma unroll
-                for (int st = 0; st < DSTEPS; ++st) cur[st] = nxt[st];
+                __builtin_amdgcn_sched_barrier(0);
+                if (bi + 1 < NB) load_batch(bi + 1, kt_first);
+                else if (PREF && (km + 4) * KT < seg) load_batch(0, kt0 + (km + 4) * KT);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // this lane's 4 consecutive keys of tile j: kb(j) + r ; tiles past the segment end belong to another workgroup
 #define KB(j) ((kt_first + (j)) * 16 + 4 * (lane >> 4))
 #define TV(j) (kt_first + (j) < kt0 + seg)
+            // wave-uniform: tile j needs per-key masking (not this workgroup's tile, or the ragged last tile)
+#define TMASK(j) (!TV(j) || (kt_first + (j) == nt - 1 && (N & 15) != 0))
+#define KVAL(j, r) (TV(j) && KB(j) + (r) < N)
 
             // Every mode runs as two register phases that each use ONE mixing matrix, so that the 64 weights
-            // of a phase stay in SGPRs (both matrices together do not fit the scalar file).
-            if (MODE == 0) {
-                // phase A (Wl): S' in place + macro-step max ; then one rescale + 4*KT exps per head
+            // of a phase stay in SGPRs (both matrices together do not fit the scalar file).  All H x H mixes are
+            // packed-fp32 FMAs (v_pk_fma_f32): either pairs over a lane's adjacent keys with a broadcast SGPR weight
+            // (mix_rows) or pairs over adjacent heads with an SGPR weight pair and a broadcast (op_sel) operand.
+            if constexpr (MODE == 0) {
+                // phase A (Wl): S' in place + macro-step max ; then one rescale + 4*KT exp2 per head
                 float wl[H][H];
                 load_w<H>(wlv, wl);
                 float tmax[H];
@@ -179,148 +235,183 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                 for (int g = 0; g < H; ++g) tmax[g] = -INFINITY;
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool kv = TV(j) && KB(j) + r < N;
-                        float sv[H];
-#pragma unroll
-                        for (int h = 0; h < H; ++h) sv[h] = acc[j][h][r];
+                    f32x2_t lo[H], hi[H];
+                    mix_rows<H>(acc[j], wl, vbl2, lo, hi);
+                    if (TMASK(j)) {
+                        const bool k0 = KVAL(j, 0), k1 = KVAL(j, 1), k2 = KVAL(j, 2), k3 = KVAL(j, 3);
 #pragma unroll
                         for (int g = 0; g < H; ++g) {
-                            float v = vbl[g];
-#pragma unroll
-                            for (int h = 0; h < H; ++h) v = fmaf(wl[g][h], sv[h], v);
-                            v = kv ? v : -INFINITY;
-                            acc[j][g][r] = v;
-                            tmax[g] = fmaxf(tmax[g], v);
+                            lo[g][0] = k0 ? lo[g][0] : -INFINITY; lo[g][1] = k1 ? lo[g][1] : -INFINITY;
+                            hi[g][0] = k2 ? hi[g][0] : -INFINITY; hi[g][1] = k3 ? hi[g][1] : -INFINITY;
                         }
+                    }
+#pragma unroll
+                    for (int g = 0; g < H; ++g) {
+                        tmax[g] = fmaxf(fmaxf(tmax[g], lo[g][0]), lo[g][1]);
+                        tmax[g] = fmaxf(fmaxf(tmax[g], hi[g][0]), hi[g][1]);
+                        acc[j][g] = PCAT(lo[g], hi[g]);
                     }
                 }
 #pragma unroll
                 for (int g = 0; g < H; ++g) {
                     const float mn = fmaxf(rm[g], tmax[g]);
-                    float sum = 0.f;
                     if (mn > -INFINITY) {
+                        f32x2_t sum2 = {0.f, 0.f};
+                        const f32x2_t mn2 = splat2(mn);
 #pragma unroll
-                        for (int j = 0; j < KT; ++j)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) sum += __expf(acc[j][g][r] - mn);
-                        rl[g] = rl[g] * __expf(rm[g] - mn) + sum;
+                        for (int j = 0; j < KT; ++j) {
+                            const f32x2_t xl = PLO(acc[j][g]) - mn2, xh = PHI(acc[j][g]) - mn2;
+                            sum2 += (f32x2_t){EXP2(xl[0]), EXP2(xl[1])};
+                            sum2 += (f32x2_t){EXP2(xh[0]), EXP2(xh[1])};
+                        }
+                        rl[g] = rl[g] * EXP2(rm[g] - mn) + (sum2[0] + sum2[1]);
                         rm[g] = mn;
                     }
                 }
-            } else if (MODE == 1 || MODE == 2) {
-                // phase A (Wl): acc <- P = exp(S' - m) / l
+            } else if constexpr (MODE == 1) {
+                // phase A (Wl): acc <- P = exp2(S' + c0)   (c0 = bl - m + log2(1/l), all in the log2 domain)
                 {
                 float wl[H][H];
                 load_w<H>(wlv, wl);
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
+                    f32x2_t lo[H], hi[H];
+                    mix_rows<H>(acc[j], wl, c0, lo, hi);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool kv = TV(j) && KB(j) + r < N;
-                        float sv[H];
-#pragma unroll
-                        for (int h = 0; h < H; ++h) sv[h] = acc[j][h][r];
+                    for (int g = 0; g < H; ++g) acc[j][g] = (f32x4_t){EXP2(lo[g][0]), EXP2(lo[g][1]), EXP2(hi[g][0]), EXP2(hi[g][1])};
+                    if (TMASK(j)) {
+                        const bool k0 = KVAL(j, 0), k1 = KVAL(j, 1), k2 = KVAL(j, 2), k3 = KVAL(j, 3);
 #pragma unroll
                         for (int g = 0; g < H; ++g) {
-                            float v = vbl[g];
-#pragma unroll
-                            for (int h = 0; h < H; ++h) v = fmaf(wl[g][h], sv[h], v);
-                            acc[j][g][r] = kv ? __expf(v - rm[g]) * rl[g] : 0.f;
+                            acc[j][g][0] = k0 ? acc[j][g][0] : 0.f; acc[j][g][1] = k1 ? acc[j][g][1] : 0.f;
+                            acc[j][g][2] = k2 ? acc[j][g][2] : 0.f; acc[j][g][3] = k3 ? acc[j][g][3] : 0.f;
                         }
-                        if (MODE == 2) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                // phase B (Ww)
+                // phase B (Ww): P'd = dropout(Ww P + bw) -> bf16
                 float ww[H][H];
                 load_w<H>(wwv, ww);
-                if (MODE == 1) {
 #pragma unroll
-                    for (int j = 0; j < KT; ++j) {
-                        float o4[H][4];
+                for (int j = 0; j < KT; ++j) {
+                    f32x2_t lo[H], hi[H];
+                    mix_rows<H>(acc[j], ww, vbw, lo, hi);
+                    if (DROP) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int key = KB(j) + r;
-                            float pv[H];
-#pragma unroll
-                            for (int h = 0; h < H; ++h) pv[h] = acc[j][h][r];
-#pragma unroll
-                            for (int g = 0; g < H; ++g) {
-                                float v = vbw[g];
-#pragma unroll
-                                for (int h = 0; h < H; ++h) v = fmaf(ww[g][h], pv[h], v);
-                                if (DROP) v *= spe_drop_scale(a.seed, a.offset, (uint64_t)((((long)b * H + g) * N + q) * (long)N + key), a.p_drop);
-                                o4[g][r] = v;
-                            }
-                        }
-                        // lane owns 4 consecutive keys of row q: one 8-B store per head
-                        if (TV(j)) {
-#pragma unroll
-                            for (int g = 0; g < H; ++g) {
-                                bf16x4_t o;
-                                o[0] = (__bf16)o4[g][0]; o[1] = (__bf16)o4[g][1]; o[2] = (__bf16)o4[g][2]; o[3] = (__bf16)o4[g][3];
-                                *reinterpret_cast<bf16x4_t*>(a.outT + (((long)b * H + g) * (nt * 16) + q) * a.ldq + KB(j)) = o;
-                            }
+                        for (int g = 0; g < H; ++g) {
+                            const uint64_t e0 = (uint64_t)((((long)b * H + g) * N + q) * (long)N + KB(j));
+                            lo[g][0] *= spe_drop_scale(a.seed, a.offset, e0, a.p_drop);
+                            lo[g][1] *= spe_drop_scale(a.seed, a.offset, e0 + 1, a.p_drop);
+                            hi[g][0] *= spe_drop_scale(a.seed, a.offset, e0 + 2, a.p_drop);
+                            hi[g][1] *= spe_drop_scale(a.seed, a.offset, e0 + 3, a.p_drop);
                         }
                     }
-                } else {
+                    // lane owns 4 consecutive keys of row q: one 8-B store per head
+                    if (TV(j)) {
 #pragma unroll
-                    for (int j = 0; j < KT; ++j) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int key = KB(j) + r;
-                            float pv[H];
-#pragma unroll
-                            for (int h = 0; h < H; ++h) pv[h] = acc[j][h][r];
-                            const bool ev = qv && TV(j) && key < N;
-                            float dpp[H];
-#pragma unroll
-                            for (int g = 0; g < H; ++g) {
-                                float v = ev ? acc2[j][g][r] : 0.f;
-                                if (DROP) v *= spe_drop_scale(a.seed, a.offset, (uint64_t)((((long)b * H + g) * N + q) * (long)N + key), a.p_drop);
-                                dpp[g] = v;
-                                gb[g] += v;
-#pragma unroll
-                                for (int h = 0; h < H; ++h) gW[g][h] = fmaf(v, pv[h], gW[g][h]);
-                            }
-#pragma unroll
-                            for (int h = 0; h < H; ++h) {
-                                float v = 0.f;
-#pragma unroll
-                                for (int g = 0; g < H; ++g) v = fmaf(ww[g][h], dpp[g], v);
-                                rD[h] = fmaf(v, pv[h], rD[h]);
-                            }
+                        for (int g = 0; g < H; ++g) {
+                            bf16x4_t o;
+                            o[0] = (__bf16)lo[g][0]; o[1] = (__bf16)lo[g][1]; o[2] = (__bf16)hi[g][0]; o[3] = (__bf16)hi[g][1];
+                            *reinterpret_cast<bf16x4_t*>(a.outT + (((((long)b * H + g) * nt + qt) * nt + (kt_first + j)) * 64 + lane) * 4) = o;
                         }
                     }
                 }
+            } else if constexpr (MODE == 2) {
+                // phase A (Wl): PT[j][r][hp] <- P of heads (2hp, 2hp+1) at key r  (head pairs adjacent: the exp2
+                // results can be written to any register, so the transposition is free)
+                f32x2_t PT[KT][4][H / 2];
+                {
+                float wl[H][H];
+                load_w<H>(wlv, wl);
+#pragma unroll
+                for (int j = 0; j < KT; ++j) {
+                    f32x2_t lo[H], hi[H];
+                    mix_rows<H>(acc[j], wl, c0, lo, hi);
+                    const bool tm = TMASK(j);
+                    const bool k0 = !tm || KVAL(j, 0), k1 = !tm || KVAL(j, 1), k2 = !tm || KVAL(j, 2), k3 = !tm || KVAL(j, 3);
+#pragma unroll
+                    for (int g = 0; g < H; ++g) {
+                        PT[j][0][g / 2][g & 1] = EXP2(lo[g][0]); PT[j][1][g / 2][g & 1] = EXP2(lo[g][1]);
+                        PT[j][2][g / 2][g & 1] = EXP2(hi[g][0]); PT[j][3][g / 2][g & 1] = EXP2(hi[g][1]);
+                    }
+                    if (tm) {
+#pragma unroll
+                        for (int hp = 0; hp < H / 2; ++hp) {
+                            if (!k0) PT[j][0][hp] = splat2(0.f);
+                            if (!k1) PT[j][1][hp] = splat2(0.f);
+                            if (!k2) PT[j][2][hp] = splat2(0.f);
+                            if (!k3) PT[j][3][hp] = splat2(0.f);
+                        }
+                    }
+                }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // phase B (Ww): dP' = (dO V^T) keepscale ; dWw += dP' P^T ; dbw += dP' ; D += (Ww^T dP') . P
+                float ww[H][H];
+                load_w<H>(wwv, ww);
+#pragma unroll
+                for (int j = 0; j < KT; ++j) {
+                    // rows q >= N have zero dO fragments and keys >= N zero V fragments, so dP' is already 0 there
+                    if (!TV(j)) {
+#pragma unroll
+                        for (int g = 0; g < H; ++g) acc2[j][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    }
+                    if (DROP) {
+#pragma unroll
+                        for (int g = 0; g < H; ++g)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                acc2[j][g][r] *= spe_drop_scale(a.seed, a.offset, (uint64_t)((((long)b * H + g) * N + q) * (long)N + KB(j) + r), a.p_drop);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        f32x2_t mt[H / 2];
+#pragma unroll
+                        for (int hp = 0; hp < H / 2; ++hp) mt[hp] = splat2(0.f);
+#pragma unroll
+                        for (int g = 0; g < H; ++g) {
+                            const float dv = acc2[j][g][r];
+                            const f32x2_t db = splat2(dv);
+                            gb[g] += dv;
+#pragma unroll
+                            for (int hp = 0; hp < H / 2; ++hp) {
+                                gWp[g * (H / 2) + hp] = fma2(db, PT[j][r][hp], gWp[g * (H / 2) + hp]);
+                                mt[hp] = fma2(db, (f32x2_t){ww[g][2 * hp], ww[g][2 * hp + 1]}, mt[hp]);
+                            }
+                        }
+#pragma unroll
+                        for (int hp = 0; hp < H / 2; ++hp) rD2[hp] = fma2(mt[hp], PT[j][r][hp], rD2[hp]);
+                    }
+                }
             } else {
-                // MODE 3.  phase A (Ww): acc2 <- dP = Ww^T (dP'd * keepscale)
+                // MODE 3.  phase A (Ww): dPT[j][r][hp] <- dP = Ww^T (dP'd * keepscale) of heads (2hp, 2hp+1) at key r
+                f32x2_t dPT[KT][4][H / 2];
                 {
                 float ww[H][H];
                 load_w<H>(wwv, ww);
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
+                    if (DROP) {
+#pragma unroll
+                        for (int g = 0; g < H; ++g)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                acc2[j][g][r] *= spe_drop_scale(a.seed, a.offset, (uint64_t)((((long)b * H + g) * N + q) * (long)N + KB(j) + r), a.p_drop);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int key = KB(j) + r;
-                        float dpp[H];
+                        f32x2_t mt[H / 2];
+#pragma unroll
+                        for (int hp = 0; hp < H / 2; ++hp) mt[hp] = splat2(0.f);
 #pragma unroll
                         for (int g = 0; g < H; ++g) {
-                            float v = acc2[j][g][r];
-                            if (DROP) v *= spe_drop_scale(a.seed, a.offset, (uint64_t)((((long)b * H + g) * N + q) * (long)N + key), a.p_drop);
-                            dpp[g] = v;
+                            const f32x2_t db = splat2(acc2[j][g][r]);
+#pragma unroll
+                            for (int hp = 0; hp < H / 2; ++hp) mt[hp] = fma2(db, (f32x2_t){ww[g][2 * hp], ww[g][2 * hp + 1]}, mt[hp]);
                         }
 #pragma unroll
-                        for (int h = 0; h < H; ++h) {
-                            float v = 0.f;
-#pragma unroll
-                            for (int g = 0; g < H; ++g) v = fmaf(ww[g][h], dpp[g], v);
-                            acc2[j][h][r] = v;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int hp = 0; hp < H / 2; ++hp) dPT[j][r][hp] = mt[hp];
                     }
                 }
                 }
@@ -330,44 +421,65 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                 // phase B (Wl both ways): P from raw S, dS' = P (dP - D), dWl += dS' S^T, dS = Wl^T dS'
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
-                    float o4[H][4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = KB(j) + r;
-                        const bool ev = qv && TV(j) && key < N;
-                        float sv[H], ds1[H];
-#pragma unroll
-                        for (int h = 0; h < H; ++h) sv[h] = acc[j][h][r];
+                    f32x2_t d2[4][H / 2];
+                    {
+                        f32x2_t lo[H], hi[H];
+                        mix_rows<H>(acc[j], wl, c0, lo, hi);
 #pragma unroll
                         for (int g = 0; g < H; ++g) {
-                            float v = vbl[g];
-#pragma unroll
-                            for (int h = 0; h < H; ++h) v = fmaf(wl[g][h], sv[h], v);
-                            const float pg = __expf(v - rm[g]) * rl[g];
-                            const float d = ev ? pg * (acc2[j][g][r] - rD[g]) : 0.f;
-                            ds1[g] = d;
-                            gb[g] += d;
-#pragma unroll
-                            for (int h = 0; h < H; ++h) gW[g][h] = fmaf(d, sv[h], gW[g][h]);
+                            d2[0][g / 2][g & 1] = EXP2(lo[g][0]); d2[1][g / 2][g & 1] = EXP2(lo[g][1]);
+                            d2[2][g / 2][g & 1] = EXP2(hi[g][0]); d2[3][g / 2][g & 1] = EXP2(hi[g][1]);
                         }
+                    }
+                    // rows q >= N: dP = 0 and rD2 = 0 (loaded as 0), so dS' = 0 there without a mask
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int gp = 0; gp < H / 2; ++gp) d2[r][gp] = d2[r][gp] * (dPT[j][r][gp] - rD2[gp]);
+                    if (TMASK(j)) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool kv = KVAL(j, r);
+#pragma unroll
+                            for (int gp = 0; gp < H / 2; ++gp) if (!kv) d2[r][gp] = splat2(0.f);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                        for (int gp = 0; gp < H / 2; ++gp) gb2[gp] += d2[r][gp];
 #pragma unroll
                         for (int h = 0; h < H; ++h) {
-                            float v = 0.f;
+                            const f32x2_t sb = splat2(acc[j][h][r]);
 #pragma unroll
-                            for (int g = 0; g < H; ++g) v = fmaf(wl[g][h], ds1[g], v);
-                            o4[h][r] = v;
+                            for (int gp = 0; gp < H / 2; ++gp) gWp[gp * H + h] = fma2(d2[r][gp], sb, gWp[gp * H + h]);
+                        }
+                    }
+                    f32x2_t ds[4][H / 2];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                        for (int hp = 0; hp < H / 2; ++hp) ds[r][hp] = splat2(0.f);
+#pragma unroll
+                        for (int g = 0; g < H; ++g) {
+                            const f32x2_t db = splat2(d2[r][g / 2][g & 1]);
+#pragma unroll
+                            for (int hp = 0; hp < H / 2; ++hp) ds[r][hp] = fma2(db, (f32x2_t){wl[g][2 * hp], wl[g][2 * hp + 1]}, ds[r][hp]);
                         }
                     }
                     if (TV(j)) {
 #pragma unroll
                         for (int h = 0; h < H; ++h) {
                             bf16x4_t o;
-                            o[0] = (__bf16)o4[h][0]; o[1] = (__bf16)o4[h][1]; o[2] = (__bf16)o4[h][2]; o[3] = (__bf16)o4[h][3];
-                            *reinterpret_cast<bf16x4_t*>(a.outT + (((long)b * H + h) * (nt * 16) + q) * a.ldq + KB(j)) = o;
+                            o[0] = (__bf16)ds[0][h / 2][h & 1]; o[1] = (__bf16)ds[1][h / 2][h & 1];
+                            o[2] = (__bf16)ds[2][h / 2][h & 1]; o[3] = (__bf16)ds[3][h / 2][h & 1];
+                            *reinterpret_cast<bf16x4_t*>(a.outT + (((((long)b * H + h) * nt + qt) * nt + (kt_first + j)) * 64 + lane) * 4) = o;
                         }
                     }
                 }
             }
+#undef TMASK
+#undef KVAL
 #undef KB
 #undef TV
         }
@@ -382,12 +494,12 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                     for (int o = 16; o <= 32; o <<= 1) {
                         const float om = __shfl_xor(m, o, 64), ol = __shfl_xor(l, o, 64);
                         const float mn = fmaxf(m, om);
-                        l = (mn > -INFINITY) ? l * __expf(m - mn) + ol * __expf(om - mn) : 0.f;
+                        l = (mn > -INFINITY) ? l * EXP2(m - mn) + ol * EXP2(om - mn) : 0.f;
                         m = mn;
                     }
                     if (lane < 16) { sred[((wave * H + g) * 16 + lane) * 2] = m; sred[((wave * H + g) * 16 + lane) * 2 + 1] = l; }
                 } else {
-                    float d = rD[g];
+                    float d = rD2[g / 2][g & 1];
                     d += __shfl_xor(d, 16, 64);
                     d += __shfl_xor(d, 32, 64);
                     if (lane < 16) sred[((wave * H + g) * 16 + lane) * 2] = d;
@@ -403,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                     for (int w = 0; w < 4; ++w) mn = fmaxf(mn, sred[((w * H * 16) + i) * 2]);
                     float l = 0.f;
                     if (mn > -INFINITY)
-                        for (int w = 0; w < 4; ++w) l += sred[((w * H * 16) + i) * 2 + 1] * __expf(sred[((w * H * 16) + i) * 2] - mn);
+                        for (int w = 0; w < 4; ++w) l += sred[((w * H * 16) + i) * 2 + 1] * EXP2(sred[((w * H * 16) + i) * 2] - mn);
                     dst[0] = mn; dst[1] = l;
                 } else {
                     float d = 0.f;
@@ -424,10 +536,11 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
         for (int g = 0; g < H; ++g) {
 #pragma unroll
             for (int h = 0; h < H; ++h) {
-                const float v = spe_wave_sum(gW[g][h]);
+                // mode 3 accumulated dS' . (log2(e) S)^T
+                const float v = (MODE == 2) ? spe_wave_sum(gWp[g * (H / 2) + h / 2][h & 1]) : SPE_LN2 * spe_wave_sum(gWp[(g / 2) * H + h][g & 1]);
                 if (lane == 0) part[wave * (H * H + H) + g * H + h] = v;
             }
-            const float v = spe_wave_sum(gb[g]);
+            const float v = spe_wave_sum((MODE == 2) ? gb[(MODE == 2) ? g : 0] : gb2[(MODE == 3) ? g / 2 : 0][g & 1]);
             if (lane == 0) part[wave * (H * H + H) + H * H + g] = v;
         }
         __syncthreads();
@@ -454,7 +567,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
         float mn = -INFINITY;
         for (int s = 0; s <= last_wg - first_wg; ++s) mn = fmaxf(mn, base[s * stride]);
         float l = 0.f;
-        for (int s = 0; s <= last_wg - first_wg; ++s) l += base[s * stride + 1] * __expf(base[s * stride] - mn);
+        for (int s = 0; s <= last_wg - first_wg; ++s) l += base[s * stride + 1] * EXP2(base[s * stride] - mn);
         out0[o] = mn; out1[o] = 1.f / l;
     } else {
         float d = 0.f;
@@ -537,7 +650,7 @@ static int launch_fused(const FusedArgs& a, int nwg, hipStream_t st) {
 // pass (4 tiles: 0.43 -> 0.48 ms, occupancy loss) and for the backward passes (H*H weight-gradient accumulators +
 // the second accumulator set)
 #ifndef SPE_FUSED_KTF
-#define SPE_FUSED_KTF 4
+#define SPE_FUSED_KTF 2
 #endif
 #ifndef SPE_FUSED_KTB
 #define SPE_FUSED_KTB 1
@@ -558,13 +671,13 @@ static int dispatch_mode(const FusedArgs& a, int mode, bool drop, int nwg, hipSt
 extern "C" int spe_talking_fused(int mode, const void* Qf, const void* Kf, const void* Vf, const void* dOf,
                                  const float* Wl, const float* bl, const float* Ww, const float* bw,
                                  const float* M, const float* IL, const float* D, float* ws_stats, float* ws_w, void* outT,
-                                 int B, int H, int N, int dh, long ldq, int nwg, float p_drop, uint64_t seed, uint64_t offset,
+                                 int B, int H, int N, int dh, int nwg, float p_drop, uint64_t seed, uint64_t offset,
                                  hipStream_t st) {
     FusedArgs a;
     a.Qf = (const u32x4_t*)Qf; a.Kf = (const u32x4_t*)Kf; a.Vf = (const u32x4_t*)Vf; a.dOf = (const u32x4_t*)dOf;
     a.Wl = Wl; a.bl = bl; a.Ww = Ww; a.bw = bw; a.M = M; a.IL = IL; a.D = D;
     a.ws_stats = ws_stats; a.ws_w = ws_w; a.outT = (unsigned short*)outT;
-    a.B = B; a.N = N; a.nt = (N + 15) / 16; a.ldq = ldq;
+    a.B = B; a.N = N; a.nt = (N + 15) / 16;
     a.total_steps = (long)B * a.nt * a.nt;
     if (a.total_steps <= 0) return 0;
     a.steps_per_wg = plan_spw(a.total_steps, a.nt, nwg);

@@ -319,11 +319,14 @@ def box_loss_bwd(srow_i64, lidx_i32, g1, g2, c1, c2, shape):
 
 
 # ---- fused talking-heads attention (bf16 mode) ----------------------------------------------
-FUSED_NWG = 512          # two workgroups per CU
+FUSED_NWG = 512          # two workgroups per CU (the planned partition is shared by all four modes)
 
 
 def fused_supported(H, dh):
     return H in (4, 8) and dh <= 64
+
+
+LOG2E = 1.4426950408889634
 
 
 def attn_pack(x4, scale=1.0):
@@ -342,9 +345,35 @@ def fused_plan(B, N):
     return spw.value, nwg.value
 
 
-def talking_fused(mode, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, ws_stats, ws_w, outT, B, H, N, dh, ldq, p_drop, seed, offset):
+def talking_fused(mode, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, ws_stats, ws_w, outT, B, H, N, dh, p_drop, seed, offset):
     _call("spe_talking_fused", mode, _p(Qf), _p(Kf), _p(Vf), _p(dOf), _p(Wl), _p(bl), _p(Ww), _p(bw), _p(M), _p(IL), _p(D),
-          _p(ws_stats), _p(ws_w), _p(outT), B, H, N, dh, ldq, FUSED_NWG, float(p_drop), seed, offset, _st())
+          _p(ws_stats), _p(ws_w), _p(outT), B, H, N, dh, FUSED_NWG, float(p_drop), seed, offset, _st())
+
+
+def score_blocks(B, H, N, device):
+    """Uninitialised blocked bf16 score tensor [B,H,nt,nt,64,4] (16x16 blocks; see csrc/attn_contract.hip)."""
+    nt = (N + 15) // 16
+    return torch.empty((B, H, nt, nt, 64, 4), device=device, dtype=torch.bfloat16)
+
+
+def attn_pack16(x4):
+    """x4: [B,N,H,dh] fp32 view (unit last stride) -> bf16 MFMA 16x16x16 A fragments [B,H,nt,ceil(dh/16),64,4]."""
+    B, N, H, dh = x4.shape
+    assert x4.stride(3) == 1
+    nt, DT = (N + 15) // 16, (dh + 15) // 16
+    out = torch.empty((B, H, nt, DT, 64, 4), device=x4.device, dtype=torch.bfloat16)
+    _call("spe_attn_pack16", _p(x4), x4.stride(0), x4.stride(1), x4.stride(2), B, N, H, dh, _p(out), _st())
+    return out
+
+
+def attn_contract(T, X16, out4, trans, alpha=1.0):
+    """out4[b, row, h, :] = alpha * sum T[b,h][q,key] x[.., :]  (trans=False: rows = q, sum over keys; True: rows = keys,
+    sum over q).  out4: [B,N,H,dh] fp32 view with unit last stride."""
+    B, N, H, dh = out4.shape
+    assert out4.stride(3) == 1
+    _call("spe_attn_contract", _p(T), _p(X16), _p(out4), out4.stride(0), out4.stride(1), out4.stride(2), B, H, N, dh,
+          int(trans), float(alpha), _st())
+    return out4
 
 
 def attn_merge(ws_stats, B, H, N, spw, mode):

@@ -7,7 +7,8 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "spe_hip.h")
-LIBPATH = os.path.join(HERE, "libspe_hip.so")
+# SPE_HIP_LIB: developer override used by tools/ab.py to A/B kernel variants built with different -D flags
+LIBPATH = os.environ.get("SPE_HIP_LIB") or os.path.join(HERE, "libspe_hip.so")
 
 _CTYPES = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,

@@ -190,8 +190,8 @@ class _TalkingHeadsAttention(Function):
 
 class _TalkingHeadsAttentionFused(Function):
     """Same operator on the fused score kernels (csrc/attn_fused.hip): no fp32 N x N tensor in HBM.
-    forward : pack q*scale,k -> statistics pass -> write pass (P'd bf16) -> O = P'd V (bf16-A GEMM)
-    backward: dV = P'd^T dO ; pass 1 (D, dWw, dbw) ; pass 2 (dS bf16, dWl, dbl) ; dQ, dK GEMMs.
+    forward : pack q*scale*log2e,k -> statistics pass -> write pass (P'd, blocked bf16) -> O = P'd V (streaming contraction)
+    backward: dV = P'd^T dO ; pass 1 (D, dWw, dbw) ; pass 2 (dS blocked bf16, dWl, dbl) ; dQ, dK contractions.
     Saved for backward: qkv, the packed q/k fragments, P'd (bf16) and the row statistics."""
 
     @staticmethod
@@ -203,51 +203,49 @@ class _TalkingHeadsAttentionFused(Function):
         v5 = qkv.view(B, N, 3, H, dh)
         q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
         nt = (N + 15) // 16
-        ld = nt * 16
         spw, nwg = K.fused_plan(B, N)
-        Qf, Kf = K.attn_pack(q, scale), K.attn_pack(k, 1.0)
+        # the fused kernels work in the log2 domain: scale * log2(e) is folded into the Q fragments
+        Qf, Kf = K.attn_pack(q, scale * K.LOG2E), K.attn_pack(k, 1.0)
         Wl, bl, Ww, bw = Wl.contiguous(), bl.contiguous(), Ww.contiguous(), bw.contiguous()
         ws_stats = torch.empty((B * nt * 8 * H * 32,), device=qkv.device, dtype=torch.float32)
         seed, off = K.next_rng() if p_drop > 0 else (0, 0)
-        K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws_stats, None, None, B, H, N, dh, ld, 0.0, 0, 0)
+        K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws_stats, None, None, B, H, N, dh, 0.0, 0, 0)
         M, IL = K.attn_merge(ws_stats, B, H, N, spw, 0)
-        Pd = torch.empty((B, H, ld, ld), device=qkv.device, dtype=torch.bfloat16)          # [q, key]
-        K.talking_fused(1, Qf, Kf, None, None, Wl, bl, Ww, bw, M, IL, None, None, None, Pd, B, H, N, dh, ld, p_drop, seed, off)
+        Pd = K.score_blocks(B, H, N, qkv.device)
+        K.talking_fused(1, Qf, Kf, None, None, Wl, bl, Ww, bw, M, IL, None, None, None, Pd, B, H, N, dh, p_drop, seed, off)
         O = torch.empty((B, N, C), device=qkv.device, dtype=torch.float32)
-        sP, sq = (H * ld * ld, ld * ld), (N * C3, dh)
-        K.gemm_bf16a(Pd, v, O, N, dh, N, ld, C3, C, False, False, B, H, sP, sq, (N * C, dh))
-        ctx.meta = (B, N, C, H, dh, nt, ld, spw, nwg, scale, p_drop, seed, off)
+        K.attn_contract(Pd, K.attn_pack16(v), O.view(B, N, H, dh), False)
+        ctx.meta = (B, N, C, H, dh, nt, spw, nwg, scale, p_drop, seed, off)
         ctx.save_for_backward(qkv, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw)
         return O
 
     @staticmethod
     def backward(ctx, dO):
         qkv, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw = ctx.saved_tensors
-        B, N, C, H, dh, nt, ld, spw, nwg, scale, p_drop, seed, off = ctx.meta
-        C3 = 3 * C
+        B, N, C, H, dh, nt, spw, nwg, scale, p_drop, seed, off = ctx.meta
         dO = dO.contiguous()
         v5 = qkv.view(B, N, 3, H, dh)
         q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
         dqkv = torch.empty_like(qkv)
         d5 = dqkv.view(B, N, 3, H, dh)
         dq, dk, dv = d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]
-        sP, sq, sO = (H * ld * ld, ld * ld), (N * C3, dh), (N * C, dh)
+        dO4 = dO.view(B, N, H, dh)
         # dV[key,d] = sum_q P'd[q,key] dO[q,d]
-        K.gemm_bf16a(Pd, dO, dv, N, dh, N, ld, C, C3, True, False, B, H, sP, sO, sq)
-        Vf, dOf = K.attn_pack(v, 1.0), K.attn_pack(dO.view(B, N, H, dh), 1.0)
+        K.attn_contract(Pd, K.attn_pack16(dO4), dv, True)
+        Vf, dOf = K.attn_pack(v, 1.0), K.attn_pack(dO4, 1.0)
         nw = 2 * (H * H + H)
         ws_stats = torch.empty((B * nt * 8 * H * 32,), device=qkv.device, dtype=torch.float32)
         ws_w = torch.empty((nwg, nw), device=qkv.device, dtype=torch.float32)
-        K.talking_fused(2, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, None, ws_stats, ws_w, None, B, H, N, dh, ld, p_drop, seed, off)
+        K.talking_fused(2, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, None, ws_stats, ws_w, None, B, H, N, dh, p_drop, seed, off)
         D, _ = K.attn_merge(ws_stats, B, H, N, spw, 2)
-        dS = torch.empty((B, H, ld, ld), device=qkv.device, dtype=torch.bfloat16)
-        K.talking_fused(3, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, None, ws_w, dS, B, H, N, dh, ld, p_drop, seed, off)
+        dS = K.score_blocks(B, H, N, qkv.device)
+        K.talking_fused(3, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, None, ws_w, dS, B, H, N, dh, p_drop, seed, off)
         g = K.colsum(ws_w)
         hh = H * H
         dWl, dbl, dWw, dbw = g[:hh].view(H, H), g[hh:hh + H], g[hh + H:2 * hh + H].view(H, H), g[2 * hh + H:]
         # dQ[q,d] = scale * sum_key dS[q,key] K[key,d] ; dK[key,d] = scale * sum_q dS[q,key] Q[q,d]
-        K.gemm_bf16a(dS, k, dq, N, dh, N, ld, C3, C3, False, False, B, H, sP, sq, sq, alpha=scale)
-        K.gemm_bf16a(dS, q, dk, N, dh, N, ld, C3, C3, True, False, B, H, sP, sq, sq, alpha=scale)
+        K.attn_contract(dS, K.attn_pack16(k), dq, False, alpha=scale)
+        K.attn_contract(dS, K.attn_pack16(q), dk, True, alpha=scale)
         return dqkv, dWl, dbl, dWw, dbw, None, None, None
 
 

@@ -16,7 +16,7 @@ q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
 nt = (N + 15) // 16; ldq = nt * 16
 spw, nwg = K.fused_plan(B, N)
 print("nt", nt, "spw", spw, "nwg", nwg)
-Qf, Kf, Vf, dOf = K.attn_pack(q, scale), K.attn_pack(k), K.attn_pack(v), K.attn_pack(dO.view(B, N, H, dh))
+Qf, Kf, Vf, dOf = K.attn_pack(q, scale * K.LOG2E), K.attn_pack(k), K.attn_pack(v), K.attn_pack(dO.view(B, N, H, dh))
 ws = torch.zeros(B * nt * 8 * H * 32, device=dev)
 K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws, None, None, B, H, N, dh, ldq, 0.0, 0, 0)
 M, IL = K.attn_merge(ws, B, H, N, spw, 0)

@@ -13,15 +13,15 @@ dO = torch.randn(B, N, C, generator=g).to(dev)
 scale = dh ** -0.5
 v5 = qkv.view(B, N, 3, H, dh)
 q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
-nt = (N + 15) // 16; ldq = nt * 16
+nt = (N + 15) // 16
 spw, nwg = K.fused_plan(B, N)
-Qf, Kf, Vf, dOf = K.attn_pack(q, scale), K.attn_pack(k), K.attn_pack(v), K.attn_pack(dO.view(B, N, H, dh))
+Qf, Kf, Vf, dOf = K.attn_pack(q, scale * K.LOG2E), K.attn_pack(k), K.attn_pack(v), K.attn_pack(dO.view(B, N, H, dh))
 ws = torch.zeros(B * nt * 8 * H * 32, device=dev)
 ws_w = torch.zeros(nwg, 2 * (H * H + H), device=dev)
-PT = torch.empty(B, H, ldq, ldq, device=dev, dtype=torch.bfloat16)
-dST = torch.empty(B, H, ldq, ldq, device=dev, dtype=torch.bfloat16)
+PT = K.score_blocks(B, H, N, dev)
+dST = K.score_blocks(B, H, N, dev)
 O = torch.empty(B, N, C, device=dev)
-K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws, None, None, B, H, N, dh, ldq, 0.0, 0, 0)
+K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws, None, None, B, H, N, dh, 0.0, 0, 0)
 M, IL = K.attn_merge(ws, B, H, N, spw, 0)
 D = torch.zeros(B, H, N, device=dev)
 def t(fn, n=5):
@@ -31,11 +31,15 @@ def t(fn, n=5):
     for _ in range(n): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
-f = lambda mode, out=None: K.talking_fused(mode, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, ws, ws_w, out, B, H, N, dh, ldq, 0.0, 0, 0)
-print("pack q", t(lambda: K.attn_pack(q, scale)))
+f = lambda mode, out=None: K.talking_fused(mode, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, ws, ws_w, out, B, H, N, dh, 0.0, 0, 0)
+print("pack q", t(lambda: K.attn_pack(q, scale * K.LOG2E)))
 for mode, out in ((0, None), (1, PT), (2, None), (3, dST)):
     print("mode", mode, "%.3f ms" % t(lambda: f(mode, out)))
-sP, sq, sO = (H * ldq * ldq, ldq * ldq), (N * 3 * C, dh), (N * C, dh)
-print("PV  gemm bf16A^T %.3f ms" % t(lambda: K.gemm_bf16a(PT, v, O, N, dh, N, ldq, 3 * C, C, False, False, B, H, sP, sq, sO)))
 dq = torch.empty_like(qkv)
-print("dV  gemm bf16A   %.3f ms" % t(lambda: K.gemm_bf16a(PT, dO, dq.view(B, N, 3, H, dh)[:, :, 2], N, dh, N, ldq, C, 3 * C, True, False, B, H, sP, sO, sq)))
+d5 = dq.view(B, N, 3, H, dh)
+print("pack16 v %.3f ms" % t(lambda: K.attn_pack16(v)))
+V16, dO16 = K.attn_pack16(v), K.attn_pack16(dO.view(B, N, H, dh))
+print("PV  contract   %.3f ms" % t(lambda: K.attn_contract(PT, V16, O.view(B, N, H, dh), False)))
+print("dV  contract^T %.3f ms" % t(lambda: K.attn_contract(PT, dO16, d5[:, :, 2], True)))
+print("dQ  contract   %.3f ms" % t(lambda: K.attn_contract(dST, V16, d5[:, :, 0], False, alpha=scale)))
+print("dK  contract^T %.3f ms" % t(lambda: K.attn_contract(dST, dO16, d5[:, :, 1], True, alpha=scale)))
