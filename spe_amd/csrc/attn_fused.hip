@@ -46,19 +46,20 @@ struct FusedArgs {
     float p_drop; uint64_t seed, offset;
 };
 
-// H*H mixing weights -> SGPRs.  `wv` holds W[lane] (one weight per lane, loaded once per kernel); a phase
-// pulls the H*H values into scalar registers with v_readlane.  The empty asm launders the vector register so
-// that the readlanes cannot be hoisted out of the tile loop: a matrix then occupies SGPRs for one register
-// phase only (both matrices at once do not fit the scalar file).  hipcc only emits s_load for pointers it can
-// prove read-only; after any laundering it falls back to per-lane VMEM loads into VGPRs, hence this form.
+// H*H mixing weights -> SGPRs, once per register phase: H*H/16 s_load_dwordx16 through the scalar cache (no
+// VALU slots; v_readlane from a staging VGPR cost ~30 % of a pass's vector instructions).  The pointer is cast to
+// the constant address space - hipcc only selects SMEM for global loads it can prove unclobbered, constant loads
+// always qualify - and laundered through an SGPR so that the invariant loads are not hoisted out of the tile
+// loop: a matrix then occupies the scalar file for one phase only (both at once do not fit).
+typedef const __attribute__((address_space(4))) float* spe_cfp;
 template <int H>
-__device__ __forceinline__ void load_w(float wv, float (&w)[H][H]) {
-    asm volatile("" : "+v"(wv));
+__device__ __forceinline__ void load_w(const float* p, float (&w)[H][H]) {
+    spe_cfp wp = (spe_cfp)p;
+    asm volatile("" : "+s"(wp));
 #pragma unroll
     for (int g = 0; g < H; ++g)
 #pragma unroll
-        for (int h = 0; h < H; ++h)
-            w[g][h] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv), g * H + h));
+        for (int h = 0; h < H; ++h) w[g][h] = wp[g * H + h];
 }
 
 #define FUSED_MAXSLOT 8
@@ -95,6 +96,13 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
 #ifndef SPE_FUSED_PREF1
 #define SPE_FUSED_PREF1 1
 #endif
+#ifndef SPE_FUSED_QG
+#define SPE_FUSED_QG 2
+#endif
+    // modes 0, 1 keep the q-tile's Q fragments in registers (64 VGPRs at H = 8, dh <= 64); the backward modes have no
+    // room and read them (and dO) from LDS in groups of QG jobs
+    constexpr bool QREG = (MODE <= 1);
+    constexpr int QG = QREG ? ((JB >= 4) ? 4 : JB) : ((JB >= SPE_FUSED_QG) ? SPE_FUSED_QG : JB);
     constexpr bool PREF = (MODE == 0) || (MODE == 1 && SPE_FUSED_PREF1) || (MODE == 2 && !DROP);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4_t* sQ = reinterpret_cast<u32x4_t*>(smem_raw);    // [NFR][64]
@@ -106,15 +114,11 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
     const long s_begin = (long)blockIdx.x * a.steps_per_wg;
     long s_end = s_begin + a.steps_per_wg; if (s_end > a.total_steps) s_end = a.total_steps;
 
-    // The mixing matrices are (re)loaded into SGPRs at the start of each register phase (see load_w): both
-    // together (2*H*H+2H values) do not fit the scalar file next to the addressing state.
     // Scores arrive in the log2 domain (spe_attn_pack folds scale * log2(e) into the Q fragments): Wl S + bl*log2(e)
     // is log2(e) * S', so every exponential is a bare v_exp_f32.
     float vbl2[H], vbw[H];
 #pragma unroll
     for (int g = 0; g < H; ++g) { vbl2[g] = a.bl[g] * SPE_LOG2E; vbw[g] = a.bw[g]; }
-    const float wlv = a.Wl[(threadIdx.x & 63) < H * H ? (threadIdx.x & 63) : 0];   // lane i holds Wl[i / H][i % H]
-    const float wwv = a.Ww[(threadIdx.x & 63) < H * H ? (threadIdx.x & 63) : 0];
     // weight-gradient accumulators (whole workgroup range)
     // as head pairs: mode 2 gWp[g*(H/2)+hp] = (dWw[g][2hp], dWw[g][2hp+1]) ; mode 3 gWp[gp*H+h] = (dWl[2gp][h], dWl[2gp+1][h])
     f32x2_t gWp[(MODE >= 2) ? H * H / 2 : 1], gb2[(MODE == 3) ? H / 2 : 1];
@@ -139,14 +143,21 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
         const int q = qt * 16 + (lane & 15);
         const bool qv = q < N;
         // ---- stage this q-tile's Q (and dO) fragments in LDS
-        __syncthreads();
-        for (int i = threadIdx.x; i < NFR * 64; i += 256) {
-            const int fr = i >> 6, ln = i & 63, h = fr / DSTEPS, st = fr % DSTEPS;
-            const long src = ((((long)b * H + h) * nt + qt) * DSTEPS + st) * 64 + ln;
-            sQ[i] = a.Qf[src];
-            if (MODE >= 2) sdO[i] = a.dOf[src];
+        u32x4_t qreg[QREG ? NFR : 1];
+        if (QREG) {
+            __syncthreads();                                   // sred of the previous segment has been consumed
+#pragma unroll
+            for (int f = 0; f < NFR; ++f) qreg[QREG ? f : 0] = a.Qf[(((long)b * H * nt + (long)(f / DSTEPS) * nt + qt) * DSTEPS + (f % DSTEPS)) * 64 + lane];
+        } else {
+            __syncthreads();
+            for (int i = threadIdx.x; i < NFR * 64; i += 256) {
+                const int fr = i >> 6, ln = i & 63, h = fr / DSTEPS, st = fr % DSTEPS;
+                const long src = ((((long)b * H + h) * nt + qt) * DSTEPS + st) * 64 + ln;
+                sQ[i] = a.Qf[src];
+                if (MODE >= 2) sdO[i] = a.dOf[src];
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // ---- per-lane row state
         float rm[(MODE == 0) ? H : 1], rl[(MODE == 0) ? H : 1], c0[(MODE >= 1) ? H : 1];
         f32x2_t rD2[(MODE >= 2) ? H / 2 : 1];
@@ -192,23 +203,43 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
             constexpr int NB = NJ / JB;
             f32x4_t acc[KT][H];
             f32x4_t acc2[(MODE >= 2) ? KT : 1][(MODE >= 2) ? H : 1];
-            u32x4_t qf[DSTEPS];
             if (!PREF || km == wave) load_batch(0, kt_first);   // first macro step of the segment: nothing prefetched yet
 #pragma unroll
             for (int bi = 0; bi < NB; ++bi) {
+                // jobs of a batch go through the matrix pipe in groups of QG: the group's Q / dO fragments are read
+                // from LDS together (modes 0, 1: they live in registers for the whole segment) and the MFMAs are
+                // issued d-step outer / job inner, so that consecutive instructions are independent (a per-job
+                // read -> wait -> 2 dependent MFMAs sequence serialises ~150 cycles per head).
 #pragma unroll
-                for (int jj = 0; jj < JB; ++jj) {
-                    const int jb = bi * JB + jj;
-                    const int hj = jb % NH, tj = jb / NH;           // head job (0..NH-1; >= H: V/dO), tile within the macro step
-                    const int hh = hj % H;
-                    const u32x4_t* lds = (hj < H) ? sQ : sdO;
+                for (int g0 = 0; g0 < JB; g0 += QG) {
+                    u32x4_t qf[QREG ? 1 : QG * DSTEPS];
+                    f32x4_t c[QG];
+                    if (!QREG) {
 #pragma unroll
-                    for (int st = 0; st < DSTEPS; ++st) qf[st] = lds[(hh * DSTEPS + st) * 64 + lane];
-                    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+                        for (int jj = 0; jj < QG; ++jj) {
+                            const int hj = (bi * JB + g0 + jj) % NH;
+                            const u32x4_t* lds = (hj < H) ? sQ : sdO;
+#pragma unroll
+                            for (int st = 0; st < DSTEPS; ++st) qf[jj * DSTEPS + st] = lds[((hj % H) * DSTEPS + st) * 64 + lane];
+                        }
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < QG; ++jj) c[jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int st = 0; st < DSTEPS; ++st)
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fr[jj * DSTEPS + st]), __builtin_bit_cast(bf16x8_t, qf[st]), c, 0, 0, 0);
-                    if (hj < H) acc[tj][hh] = c; else acc2[(MODE >= 2) ? tj : 0][(MODE >= 2) ? hh : 0] = c;
+#pragma unroll
+                        for (int jj = 0; jj < QG; ++jj) {
+                            const int hj = (bi * JB + g0 + jj) % NH;
+                            const u32x4_t qv4 = QREG ? qreg[QREG ? (hj % H) * DSTEPS + st : 0] : qf[QREG ? 0 : jj * DSTEPS + st];
+                            c[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fr[(g0 + jj) * DSTEPS + st]),
+                                                                           __builtin_bit_cast(bf16x8_t, qv4), c[jj], 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int jj = 0; jj < QG; ++jj) {
+                        const int jb = bi * JB + g0 + jj;
+                        const int hj = jb % NH, tj = jb / NH, hh = hj % H;   // head job (>= H: V/dO), tile within the macro step
+                        if (hj < H) acc[tj][hh] = c[jj]; else acc2[(MODE >= 2) ? tj : 0][(MODE >= 2) ? hh : 0] = c[jj];
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (bi + 1 < NB) load_batch(bi + 1, kt_first);
@@ -229,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
             if constexpr (MODE == 0) {
                 // phase A (Wl): S' in place + macro-step max ; then one rescale + 4*KT exp2 per head
                 float wl[H][H];
-                load_w<H>(wlv, wl);
+                load_w<H>(a.Wl, wl);
                 float tmax[H];
 #pragma unroll
                 for (int g = 0; g < H; ++g) tmax[g] = -INFINITY;
@@ -272,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                 // phase A (Wl): acc <- P = exp2(S' + c0)   (c0 = bl - m + log2(1/l), all in the log2 domain)
                 {
                 float wl[H][H];
-                load_w<H>(wlv, wl);
+                load_w<H>(a.Wl, wl);
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     f32x2_t lo[H], hi[H];
@@ -292,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 // phase B (Ww): P'd = dropout(Ww P + bw) -> bf16
                 float ww[H][H];
-                load_w<H>(wwv, ww);
+                load_w<H>(a.Ww, ww);
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     f32x2_t lo[H], hi[H];
@@ -323,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                 f32x2_t PT[KT][4][H / 2];
                 {
                 float wl[H][H];
-                load_w<H>(wlv, wl);
+                load_w<H>(a.Wl, wl);
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     f32x2_t lo[H], hi[H];
@@ -349,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 // phase B (Ww): dP' = (dO V^T) keepscale ; dWw += dP' P^T ; dbw += dP' ; D += (Ww^T dP') . P
                 float ww[H][H];
-                load_w<H>(wwv, ww);
+                load_w<H>(a.Ww, ww);
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     // rows q >= N have zero dO fragments and keys >= N zero V fragments, so dP' is already 0 there
@@ -389,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                 f32x2_t dPT[KT][4][H / 2];
                 {
                 float ww[H][H];
-                load_w<H>(wwv, ww);
+                load_w<H>(a.Ww, ww);
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     if (DROP) {
@@ -417,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 float wl[H][H];
-                load_w<H>(wlv, wl);
+                load_w<H>(a.Wl, wl);
                 // phase B (Wl both ways): P from raw S, dS' = P (dP - D), dWl += dS' S^T, dS = Wl^T dS'
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
@@ -650,7 +681,7 @@ static int launch_fused(const FusedArgs& a, int nwg, hipStream_t st) {
 // pass (4 tiles: 0.43 -> 0.48 ms, occupancy loss) and for the backward passes (H*H weight-gradient accumulators +
 // the second accumulator set)
 #ifndef SPE_FUSED_KTF
-#define SPE_FUSED_KTF 2
+#define SPE_FUSED_KTF 1
 #endif
 #ifndef SPE_FUSED_KTB
 #define SPE_FUSED_KTB 1

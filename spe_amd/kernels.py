@@ -4,6 +4,7 @@ Every function takes CUDA fp32 tensors, allocates its outputs with torch (device
 PyTorch's job on this path) and enqueues the kernel on torch's current HIP stream.
 """
 import ctypes
+import os
 
 import torch
 
@@ -319,7 +320,9 @@ def box_loss_bwd(srow_i64, lidx_i32, g1, g2, c1, c2, shape):
 
 
 # ---- fused talking-heads attention (bf16 mode) ----------------------------------------------
-FUSED_NWG = 512          # two workgroups per CU (the planned partition is shared by all four modes)
+# workgroups per fused pass (256 CUs): the statistics and write passes need <= 168 VGPRs (3 waves per SIMD), the
+# backward passes ~250 (2 per SIMD).  Modes 2 and 3 share ws_w rows, so they use the same count.
+FUSED_NWG = {0: int(os.environ.get("SPE_FUSED_NWG0", 768)), 1: int(os.environ.get("SPE_FUSED_NWG1", 768)), 2: 512, 3: 512}
 
 
 def fused_supported(H, dh):
@@ -339,15 +342,16 @@ def attn_pack(x4, scale=1.0):
     return out
 
 
-def fused_plan(B, N):
+def fused_plan(B, N, mode):
+    """(steps per workgroup, workgroups) the launcher uses for pass `mode` (sizes ws_w, parametrises attn_merge)."""
     spw, nwg = ctypes.c_int(0), ctypes.c_int(0)
-    lib.call("spe_talking_fused_plan", B, N, FUSED_NWG, ctypes.byref(spw), ctypes.byref(nwg))
+    lib.call("spe_talking_fused_plan", B, N, FUSED_NWG[mode], ctypes.byref(spw), ctypes.byref(nwg))
     return spw.value, nwg.value
 
 
 def talking_fused(mode, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, ws_stats, ws_w, outT, B, H, N, dh, p_drop, seed, offset):
     _call("spe_talking_fused", mode, _p(Qf), _p(Kf), _p(Vf), _p(dOf), _p(Wl), _p(bl), _p(Ww), _p(bw), _p(M), _p(IL), _p(D),
-          _p(ws_stats), _p(ws_w), _p(outT), B, H, N, dh, FUSED_NWG, float(p_drop), seed, offset, _st())
+          _p(ws_stats), _p(ws_w), _p(outT), B, H, N, dh, FUSED_NWG[mode], float(p_drop), seed, offset, _st())
 
 
 def score_blocks(B, H, N, device):

@@ -203,26 +203,27 @@ class _TalkingHeadsAttentionFused(Function):
         v5 = qkv.view(B, N, 3, H, dh)
         q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
         nt = (N + 15) // 16
-        spw, nwg = K.fused_plan(B, N)
+        spw0, _ = K.fused_plan(B, N, 0)
         # the fused kernels work in the log2 domain: scale * log2(e) is folded into the Q fragments
         Qf, Kf = K.attn_pack(q, scale * K.LOG2E), K.attn_pack(k, 1.0)
         Wl, bl, Ww, bw = Wl.contiguous(), bl.contiguous(), Ww.contiguous(), bw.contiguous()
         ws_stats = torch.empty((B * nt * 8 * H * 32,), device=qkv.device, dtype=torch.float32)
         seed, off = K.next_rng() if p_drop > 0 else (0, 0)
         K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws_stats, None, None, B, H, N, dh, 0.0, 0, 0)
-        M, IL = K.attn_merge(ws_stats, B, H, N, spw, 0)
+        M, IL = K.attn_merge(ws_stats, B, H, N, spw0, 0)
         Pd = K.score_blocks(B, H, N, qkv.device)
         K.talking_fused(1, Qf, Kf, None, None, Wl, bl, Ww, bw, M, IL, None, None, None, Pd, B, H, N, dh, p_drop, seed, off)
         O = torch.empty((B, N, C), device=qkv.device, dtype=torch.float32)
         K.attn_contract(Pd, K.attn_pack16(v), O.view(B, N, H, dh), False)
-        ctx.meta = (B, N, C, H, dh, nt, spw, nwg, scale, p_drop, seed, off)
+        ctx.meta = (B, N, C, H, dh, nt, scale, p_drop, seed, off)
         ctx.save_for_backward(qkv, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw)
         return O
 
     @staticmethod
     def backward(ctx, dO):
         qkv, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw = ctx.saved_tensors
-        B, N, C, H, dh, nt, spw, nwg, scale, p_drop, seed, off = ctx.meta
+        B, N, C, H, dh, nt, scale, p_drop, seed, off = ctx.meta
+        spw, nwg = K.fused_plan(B, N, 2)
         dO = dO.contiguous()
         v5 = qkv.view(B, N, 3, H, dh)
         q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]

@@ -14,12 +14,13 @@ scale = dh ** -0.5
 v5 = qkv.view(B, N, 3, H, dh)
 q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
 nt = (N + 15) // 16; ldq = nt * 16
-spw, nwg = K.fused_plan(B, N)
+spw0, _ = K.fused_plan(B, N, 0)
+spw, nwg = K.fused_plan(B, N, 2)
 print("nt", nt, "spw", spw, "nwg", nwg)
 Qf, Kf, Vf, dOf = K.attn_pack(q, scale * K.LOG2E), K.attn_pack(k), K.attn_pack(v), K.attn_pack(dO.view(B, N, H, dh))
 ws = torch.zeros(B * nt * 8 * H * 32, device=dev)
 K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws, None, None, B, H, N, dh, ldq, 0.0, 0, 0)
-M, IL = K.attn_merge(ws, B, H, N, spw, 0)
+M, IL = K.attn_merge(ws, B, H, N, spw0, 0)
 # reference (bf16-rounded q,k like the kernel)
 bf = lambda t: t.to(torch.bfloat16).double()
 qd, kd, vd, dOd = bf(q * scale), bf(k), bf(v), bf(dO.view(B, N, H, dh))

@@ -14,7 +14,8 @@ scale = dh ** -0.5
 v5 = qkv.view(B, N, 3, H, dh)
 q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
 nt = (N + 15) // 16
-spw, nwg = K.fused_plan(B, N)
+spw0, _ = K.fused_plan(B, N, 0)
+spw, nwg = K.fused_plan(B, N, 2)
 Qf, Kf, Vf, dOf = K.attn_pack(q, scale * K.LOG2E), K.attn_pack(k), K.attn_pack(v), K.attn_pack(dO.view(B, N, H, dh))
 ws = torch.zeros(B * nt * 8 * H * 32, device=dev)
 ws_w = torch.zeros(nwg, 2 * (H * H + H), device=dev)
@@ -22,7 +23,7 @@ PT = K.score_blocks(B, H, N, dev)
 dST = K.score_blocks(B, H, N, dev)
 O = torch.empty(B, N, C, device=dev)
 K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws, None, None, B, H, N, dh, 0.0, 0, 0)
-M, IL = K.attn_merge(ws, B, H, N, spw, 0)
+M, IL = K.attn_merge(ws, B, H, N, spw0, 0)
 D = torch.zeros(B, H, N, device=dev)
 def t(fn, n=5):
     fn(); torch.cuda.synchronize()
