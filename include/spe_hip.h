@@ -66,6 +66,19 @@ int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const
                       const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,
                       spe_stream_t stream);
 
+/* ---- bf16-operand Linear GEMM (benchmark precision mode): C = act(alpha * A16 B16^T + bias), both operands
+ * k-contiguous bf16 (lda, ldb, K multiples of 8; 16-B aligned bases), fp32 C / C2 (pre-activation) / bias.
+ * splitk < 0: |splitk| K-slices write private slabs C + z*M*ldc (no bias/act; sum them with spe_colsum).
+ * The three products of nn.Linear and its autograd (reference models/cait.py:376,390,409;
+ * models/transformer.py:368-425) are NT products of copies made by spe_cvt_bf16:
+ *   y = x W^T: (x16, W16) ; dx = dy W: (dy16, W16T) ; dW = dy^T x: (dy16T, x16T), contraction zero padded.
+ * spe_cvt_bf16: out[R][ldo] = bf16(x) (round to nearest even, the rounding spe_gemm_f32 applies while staging)
+ * and/or outT[C][ldt] = transpose, columns R..ldt-1 zero filled.  Either output may be NULL. */
+int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const float* bias, float* C2,
+                    int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int splitk,
+                    spe_stream_t stream);
+int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, long ldo, void* outT, long ldt, spe_stream_t stream);
+
 /* ---- masked softmax over scores[B,H,Nq,ld] (Nk valid columns per row).
  * mask[B,Nk] (1 = padded key, -inf) or null; P = softmax; Pd = dropout(P) written only when
  * p_drop > 0.  Reference models/attention.py:363-373, models/cait.py:125-131 (class attention).

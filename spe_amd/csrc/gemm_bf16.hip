@@ -1,0 +1,327 @@
+// bf16-operand GEMM for the Linear layers of the SPE hot path (gfx950), benchmark ("bf16") precision mode:
+//
+//   C[m][n] = act( alpha * sum_k A16[m][k] * B16[n][k] + bias[n] )        ("NT": both operands k-contiguous)
+//
+// spe_gemm_f32 rounds its fp32 operands to bf16 while staging them, so feeding it the SAME values already rounded
+// (spe_cvt_bf16, round-to-nearest-even) gives bit-identical products with half the bytes moved and - because a
+// thread's staging registers now hold twice the elements - two K tiles in flight per workgroup instead of one.
+// The M = 8300 layers of the backbone (12 K-iterations of ~0.2 us of MFMA against > 1 us of memory latency) are
+// bound by bytes-in-flight / latency, which is what this kernel raises.  All three products of a Linear map to NT:
+//   y  = x  W^T          A = x16   [R, K]      B = W16   [N, K]
+//   dx = dy W            A = dy16  [R, N]      B = W16T  [K, N]        (transposed weight copy, once per step)
+//   dW = dy^T x          A = dy16T [N, Rp]     B = x16T  [K, Rp]       (transposed activations, zero padded to Rp)
+// Replaces the nn.Linear GEMMs of reference models/cait.py:376,390,409 and models/transformer.py:368-425.
+//
+// Block = 256 threads = 4 waves (2x2); block tile BM x BN x 64 (BM, BN in {128, 64}); v_mfma_f32_16x16x32_bf16.
+// Pipeline per workgroup: tile t is multiplied out of LDS buffer t&1 while tile t+1 waits in registers and tile
+// t+2 is being fetched (16-B loads of 8 elements, no conversion work).
+#include "common.h"
+
+#define GB_BK 64
+#define GB_LDR 72      // bf16 per LDS row: 64 + 8 pad (144-B rows: 16-B aligned, conflict-light ds_read_b128)
+
+typedef unsigned int u32x4g_t __attribute__((ext_vector_type(4)));
+
+struct Gemm16Args {
+    const unsigned short* A; const unsigned short* B; float* C; float* C2; const float* bias;
+    int M, N, K;               // K: logical contraction length (multiple of 8; operands zero padded beyond it if needed)
+    long lda, ldb, ldc;
+    float alpha;
+    int act;                   // 0 none, 1 relu, 2 gelu(erf)
+    int splitk; long slab; int kt_per_split;
+    int xcd_bind;              // 0: plain tile order, 1: M-panels bound to XCDs, 2: N-panels bound to XCDs
+};
+
+__device__ __forceinline__ float gelu_erf16(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// thread t fetches 16-B chunk (t & 7) of rows (t >> 3) + 32*i ; rows are clamped (never stored), chunks past K zeroed
+template <int R>
+__device__ __forceinline__ void g16_load(const unsigned short* __restrict__ base, long ld, int row0, int nrows, int k0, int K,
+                                         u32x4g_t (&v)[R / 32]) {
+    const int t = threadIdx.x;
+    const int k = k0 + (t & 7) * 8;
+    const bool kv = k < K;
+    const int kc = kv ? k : 0;
+#pragma unroll
+    for (int i = 0; i < R / 32; ++i) {
+        const int r = min(row0 + (t >> 3) + 32 * i, nrows - 1);
+        const u32x4g_t q = *reinterpret_cast<const u32x4g_t*>(base + (long)r * ld + kc);
+        v[i] = kv ? q : (u32x4g_t){0u, 0u, 0u, 0u};
+    }
+}
+template <int R>
+__device__ __forceinline__ void g16_stage(unsigned short* lds, const u32x4g_t (&v)[R / 32]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < R / 32; ++i)
+        *reinterpret_cast<u32x4g_t*>(lds + ((t >> 3) + 32 * i) * GB_LDR + (t & 7) * 8) = v[i];
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    constexpr int NFM = BM / 32, NFN = BN / 32;        // 16x16 MFMA tiles per wave (wave tile BM/2 x BN/2)
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TA_ = BM * GB_LDR, TB_ = BN * GB_LDR;
+    auto sA = [&](int buf) { return smem16 + buf * (TA_ + TB_); };
+    auto sB = [&](int buf) { return smem16 + buf * (TA_ + TB_) + TA_; };
+
+    // workgroup b runs on XCD b % 8: the panels of the operand with more rows are bound to XCDs (all tiles reading
+    // one such panel run on the same XCD), so that operand is fetched into one L2 only; the other one is re-fetched
+    // per XCD.  Same mapping as spe_gemm_kernel.
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    int tm, tn;
+    if (p.xcd_bind == 0) { tm = blockIdx.x % tiles_m; tn = blockIdx.x / tiles_m; }
+    else {
+        const int no = (p.xcd_bind == 1) ? tiles_n : tiles_m;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int tb = xcd + 8 * (idx / no), to = idx % no;
+        tm = (p.xcd_bind == 1) ? tb : to; tn = (p.xcd_bind == 1) ? to : tb;
+        if (tm >= tiles_m || tn >= tiles_n) return;
+    }
+    const int zs = blockIdx.z;
+    float* C = p.C + (long)zs * p.slab;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int ktiles = (p.K + GB_BK - 1) / GB_BK;
+    const int kt_begin = zs * p.kt_per_split;
+    int kt_end = kt_begin + p.kt_per_split; if (kt_end > ktiles) kt_end = ktiles;
+    const int nt = kt_end - kt_begin;
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+
+    f32x4_t acc[NFM][NFN];
+#pragma unroll
+    for (int i = 0; i < NFM; ++i)
+#pragma unroll
+        for (int j = 0; j < NFN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    u32x4g_t ca[BM / 32], cb[BN / 32];     // tile t+1 (landed or landing)
+    u32x4g_t na[BM / 32], nb[BN / 32];     // tile t+2 (being fetched)
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) na[i] = (u32x4g_t){0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) nb[i] = (u32x4g_t){0u, 0u, 0u, 0u};
+    if (nt > 0) {
+        g16_load<BM>(p.A, p.lda, m0, p.M, kt_begin * GB_BK, p.K, ca);
+        g16_load<BN>(p.B, p.ldb, n0, p.N, kt_begin * GB_BK, p.K, cb);
+        g16_stage<BM>(sA(0), ca);
+        g16_stage<BN>(sB(0), cb);
+        if (nt > 1) {
+            g16_load<BM>(p.A, p.lda, m0, p.M, (kt_begin + 1) * GB_BK, p.K, ca);
+            g16_load<BN>(p.B, p.ldb, n0, p.N, (kt_begin + 1) * GB_BK, p.K, cb);
+        }
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            if (t + 2 < nt) {
+                g16_load<BM>(p.A, p.lda, m0, p.M, (kt_begin + t + 2) * GB_BK, p.K, na);
+                g16_load<BN>(p.B, p.ldb, n0, p.N, (kt_begin + t + 2) * GB_BK, p.K, nb);
+            }
+#pragma unroll
+            for (int ks = 0; ks < GB_BK / 32; ++ks) {
+                bf16x8_t a[NFM], b[NFN];
+#pragma unroll
+                for (int i = 0; i < NFM; ++i)
+                    a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sA(buf) + (wm * WM + i * 16 + fr) * GB_LDR + ks * 32 + fk));
+#pragma unroll
+                for (int j = 0; j < NFN; ++j)
+                    b[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sB(buf) + (wn * WN + j * 16 + fr) * GB_LDR + ks * 32 + fk));
+#pragma unroll
+                for (int i = 0; i < NFM; ++i)
+#pragma unroll
+                    for (int j = 0; j < NFN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+            if (t + 1 < nt) {
+                g16_stage<BM>(sA(buf ^ 1), ca);
+                g16_stage<BN>(sB(buf ^ 1), cb);
+            }
+#pragma unroll
+            for (int i = 0; i < BM / 32; ++i) ca[i] = na[i];
+#pragma unroll
+            for (int i = 0; i < BN / 32; ++i) cb[i] = nb[i];
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (same ownership as spe_gemm_kernel: MFMAs issued as (B-frag, A-frag), so
+    // acc[i][j][r] = C[m0 + wm*WM + i*16 + (lane&15)][n0 + wn*WN + j*16 + (lane>>4)*4 + r]: one 16-B store per tile)
+    float* C2 = p.C2;
+    const bool vst = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                     (!C2 || (reinterpret_cast<uintptr_t>(C2) & 15) == 0);
+#pragma unroll
+    for (int j = 0; j < NFN; ++j) {
+        const int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+        if (n >= p.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && p.splitk == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = p.bias[min(n + r, p.N - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < NFM; ++i) {
+            const int m = m0 + wm * WM + i * 16 + fr;
+            if (m >= p.M) continue;
+            const long off = (long)m * p.ldc + n;
+            const bool full = vst && (n + 3 < p.N);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+            if (p.splitk == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bv[r];
+                if (C2) {
+                    if (full) *reinterpret_cast<float4*>(C2 + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) C2[off + r] = v[r];
+                    }
+                }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                } else if (p.act == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf16(v[r]);
+                }
+            }
+            // split-K: the private slab of this split (zeros if the split was empty), summed by the caller
+            if (full) *reinterpret_cast<float4*>(C + off) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) C[off + r] = v[r];
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+static int launch_gemm16(const Gemm16Args& p, hipStream_t stream) {
+    constexpr int smem = 2 * (BM + BN) * GB_LDR * (int)sizeof(unsigned short);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16nt_kernel<BM, BN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    Gemm16Args q = p;
+    q.xcd_bind = 0;
+    if (p.M >= p.N && tiles_m >= 16) q.xcd_bind = 1;
+    else if (p.N > p.M && tiles_n >= 16) q.xcd_bind = 2;
+    else if (tiles_m >= 16) q.xcd_bind = 1;
+    else if (tiles_n >= 16) q.xcd_bind = 2;
+    int tiles = tiles_m * tiles_n;
+    if (q.xcd_bind == 1) tiles = 8 * ((tiles_m + 7) / 8) * tiles_n;
+    if (q.xcd_bind == 2) tiles = 8 * ((tiles_n + 7) / 8) * tiles_m;
+    dim3 grid(tiles, 1, p.splitk);
+    hipLaunchKernelGGL((gemm_bf16nt_kernel<BM, BN>), grid, dim3(256), smem, stream, q);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// C-ABI: see include/spe_hip.h (spe_gemm_bf16nt).  -2: unsupported alignment, -3: bias/act with split-K,
+// -5: more splits than K tiles.
+extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const float* bias, float* C2,
+                               int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int splitk,
+                               hipStream_t stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0) return -4;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al16(A16) || !al16(B16) || (lda & 7) || (ldb & 7) || (K & 7)) return -2;
+    Gemm16Args p;
+    p.A = reinterpret_cast<const unsigned short*>(A16); p.B = reinterpret_cast<const unsigned short*>(B16);
+    p.C = C; p.C2 = C2; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.alpha = alpha; p.act = act; p.slab = 0;
+    const int ktiles = (K + GB_BK - 1) / GB_BK;
+    if (splitk < 0) {           // slab mode: C holds |splitk| slabs of M*ldc floats
+        splitk = -splitk; p.slab = (long)M * ldc;
+        if (splitk > ktiles) return -5;
+    } else if (splitk > 1) return -2;     // no atomic mode here
+    if (splitk < 1) splitk = 1;
+    p.kt_per_split = (ktiles + splitk - 1) / splitk;
+    p.splitk = splitk;
+    if (splitk > 1 && (act != 0 || C2 != nullptr || bias != nullptr)) return -3;
+    // tile: 128x128 when that already fills the chip, else narrower tiles (more workgroups in flight)
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splitk;
+    if (t128 >= 384 && N > 64) return launch_gemm16<128, 128>(p, stream);
+    const long t64n = (long)((M + 127) / 128) * ((N + 63) / 64) * splitk;
+    if (t64n >= 256 && M > 64) return launch_gemm16<128, 64>(p, stream);
+    return launch_gemm16<64, 64>(p, stream);
+}
+
+// ---- fp32 -> bf16 (round to nearest even) copies of a [R, C] matrix: out[R][ldo] (row-major) and/or the
+// transpose outT[C][ldt] whose columns R..ldt-1 are zero filled (the contraction padding of the dW GEMM).
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ x, long ldx, int R, int C,
+                                                       unsigned short* __restrict__ out, long ldo,
+                                                       unsigned short* __restrict__ outT, long ldt) {
+    __shared__ unsigned short tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;        // 16 column quads x 16 row lanes
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 16 * i, c = c0 + tx * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < R) {
+            if (c + 3 < C && ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
+                const float4 q = *reinterpret_cast<const float4*>(x + (long)r * ldx + c);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (c + j < C) v[j] = x[(long)r * ldx + c + j];
+            }
+        }
+        typedef __bf16 bf16x4v_t __attribute__((ext_vector_type(4)));
+        bf16x4v_t h;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        const uint2 u = __builtin_bit_cast(uint2, h);
+        if (out && r < R) {
+            if (c + 3 < C && ((ldo & 3) == 0)) *reinterpret_cast<uint2*>(out + (long)r * ldo + c) = u;
+            else {
+                const unsigned short e[4] = {(unsigned short)(u.x & 0xffff), (unsigned short)(u.x >> 16), (unsigned short)(u.y & 0xffff), (unsigned short)(u.y >> 16)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (c + j < C) out[(long)r * ldo + c + j] = e[j];
+            }
+        }
+        if (outT) {
+            tile[ty + 16 * i][tx * 4 + 0] = (unsigned short)(u.x & 0xffff); tile[ty + 16 * i][tx * 4 + 1] = (unsigned short)(u.x >> 16);
+            tile[ty + 16 * i][tx * 4 + 2] = (unsigned short)(u.y & 0xffff); tile[ty + 16 * i][tx * 4 + 3] = (unsigned short)(u.y >> 16);
+        }
+    }
+    if (!outT) return;
+    __syncthreads();
+    // transposed write: thread -> (column c0 + ty + 16*i, rows r0 + 4*tx .. +3); rows beyond R were staged as zeros
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 16 * i;
+        const int r = r0 + tx * 4;
+        if (c >= C || r >= ldt) continue;
+        const unsigned short e0 = tile[tx * 4 + 0][ty + 16 * i], e1 = tile[tx * 4 + 1][ty + 16 * i];
+        const unsigned short e2 = tile[tx * 4 + 2][ty + 16 * i], e3 = tile[tx * 4 + 3][ty + 16 * i];
+        if (r + 3 < ldt && ((ldt & 3) == 0)) {
+            uint2 u; u.x = (unsigned)e0 | ((unsigned)e1 << 16); u.y = (unsigned)e2 | ((unsigned)e3 << 16);
+            *reinterpret_cast<uint2*>(outT + (long)c * ldt + r) = u;
+        } else {
+            const unsigned short e[4] = {e0, e1, e2, e3};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (r + j < ldt) outT[(long)c * ldt + r + j] = e[j];
+        }
+    }
+}
+
+// C-ABI: see include/spe_hip.h (spe_cvt_bf16).
+extern "C" int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, long ldo, void* outT, long ldt, hipStream_t stream) {
+    if (R <= 0 || C <= 0) return 0;
+    if (!out && !outT) return 0;
+    if (outT && ldt < R) return -2;
+    // the grid covers the padded row range of the transpose so that its zero columns are written too
+    const long rows = outT ? ((ldt > R) ? ldt : R) : R;
+    dim3 grid((C + 63) / 64, (unsigned)((rows + 63) / 64));
+    hipLaunchKernelGGL(cvt_bf16_kernel, grid, dim3(256), 0, stream, x, ldx, R, C, reinterpret_cast<unsigned short*>(out), ldo,
+                       reinterpret_cast<unsigned short*>(outT), ldt);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}

@@ -214,9 +214,46 @@ extern "C" int spe_softmax_bwd(const float* dPd, const float* P, float* dS, int 
 }
 
 // ------------------------------------------------------------------------------------------
-// Column sum: out[c] += sum_r in[r*ld + c]  (bias gradients).  out must be pre-zeroed / hold
-// the running gradient.  Block = 64 columns x 4 row-lanes; grid.y row chunks.
+// Column sum: out[c] += sum_r in[r*ld + c]  (bias gradients, split-K slab sums).  out must be pre-zeroed / hold
+// the running gradient.
 // ------------------------------------------------------------------------------------------
+// Two shapes occur: a few very wide rows (the split-K slabs of a weight gradient: R <= 32, C ~ 1e5..1e6) and
+// tall narrow matrices (bias gradients: R ~ 1e4, C <= 2048).
+//   wide: one thread per 4 columns, float4 loads down the R rows, plain read-modify-write of out (no atomics)
+//   tall: block = 16 column quads (64 columns) x 16 row lanes, float4 loads, LDS reduce, one atomic per column
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const float* __restrict__ in, float* __restrict__ out, int R, long C, long ld) {
+    const long c = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= C) return;
+    float4 acc = *reinterpret_cast<const float4*>(out + c);
+#pragma unroll 4
+    for (int r = 0; r < R; ++r) {
+        const float4 v = *reinterpret_cast<const float4*>(in + r * ld + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + c) = acc;
+}
+__global__ __launch_bounds__(256) void colsum_tall4_kernel(const float* __restrict__ in, float* __restrict__ out, long R, int C, long ld) {
+    __shared__ float4 red[16][16];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = (blockIdx.x * 16 + cq) * 4;
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < C)
+        for (long r = (long)blockIdx.y * 16 + rl; r < R; r += (long)gridDim.y * 16) {
+            const float4 v = *reinterpret_cast<const float4*>(in + r * ld + c);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    red[rl][cq] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int q = threadIdx.x >> 2, e = threadIdx.x & 3;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += reinterpret_cast<const float*>(&red[i][q])[e];
+        const int cc = (blockIdx.x * 16 + q) * 4 + e;
+        if (cc < C) atomicAdd(out + cc, s);
+    }
+}
+// generic fallback (unaligned pointers / leading dimension): block = 64 columns x 4 row lanes
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, long R, int C,
                                                      long ld) {
     __shared__ float red[4][64];
@@ -231,8 +268,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
 }
 extern "C" int spe_colsum(const float* in, float* out, long R, int C, long ld, hipStream_t st) {
     if (R <= 0 || C <= 0) return 0;
-    long ry = (R + 255) / 256; if (ry > 64) ry = 64; if (ry < 1) ry = 1;
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, (unsigned)ry), dim3(256), 0, st, in, out, R, C, ld);
+    const bool al4 = (C % 4 == 0) && (ld % 4 == 0) && ((((uintptr_t)in) | ((uintptr_t)out)) % 16 == 0);
+    if (al4 && R <= 64 && C >= 4096) {
+        hipLaunchKernelGGL(colsum_wide_kernel, dim3((unsigned)((C / 4 + 255) / 256)), dim3(256), 0, st, in, out, (int)R, (long)C, ld);
+    } else if (al4) {
+        const int gx = (C / 4 + 15) / 16;
+        long ry = (R + 63) / 64;                       // >= 4 rows per thread
+        const long cap = (2048 + gx - 1) / gx;         // ~8 blocks per CU overall
+        if (ry > cap) ry = cap; if (ry < 1) ry = 1;
+        hipLaunchKernelGGL(colsum_tall4_kernel, dim3(gx, (unsigned)ry), dim3(256), 0, st, in, out, R, C, ld);
+    } else {
+        long ry = (R + 255) / 256; if (ry > 64) ry = 64; if (ry < 1) ry = 1;
+        hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, (unsigned)ry), dim3(256), 0, st, in, out, R, C, ld);
+    }
     SPE_CHECK_LAUNCH();
     return 0;
 }

@@ -39,23 +39,30 @@ class GradAllReducer:
 
     def _make_bucket(self, plist):
         dev, dt = plist[0].device, plist[0].dtype
-        n = sum(p.numel() for p in plist)
+        al = lambda k: (k + 63) & ~63                        # 256-B aligned views: vectorised kernels write into them
+        n = sum(al(p.numel()) for p in plist)
         flat = torch.zeros(n, device=dev, dtype=dt)
         off = 0
         for p in plist:
             v = flat[off:off + p.numel()].view_as(p)
-            p.grad = v                                       # gradient accumulates in place into the bucket
             self._views[p] = v
-            off += p.numel()
+            p._spe_grad_buf = v                              # spe_amd backward kernels write here (kernels.grad_buffer)
+            off += al(p.numel())
             self._bucket_of[p] = len(self.buckets)
         self.buckets.append({"flat": flat, "params": list(plist), "pending": 0, "work": None})
 
     def reset(self):
-        """Call before every backward (after the optimizer consumed the gradients): zero the buckets."""
+        """Call before every backward (after the optimizer consumed the gradients): zero the buckets and detach
+        the .grad views.  With .grad = None autograd adopts the first incoming gradient tensor instead of adding
+        it: kernels that wrote into the bucket view (kernels.grad_buffer) cost nothing extra, any other gradient is
+        moved into the bucket by `_on_grad`; a parameter that gets no gradient keeps its zeros in the bucket."""
         for b in self.buckets:
             b["flat"].zero_()
             b["pending"] = len(b["params"])
             b["work"] = None
+            for p in b["params"]:
+                p.grad = None
+                p._spe_grad_fresh = True
         self._next = 0
 
     def zero_grad(self):
@@ -71,8 +78,10 @@ class GradAllReducer:
         b = self.buckets[self._bucket_of[p]]
         view = self._views[p]
         if p.grad.data_ptr() != view.data_ptr():
-            # someone replaced .grad (e.g. zero_grad(set_to_none=True)); move it back into the bucket
+            # the gradient was produced outside the bucket (torch op, or a parameter used twice whose contributions
+            # autograd summed into a temporary): AccumulateGrad runs once per backward with the TOTAL, so copy it in
             view.copy_(p.grad)
+            p._spe_grad_fresh = False
             p.grad = view
         b["pending"] -= 1
         # collectives are issued strictly in bucket order so every rank enqueues the same sequence
@@ -90,6 +99,9 @@ class GradAllReducer:
                 b["work"].wait()
             if self.average and self.world > 1:
                 b["flat"].div_(self.world)
+            for p in b["params"]:
+                if p.grad is None:                            # unused this step: zeros, like DDP's unused-parameter path
+                    p.grad = self._views[p]
 
     def remove(self):
         for h in self._hooks:

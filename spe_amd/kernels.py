@@ -86,6 +86,23 @@ def zeros_small(n, device):
     return out
 
 
+def grad_buffer(param):
+    """Zeroed, still unclaimed gradient storage of `param` inside its all-reduce bucket (spe_amd.dp.GradAllReducer
+    publishes it as `param._spe_grad_buf` and re-arms `_spe_grad_fresh` every step), or None.  A backward kernel
+    that writes its parameter gradient straight into this view - and returns it - makes autograd's AccumulateGrad
+    adopt the tensor as `.grad` without a copy or an add (one elementwise launch per parameter otherwise).  Handed
+    out once per step: a parameter used twice gets an ordinary temporary the second time and autograd adds it."""
+    if param is None or not getattr(param, "_spe_grad_fresh", False):
+        return None
+    param._spe_grad_fresh = False
+    buf = param._spe_grad_buf
+    return buf.view_as(buf)            # fresh alias: AccumulateGrad only steals a tensor nobody else references
+
+
+def _zeros_or(buf, n, device):
+    return buf.view(-1) if buf is not None else zeros_small(n, device)
+
+
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -124,45 +141,121 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
 
 
 # ---- nn.Linear ------------------------------------------------------------------------------
-def linear_fwd(x2, W, b, act=0, want_pre=False):
-    """y = act(x2 @ W.T + b); x2 [R,K] contiguous, W [N,K]."""
+# Benchmark ("bf16") precision, large row counts: the three GEMMs of a Linear run on bf16 copies of their operands
+# (csrc/gemm_bf16.hip) - the same roundings spe_gemm_f32 applies while staging, so the products are identical, with
+# half the operand bytes and a deeper load pipeline.  Small GEMMs (decoder, heads) and the bf16x3 parity mode keep the
+# fp32-operand kernel.
+LINEAR16 = os.environ.get("SPE_LINEAR16", "1") != "0"
+LINEAR16_MIN_ROWS = 2048
+_W16 = {}        # id(W) -> (weakref, version, data_ptr, W16 [N,K], W16T [K,N])
+
+
+def _lin16_ok(R, N, K):
+    return LINEAR16 and _PRECISION == 0 and R >= LINEAR16_MIN_ROWS and N % 8 == 0 and K % 8 == 0
+
+
+def cvt_bf16(x2, want=True, wantT=False, ldt=None):
+    """bf16 (RNE) copies of a contiguous fp32 [R, C]: row-major [R, C] and/or the transpose [C, ldt] (zero padded)."""
+    _chk(x2)
+    R, C = x2.shape
+    out = torch.empty((R, C), device=x2.device, dtype=torch.bfloat16) if want else None
+    outT = None
+    if wantT:
+        ldt = ldt or ((R + 63) // 64) * 64
+        outT = torch.empty((C, ldt), device=x2.device, dtype=torch.bfloat16)
+    _call("spe_cvt_bf16", _p(x2), x2.stride(0), R, C, _p(out), C, _p(outT), ldt or 0, _st())
+    return out, outT
+
+
+def weight16(W):
+    """(W16 [N,K], W16T [K,N]) of a weight, cached until the optimizer (or a state-dict load) changes it."""
+    import weakref
+    key = id(W)
+    ent = _W16.get(key)
+    if ent is not None and ent[0]() is W and ent[1] == W._version and ent[2] == W.data_ptr():
+        return ent[3], ent[4]
+    with torch.no_grad():
+        W16, W16T = cvt_bf16(W.detach(), True, True, ldt=W.shape[0])
+    if len(_W16) > 4096:
+        _W16.clear()
+    _W16[key] = (weakref.ref(W), W._version, W.data_ptr(), W16, W16T)
+    return W16, W16T
+
+
+def gemm16(A16, B16, C, M, N, K, lda, ldb, ldc, bias=None, C2=None, alpha=1.0, act=0, splitk=1):
+    """C = act(alpha * A16 @ B16.T + bias) on bf16 operands (both k-contiguous); splitk < 0: slabs."""
+    _call("spe_gemm_bf16nt", _p(A16), _p(B16), _p(C), _p(bias), _p(C2), M, N, K, lda, ldb, ldc, float(alpha), int(act),
+          int(splitk), _st())
+    return C
+
+
+def linear_fwd(x2, W, b, act=0, want_pre=False, save_for_dw=True):
+    """y = act(x2 @ W.T + b); x2 [R,K] contiguous, W [N,K].  -> (y, pre-activation or None, xsave): xsave is what
+    linear_bwd needs of x - x2 itself, or on the bf16 path the padded bf16 transpose x16T [K, Rp]."""
     _chk(x2, W, b)
     R, K = x2.shape
     N = W.shape[0]
     y = torch.empty((R, N), device=x2.device, dtype=torch.float32)
     pre = torch.empty_like(y) if want_pre else None
+    if _lin16_ok(R, N, K) and W.is_contiguous():
+        x16, x16T = cvt_bf16(x2, True, save_for_dw)
+        gemm16(x16, weight16(W)[0], y, R, N, K, K, K, N, bias=b, C2=pre, act=act)
+        return y, pre, (x16T if save_for_dw else x2)
     gemm(x2, W, y, R, N, K, K, K, N, False, True, bias=b, C2=pre, act=act)
-    return (y, pre) if want_pre else y
+    return y, pre, x2
 
 
-def linear_bwd(dy2, x2, W, need_dx=True, need_dw=True, need_db=True):
-    """dx = dy @ W ; dW = dy.T @ x ; db = colsum(dy)."""
-    _chk(dy2, x2, W)
+def linear_bwd(dy2, xsave, W, need_dx=True, need_dw=True, need_db=True, dW_out=None, db_out=None):
+    """dx = dy @ W ; dW = dy.T @ x ; db = colsum(dy).  xsave: third result of linear_fwd.
+    dW_out / db_out: zeroed destination buffers (grad_buffer)."""
+    _chk(dy2, W)
     R, N = dy2.shape
     K = W.shape[1]
     dx = dW = db = None
-    if need_dx:
-        dx = torch.empty((R, K), device=dy2.device, dtype=torch.float32)
-        gemm(dy2, W, dx, R, K, N, N, K, K, False, False)
-    if need_dw:
-        sk = auto_splitk(N, K, R, 1)
-        if sk > 1:       # slab split-K: no atomics; the slabs are summed by one column-sum launch
-            ws = torch.empty((sk, N * K), device=dy2.device, dtype=torch.float32)
-            gemm(dy2, x2, ws, N, K, R, N, K, K, True, False, splitk=-sk)
-            dW = colsum(ws).view(N, K)
-        else:
-            dW = torch.empty((N, K), device=dy2.device, dtype=torch.float32)
-            gemm(dy2, x2, dW, N, K, R, N, K, K, True, False)
+    x16 = xsave.dtype == torch.bfloat16
+    if (x16 or not need_dw) and _lin16_ok(R, N, K) and W.is_contiguous():
+        Rp = xsave.shape[1] if x16 else None
+        dy16, dy16T = cvt_bf16(dy2, need_dx, need_dw and x16, ldt=Rp)
+        if need_dx:
+            dx = torch.empty((R, K), device=dy2.device, dtype=torch.float32)
+            gemm16(dy16, weight16(W)[1], dx, R, K, N, N, N, K)
+        if need_dw:
+            sk = min(auto_splitk(N, K, R, 1), Rp // 64)
+            if sk > 1:
+                ws = torch.empty((sk, N * K), device=dy2.device, dtype=torch.float32)
+                gemm16(dy16T, xsave, ws, N, K, Rp, Rp, Rp, K, splitk=-sk)
+                dW = colsum(ws, out=None if dW_out is None else dW_out.view(-1)).view(N, K)
+            else:
+                dW = dW_out if dW_out is not None else torch.empty((N, K), device=dy2.device, dtype=torch.float32)
+                gemm16(dy16T, xsave, dW, N, K, Rp, Rp, Rp, K)
+    else:
+        if x16:
+            raise RuntimeError("linear_bwd: bf16 activations were saved but the bf16 GEMM path is disabled now")
+        x2 = xsave
+        if need_dx:
+            dx = torch.empty((R, K), device=dy2.device, dtype=torch.float32)
+            gemm(dy2, W, dx, R, K, N, N, K, K, False, False)
+        if need_dw:
+            sk = auto_splitk(N, K, R, 1)
+            if sk > 1:       # slab split-K: no atomics; the slabs are summed by one column-sum launch
+                ws = torch.empty((sk, N * K), device=dy2.device, dtype=torch.float32)
+                gemm(dy2, x2, ws, N, K, R, N, K, K, True, False, splitk=-sk)
+                dW = colsum(ws, out=None if dW_out is None else dW_out.view(-1)).view(N, K)
+            else:
+                dW = dW_out if dW_out is not None else torch.empty((N, K), device=dy2.device, dtype=torch.float32)
+                gemm(dy2, x2, dW, N, K, R, N, K, K, True, False)
     if need_db:
-        db = zeros_small(N, dy2.device)
+        db = _zeros_or(db_out, N, dy2.device)
         _call("spe_colsum", _p(dy2), _p(db), R, N, N, _st())
     return dx, dW, db
 
 
-def colsum(x2):
+def colsum(x2, out=None):
+    """out (zeroed, or holding a running sum) += column sums of x2."""
     _chk(x2)
     R, C = x2.shape
-    out = zeros_small(C, x2.device)
+    if out is None:
+        out = zeros_small(C, x2.device)
     _call("spe_colsum", _p(x2), _p(out), R, C, x2.stride(0), _st())
     return out
 
@@ -185,12 +278,12 @@ def layernorm_fwd(x2, g, b, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy2, x2, g, mean, rstd):
+def layernorm_bwd(dy2, x2, g, mean, rstd, dg_out=None, db_out=None):
     _chk(dy2, x2, g)
     R, C = x2.shape
     dx = torch.empty_like(x2)
-    dg = zeros_small(C, x2.device)
-    db = zeros_small(C, x2.device)
+    dg = _zeros_or(dg_out, C, x2.device)
+    db = _zeros_or(db_out, C, x2.device)
     _call("spe_layernorm_bwd", _p(dy2), _p(x2), _p(g), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), R, C, _st())
     return dx, dg, db
 
@@ -205,11 +298,11 @@ def layerscale_residual_fwd(x2, y2, gamma, sample_scale, rows_per_sample):
     return out
 
 
-def layerscale_residual_bwd(dout2, y2, gamma, sample_scale, rows_per_sample):
+def layerscale_residual_bwd(dout2, y2, gamma, sample_scale, rows_per_sample, dg_out=None):
     _chk(dout2, y2, gamma, sample_scale)
     R, C = dout2.shape
     dy = torch.empty_like(dout2)
-    dg = zeros_small(C, dout2.device)
+    dg = _zeros_or(dg_out, C, dout2.device)
     _call("spe_layerscale_residual_bwd", _p(dout2), _p(y2), _p(gamma), _p(sample_scale), _p(dy), _p(dg), R, C,
              rows_per_sample, _st())
     return dy, dg

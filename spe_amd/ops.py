@@ -24,16 +24,12 @@ class _Linear(Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         Wc = W if W.is_contiguous() else W.contiguous()
-        aux = None
-        if act == ACT_GELU:
-            y, aux = K.linear_fwd(x2, Wc, b, act, want_pre=True)
-        else:
-            y = K.linear_fwd(x2, Wc, b, act)
-            if act == ACT_RELU:
-                aux = y
+        y, pre, xsave = K.linear_fwd(x2, Wc, b, act, want_pre=(act == ACT_GELU), save_for_dw=ctx.needs_input_grad[1])
+        aux = pre if act == ACT_GELU else (y if act == ACT_RELU else None)
         ctx.act = act
         ctx.has_bias = b is not None
-        ctx.save_for_backward(x2, Wc, aux)
+        ctx.params = (W, b)                 # leaves: looked up in backward for their gradient buckets
+        ctx.save_for_backward(xsave, Wc, aux)
         return y.view(*shp[:-1], W.shape[0])
 
     @staticmethod
@@ -44,8 +40,11 @@ class _Linear(Function):
             dy2 = dy2.contiguous()
         if ctx.act != ACT_NONE:
             dy2 = K.act_bwd(dy2, aux, ctx.act)
-        dx, dW, db = K.linear_bwd(dy2, x2, W, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                  ctx.has_bias and ctx.needs_input_grad[2])
+        Wp, bp = ctx.params
+        need_dw, need_db = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx, dW, db = K.linear_bwd(dy2, x2, W, ctx.needs_input_grad[0], need_dw, need_db,
+                                  dW_out=K.grad_buffer(Wp) if need_dw and Wp.is_contiguous() else None,
+                                  db_out=K.grad_buffer(bp) if need_db else None)
         if dx is not None:
             dx = dx.view(*dy.shape[:-1], W.shape[1])
         return dx, dW, db, None
@@ -63,6 +62,7 @@ class _LayerNorm(Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         y, mean, rstd = K.layernorm_fwd(x2, g, b, eps)
+        ctx.params = (g, b)
         ctx.save_for_backward(x2, g, mean, rstd)
         return y.view(x.shape)
 
@@ -72,8 +72,9 @@ class _LayerNorm(Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        dx, dg, db = K.layernorm_bwd(dy2, x2, g, mean, rstd)
-        return dx.view(dy.shape), dg, db, None
+        gp, bp = ctx.params
+        dx, dg, db = K.layernorm_bwd(dy2, x2, g, mean, rstd, dg_out=K.grad_buffer(gp), db_out=K.grad_buffer(bp))
+        return dx.view(dy.shape), dg.view_as(gp), db.view_as(bp), None
 
 
 def layer_norm(x, g, b, eps):
@@ -92,6 +93,7 @@ class _LayerScaleResidual(Function):
         rps = x2.shape[0] // B
         out = K.layerscale_residual_fwd(x2, y2, gamma, sample_scale, rps)
         ctx.rps = rps
+        ctx.gamma = gamma
         ctx.save_for_backward(y2, gamma, sample_scale)
         return out.view(x.shape)
 
@@ -99,8 +101,8 @@ class _LayerScaleResidual(Function):
     def backward(ctx, dout):
         y2, gamma, ss = ctx.saved_tensors
         d2 = dout.reshape(-1, dout.shape[-1]).contiguous()
-        dy, dg = K.layerscale_residual_bwd(d2, y2, gamma, ss, ctx.rps)
-        return dout, dy.view(dout.shape), dg, None
+        dy, dg = K.layerscale_residual_bwd(d2, y2, gamma, ss, ctx.rps, dg_out=K.grad_buffer(ctx.gamma))
+        return dout, dy.view(dout.shape), dg.view_as(ctx.gamma), None
 
 
 def layerscale_residual(x, y, gamma, sample_scale=None):
@@ -340,16 +342,16 @@ class _PatchEmbed(Function):
         B, Cin, Hi, Wi = img.shape
         cols = K.patchify(img.contiguous(), P)
         W2 = W.reshape(W.shape[0], -1)
-        y = K.linear_fwd(cols, W2, b)
-        ctx.save_for_backward(cols, W2)
+        y, _, xsave = K.linear_fwd(cols, W2, b, save_for_dw=ctx.needs_input_grad[1])
+        ctx.save_for_backward(xsave, W2)
         ctx.wshape = W.shape
         return y.view(B, (Hi // P) * (Wi // P), W.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        cols, W2 = ctx.saved_tensors
+        xsave, W2 = ctx.saved_tensors
         dy2 = dy.reshape(-1, W2.shape[0]).contiguous()
-        _, dW, db = K.linear_bwd(dy2, cols, W2, need_dx=False)
+        _, dW, db = K.linear_bwd(dy2, xsave, W2, need_dx=False)
         return None, dW.view(ctx.wshape), db, None
 
 

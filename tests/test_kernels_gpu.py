@@ -52,11 +52,11 @@ def test_gemm_epilogue_splitk_batched(dev, prec):
     x = torch.randn(333, 96, generator=g).to(dev)
     W = torch.randn(200, 96, generator=g).to(dev)
     b = torch.randn(200, generator=g).to(dev)
-    y, pre = K.linear_fwd(x, W, b, act=2, want_pre=True)
+    y, pre, _ = K.linear_fwd(x, W, b, act=2, want_pre=True)
     refpre = x.double() @ W.double().t() + b.double()
     assert rel(pre, refpre) < TOL[prec]
     assert rel(y, torch.nn.functional.gelu(refpre)) < TOL[prec]
-    y1 = K.linear_fwd(x, W, b, act=1)
+    y1 = K.linear_fwd(x, W, b, act=1)[0]
     assert rel(y1, torch.relu(refpre)) < TOL[prec]
     # split-K (TN, long contraction)
     dy = torch.randn(5000, 64, generator=g).to(dev)
@@ -403,3 +403,119 @@ def test_talking_heads_attention_fused(dev, H, N, dh, B):
     g2 = torch.autograd.grad(out2, (qkv, Wl, Ww), go)
     assert rel(out, out2) < 8e-3
     assert rel(grads[0], g2[0]) < 1.5e-2 and rel(grads[1], g2[1]) < 1.5e-2 and rel(grads[3], g2[2]) < 1.5e-2
+
+
+@pytest.mark.parametrize("R,C", [(15, 8192), (16, 589824), (8300, 384), (8300, 1536), (777, 91), (3, 100), (200, 2048)])
+def test_colsum_shapes(dev, R, C):
+    """wide (split-K slabs), tall (bias gradients) and unaligned fallbacks; out accumulates."""
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(R * 7 + C)
+    x = torch.randn(R, C, generator=g).to(dev)
+    ref = x.double().sum(0)
+    out = K.colsum(x)
+    assert rel(out, ref) < 2e-6
+    K.colsum(x, out=out)                       # += semantics
+    assert rel(out, 2 * ref) < 2e-6
+
+
+def test_grad_buffer_direct_placement(dev):
+    """Parameter gradients written straight into the GradAllReducer buckets (kernels.grad_buffer) equal the plain
+    autograd gradients - including a weight used twice, a torch-op parameter and an unused parameter."""
+    from spe_amd import kernels as K
+    from spe_amd import ops
+    from spe_amd.dp import GradAllReducer
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(3)
+            self.w1 = torch.nn.Parameter(torch.randn(64, 32, generator=g) * 0.2)
+            self.b1 = torch.nn.Parameter(torch.randn(64, generator=g) * 0.1)
+            self.w2 = torch.nn.Parameter(torch.randn(32, 64, generator=g) * 0.2)      # used twice
+            self.lg = torch.nn.Parameter(torch.rand(32, generator=g) + 0.5)
+            self.lb = torch.nn.Parameter(torch.randn(32, generator=g) * 0.1)
+            self.gam = torch.nn.Parameter(torch.rand(32, generator=g))
+            self.pos = torch.nn.Parameter(torch.randn(1, 50, 32, generator=g) * 0.1)  # plain torch add
+            self.unused = torch.nn.Parameter(torch.ones(5))
+
+        def forward(self, x):
+            x = x + self.pos
+            h = ops.linear(ops.layer_norm(x, self.lg, self.lb, 1e-6), self.w1, self.b1, ops.ACT_GELU)
+            y = ops.linear(h, self.w2)
+            x = ops.layerscale_residual(x, y, self.gam)
+            h2 = ops.linear(x, self.w1, self.b1, ops.ACT_RELU)
+            return ops.linear(h2, self.w2)
+
+    K.set_precision("bf16x3")
+    try:
+        net = Net().to(dev)
+        x = torch.randn(4, 50, 32, generator=torch.Generator().manual_seed(5)).to(dev)
+        go = torch.randn(4, 50, 32, generator=torch.Generator().manual_seed(6)).to(dev)
+        named = dict(net.named_parameters())
+        ref = torch.autograd.grad(net(x), [p for n, p in named.items() if n != "unused"], go)
+        ref = dict(zip([n for n in named if n != "unused"], ref))
+        red = GradAllReducer(list(net.parameters()), bucket_bytes=4096)
+        for it in range(2):                      # second step: buckets re-armed
+            red.reset()
+            net(x).backward(go)
+            red.finish()
+            for n, p in named.items():
+                assert p.grad is not None and p.grad.data_ptr() == p._spe_grad_buf.data_ptr(), n
+                if n == "unused":
+                    assert float(p.grad.abs().sum()) == 0.0
+                else:
+                    assert rel(p.grad, ref[n]) < 1e-5, (n, it, rel(p.grad, ref[n]))
+        red.remove()
+    finally:
+        K.set_precision("bf16")
+
+
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (300, 384, 384), (8300, 1536, 384), (8300, 384, 1536), (77, 136, 4152), (65, 72, 8), (1000, 64, 200)])
+def test_gemm_bf16nt(dev, M, N, K_):
+    """bf16-operand NT GEMM: exact products of the bf16-rounded operands (fp32 accumulate) + epilogues + slabs."""
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(M + N + K_)
+    A = torch.randn(M, K_, generator=g).to(dev)
+    B = torch.randn(N, K_, generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    A16, A16T = K.cvt_bf16(A, True, True)
+    B16, _ = K.cvt_bf16(B)
+    assert torch.equal(A16, A.to(torch.bfloat16)) and torch.equal(B16, B.to(torch.bfloat16))
+    Rp = A16T.shape[1]
+    assert Rp % 64 == 0 and torch.equal(A16T[:, :M], A.to(torch.bfloat16).t()) and float(A16T[:, M:].float().abs().sum()) == 0.0
+    ref = A16.double() @ B16.double().t()
+    C = torch.full((M, N), float("nan"), device=dev)
+    K.gemm16(A16, B16, C, M, N, K_, K_, K_, N)
+    assert rel(C, ref) < 2e-6
+    C2 = torch.full((M, N), float("nan"), device=dev)
+    K.gemm16(A16, B16, C, M, N, K_, K_, K_, N, bias=bias, C2=C2, act=2, alpha=0.5)
+    pre = 0.5 * ref + bias.double()
+    assert rel(C2, pre) < 2e-6 and rel(C, torch.nn.functional.gelu(pre)) < 2e-6
+    if K_ >= 256:
+        sk = min(4, (K_ + 63) // 64)
+        ws = torch.full((sk, M * N), float("nan"), device=dev)
+        K.gemm16(A16, B16, ws, M, N, K_, K_, K_, N, splitk=-sk)
+        assert rel(ws.sum(0).view(M, N), ref) < 2e-6
+
+
+def test_linear_bf16_path_matches_fp32_operand_path(dev):
+    """ops.linear on the bf16-copy GEMMs == the fp32-operand kernel in bf16 mode (same roundings), fwd and bwd."""
+    from spe_amd import kernels as K
+    from spe_amd import ops
+    g = torch.Generator().manual_seed(11)
+    R, Kd, N = 4150, 384, 1152
+    x = torch.randn(2, R // 2, Kd, generator=g).to(dev).requires_grad_()
+    W = (torch.randn(N, Kd, generator=g) * 0.05).to(dev).requires_grad_()
+    b = torch.randn(N, generator=g).to(dev).requires_grad_()
+    go = torch.randn(2, R // 2, N, generator=g).to(dev)
+    res = {}
+    old = K.LINEAR16
+    try:
+        for mode in (True, False):
+            K.LINEAR16 = mode
+            y = ops.linear(x, W, b, ops.ACT_GELU)
+            res[mode] = (y,) + torch.autograd.grad(y, (x, W, b), go)
+    finally:
+        K.LINEAR16 = old
+    for a, c in zip(res[True], res[False]):
+        assert rel(a, c) < 1e-5

@@ -57,5 +57,41 @@ def main():
       run("dec proj NT", 200, 384, 384, False, True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "bf16nt"):
     main()
+
+
+def run16(name, M, N, Kd, splitk=1):
+    """bf16-operand NT kernel on the same logical shapes (operands pre-converted)."""
+    A = torch.randn(M, Kd, device=dev).to(torch.bfloat16)
+    B = torch.randn(N, Kd, device=dev).to(torch.bfloat16)
+    C = torch.zeros(max(1, abs(splitk)), M * N, device=dev)
+    f = lambda: K.gemm16(A, B, C, M, N, Kd, Kd, Kd, N, splitk=splitk)
+    t = timeit(f)
+    fl = 2.0 * M * N * Kd
+    by = 2.0 * (M * Kd + N * Kd) + 4.0 * M * N * abs(splitk)
+    print(f"{name:34s} M={M:5d} N={N:5d} K={Kd:5d} sk={splitk:3d} {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.0f} GB/s")
+
+
+def main16():
+    R = 8300
+    run16("qkv fwd", R, 1152, 384)
+    run16("fc1 fwd", R, 1536, 384)
+    run16("fc2 fwd", R, 384, 1536)
+    run16("proj fwd", R, 384, 384)
+    run16("fc1 dx", R, 384, 1536)
+    run16("fc2 dx", R, 1536, 384)
+    run16("qkv dx", R, 384, 1152)
+    run16("fc1 dW", 1536, 384, 8320, splitk=-15)
+    run16("fc2 dW", 384, 1536, 8320, splitk=-15)
+    run16("qkv dW", 1152, 384, 8320, splitk=-16)
+    run16("proj dW", 384, 384, 8320, splitk=-16)
+    x = torch.randn(R, 1536, device=dev)
+    print("cvt 8300x1536 out+outT %.1f us" % (timeit(lambda: K.cvt_bf16(x, True, True)) * 1e6))
+    print("cvt 8300x1536 out      %.1f us" % (timeit(lambda: K.cvt_bf16(x, True, False)) * 1e6))
+    x = torch.randn(R, 384, device=dev)
+    print("cvt 8300x384  out+outT %.1f us" % (timeit(lambda: K.cvt_bf16(x, True, True)) * 1e6))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "bf16nt":
+    main16()
