@@ -49,7 +49,7 @@ def synth_batch(seed, device, batch=2, H=800, W=1333, K=90, n_tgt=7):
         il = torch.zeros(K, dtype=torch.int64)
         il[labels - 1] = 1
         targets.append({"boxes": torch.cat([c, wh], 1), "labels": labels, "img_label": il,
-                        "orig_size": torch.tensor([H, W])})
+                        "orig_size": torch.tensor([H, W]), "labels_unique": torch.unique(labels)})
     mask = torch.zeros(batch, H, W, dtype=torch.bool)
     to = lambda t: t.to(device)
     return to(imgs), to(mask), [{k: to(v) for k, v in t.items()} for t in targets]

@@ -174,6 +174,13 @@ int spe_matcher_cost(const float* logits, const float* boxes, const int* tgt_ids
                      const int* toff, int total_targets, float* cost, int* err, int L, int B, int Q, int Kc,
                      float w_class, float w_bbox, float w_giou, spe_stream_t stream);
 
+/* ---- the assignment itself, on the device (reference models/matcher.py:83-86: scipy.optimize.linear_sum_assignment
+ * per image on the host).  cost / toff as produced for spe_matcher_cost; every image needs M_b <= Q <= 1024 (-2
+ * otherwise: fall back to the host).  Writes, for problem (l, b), M_b triples at offset l*total + toff[b] in ascending
+ * query order: srow = (l*B+b)*Q + q, gidx = toff[b] + j (int64 each), lidx = l (int32).  fp64 potentials like SciPy. */
+int spe_hungarian(const float* cost, const int* toff, long* srow, long* gidx, int* lidx, int L, int B, int Q,
+                  spe_stream_t stream);
+
 /* ---- weighted sigmoid focal loss (reference models/conditional_detr.py:468-494, 504-535):
  * logits[L*rows_per_l, Kc]; tclass[row] in [0,Kc] (Kc = no object); roww[row] row weight or
  * null.  loss[l] += sum (pre-zeroed by caller); grad = d(sum)/d(logit); argmax = top-1 class. */

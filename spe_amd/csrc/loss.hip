@@ -60,6 +60,96 @@ extern "C" int spe_matcher_cost(const float* logits, const float* boxes, const i
     return 0;
 }
 
+// Device-side assignment (reference models/matcher.py:83-86 calls scipy.optimize.linear_sum_assignment on the host
+// per image; here the optimum is computed where the costs are, so the criterion needs no device->host round trip
+// and the host keeps running ahead of the GPU).  One wave per (layer, image) problem: the M_b targets of the image
+// are assigned to distinct queries by the shortest-augmenting-path Hungarian algorithm with dual potentials, in
+// fp64 like SciPy (which promotes the fp32 costs to double).  The minimum-cost assignment is unique unless two
+// assignments tie exactly, so the result equals SciPy's.  Output for problem (l, b): M_b triples at offset
+// l*total + toff[b], ordered by query index (the order linear_sum_assignment returns):
+//   srow = (l*B + b)*Q + q        (row of the flattened [L*B*Q] predictions)
+//   gidx = toff[b] + j            (index into the concatenated targets)
+//   lidx = l
+#define HUNG_QMAX 1024
+__global__ __launch_bounds__(64) void hungarian_kernel(const float* __restrict__ cost, const int* __restrict__ toff,
+                                                       long* __restrict__ srow, long* __restrict__ gidx, int* __restrict__ lidx,
+                                                       int B, int Q) {
+    __shared__ double u[HUNG_QMAX + 1], v[HUNG_QMAX + 1], minv[HUNG_QMAX + 1];
+    __shared__ int p[HUNG_QMAX + 1], way[HUNG_QMAX + 1];
+    __shared__ unsigned char used[HUNG_QMAX + 1];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x, l = blockIdx.y;
+    const int total = toff[B];
+    const int n = toff[b + 1] - toff[b], m = Q;          // n targets (rows, 1-based i), m queries (columns, 1-based j)
+    if (n <= 0) return;
+    const float* a = cost + (long)l * Q * total + (long)Q * toff[b];      // a(i, j) = a[(j-1)*n + (i-1)]
+    for (int j = lane; j <= m; j += 64) { v[j] = 0.0; p[j] = 0; }
+    for (int i = lane; i <= n; i += 64) u[i] = 0.0;
+    __syncthreads();
+    for (int i = 1; i <= n; ++i) {
+        if (lane == 0) p[0] = i;
+        for (int j = lane; j <= m; j += 64) { minv[j] = INFINITY; used[j] = 0; }
+        __syncthreads();
+        int j0 = 0;
+        do {
+            if (lane == 0) used[j0] = 1;
+            __syncthreads();
+            const int i0 = p[j0];
+            const double ui0 = u[i0];
+            double best = INFINITY; int bj = 0x7fffffff;
+            for (int j = lane + 1; j <= m; j += 64) {
+                if (used[j]) continue;
+                const double cur = (double)a[(long)(j - 1) * n + (i0 - 1)] - ui0 - v[j];
+                double mv = minv[j];
+                if (cur < mv) { mv = cur; minv[j] = cur; way[j] = j0; }
+                if (mv < best) { best = mv; bj = j; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o, 64); const int oj = __shfl_xor(bj, o, 64);
+                if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+            }
+            const double delta = best; const int j1 = bj;
+            __syncthreads();
+            for (int j = lane; j <= m; j += 64) {
+                if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
+                else minv[j] -= delta;
+            }
+            j0 = j1;
+            __syncthreads();
+        } while (p[j0] != 0);
+        if (lane == 0) {
+            do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0);
+        }
+        __syncthreads();
+    }
+    // emit the pairs in ascending query order
+    const long obase = (long)l * total + toff[b];
+    int base = 0;
+    for (int jc = 1; jc <= m; jc += 64) {
+        const int j = jc + lane;
+        const bool has = j <= m && p[j] != 0;
+        const unsigned long long mask = __ballot(has);
+        if (has) {
+            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            srow[obase + pos] = ((long)l * B + b) * Q + (j - 1);
+            gidx[obase + pos] = toff[b] + (p[j] - 1);
+            lidx[obase + pos] = l;
+        }
+        base += __popcll(mask);
+    }
+}
+
+// C-ABI: see include/spe_hip.h (spe_hungarian).  -2: Q above HUNG_QMAX (callers fall back to the host solver).
+extern "C" int spe_hungarian(const float* cost, const int* toff, long* srow, long* gidx, int* lidx, int L, int B, int Q,
+                             hipStream_t st) {
+    if (L <= 0 || B <= 0 || Q <= 0) return 0;
+    if (Q > HUNG_QMAX) return -2;
+    hipLaunchKernelGGL(hungarian_kernel, dim3(B, L), dim3(64), 0, st, cost, toff, srow, gidx, lidx, B, Q);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
 // Weighted sigmoid focal loss, forward value + d(sum)/d(logit) in one pass (one wave per
 // (l,b,q) row).  tclass[row] in [0,Kc] (Kc = no object -> all-zero one-hot), roww[row] = weight
 // of the row (nullptr = 1).  loss[l] += sum_row sum_c w * alpha_t * ce * (1-clamp(p_t))^gamma.

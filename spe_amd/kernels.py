@@ -383,6 +383,17 @@ def matcher_cost(logits, boxes, tgt_ids_i32, tgt_boxes, toff_i32, total_targets,
     return cost, err
 
 
+def hungarian(cost, toff_i32, L, B, Q, total_targets):
+    """Device-side linear_sum_assignment of every (layer, image) block of `cost` -> (srow, gidx) int64 and lidx int32,
+    each [L*total_targets] (see csrc/loss.hip: hungarian_kernel)."""
+    dev = cost.device
+    srow = torch.empty((L * total_targets,), device=dev, dtype=torch.int64)
+    gidx = torch.empty_like(srow)
+    lidx = torch.empty((L * total_targets,), device=dev, dtype=torch.int32)
+    _call("spe_hungarian", _p(cost), _p(toff_i32), _p(srow), _p(gidx), _p(lidx), L, B, Q, _st())
+    return srow, gidx, lidx
+
+
 def focal_loss(logits, tclass_i32, roww, alpha, gamma):
     """logits [L,R,Kc] -> loss_sum [L], grad [L,R,Kc], argmax [L,R]."""
     _chk(logits, roww)

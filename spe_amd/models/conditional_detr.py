@@ -191,27 +191,33 @@ class SetCriterion(nn.Module):
                 targets_cp = jitter_targets(targets, self.hung_match_ratio, self.box_jitter)
             else:
                 targets_cp = copy.deepcopy(targets)
-        indices = self.matcher.match_many(logits, boxes, targets_cp)
-
         sizes = [int(len(t["labels"])) for t in targets_cp]
-        num_boxes = torch.as_tensor([float(sum(sizes))], dtype=torch.float, device=dev)
-        if is_dist_avail_and_initialized():
-            torch.distributed.all_reduce(num_boxes)
-        num_boxes = torch.clamp(num_boxes / get_world_size(), min=1).item()
+        # normaliser: a host number on one GPU; across ranks it stays a device scalar (no .item() stall per step)
+        if is_dist_avail_and_initialized() and get_world_size() > 1:
+            nb = torch.as_tensor([float(sum(sizes))], dtype=torch.float, device=dev)
+            torch.distributed.all_reduce(nb)
+            num_boxes = torch.clamp(nb / get_world_size(), min=1)[0]
+        else:
+            num_boxes = max(float(sum(sizes)), 1.0)
 
-        # ---- host: flatten the assignment into (prediction row, global target index, layer) triples
         toff = [0]
         for s in sizes:
             toff.append(toff[-1] + s)
-        srow, gidx, lidx = [], [], []
-        for l in range(L):
-            for b in range(B):
-                I, J = indices[l][b]
-                srow.append((l * B + b) * Q + I)
-                gidx.append(toff[b] + J)
-                lidx.append(torch.full_like(I, l))
-        trip = torch.stack([torch.cat(srow), torch.cat(gidx), torch.cat(lidx)]).to(dev)      # one H2D copy
-        srow, gidx, lidx = trip[0].contiguous(), trip[1], trip[2].to(torch.int32).contiguous()
+        flat = self.matcher.match_flat(logits, boxes, targets_cp) if hasattr(self.matcher, "match_flat") else None
+        if flat is not None:                   # assignment solved on the device: nothing comes back to the host
+            srow, gidx, lidx = flat
+        else:
+            indices = self.matcher.match_many(logits, boxes, targets_cp)
+            # ---- host: flatten the assignment into (prediction row, global target index, layer) triples
+            srow, gidx, lidx = [], [], []
+            for l in range(L):
+                for b in range(B):
+                    I, J = indices[l][b]
+                    srow.append((l * B + b) * Q + I)
+                    gidx.append(toff[b] + J)
+                    lidx.append(torch.full_like(I, l))
+            trip = torch.stack([torch.cat(srow), torch.cat(gidx), torch.cat(lidx)]).to(dev)      # one H2D copy
+            srow, gidx, lidx = trip[0].contiguous(), trip[1], trip[2].to(torch.int32).contiguous()
         n_match = srow.numel()
         tgt_labels = torch.cat([t["labels"] for t in targets_cp]).to(dev)
         tgt_boxes = torch.cat([t["boxes"] for t in targets_cp]).to(dev).float()
@@ -229,20 +235,19 @@ class SetCriterion(nn.Module):
                 roww = avg.view(1, B, 1).expand(L, B, Q).reshape(-1).clone()
                 roww[srow] = (scores[gidx] * 3).clamp(max=1.0)
             loss_ce, amax = _FocalLoss.apply(logits.view(L, B * Q, Kc), tclass.view(L, B * Q), None if roww is None else
-                                             roww.view(L, B * Q), float(self.focal_alpha), float(self.gamma), num_boxes)
+                                             roww.view(L, B * Q), float(self.focal_alpha), float(self.gamma), 1.0)
+            loss_ce = loss_ce / num_boxes
         if "boxes" in self.losses:
             w = scores[gidx].contiguous() if self.refine else None
-            bl = _BoxLoss.apply(boxes.view(-1, 4), srow, tgt_boxes[gidx].contiguous(), w, lidx, L, num_boxes)
+            bl = _BoxLoss.apply(boxes.view(-1, 4), srow, tgt_boxes[gidx].contiguous(), w, lidx, L, 1.0) / num_boxes
         for l in range(L):
             sfx = suffix[l]
             if "labels" in self.losses:
                 losses["loss_ce" + sfx] = loss_ce[l]
                 if l == 0:                                                      # top-1 error on matched rows (logging)
-                    m0 = lidx == 0
-                    if int(m0.sum()) == 0:
-                        acc = torch.zeros([], device=dev)
-                    else:
-                        acc = (amax.view(-1)[srow[m0]].long() == labels_o[m0]).float().mean() * 100
+                    m0 = (lidx == 0).float()          # sync-free masked mean (0 when nothing is matched)
+                    hit = (amax.view(-1)[srow].long() == labels_o).float()
+                    acc = (hit * m0).sum() / m0.sum().clamp(min=1) * 100
                     losses["class_error"] = 100 - acc
             if "boxes" in self.losses:
                 losses["loss_bbox" + sfx] = bl[l, 0]
@@ -292,8 +297,13 @@ class PostProcessRefine(nn.Module):
         top_values, top_indexes = torch.max(prob, dim=1)                        # [B,Kc]
         res = []
         for b, t in enumerate(targets):
-            lab = torch.unique(t["labels"])                                     # sorted ascending
-            lab = lab[lab < out_logits.shape[2]].to(out_logits.device)
+            # `labels_unique` (sorted unique class ids < Kc, e.g. attached by the data loader on the host) avoids the
+            # device synchronisation of torch.unique / boolean indexing on device tensors
+            lab = t.get("labels_unique")
+            if lab is None:
+                lab = torch.unique(t["labels"])                                 # sorted ascending
+                lab = lab[lab < out_logits.shape[2]]
+            lab = lab.to(out_logits.device)
             res.append({"scores": top_values[b, lab], "labels": lab, "boxes": out_bbox[b, top_indexes[b, lab]]})
         return res
 

@@ -21,6 +21,48 @@ class HungarianMatcher(nn.Module):
         self.match_ratio = match_ratio
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
 
+    def _costs(self, logits, boxes, targets):
+        L, B, Q, _ = logits.shape
+        dev = logits.device
+        sizes = [int(len(t["boxes"])) for t in targets]
+        toff = [0]
+        for s in sizes:
+            toff.append(toff[-1] + s)
+        tgt_ids = torch.cat([t["labels"] for t in targets]).to(device=dev, dtype=torch.int32).contiguous()
+        tgt_box = torch.cat([t["boxes"] for t in targets]).to(device=dev, dtype=torch.float32).contiguous()
+        toff_t = torch.tensor(toff, dtype=torch.int32).to(dev, non_blocking=True)
+        cost, err = K.matcher_cost(logits.contiguous().float(), boxes.contiguous().float(), tgt_ids, tgt_box, toff_t,
+                                   toff[-1], self.cost_class, self.cost_bbox, self.cost_giou)
+        return cost, err, toff_t, sizes, toff
+
+    def _check_degenerate_async(self, err):
+        """box_ops.py:64-65 asserts non-degenerate boxes.  On the device path the flag of step t is inspected at
+        step t+1 (pinned host copy + event), so the check costs no synchronisation."""
+        prev = getattr(self, "_err_prev", None)
+        if prev is not None:
+            host, ev = prev
+            ev.synchronize()            # a step old: already complete
+            assert int(host[0]) == 0, "degenerate box (x1 < x0 or y1 < y0) in matcher inputs"
+        host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+        host.copy_(err, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._err_prev = (host, ev)
+
+    @torch.no_grad()
+    def match_flat(self, logits, boxes, targets):
+        """Device-side assignment for all layers and images at once (csrc/loss.hip: hungarian_kernel): ->
+        (srow, gidx int64, lidx int32) device tensors of length L*sum(M_b), ordered (layer, image, query) - the
+        flattened form SetCriterion consumes - or None when a problem does not fit the kernel (M_b > Q or Q > 1024;
+        the caller then uses match_many)."""
+        L, B, Q, _ = logits.shape
+        sizes = [int(len(t["boxes"])) for t in targets]
+        if sum(sizes) == 0 or max(sizes) > Q or Q > 1024 or not logits.is_cuda:
+            return None
+        cost, err, toff_t, sizes, toff = self._costs(logits, boxes, targets)
+        self._check_degenerate_async(err)
+        return K.hungarian(cost, toff_t, L, B, Q, toff[-1])
+
     @torch.no_grad()
     def match_many(self, logits, boxes, targets):
         """logits [L,B,Q,Kc], boxes [L,B,Q,4]; -> list (len L) of per-image [(idx_i, idx_j)] int64 CPU tensors."""

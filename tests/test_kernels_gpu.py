@@ -519,3 +519,62 @@ def test_linear_bf16_path_matches_fp32_operand_path(dev):
         K.LINEAR16 = old
     for a, c in zip(res[True], res[False]):
         assert rel(a, c) < 1e-5
+
+
+@pytest.mark.parametrize("L,Q,sizes", [(1, 100, [7, 7]), (7, 100, [1, 20, 0, 64]), (2, 300, [93, 5]), (3, 16, [16, 15]), (1, 1000, [100])])
+def test_hungarian_device_vs_scipy(dev, L, Q, sizes):
+    """hungarian_kernel == scipy.optimize.linear_sum_assignment on every (layer, image) block, same pair order."""
+    from scipy.optimize import linear_sum_assignment
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(Q + sum(sizes) + L)
+    B, total = len(sizes), sum(sizes)
+    toff = [0]
+    for s in sizes:
+        toff.append(toff[-1] + s)
+    cost = (torch.randn(L, Q * total, generator=g) * 3).to(dev)
+    toff_t = torch.tensor(toff, dtype=torch.int32, device=dev)
+    srow, gidx, lidx = K.hungarian(cost, toff_t, L, B, Q, total)
+    ch = cost.cpu()
+    es, eg, el = [], [], []
+    for l in range(L):
+        for b in range(B):
+            if sizes[b] == 0:
+                continue
+            blk = ch[l, Q * toff[b]:Q * toff[b + 1]].view(Q, sizes[b]).numpy()
+            i, j = linear_sum_assignment(blk)
+            es.append(torch.as_tensor(i) + (l * B + b) * Q)
+            eg.append(torch.as_tensor(j) + toff[b])
+            el.append(torch.full((len(i),), l))
+    assert torch.equal(srow.cpu(), torch.cat(es)) and torch.equal(gidx.cpu(), torch.cat(eg))
+    assert torch.equal(lidx.cpu().long(), torch.cat(el))
+
+
+def test_criterion_device_matching_equals_host_matching(dev):
+    """SetCriterion with the device-side assignment == the host (SciPy) fallback path, loss by loss."""
+    import argparse
+    from spe_amd.models.conditional_detr import SetCriterion
+    from spe_amd.models.matcher import HungarianMatcher
+    g = torch.Generator().manual_seed(9)
+    L, B, Q, Kc = 3, 2, 50, 21
+    outs = []
+    for l in range(L):
+        outs.append({"pred_logits": torch.randn(B, Q, Kc, generator=g).to(dev),
+                     "pred_boxes": (torch.rand(B, Q, 4, generator=g) * 0.4 + 0.2).to(dev)})
+    outputs = dict(outs[0]); outputs["aux_outputs"] = outs[1:]
+    targets = []
+    for b in range(B):
+        n = 5 + b
+        lab = torch.randint(0, Kc, (n,), generator=g)
+        il = torch.zeros(Kc, dtype=torch.int64); il[lab] = 1
+        targets.append({"labels": lab.to(dev), "boxes": (torch.rand(n, 4, generator=g) * 0.4 + 0.2).to(dev), "img_label": il.to(dev)})
+    crit = SetCriterion(Kc, HungarianMatcher(2.0, 5.0, 2.0), {"loss_ce": 2.0}, 0.25, ["labels", "boxes", "cardinality"], 2.0, 0.1).to(dev).eval()
+    a = crit(outputs, targets)
+    orig = HungarianMatcher.match_flat
+    try:
+        HungarianMatcher.match_flat = lambda self, *args: None
+        b_ = crit(outputs, targets)
+    finally:
+        HungarianMatcher.match_flat = orig
+    assert set(a) == set(b_)
+    for k in a:
+        assert torch.allclose(a[k], b_[k], rtol=1e-6, atol=1e-7), (k, a[k], b_[k])
