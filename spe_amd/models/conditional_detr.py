@@ -17,7 +17,7 @@ from torch.autograd import Function
 
 from .. import kernels as K
 from ..util import box_ops
-from ..util.misc import (NestedTensor, get_world_size, inverse_sigmoid, is_dist_avail_and_initialized,
+from ..util.misc import (NestedTensor, get_world_size, host_to_device, inverse_sigmoid, is_dist_avail_and_initialized,
                          nested_tensor_from_tensor_list)
 from .cait_backbone import build_backbone
 from .layers import MLP, Linear
@@ -194,7 +194,7 @@ class SetCriterion(nn.Module):
         sizes = [int(len(t["labels"])) for t in targets_cp]
         # normaliser: a host number on one GPU; across ranks it stays a device scalar (no .item() stall per step)
         if is_dist_avail_and_initialized() and get_world_size() > 1:
-            nb = torch.as_tensor([float(sum(sizes))], dtype=torch.float, device=dev)
+            nb = host_to_device([float(sum(sizes))], torch.float, dev)
             torch.distributed.all_reduce(nb)
             num_boxes = torch.clamp(nb / get_world_size(), min=1)[0]
         else:
@@ -240,6 +240,7 @@ class SetCriterion(nn.Module):
         if "boxes" in self.losses:
             w = scores[gidx].contiguous() if self.refine else None
             bl = _BoxLoss.apply(boxes.view(-1, 4), srow, tgt_boxes[gidx].contiguous(), w, lidx, L, 1.0) / num_boxes
+        sizes_t = host_to_device(sizes, torch.float, dev) if "cardinality" in self.losses else None
         for l in range(L):
             sfx = suffix[l]
             if "labels" in self.losses:
@@ -254,7 +255,7 @@ class SetCriterion(nn.Module):
                 losses["loss_giou" + sfx] = bl[l, 1]
             if "cardinality" in self.losses:                                    # conditional_detr.py:286-298 (logging)
                 card = (amax.view(L, B, Q)[l] != Kc - 1).sum(1).float()
-                losses["cardinality_error" + sfx] = F.l1_loss(card, torch.tensor(sizes, dtype=torch.float, device=dev))
+                losses["cardinality_error" + sfx] = F.l1_loss(card, sizes_t)
             if l == 0 and "image_label" in self.losses:
                 losses.update(self.loss_img_label(outputs, targets_cp))
         return losses

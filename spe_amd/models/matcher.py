@@ -10,6 +10,7 @@ from scipy.optimize import linear_sum_assignment
 from torch import nn
 
 from .. import kernels as K
+from ..util.misc import host_to_device
 
 
 class HungarianMatcher(nn.Module):
@@ -30,7 +31,7 @@ class HungarianMatcher(nn.Module):
             toff.append(toff[-1] + s)
         tgt_ids = torch.cat([t["labels"] for t in targets]).to(device=dev, dtype=torch.int32).contiguous()
         tgt_box = torch.cat([t["boxes"] for t in targets]).to(device=dev, dtype=torch.float32).contiguous()
-        toff_t = torch.tensor(toff, dtype=torch.int32).to(dev, non_blocking=True)
+        toff_t = host_to_device(toff, torch.int32, dev)
         cost, err = K.matcher_cost(logits.contiguous().float(), boxes.contiguous().float(), tgt_ids, tgt_box, toff_t,
                                    toff[-1], self.cost_class, self.cost_bbox, self.cost_giou)
         return cost, err, toff_t, sizes, toff

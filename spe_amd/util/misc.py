@@ -57,3 +57,12 @@ def get_world_size():
 
 def get_rank():
     return dist.get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def host_to_device(values, dtype, device):
+    """Small host list -> device tensor through pinned memory with an asynchronous copy.  `torch.tensor(list,
+    device=cuda)` stages through pageable memory and blocks the host until every kernel queued before it has run."""
+    t = torch.tensor(values, dtype=dtype)
+    if torch.device(device).type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)

@@ -1,0 +1,60 @@
+"""List host<->device synchronisation points of one training step (torch.cuda.set_sync_debug_mode('warn'))."""
+import os
+import sys
+import warnings
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+from spe_amd import kernels as K
+from spe_amd import lib
+from spe_amd.dp import GradAllReducer
+from spe_amd.models import build_model
+from spe_amd.util.misc import NestedTensor
+
+dev = torch.device("cuda", 0)
+lib.load()
+K.set_precision("bf16")
+K.manual_seed(1)
+args = bench.model_args()
+torch.manual_seed(0)
+model, crit, crit_r, pp, rpp = build_model(args)
+model.to(dev).train(); crit.to(dev).train(); crit_r.to(dev).train()
+wd = crit.weight_dict
+params = [p for p in model.parameters() if p.requires_grad]
+reducer = GradAllReducer(params)
+opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True)
+img, mask, targets = bench.synth_batch(1, dev)
+samples = NestedTensor(img, mask)
+
+
+def step():
+    reducer.reset()
+    out = model(samples)
+    l0 = crit(out[0], targets)
+    with torch.no_grad():
+        ps = bench.pseudo_labels(rpp, out[0], targets)
+    l1 = crit_r(out[1], ps)
+    total = bench.weighted_total(l0, l1, wd)
+    total.backward()
+    reducer.finish()
+    torch.nn.utils.clip_grad_norm_(params, 0.1)
+    opt.step()
+
+
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+torch.cuda.set_sync_debug_mode("warn")
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    step()
+torch.cuda.set_sync_debug_mode("default")
+import collections
+c = collections.Counter()
+for x in w:
+    c[(str(x.message)[:80], x.filename.replace(os.getcwd(), "."), x.lineno)] += 1
+for k, v in c.most_common():
+    print(v, k)
+print("sync warnings:", len(w))
