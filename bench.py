@@ -157,6 +157,7 @@ def main():
     from spe_amd import kernels as K
     from spe_amd import lib
     from spe_amd.dp import GradAllReducer
+    from spe_amd.optim import FlatAdamW
     from spe_amd.models import build_model
     from spe_amd.util.misc import NestedTensor
     lib.load()
@@ -171,8 +172,11 @@ def main():
     crit_r.to(dev).train()
     wd = crit.weight_dict
     params = [p for p in model.parameters() if p.requires_grad]
-    reducer = GradAllReducer(params)
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True)
+    reducer = GradAllReducer(params, flatten_params=True)
+    # reference main.py:177-191: AdamW, backbone parameters at lr_backbone; engine.py:161-165: clip_grad_norm_(0.1)
+    groups = [{"params": [p for n, p in model.named_parameters() if "backbone" not in n and p.requires_grad], "lr": 1e-4},
+              {"params": [p for n, p in model.named_parameters() if "backbone" in n and p.requires_grad], "lr": 1e-5}]
+    opt = FlatAdamW(groups, reducer, lr=1e-4, weight_decay=1e-4, max_grad_norm=0.1)
     torch.manual_seed(1234 + rank)
     img, mask, targets = synth_batch(1234 + rank, dev, batch=a.batch, H=a.height, W=a.width)
     samples = NestedTensor(img, mask)
@@ -187,8 +191,7 @@ def main():
         total = weighted_total(l0, l1, wd)
         total.backward()
         reducer.finish()
-        torch.nn.utils.clip_grad_norm_(params, 0.1)
-        opt.step()
+        opt.step()                      # global-norm clip (0.1) + AdamW, fused on the flat buckets
         return total
 
     def sync():

@@ -196,6 +196,17 @@ int spe_box_loss(const float* pred_boxes, const long* srow, const float* tbox, c
 int spe_box_loss_bwd(const long* srow, const int* lidx, const float* g_l1, const float* g_giou, const float* c1,
                      const float* c2, float* dpred, long n, spe_stream_t stream);
 
+/* ---- optimiser step on flat buffers (reference engine.py:161-165: clip_grad_norm_(params, 0.1) + AdamW.step(),
+ * parameter groups of main.py:177-191).  spe_sqnorm_partials: partials[b] = sum g^2 over the b-th of nblocks chunks.
+ * spe_adamw_flat: clip = min(1, max_norm / (sqrt(sum partials) + 1e-6)) (max_norm <= 0: no clipping), g *= clip,
+ * then torch.optim.AdamW's update with bias corrections bias_c1 = 1 - beta1^t, bias_c2 = 1 - beta2^t; element i uses
+ * (lr, weight decay) of the segment s with seg_end[s-1] <= i < seg_end[s] (nseg <= 64).  write_grad != 0 stores the
+ * clipped gradient back (what clip_grad_norm_ leaves in .grad).  Buffers 16-B aligned. */
+int spe_sqnorm_partials(const float* g, long n, float* partials, int nblocks, spe_stream_t stream);
+int spe_adamw_flat(float* p, float* g, float* m, float* v, long n, const long* seg_end, const float* seg_lr,
+                   const float* seg_wd, int nseg, float beta1, float beta2, float eps, float bias_c1, float bias_c2,
+                   const float* partials, int npartials, float max_norm, int write_grad, spe_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,8 +17,11 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, params, bucket_bytes=64 << 20, average=True, group=None):
+    def __init__(self, params, bucket_bytes=64 << 20, average=True, group=None, flatten_params=False):
+        """flatten_params: also move the parameters themselves into flat per-bucket buffers with the gradient layout
+        (param.data becomes a view) - what spe_amd.optim.FlatAdamW steps in one launch per bucket."""
         self.params = [p for p in params if p.requires_grad]
+        self.flatten_params = flatten_params
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.average = average
@@ -42,14 +45,23 @@ class GradAllReducer:
         al = lambda k: (k + 63) & ~63                        # 256-B aligned views: vectorised kernels write into them
         n = sum(al(p.numel()) for p in plist)
         flat = torch.zeros(n, device=dev, dtype=dt)
+        flat_p = torch.zeros(n, device=dev, dtype=dt) if self.flatten_params else None
         off = 0
+        offsets = []
         for p in plist:
             v = flat[off:off + p.numel()].view_as(p)
             self._views[p] = v
             p._spe_grad_buf = v                              # spe_amd backward kernels write here (kernels.grad_buffer)
+            if flat_p is not None:
+                pv = flat_p[off:off + p.numel()].view_as(p)
+                with torch.no_grad():
+                    pv.copy_(p.data)
+                p.data = pv
+            offsets.append((p, off))
             off += al(p.numel())
             self._bucket_of[p] = len(self.buckets)
-        self.buckets.append({"flat": flat, "params": list(plist), "pending": 0, "work": None})
+        self.buckets.append({"flat": flat, "flat_p": flat_p, "offsets": offsets, "params": list(plist), "pending": 0,
+                             "work": None})
 
     def reset(self):
         """Call before every backward (after the optimizer consumed the gradients): zero the buckets and detach

@@ -508,3 +508,14 @@ def bicubic(src, gh, gw, h, w, backward=False):
         out = torch.empty((h * w, C), device=src.device, dtype=torch.float32)
     _call("spe_bicubic", _p(src), _p(out), gh, gw, h, w, C, int(backward), _st())
     return out
+
+
+# ---- optimiser (flat buffers) ----------------------------------------------------------------
+def sqnorm_partials(g_flat, partials):
+    _call("spe_sqnorm_partials", _p(g_flat), g_flat.numel(), _p(partials), partials.numel(), _st())
+
+
+def adamw_flat(p, g, m, v, seg_end_i64, seg_lr, seg_wd, beta1, beta2, eps, bias_c1, bias_c2, partials, max_norm, write_grad):
+    _call("spe_adamw_flat", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(seg_end_i64), _p(seg_lr), _p(seg_wd), seg_end_i64.numel(),
+          float(beta1), float(beta2), float(eps), float(bias_c1), float(bias_c2), _p(partials), partials.numel(),
+          float(max_norm), int(bool(write_grad)), _st())

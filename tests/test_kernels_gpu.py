@@ -578,3 +578,41 @@ def test_criterion_device_matching_equals_host_matching(dev):
     assert set(a) == set(b_)
     for k in a:
         assert torch.allclose(a[k], b_[k], rtol=1e-6, atol=1e-7), (k, a[k], b_[k])
+
+
+def test_flat_adamw_matches_torch(dev):
+    """FlatAdamW (+ fused global-norm clip) == clip_grad_norm_ + torch.optim.AdamW with two parameter groups, 3 steps,
+    LR change in between; state_dict round trip."""
+    from spe_amd.dp import GradAllReducer
+    from spe_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(21)
+    shapes = [(64, 32), (64,), (7, 5, 3), (1,), (300, 17), (33,)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(*s, generator=torch.Generator().manual_seed(i)).to(dev)) for i, s in enumerate(shapes)]
+    pa, pb = mk(), mk()
+    groups = lambda ps: [{"params": ps[:3], "lr": 1e-2, "weight_decay": 1e-2}, {"params": ps[3:], "lr": 3e-3, "weight_decay": 0.0}]
+    ref = torch.optim.AdamW(groups(pa), betas=(0.9, 0.999), eps=1e-8)
+    red = GradAllReducer(pb, bucket_bytes=4096, flatten_params=True)
+    opt = FlatAdamW(groups(pb), red, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=0.1)
+    for it in range(3):
+        red.reset()
+        for x, y in zip(pa, pb):
+            gr = torch.randn(x.shape, generator=g).to(dev) * (10.0 if it == 1 else 0.01)      # clipped and unclipped steps
+            x.grad = gr.clone()
+            y.grad = red._views[y]; y.grad.copy_(gr)
+        red.finish()
+        tn = torch.nn.utils.clip_grad_norm_(pa, 0.1)
+        ref.step(); opt.step()
+        for x, y in zip(pa, pb):
+            assert rel(y, x) < 2e-6, (it, rel(y, x))
+            assert rel(y.grad, x.grad) < 2e-6
+        if it == 0:
+            for o in (ref, opt):
+                o.param_groups[1]["lr"] = 1e-3
+    sd = opt.state_dict()
+    opt.load_state_dict(sd)
+    mbuf = opt._buckets[red._bucket_of[pb[0]]]["m"]           # the state entries are still views of the flat moments
+    assert mbuf.data_ptr() <= opt.state[pb[0]]["exp_avg"].data_ptr() < mbuf.data_ptr() + mbuf.numel() * 4
+    for x, y in zip(pa, pb):
+        assert rel(opt.state[y]["exp_avg"], ref.state[x]["exp_avg"]) < 2e-6
+        # v accumulates (clip * g)^2: twice the relative rounding difference of the two global-norm reductions
+        assert rel(opt.state[y]["exp_avg_sq"], ref.state[x]["exp_avg_sq"]) < 5e-5
