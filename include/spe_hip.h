@@ -73,11 +73,13 @@ int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const
  * models/transformer.py:368-425) are NT products of copies made by spe_cvt_bf16:
  *   y = x W^T: (x16, W16) ; dx = dy W: (dy16, W16T) ; dW = dy^T x: (dy16T, x16T), contraction zero padded.
  * spe_cvt_bf16: out[R][ldo] = bf16(x) (round to nearest even, the rounding spe_gemm_f32 applies while staging)
- * and/or outT[C][ldt] = transpose, columns R..ldt-1 zero filled.  Either output may be NULL. */
+ * and/or outT[C][ldt] = transpose, columns R..ldt-1 zero filled; colsum[c] += sum_r x[r][c] (fp32; the bias gradient
+ * of the Linear, from the same read).  Any of the three outputs may be NULL. */
 int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const float* bias, float* C2,
                     int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int splitk,
                     spe_stream_t stream);
-int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, long ldo, void* outT, long ldt, spe_stream_t stream);
+int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, long ldo, void* outT, long ldt, float* colsum,
+                 spe_stream_t stream);
 
 /* ---- masked softmax over scores[B,H,Nq,ld] (Nk valid columns per row).
  * mask[B,Nk] (1 = padded key, -inf) or null; P = softmax; Pd = dropout(P) written only when
@@ -132,6 +134,11 @@ int spe_attn_merge(const float* ws, float* out0, float* out1, int B, int H, int 
  * (x element strides sb, sn, sh; 0 outside).  out element strides ob (batch), on (row), oh (head), unit d stride.
  * Head dim <= 64, returns -2 otherwise. */
 int spe_attn_pack16(const float* x, long sb, long sn, long sh, int B, int N, int H, int dh, void* out, spe_stream_t stream);
+/* njobs <= 6 packs of same-shape [B,N,H,dh] views in one launch: job i reads xs[i] (element strides strides[3i..3i+2] =
+ * batch, row, head), multiplies by scales[i] and writes the spe_attn_pack (kinds[i] = 0) or spe_attn_pack16 (1) layout
+ * to outs[i].  The pointer/stride tables are HOST arrays (copied into the kernel arguments). */
+int spe_attn_pack_multi(int njobs, const float* const* xs, const long* strides, const float* scales, const int* kinds,
+                        void* const* outs, int B, int N, int H, int dh, spe_stream_t stream);
 int spe_attn_contract(const void* T, const void* X16, float* out, long ob, long on, long oh, int B, int H, int N, int dh,
                       int trans, float alpha, spe_stream_t stream);
 

@@ -25,6 +25,9 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4c_t __attribute__((ext_vector_type(4)));
 
 #define CONTRACT_R 4
+#ifndef CONTRACT_PD
+#define CONTRACT_PD 2
+#endif
 
 template <int DT, bool TRANS>
 __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restrict__ T, const uint2* __restrict__ X,
@@ -53,8 +56,10 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
 #pragma unroll
     for (int r = 0; r < R; ++r) tr[r] = min(t0 + r, nt - 1);
 
-    uint2 tb[R], xf[DT], tb_n[R], xf_n[DT];
-    // loads are unconditional with clamped indices (a branch around a load costs a full vmcnt(0) drain)
+    // PD contraction steps are in flight per wave (register ring; loads are unconditional with clamped indices - a
+    // branch around a load costs a full vmcnt(0) drain); a step's registers are re-armed right after its MFMAs issued
+    constexpr int PD = CONTRACT_PD;
+    uint2 tb[PD][R], xf[PD][DT];
 #define LOAD_STEP(c_, tb_, xf_)                                                                         \
     {                                                                                                   \
         const int cc = min((c_), nt - 1);                                                               \
@@ -62,29 +67,32 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
         _Pragma("unroll") for (int r = 0; r < R; ++r)                                                   \
             tb_[r] = TRANS ? Tb[((long)cc * nt + tr[r]) * 64 + lane] : Tb[((long)tr[r] * nt + cc) * 64 + lane]; \
     }
-    LOAD_STEP(wave, tb, xf);
-    for (int c = wave; c < nt; c += 4) {
-        LOAD_STEP(c + 4, tb_n, xf_n);
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            s16x4_t bt;
-            if (TRANS) {
-                const f32x4_t t = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, tb[r]), ident,
-                                                                              (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                bf16x4c_t tv;
-                tv[0] = (__bf16)t[0]; tv[1] = (__bf16)t[1]; tv[2] = (__bf16)t[2]; tv[3] = (__bf16)t[3];
-                bt = __builtin_bit_cast(s16x4_t, tv);
-            } else {
-                bt = __builtin_bit_cast(s16x4_t, tb[r]);
+    for (int s = 0; s < PD; ++s) LOAD_STEP(wave + 4 * s, tb[s], xf[s]);
+    for (int c0 = wave; c0 < nt; c0 += 4 * PD) {
+#pragma unroll
+        for (int s = 0; s < PD; ++s) {
+            const int c = c0 + 4 * s;
+            if (c < nt) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    s16x4_t bt;
+                    if (TRANS) {
+                        const f32x4_t t = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, tb[s][r]), ident,
+                                                                                      (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        bf16x4c_t tv;
+                        tv[0] = (__bf16)t[0]; tv[1] = (__bf16)t[1]; tv[2] = (__bf16)t[2]; tv[3] = (__bf16)t[3];
+                        bt = __builtin_bit_cast(s16x4_t, tv);
+                    } else {
+                        bt = __builtin_bit_cast(s16x4_t, tb[s][r]);
+                    }
+#pragma unroll
+                    for (int d = 0; d < DT; ++d)
+                        acc[r][d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, xf[s][d]), bt, acc[r][d], 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int d = 0; d < DT; ++d)
-                acc[r][d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, xf[d]), bt, acc[r][d], 0, 0, 0);
+            LOAD_STEP(c + 4 * PD, tb[s], xf[s]);
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r) tb[r] = tb_n[r];
-#pragma unroll
-        for (int d = 0; d < DT; ++d) xf[d] = xf_n[d];
     }
 #undef LOAD_STEP
 
@@ -162,6 +170,75 @@ extern "C" int spe_attn_pack16(const float* x, long sb, long sn, long sh, int B,
     long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(attn_pack16_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, sb, sn, sh, B, N, H, dh, nt, DT,
                        reinterpret_cast<uint2*>(out));
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// Several packs of one attention call in ONE launch (forward: q, k -> 32-wide fragments, v -> 16-wide; backward: v, dO
+// -> 32-wide, dO, k, q -> 16-wide): the packs are ~10 us each and launch-latency bound.  blockIdx.y = job.
+#define PACK_MAXJOBS 6
+struct PackJob { const float* x; long sb, sn, sh; float scale; int kind; void* out; };   // kind 0: spe_attn_pack layout, 1: spe_attn_pack16
+struct PackJobs { PackJob j[PACK_MAXJOBS]; int B, N, H, dh, nt; };
+typedef unsigned int u32x4p_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void attn_pack_multi_kernel(PackJobs a) {
+    const PackJob jb = a.j[blockIdx.y];
+    const int nt = a.nt, N = a.N, H = a.H, dh = a.dh;
+    if (jb.kind == 0) {
+        const int dsteps = (dh + 31) / 32;
+        const long total = (long)a.B * H * nt * dsteps * 64;
+        u32x4p_t* out = reinterpret_cast<u32x4p_t*>(jb.out);
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int ln = (int)(i & 63); long t = i >> 6;
+            const int st = (int)(t % dsteps); t /= dsteps;
+            const int tile = (int)(t % nt); t /= nt;
+            const int h = (int)(t % H); const int b = (int)(t / H);
+            const int row = tile * 16 + (ln & 15), d0 = st * 32 + (ln >> 4) * 8;
+            const float* src = jb.x + b * jb.sb + (long)min(row, N - 1) * jb.sn + h * jb.sh;
+            typedef __bf16 bf16x8p_t __attribute__((ext_vector_type(8)));
+            bf16x8p_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = src[min(d0 + j, dh - 1)];
+                o[j] = (__bf16)((row < N && d0 + j < dh) ? f * jb.scale : 0.f);
+            }
+            out[i] = __builtin_bit_cast(u32x4p_t, o);
+        }
+    } else {
+        const int DT = (dh + 15) / 16;
+        const long total = (long)a.B * H * nt * DT * 64;
+        uint2* out = reinterpret_cast<uint2*>(jb.out);
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int ln = (int)(i & 63); long t = i >> 6;
+            const int dt = (int)(t % DT); t /= DT;
+            const int tile = (int)(t % nt); t /= nt;
+            const int h = (int)(t % H); const int b = (int)(t / H);
+            const int d = dt * 16 + (ln & 15), r0 = tile * 16 + 4 * (ln >> 4);
+            bf16x4c_t o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = r0 + j;
+                const float f = jb.x[b * jb.sb + (long)min(row, N - 1) * jb.sn + h * jb.sh + min(d, dh - 1)];
+                o[j] = (__bf16)((row < N && d < dh) ? f * jb.scale : 0.f);
+            }
+            out[i] = __builtin_bit_cast(uint2, o);
+        }
+    }
+}
+
+// C-ABI: see include/spe_hip.h (spe_attn_pack_multi).  xs/outs/scales/kinds: njobs entries; common strides.
+extern "C" int spe_attn_pack_multi(int njobs, const float* const* xs, const long* strides, const float* scales, const int* kinds,
+                                   void* const* outs, int B, int N, int H, int dh, hipStream_t st) {
+    if (njobs <= 0 || B <= 0 || N <= 0) return 0;
+    if (njobs > PACK_MAXJOBS) return -2;
+    PackJobs a;
+    for (int i = 0; i < njobs; ++i) {
+        a.j[i].x = xs[i]; a.j[i].sb = strides[3 * i]; a.j[i].sn = strides[3 * i + 1]; a.j[i].sh = strides[3 * i + 2];
+        a.j[i].scale = scales[i]; a.j[i].kind = kinds[i]; a.j[i].out = outs[i];
+    }
+    a.B = B; a.N = N; a.H = H; a.dh = dh; a.nt = (N + 15) / 16;
+    const long total = (long)B * H * a.nt * ((dh + 15) / 16) * 64;        // the larger (16-wide) item count
+    long nb = (total + 255) / 256; if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(attn_pack_multi_kernel, dim3((unsigned)nb, njobs), dim3(256), 0, st, a);
     SPE_CHECK_LAUNCH();
     return 0;
 }

@@ -255,10 +255,13 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const
 
 // ---- fp32 -> bf16 (round to nearest even) copies of a [R, C] matrix: out[R][ldo] (row-major) and/or the
 // transpose outT[C][ldt] whose columns R..ldt-1 are zero filled (the contraction padding of the dW GEMM).
+// colsum (optional): colsum[c] += sum_r x[r][c] in fp32 - the bias gradient of a Linear, taken from the same read of dy.
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ x, long ldx, int R, int C,
                                                        unsigned short* __restrict__ out, long ldo,
-                                                       unsigned short* __restrict__ outT, long ldt) {
+                                                       unsigned short* __restrict__ outT, long ldt, float* __restrict__ colsum) {
     __shared__ unsigned short tile[64][66];
+    __shared__ float csum[16][64];
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;        // 16 column quads x 16 row lanes
 #pragma unroll
@@ -274,6 +277,7 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
                 for (int j = 0; j < 4; ++j) if (c + j < C) v[j] = x[(long)r * ldx + c + j];
             }
         }
+        cs[0] += v[0]; cs[1] += v[1]; cs[2] += v[2]; cs[3] += v[3];
         typedef __bf16 bf16x4v_t __attribute__((ext_vector_type(4)));
         bf16x4v_t h;
         h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
@@ -289,6 +293,17 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
         if (outT) {
             tile[ty + 16 * i][tx * 4 + 0] = (unsigned short)(u.x & 0xffff); tile[ty + 16 * i][tx * 4 + 1] = (unsigned short)(u.x >> 16);
             tile[ty + 16 * i][tx * 4 + 2] = (unsigned short)(u.y & 0xffff); tile[ty + 16 * i][tx * 4 + 3] = (unsigned short)(u.y >> 16);
+        }
+    }
+    if (colsum && r0 < R) {          // block-uniform: rows of this tile are inside the matrix
+#pragma unroll
+        for (int j = 0; j < 4; ++j) csum[ty][tx * 4 + j] = cs[j];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += csum[i][threadIdx.x];
+            if (c0 + (int)threadIdx.x < C) atomicAdd(colsum + c0 + threadIdx.x, t);
         }
     }
     if (!outT) return;
@@ -313,15 +328,16 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
 }
 
 // C-ABI: see include/spe_hip.h (spe_cvt_bf16).
-extern "C" int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, long ldo, void* outT, long ldt, hipStream_t stream) {
+extern "C" int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, long ldo, void* outT, long ldt, float* colsum,
+                            hipStream_t stream) {
     if (R <= 0 || C <= 0) return 0;
-    if (!out && !outT) return 0;
+    if (!out && !outT && !colsum) return 0;
     if (outT && ldt < R) return -2;
     // the grid covers the padded row range of the transpose so that its zero columns are written too
     const long rows = outT ? ((ldt > R) ? ldt : R) : R;
     dim3 grid((C + 63) / 64, (unsigned)((rows + 63) / 64));
     hipLaunchKernelGGL(cvt_bf16_kernel, grid, dim3(256), 0, stream, x, ldx, R, C, reinterpret_cast<unsigned short*>(out), ldo,
-                       reinterpret_cast<unsigned short*>(outT), ldt);
+                       reinterpret_cast<unsigned short*>(outT), ldt, colsum);
     SPE_CHECK_LAUNCH();
     return 0;
 }

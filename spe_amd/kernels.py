@@ -154,8 +154,9 @@ def _lin16_ok(R, N, K):
     return LINEAR16 and _PRECISION == 0 and R >= LINEAR16_MIN_ROWS and N % 8 == 0 and K % 8 == 0
 
 
-def cvt_bf16(x2, want=True, wantT=False, ldt=None):
-    """bf16 (RNE) copies of a contiguous fp32 [R, C]: row-major [R, C] and/or the transpose [C, ldt] (zero padded)."""
+def cvt_bf16(x2, want=True, wantT=False, ldt=None, colsum_out=None):
+    """bf16 (RNE) copies of a contiguous fp32 [R, C]: row-major [R, C] and/or the transpose [C, ldt] (zero padded);
+    colsum_out (zeroed or running fp32 [C]) += column sums of x2 from the same pass."""
     _chk(x2)
     R, C = x2.shape
     out = torch.empty((R, C), device=x2.device, dtype=torch.bfloat16) if want else None
@@ -163,7 +164,7 @@ def cvt_bf16(x2, want=True, wantT=False, ldt=None):
     if wantT:
         ldt = ldt or ((R + 63) // 64) * 64
         outT = torch.empty((C, ldt), device=x2.device, dtype=torch.bfloat16)
-    _call("spe_cvt_bf16", _p(x2), x2.stride(0), R, C, _p(out), C, _p(outT), ldt or 0, _st())
+    _call("spe_cvt_bf16", _p(x2), x2.stride(0), R, C, _p(out), C, _p(outT), ldt or 0, _p(colsum_out), _st())
     return out, outT
 
 
@@ -215,7 +216,10 @@ def linear_bwd(dy2, xsave, W, need_dx=True, need_dw=True, need_db=True, dW_out=N
     x16 = xsave.dtype == torch.bfloat16
     if (x16 or not need_dw) and _lin16_ok(R, N, K) and W.is_contiguous():
         Rp = xsave.shape[1] if x16 else None
-        dy16, dy16T = cvt_bf16(dy2, need_dx, need_dw and x16, ldt=Rp)
+        if need_db:                     # the bias gradient rides on the conversion pass over dy
+            db = _zeros_or(db_out, N, dy2.device)
+        dy16, dy16T = cvt_bf16(dy2, need_dx, need_dw and x16, ldt=Rp, colsum_out=db)
+        need_db = False
         if need_dx:
             dx = torch.empty((R, K), device=dy2.device, dtype=torch.float32)
             gemm16(dy16, weight16(W)[1], dx, R, K, N, N, N, K)
@@ -472,6 +476,26 @@ def attn_pack16(x4):
     out = torch.empty((B, H, nt, DT, 64, 4), device=x4.device, dtype=torch.bfloat16)
     _call("spe_attn_pack16", _p(x4), x4.stride(0), x4.stride(1), x4.stride(2), B, N, H, dh, _p(out), _st())
     return out
+
+
+def attn_pack_multi(jobs):
+    """jobs: list of (x4 [B,N,H,dh] fp32 view with unit last stride, scale, kind) with kind 32 -> attn_pack layout,
+    16 -> attn_pack16 layout; all views the same shape.  One launch; -> list of packed bf16 tensors."""
+    B, N, H, dh = jobs[0][0].shape
+    nt = (N + 15) // 16
+    n = len(jobs)
+    outs = []
+    for x4, scale, kind in jobs:
+        assert x4.shape == (B, N, H, dh) and x4.stride(3) == 1 and x4.dtype == torch.float32
+        shape = (B, H, nt, (dh + 31) // 32, 64, 8) if kind == 32 else (B, H, nt, (dh + 15) // 16, 64, 4)
+        outs.append(torch.empty(shape, device=x4.device, dtype=torch.bfloat16))
+    xs = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs])
+    strides = (ctypes.c_long * (3 * n))(*[s for j in jobs for s in (j[0].stride(0), j[0].stride(1), j[0].stride(2))])
+    scales = (ctypes.c_float * n)(*[float(j[1]) for j in jobs])
+    kinds = (ctypes.c_int * n)(*[0 if j[2] == 32 else 1 for j in jobs])
+    optr = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    _call("spe_attn_pack_multi", n, xs, strides, scales, kinds, optr, B, N, H, dh, _st())
+    return outs
 
 
 def attn_contract(T, X16, out4, trans, alpha=1.0):

@@ -207,7 +207,7 @@ class _TalkingHeadsAttentionFused(Function):
         nt = (N + 15) // 16
         spw0, _ = K.fused_plan(B, N, 0)
         # the fused kernels work in the log2 domain: scale * log2(e) is folded into the Q fragments
-        Qf, Kf = K.attn_pack(q, scale * K.LOG2E), K.attn_pack(k, 1.0)
+        Qf, Kf, V16 = K.attn_pack_multi([(q, scale * K.LOG2E, 32), (k, 1.0, 32), (v, 1.0, 16)])
         Wl, bl, Ww, bw = Wl.contiguous(), bl.contiguous(), Ww.contiguous(), bw.contiguous()
         ws_stats = torch.empty((B * nt * 8 * H * 32,), device=qkv.device, dtype=torch.float32)
         seed, off = K.next_rng() if p_drop > 0 else (0, 0)
@@ -216,7 +216,7 @@ class _TalkingHeadsAttentionFused(Function):
         Pd = K.score_blocks(B, H, N, qkv.device)
         K.talking_fused(1, Qf, Kf, None, None, Wl, bl, Ww, bw, M, IL, None, None, None, Pd, B, H, N, dh, p_drop, seed, off)
         O = torch.empty((B, N, C), device=qkv.device, dtype=torch.float32)
-        K.attn_contract(Pd, K.attn_pack16(v), O.view(B, N, H, dh), False)
+        K.attn_contract(Pd, V16, O.view(B, N, H, dh), False)
         ctx.meta = (B, N, C, H, dh, nt, scale, p_drop, seed, off)
         ctx.save_for_backward(qkv, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw)
         return O
@@ -233,9 +233,9 @@ class _TalkingHeadsAttentionFused(Function):
         d5 = dqkv.view(B, N, 3, H, dh)
         dq, dk, dv = d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]
         dO4 = dO.view(B, N, H, dh)
+        Vf, dOf, dO16, K16, Q16 = K.attn_pack_multi([(v, 1.0, 32), (dO4, 1.0, 32), (dO4, 1.0, 16), (k, 1.0, 16), (q, 1.0, 16)])
         # dV[key,d] = sum_q P'd[q,key] dO[q,d]
-        K.attn_contract(Pd, K.attn_pack16(dO4), dv, True)
-        Vf, dOf = K.attn_pack(v, 1.0), K.attn_pack(dO4, 1.0)
+        K.attn_contract(Pd, dO16, dv, True)
         nw = 2 * (H * H + H)
         ws_stats = torch.empty((B * nt * 8 * H * 32,), device=qkv.device, dtype=torch.float32)
         ws_w = torch.empty((nwg, nw), device=qkv.device, dtype=torch.float32)
@@ -247,8 +247,8 @@ class _TalkingHeadsAttentionFused(Function):
         hh = H * H
         dWl, dbl, dWw, dbw = g[:hh].view(H, H), g[hh:hh + H], g[hh + H:2 * hh + H].view(H, H), g[2 * hh + H:]
         # dQ[q,d] = scale * sum_key dS[q,key] K[key,d] ; dK[key,d] = scale * sum_q dS[q,key] Q[q,d]
-        K.attn_contract(dS, K.attn_pack16(k), dq, False, alpha=scale)
-        K.attn_contract(dS, K.attn_pack16(q), dk, True, alpha=scale)
+        K.attn_contract(dS, K16, dq, False, alpha=scale)
+        K.attn_contract(dS, Q16, dk, True, alpha=scale)
         return dqkv, dWl, dbl, dWw, dbw, None, None, None
 
 
