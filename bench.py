@@ -203,8 +203,8 @@ def main():
         step()
     # dominant kernel (largest single-shape kernel of the step: backward pass 2 of the fused talking-heads
     # attention) timed live with HIP events on the launch stream
-    DOM = "spe_talking_fused"
-    K.enable_timing([DOM])
+    DOM, HBMK = "spe_talking_fused", "spe_attn_contract"
+    K.enable_timing([DOM, HBMK])
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -232,6 +232,11 @@ def main():
         # per score and head): reported alongside against the 157.3 TFLOP/s vector peak
         valu_flop = 4 * (2.0 * Hh * Hh) * N * N * a.batch
         valu = valu_flop / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
+        # second-largest kernel family, HBM-bound: the streaming contractions over the blocked bf16 score tensors
+        # (algorithmic bytes per launch: B*H*N*N*2 B read once; operands/outputs are < 2 % of that)
+        c_launch, c_ms = K_res.get(HBMK, (0, 0.0))
+        c_bytes = 2.0 * a.batch * Hh * N * N
+        c_bw = c_bytes / (c_ms * 1e-3) / 1e9 if c_ms > 0 else 0.0
         res = {
             "metric": "images/sec (whole node) at 3x800x1333 bs=2/GPU", "value": imgs / dt, "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -244,9 +249,12 @@ def main():
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": loss_val},
             "roofline": {"bound": "mfma", "kernel": "talking_fused_kernel<8,2,3> (attention backward pass 2)", "launches": launches,
                          "avg_ms": mean_ms, "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
-                         "traffic": 2.59e9,   # bytes/launch, profiles/r01_pmc_fetch_write.txt (2*FETCH_SIZE + WRITE_SIZE)
-                         "note": "VALU-bound: fp32 head mixes have no MFMA form", "valu_achieved": valu, "valu_peak": 157.3,
-                         "valu_frac": valu / 157.3},
+                         "traffic": 1.54e9,   # bytes/launch, profiles/r01_pmc_fetch_write_v2.txt (2*FETCH_SIZE + WRITE_SIZE)
+                         "note": "issue-bound on the fp32 head mixes (no MFMA form)", "valu_achieved": valu, "valu_peak": 157.3,
+                         "valu_frac": valu / 157.3,
+                         "hbm_kernel": {"bound": "hbm", "kernel": "attn_contract_kernel<3,*> (PV / dV / dQ / dK over blocked bf16 scores)",
+                                        "launches": c_launch, "avg_ms": c_ms, "achieved": c_bw, "peak": 8000.0, "unit": "GB/s",
+                                        "frac": c_bw / 8000.0, "traffic": 6.14e8}},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:

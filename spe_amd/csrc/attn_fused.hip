@@ -64,6 +64,17 @@ __device__ __forceinline__ void load_w(const float* p, float (&w)[H][H]) {
 
 #define FUSED_MAXSLOT 8
 
+// Key chunks bound to XCDs.  A workgroup with blockIdx b runs on XCD b % 8 (8 private 4 MB L2s).  The K and V
+// fragments of an image are 4-8 MB; when every workgroup sweeps all keys each L2 thrashes on them (rocprof: 1.9 GB of
+// L2 fetches per backward launch against 34 MB of operands).  So the key tiles are cut into NCH chunks and XCD x only
+// works on chunk x % NCH: its L2 holds 1/NCH of the K/V fragments.  Within a chunk the (b, q-tile, k-tile) steps are
+// flattened q-major and split evenly over the chunk's workgroups as before.
+#ifndef SPE_FUSED_NCH
+#define SPE_FUSED_NCH 4
+#endif
+__host__ __device__ __forceinline__ int fused_nch(int nt) { return (nt >= 16 * SPE_FUSED_NCH) ? SPE_FUSED_NCH : 1; }
+__host__ __device__ __forceinline__ int fused_kbeg(int c, int nt, int nch) { return (int)((long)c * nt / nch); }
+
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #define PLO(v) __builtin_shufflevector(v, v, 0, 1)
 #define PHI(v) __builtin_shufflevector(v, v, 2, 3)
@@ -111,8 +122,12 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nt = a.nt, N = a.N;
-    const long s_begin = (long)blockIdx.x * a.steps_per_wg;
-    long s_end = s_begin + a.steps_per_wg; if (s_end > a.total_steps) s_end = a.total_steps;
+    const int nch = fused_nch(nt);
+    const int chunk = (blockIdx.x & 7) % nch, wg_j = (blockIdx.x >> 3) * (8 / nch) + (blockIdx.x & 7) / nch;   // index within the chunk
+    const int kbeg = fused_kbeg(chunk, nt, nch), klen = fused_kbeg(chunk + 1, nt, nch) - kbeg;
+    const long total_c = (long)a.B * nt * klen;
+    const long s_begin = (long)wg_j * a.steps_per_wg;
+    long s_end = s_begin + a.steps_per_wg; if (s_end > total_c) s_end = total_c;
 
     // Scores arrive in the log2 domain (spe_attn_pack folds scale * log2(e) into the Q fragments): Wl S + bl*log2(e)
     // is log2(e) * S', so every exponential is a bare v_exp_f32.
@@ -137,8 +152,8 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
 
     long s = s_begin;
     while (s < s_end) {
-        const int bq = (int)(s / nt), kt0 = (int)(s % nt);
-        int seg = nt - kt0; if (seg > s_end - s) seg = (int)(s_end - s);
+        const int bq = (int)(s / klen), kt0 = kbeg + (int)(s % klen);
+        int seg = kbeg + klen - kt0; if (seg > s_end - s) seg = (int)(s_end - s);
         const int b = bq / nt, qt = bq % nt;
         const int q = qt * 16 + (lane & 15);
         const bool qv = q < N;
@@ -537,8 +552,8 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                 }
             }
             __syncthreads();
-            const int first_wg = (int)(((long)bq * nt) / a.steps_per_wg);
-            const int slot = blockIdx.x - first_wg;
+            const int first_j = (int)(((long)bq * klen) / a.steps_per_wg);
+            const int slot = chunk * (FUSED_MAXSLOT / nch) + (wg_j - first_j);
             for (int i = threadIdx.x; i < H * 16; i += 256) {
                 float* dst = a.ws_stats + ((((long)bq * FUSED_MAXSLOT + slot) * H * 16) + i) * 2;
                 if (MODE == 0) {
@@ -590,21 +605,26 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
     const int ql = (int)(i & 15); const int g = (int)((i >> 4) % H); const int bq = (int)(i / (16L * H));
     const int b = bq / nt, qt = bq % nt, q = qt * 16 + ql;
     if (q >= N) return;
-    const int first_wg = (int)(((long)bq * nt) / steps_per_wg), last_wg = (int)((((long)bq + 1) * nt - 1) / steps_per_wg);
     const float* base = ws + (((long)bq * FUSED_MAXSLOT) * H * 16 + (long)g * 16 + ql) * 2;
     const long stride = (long)H * 16 * 2;
     const long o = ((long)b * H + g) * N + q;
-    if (mode == 0) {
-        float mn = -INFINITY;
-        for (int s = 0; s <= last_wg - first_wg; ++s) mn = fmaxf(mn, base[s * stride]);
-        float l = 0.f;
-        for (int s = 0; s <= last_wg - first_wg; ++s) l += base[s * stride + 1] * EXP2(base[s * stride] - mn);
-        out0[o] = mn; out1[o] = 1.f / l;
-    } else {
-        float d = 0.f;
-        for (int s = 0; s <= last_wg - first_wg; ++s) d += base[s * stride];
-        out0[o] = d;
-    }
+    const int nch = fused_nch(nt), spc = FUSED_MAXSLOT / nch;
+    // the slots of chunk c that received a partial: workgroups first_j..last_j of the chunk touch this q-tile
+    float mn = -INFINITY, l = 0.f, d = 0.f;
+    for (int pass = 0; pass < (mode == 0 ? 2 : 1); ++pass)
+        for (int c = 0; c < nch; ++c) {
+            const int klen = fused_kbeg(c + 1, nt, nch) - fused_kbeg(c, nt, nch);
+            if (klen <= 0) continue;
+            const int first_j = (int)(((long)bq * klen) / steps_per_wg), last_j = (int)((((long)bq + 1) * klen - 1) / steps_per_wg);
+            for (int s = 0; s <= last_j - first_j; ++s) {
+                const float* e = base + (c * spc + s) * stride;
+                if (mode != 0) d += e[0];
+                else if (pass == 0) mn = fmaxf(mn, e[0]);
+                else l += e[1] * EXP2(e[0] - mn);
+            }
+        }
+    if (mode == 0) { out0[o] = mn; out1[o] = 1.f / l; }
+    else out0[o] = d;
 }
 
 // Pack rows of x[b][n][h][d] (strides sb, sn, sh; unit d stride) into bf16 row fragments
@@ -652,13 +672,17 @@ extern "C" int spe_attn_merge(const float* ws, float* out0, float* out1, int B, 
     return 0;
 }
 
-// steps per workgroup: even split, but a q-tile (nt steps) may spread over at most FUSED_MAXSLOT workgroups
-static int plan_spw(long total, int nt, int nwg) {
-    if (nwg < 1) nwg = 1;
-    long spw = (total + nwg - 1) / nwg;
-    const long min_spw = (nt + FUSED_MAXSLOT - 3) / (FUSED_MAXSLOT - 2);   // ceil(nt / (MAXSLOT-2)): <= MAXSLOT-1 slots
+// steps per workgroup of a chunk: even split over the chunk's workgroups, but the chunk's part of a q-tile may
+// spread over at most FUSED_MAXSLOT / nch workgroups (its slots in the statistics workspace)
+static void make_plan(int B, int nt, int nwg, int* spw_out, int* nwg_out) {
+    const int nch = fused_nch(nt), spc = FUSED_MAXSLOT / nch;
+    int nwg8 = nwg & ~7; if (nwg8 < 8) nwg8 = 8;
+    const int wpc = nwg8 / nch;
+    const int len_max = (nt + nch - 1) / nch;
+    long spw = ((long)B * nt * len_max + wpc - 1) / wpc;
+    const long min_spw = (len_max + (spc - 1) - 1) / (spc - 1);       // ceil(len / (spc-1)): <= spc slots
     if (spw < min_spw) spw = min_spw;
-    return (int)spw;
+    *spw_out = (int)spw; *nwg_out = nwg8;
 }
 
 template <int H, int DSTEPS, int MODE, bool DROP, int KT>
@@ -711,8 +735,7 @@ extern "C" int spe_talking_fused(int mode, const void* Qf, const void* Kf, const
     a.B = B; a.N = N; a.nt = (N + 15) / 16;
     a.total_steps = (long)B * a.nt * a.nt;
     if (a.total_steps <= 0) return 0;
-    a.steps_per_wg = plan_spw(a.total_steps, a.nt, nwg);
-    nwg = (int)((a.total_steps + a.steps_per_wg - 1) / a.steps_per_wg);
+    make_plan(B, a.nt, nwg, &a.steps_per_wg, &nwg);
     a.p_drop = p_drop; a.seed = seed; a.offset = offset;
     const bool drop = p_drop > 0.f;
     const int ds = (dh + 31) / 32;
@@ -726,10 +749,7 @@ extern "C" int spe_talking_fused(int mode, const void* Qf, const void* Kf, const
 // steps_per_wg the launcher will use for (B, N, nwg): callers size the workspaces with it.
 extern "C" int spe_talking_fused_plan(int B, int N, int nwg, int* steps_per_wg, int* nwg_used) {
     const int nt = (N + 15) / 16;
-    const long total = (long)B * nt * nt;
-    if (total <= 0) { *steps_per_wg = 0; *nwg_used = 0; return 0; }
-    const int spw = plan_spw(total, nt, nwg);
-    *steps_per_wg = spw;
-    *nwg_used = (int)((total + spw - 1) / spw);
+    if ((long)B * nt * nt <= 0) { *steps_per_wg = 0; *nwg_used = 0; return 0; }
+    make_plan(B, nt, nwg, steps_per_wg, nwg_used);
     return 0;
 }

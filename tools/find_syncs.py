@@ -10,6 +10,7 @@ import bench
 from spe_amd import kernels as K
 from spe_amd import lib
 from spe_amd.dp import GradAllReducer
+from spe_amd.optim import FlatAdamW
 from spe_amd.models import build_model
 from spe_amd.util.misc import NestedTensor
 
@@ -23,8 +24,8 @@ model, crit, crit_r, pp, rpp = build_model(args)
 model.to(dev).train(); crit.to(dev).train(); crit_r.to(dev).train()
 wd = crit.weight_dict
 params = [p for p in model.parameters() if p.requires_grad]
-reducer = GradAllReducer(params)
-opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True)
+reducer = GradAllReducer(params, flatten_params=True)
+opt = FlatAdamW(params, reducer, lr=1e-4, weight_decay=1e-4, max_grad_norm=0.1)
 img, mask, targets = bench.synth_batch(1, dev)
 samples = NestedTensor(img, mask)
 
@@ -39,7 +40,6 @@ def step():
     total = bench.weighted_total(l0, l1, wd)
     total.backward()
     reducer.finish()
-    torch.nn.utils.clip_grad_norm_(params, 0.1)
     opt.step()
 
 
