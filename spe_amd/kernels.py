@@ -146,7 +146,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
 # half the operand bytes and a deeper load pipeline.  Small GEMMs (decoder, heads) and the bf16x3 parity mode keep the
 # fp32-operand kernel.
 LINEAR16 = os.environ.get("SPE_LINEAR16", "1") != "0"
-LINEAR16_MIN_ROWS = 2048
+LINEAR16_MIN_ROWS = int(os.environ.get("SPE_LINEAR16_MIN_ROWS", "128"))
 _W16 = {}        # id(W) -> (weakref, version, data_ptr, W16 [N,K], W16T [K,N])
 
 
