@@ -103,8 +103,9 @@ int spe_talking_softmax_bwd(const float* dPd, const float* P, const float* S, co
                             float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
 
 /* ---- fused talking-heads attention scores (reference models/cait.py:377-389 + autograd): no fp32
- * N x N tensor in HBM.  spe_attn_pack writes bf16 "row fragment" operands
- *   out[b][h][tile][dstep][lane][8] = scale * x[b, tile*16 + (lane&15), h, dstep*32 + (lane>>4)*8 + i]
+ * N x N tensor in HBM.  spe_attn_pack writes bf16 MFMA operand fragment records, per (b, h, 16-row tile):
+ *   FULL steps of [lane][8] = scale * x[b, tile*16 + (lane&15), h, st*32 + (lane>>4)*8 + i], then - when dh % 32 is in
+ *   1..16 - one 16-wide tail step of [lane][4] = scale * x[.., FULL*32 + (lane>>4)*4 + i]   (dh = 48: 1.5 KB/record)
  * from x[b][n][h][d] (element strides sb, sn, sh).  spe_talking_fused(mode):
  *   0: partial softmax statistics of S' = proj_l(scale q k^T) per (b,g,q)        -> ws_stats
  *   1: P'd = bf16(attn_drop(proj_w(softmax(S'))))                                  -> outT (blocks)

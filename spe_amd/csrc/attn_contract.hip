@@ -20,6 +20,7 @@
 // tiles of one (b, h) (so the X fragments of a step are loaded once for 4 blocks), its 4 waves take the
 // contraction steps round-robin and the partial tiles are summed through LDS.
 #include "common.h"
+#include "attn_pack.h"
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4c_t __attribute__((ext_vector_type(4)));
@@ -179,30 +180,13 @@ extern "C" int spe_attn_pack16(const float* x, long sb, long sn, long sh, int B,
 #define PACK_MAXJOBS 6
 struct PackJob { const float* x; long sb, sn, sh; float scale; int kind; void* out; };   // kind 0: spe_attn_pack layout, 1: spe_attn_pack16
 struct PackJobs { PackJob j[PACK_MAXJOBS]; int B, N, H, dh, nt; };
-typedef unsigned int u32x4p_t __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void attn_pack_multi_kernel(PackJobs a) {
     const PackJob jb = a.j[blockIdx.y];
     const int nt = a.nt, N = a.N, H = a.H, dh = a.dh;
     if (jb.kind == 0) {
-        const int dsteps = (dh + 31) / 32;
-        const long total = (long)a.B * H * nt * dsteps * 64;
-        u32x4p_t* out = reinterpret_cast<u32x4p_t*>(jb.out);
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-            const int ln = (int)(i & 63); long t = i >> 6;
-            const int st = (int)(t % dsteps); t /= dsteps;
-            const int tile = (int)(t % nt); t /= nt;
-            const int h = (int)(t % H); const int b = (int)(t / H);
-            const int row = tile * 16 + (ln & 15), d0 = st * 32 + (ln >> 4) * 8;
-            const float* src = jb.x + b * jb.sb + (long)min(row, N - 1) * jb.sn + h * jb.sh;
-            typedef __bf16 bf16x8p_t __attribute__((ext_vector_type(8)));
-            bf16x8p_t o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float f = src[min(d0 + j, dh - 1)];
-                o[j] = (__bf16)((row < N && d0 + j < dh) ? f * jb.scale : 0.f);
-            }
-            out[i] = __builtin_bit_cast(u32x4p_t, o);
-        }
+        const long total = attn_pack_units(a.B, N, H, dh);
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+            attn_pack_unit(jb.x, jb.sb, jb.sn, jb.sh, N, H, dh, nt, jb.scale, i, reinterpret_cast<uint2*>(jb.out));
     } else {
         const int DT = (dh + 15) / 16;
         const long total = (long)a.B * H * nt * DT * 64;

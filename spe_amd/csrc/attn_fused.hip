@@ -30,6 +30,7 @@
 // Per-segment row statistics go to a workspace indexed by (q-tile, slot = workgroup - first workgroup of
 // the q-tile) and are merged by spe_attn_merge.
 #include "common.h"
+#include "attn_pack.h"
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
@@ -99,7 +100,30 @@ __device__ __forceinline__ void mix_rows(const f32x4_t (&s)[H], const float (&w)
     }
 }
 
-template <int H, int DSTEPS, int MODE, bool DROP, int KT>
+// Fragment record of one (b, h, 16-row tile): FULL = DSTEPS - TAIL16 steps of 32 head dims (64 lanes x 16 B) followed,
+// when TAIL16, by one step of 16 dims (64 lanes x 8 B: the v_mfma_f32_16x16x16_bf16 operand).  dh = 48 is 32 + 16:
+// 1.5 KB per record instead of the 2 KB of two padded 32-steps - the score kernels are sensitive to exactly this
+// L2 -> register traffic (measured: dh 32 vs 48-padded-to-64 differ by 0.2 ms per block over the four passes).
+template <int DSTEPS, bool TAIL16>
+__device__ __forceinline__ u32x4_t frag_load(const u32x4_t* __restrict__ base, long rec, int st, int lane) {
+    constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0);
+    constexpr int REC8 = FULL * 128 + (TAIL16 ? 64 : 0);           // record size in 8-B units
+    const uint2* p = reinterpret_cast<const uint2*>(base) + rec * REC8;
+    if (TAIL16 && st == FULL) {
+        const uint2 v = p[FULL * 128 + lane];
+        return (u32x4_t){v.x, v.y, 0u, 0u};
+    }
+    return *reinterpret_cast<const u32x4_t*>(p + st * 128 + lane * 2);
+}
+// The tail step's 8-B operands are zero-extended (frag_load) and go through the same 16x16x32 instruction: lane group
+// g then holds k-slots 8g..8g+3 = head dims FULL*32 + 4g..4g+3 in BOTH operands and zeros in slots 8g+4..8g+7, so the
+// products line up - the saving of the tail step is its load bytes, the matrix pipe is idle anyway.
+template <int DSTEPS, bool TAIL16>
+__device__ __forceinline__ f32x4_t frag_mfma(int st, u32x4_t a, u32x4_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+template <int H, int DSTEPS, bool TAIL16, int MODE, bool DROP, int KT>
 __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
     constexpr int NFR = H * DSTEPS;                        // fragments (16 B per lane) per q-tile
     constexpr int JB = (MODE >= 2) ? ((H >= 4) ? 4 : H) : H;  // MFMA jobs per operand-fragment batch
@@ -162,14 +186,14 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
         if (QREG) {
             __syncthreads();                                   // sred of the previous segment has been consumed
 #pragma unroll
-            for (int f = 0; f < NFR; ++f) qreg[QREG ? f : 0] = a.Qf[(((long)b * H * nt + (long)(f / DSTEPS) * nt + qt) * DSTEPS + (f % DSTEPS)) * 64 + lane];
+            for (int f = 0; f < NFR; ++f) qreg[QREG ? f : 0] = frag_load<DSTEPS, TAIL16>(a.Qf, ((long)b * H + f / DSTEPS) * nt + qt, f % DSTEPS, lane);
         } else {
             __syncthreads();
             for (int i = threadIdx.x; i < NFR * 64; i += 256) {
                 const int fr = i >> 6, ln = i & 63, h = fr / DSTEPS, st = fr % DSTEPS;
-                const long src = ((((long)b * H + h) * nt + qt) * DSTEPS + st) * 64 + ln;
-                sQ[i] = a.Qf[src];
-                if (MODE >= 2) sdO[i] = a.dOf[src];
+                const long rec = ((long)b * H + h) * nt + qt;
+                sQ[i] = frag_load<DSTEPS, TAIL16>(a.Qf, rec, st, ln);
+                if (MODE >= 2) sdO[i] = frag_load<DSTEPS, TAIL16>(a.dOf, rec, st, ln);
             }
             __syncthreads();
         }
@@ -203,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                 const u32x4_t* srcp = (hj < H) ? a.Kf : a.Vf;
                 const int ktl = min(kt_first_ + tj, nt - 1);
 #pragma unroll
-                for (int st = 0; st < DSTEPS; ++st) fr[jj * DSTEPS + st] = srcp[((((long)b * H + (hj % H)) * nt + ktl) * DSTEPS + st) * 64 + lane];
+                for (int st = 0; st < DSTEPS; ++st) fr[jj * DSTEPS + st] = frag_load<DSTEPS, TAIL16>(srcp, ((long)b * H + (hj % H)) * nt + ktl, st, lane);
             }
         };
         for (int km = wave; km * KT < seg; km += 4) {
@@ -246,8 +270,7 @@ __global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
                         for (int jj = 0; jj < QG; ++jj) {
                             const int hj = (bi * JB + g0 + jj) % NH;
                             const u32x4_t qv4 = QREG ? qreg[QREG ? (hj % H) * DSTEPS + st : 0] : qf[QREG ? 0 : jj * DSTEPS + st];
-                            c[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fr[(g0 + jj) * DSTEPS + st]),
-                                                                           __builtin_bit_cast(bf16x8_t, qv4), c[jj], 0, 0, 0);
+                            c[jj] = frag_mfma<DSTEPS, TAIL16>(st, fr[(g0 + jj) * DSTEPS + st], qv4, c[jj]);
                         }
 #pragma unroll
                     for (int jj = 0; jj < QG; ++jj) {
@@ -627,36 +650,23 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
     else out0[o] = d;
 }
 
-// Pack rows of x[b][n][h][d] (strides sb, sn, sh; unit d stride) into bf16 row fragments
-// out[b][h][tile][dstep][lane][8] = scale * x[b, tile*16 + (lane&15), h, dstep*32 + (lane>>4)*8 + i]  (0 outside)
+// Pack rows of x[b][n][h][d] (strides sb, sn, sh; unit d stride) into bf16 fragment records (see frag_load):
+// per (b, h, tile): FULL steps of [lane][8] = scale * x[tile*16 + (lane&15)][st*32 + (lane>>4)*8 + i], then (tail) one
+// step of [lane][4] = scale * x[tile*16 + (lane&15)][FULL*32 + (lane>>4)*4 + i]; 0 outside N x dh.  One thread per 8-B unit.
 __global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict__ x, long sb, long sn, long sh, int B, int N, int H,
-                                                        int dh, int nt, int dsteps, float scale, u32x4_t* __restrict__ out) {
-    const long total = (long)B * H * nt * dsteps * 64;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int ln = (int)(i & 63); long t = i >> 6;
-        const int st = (int)(t % dsteps); t /= dsteps;
-        const int tile = (int)(t % nt); t /= nt;
-        const int h = (int)(t % H); const int b = (int)(t / H);
-        const int row = tile * 16 + (ln & 15), d0 = st * 32 + (ln >> 4) * 8;
-        float v[8];
-        const float* src = x + b * sb + (long)min(row, N - 1) * sn + h * sh;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float f = src[min(d0 + j, dh - 1)]; v[j] = (row < N && d0 + j < dh) ? f * scale : 0.f; }
-        bf16x8_t o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
-        out[i] = __builtin_bit_cast(u32x4_t, o);
-    }
+                                                        int dh, int nt, float scale, uint2* __restrict__ out, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+        attn_pack_unit(x, sb, sn, sh, N, H, dh, nt, scale, i, out);
 }
 
 extern "C" int spe_attn_pack(const float* x, long sb, long sn, long sh, int B, int N, int H, int dh, float scale,
                              void* out, hipStream_t st) {
-    const int nt = (N + 15) / 16, dsteps = (dh + 31) / 32;
-    const long total = (long)B * H * nt * dsteps * 64;
+    const int nt = (N + 15) / 16;
+    const long total = attn_pack_units(B, N, H, dh);
     if (total <= 0) return 0;
     long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(attn_pack_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, sb, sn, sh, B, N, H, dh, nt, dsteps, scale,
-                       reinterpret_cast<u32x4_t*>(out));
+    hipLaunchKernelGGL(attn_pack_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, sb, sn, sh, B, N, H, dh, nt, scale,
+                       reinterpret_cast<uint2*>(out), total);
     SPE_CHECK_LAUNCH();
     return 0;
 }
@@ -685,18 +695,18 @@ static void make_plan(int B, int nt, int nwg, int* spw_out, int* nwg_out) {
     *spw_out = (int)spw; *nwg_out = nwg8;
 }
 
-template <int H, int DSTEPS, int MODE, bool DROP, int KT>
+template <int H, int DSTEPS, bool TAIL16, int MODE, bool DROP, int KT>
 static int launch_fused(const FusedArgs& a, int nwg, hipStream_t st) {
     constexpr int NFR = H * DSTEPS;
     constexpr int smem = NFR * 64 * 16 * ((MODE >= 2) ? 2 : 1) + 4 * (H * 16 * 2 > (H * H + H) ? H * 16 * 2 : (H * H + H)) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&talking_fused_kernel<H, DSTEPS, MODE, DROP, KT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&talking_fused_kernel<H, DSTEPS, TAIL16, MODE, DROP, KT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((talking_fused_kernel<H, DSTEPS, MODE, DROP, KT>), dim3(nwg), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((talking_fused_kernel<H, DSTEPS, TAIL16, MODE, DROP, KT>), dim3(nwg), dim3(256), smem, st, a);
     SPE_CHECK_LAUNCH();
     return 0;
 }
@@ -710,14 +720,14 @@ static int launch_fused(const FusedArgs& a, int nwg, hipStream_t st) {
 #ifndef SPE_FUSED_KTB
 #define SPE_FUSED_KTB 1
 #endif
-template <int H, int DSTEPS>
+template <int H, int DSTEPS, bool TAIL16>
 static int dispatch_mode(const FusedArgs& a, int mode, bool drop, int nwg, hipStream_t st) {
     constexpr int KF = SPE_FUSED_KTF, KB_ = SPE_FUSED_KTB;
     switch (mode) {
-        case 0: return launch_fused<H, DSTEPS, 0, false, KF>(a, nwg, st);
-        case 1: return drop ? launch_fused<H, DSTEPS, 1, true, KB_>(a, nwg, st) : launch_fused<H, DSTEPS, 1, false, KB_>(a, nwg, st);
-        case 2: return drop ? launch_fused<H, DSTEPS, 2, true, KB_>(a, nwg, st) : launch_fused<H, DSTEPS, 2, false, KB_>(a, nwg, st);
-        case 3: return drop ? launch_fused<H, DSTEPS, 3, true, KB_>(a, nwg, st) : launch_fused<H, DSTEPS, 3, false, KB_>(a, nwg, st);
+        case 0: return launch_fused<H, DSTEPS, TAIL16, 0, false, KF>(a, nwg, st);
+        case 1: return drop ? launch_fused<H, DSTEPS, TAIL16, 1, true, KB_>(a, nwg, st) : launch_fused<H, DSTEPS, TAIL16, 1, false, KB_>(a, nwg, st);
+        case 2: return drop ? launch_fused<H, DSTEPS, TAIL16, 2, true, KB_>(a, nwg, st) : launch_fused<H, DSTEPS, TAIL16, 2, false, KB_>(a, nwg, st);
+        case 3: return drop ? launch_fused<H, DSTEPS, TAIL16, 3, true, KB_>(a, nwg, st) : launch_fused<H, DSTEPS, TAIL16, 3, false, KB_>(a, nwg, st);
     }
     return -2;
 }
@@ -738,11 +748,18 @@ extern "C" int spe_talking_fused(int mode, const void* Qf, const void* Kf, const
     make_plan(B, a.nt, nwg, &a.steps_per_wg, &nwg);
     a.p_drop = p_drop; a.seed = seed; a.offset = offset;
     const bool drop = p_drop > 0.f;
-    const int ds = (dh + 31) / 32;
-    if (H == 8 && ds == 2) return dispatch_mode<8, 2>(a, mode, drop, nwg, st);
-    if (H == 4 && ds == 2) return dispatch_mode<4, 2>(a, mode, drop, nwg, st);
-    if (H == 4 && ds == 1) return dispatch_mode<4, 1>(a, mode, drop, nwg, st);
-    if (H == 8 && ds == 1) return dispatch_mode<8, 1>(a, mode, drop, nwg, st);
+    // head dim -> d-steps: full 32-wide steps, plus a 16-wide tail step when the remainder is 1..16
+    const int rem = dh % 32, full = dh / 32 + (rem > 16 ? 1 : 0), tail = (rem > 0 && rem <= 16) ? 1 : 0;
+    const int ds = full + tail;
+    if (dh < 1 || dh > 64) return -2;
+#define SPE_FUSED_DISPATCH(HH)                                                                       \
+    if (H == HH && ds == 2 && tail) return dispatch_mode<HH, 2, true>(a, mode, drop, nwg, st);       \
+    if (H == HH && ds == 2 && !tail) return dispatch_mode<HH, 2, false>(a, mode, drop, nwg, st);     \
+    if (H == HH && ds == 1 && tail) return dispatch_mode<HH, 1, true>(a, mode, drop, nwg, st);       \
+    if (H == HH && ds == 1 && !tail) return dispatch_mode<HH, 1, false>(a, mode, drop, nwg, st);
+    SPE_FUSED_DISPATCH(8)
+    SPE_FUSED_DISPATCH(4)
+#undef SPE_FUSED_DISPATCH
     return -2;
 }
 

@@ -441,11 +441,11 @@ LOG2E = 1.4426950408889634
 
 
 def attn_pack(x4, scale=1.0):
-    """x4 [B,N,H,dh] view (unit last stride) -> bf16 row-fragment array (int32 storage)."""
+    """x4 [B,N,H,dh] view (unit last stride) -> bf16 fragment records [B,H,nt,frag_record_elems(dh)]."""
     _chk(x4)
     B, N, H, dh = x4.shape
-    nt, ds = (N + 15) // 16, (dh + 31) // 32
-    out = torch.empty((B * H * nt * ds * 64 * 4,), device=x4.device, dtype=torch.int32)
+    nt = (N + 15) // 16
+    out = torch.empty((B, H, nt, frag_record_elems(dh)), device=x4.device, dtype=torch.bfloat16)
     _call("spe_attn_pack", _p(x4), x4.stride(0), x4.stride(1), x4.stride(2), B, N, H, dh, float(scale), _p(out), _st())
     return out
 
@@ -478,6 +478,14 @@ def attn_pack16(x4):
     return out
 
 
+def frag_record_elems(dh):
+    """bf16 elements of one (b, h, 16-row tile) fragment record of the score kernels: full 32-wide d-steps of 64 x 8
+    plus a 16-wide tail step of 64 x 4 when dh % 32 is in 1..16 (csrc/attn_fused.hip: frag_load)."""
+    rem = dh % 32
+    full = dh // 32 + (1 if rem > 16 else 0)
+    return full * 512 + (256 if 0 < rem <= 16 else 0)
+
+
 def attn_pack_multi(jobs):
     """jobs: list of (x4 [B,N,H,dh] fp32 view with unit last stride, scale, kind) with kind 32 -> attn_pack layout,
     16 -> attn_pack16 layout; all views the same shape.  One launch; -> list of packed bf16 tensors."""
@@ -487,7 +495,7 @@ def attn_pack_multi(jobs):
     outs = []
     for x4, scale, kind in jobs:
         assert x4.shape == (B, N, H, dh) and x4.stride(3) == 1 and x4.dtype == torch.float32
-        shape = (B, H, nt, (dh + 31) // 32, 64, 8) if kind == 32 else (B, H, nt, (dh + 15) // 16, 64, 4)
+        shape = (B, H, nt, frag_record_elems(dh)) if kind == 32 else (B, H, nt, (dh + 15) // 16, 64, 4)
         outs.append(torch.empty(shape, device=x4.device, dtype=torch.bfloat16))
     xs = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs])
     strides = (ctypes.c_long * (3 * n))(*[s for j in jobs for s in (j[0].stride(0), j[0].stride(1), j[0].stride(2))])

@@ -3,7 +3,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from spe_amd import kernels as K
 dev = torch.device("cuda:0")
-H, N, dh, B = 8, 4150, 48, 2
+import os
+H, N, dh, B = 8, 4150, int(os.environ.get("DH", "48")), 2
 g = torch.Generator().manual_seed(1)
 C = H * dh
 qkv = torch.randn(B, N, 3 * C, generator=g).to(dev)
