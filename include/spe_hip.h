@@ -204,6 +204,13 @@ int spe_box_loss(const float* pred_boxes, const long* srow, const float* tbox, c
 int spe_box_loss_bwd(const long* srow, const int* lidx, const float* g_l1, const float* g_giou, const float* c1,
                      const float* c2, float* dpred, long n, spe_stream_t stream);
 
+/* ---- per-class greedy NMS (reference engine_loc.py:154-174: torchvision.ops.nms(boxes, scores, 0.5) per predicted
+ * class, results concatenated in ascending class order).  boxes [nimg, nmax, 4] xyxy and labels [nimg, nmax] (int64)
+ * ALREADY ordered by (label ascending, score descending) per image; counts[img] valid detections (NULL: nmax).
+ * keep[img][i] = 1 iff detection i survives (suppress IoU > iou_threshold within a class).  nmax <= 4096. */
+int spe_nms_sorted(const float* boxes, const long* labels, const int* counts, unsigned char* keep, int nimg, int nmax,
+                   float iou_threshold, spe_stream_t stream);
+
 /* ---- optimiser step on flat buffers (reference engine.py:161-165: clip_grad_norm_(params, 0.1) + AdamW.step(),
  * parameter groups of main.py:177-191).  spe_sqnorm_partials: partials[b] = sum g^2 over the b-th of nblocks chunks.
  * spe_adamw_flat: clip = min(1, max_norm / (sqrt(sum partials) + 1e-6)) (max_norm <= 0: no clipping), g *= clip,

@@ -560,3 +560,53 @@ def total_loss(sd, cfg, img, mask, targets, targets_refine_scores=None):
     wd = weight_dict(cfg)
     tot = sum(l0[k] * wd[k] for k in l0 if k in wd) + sum(l1[k] * wd[k] for k in l1 if k in wd)
     return tot, out, l0, l1
+
+
+# ---- inference post-processing (engine_loc.py:99-124, 150-174) -------------------------------------
+def nms_greedy(boxes, scores, iou_threshold):
+    """torchvision.ops.nms semantics (the package is absent here; published algorithm): visit boxes by decreasing
+    score, keep a box unless an already kept box overlaps it with IoU > threshold; returns kept indices in that order."""
+    order = torch.argsort(scores, descending=True, stable=True).tolist()
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    keep = []
+    for i in order:
+        ok = True
+        for j in keep:
+            w = (torch.min(boxes[i, 2], boxes[j, 2]) - torch.max(boxes[i, 0], boxes[j, 0])).clamp(min=0)
+            h = (torch.min(boxes[i, 3], boxes[j, 3]) - torch.max(boxes[i, 1], boxes[j, 1])).clamp(min=0)
+            inter = w * h
+            if inter / (area[i] + area[j] - inter) > iou_threshold:
+                ok = False
+                break
+        if ok:
+            keep.append(i)
+    return torch.tensor(keep, dtype=torch.long)
+
+
+def per_class_nms(result, iou_threshold=0.5):
+    """engine_loc.py:154-174 for one image's PostProcess result."""
+    kb, ks, kl = [], [], []
+    for pc in result["labels"].unique().tolist():
+        idx = (result["labels"] == pc).nonzero().reshape(-1)
+        b, s, l = result["boxes"][idx], result["scores"][idx], result["labels"][idx]
+        k = nms_greedy(b, s, iou_threshold)
+        kb.append(b[k]); ks.append(s[k]); kl.append(l[k])
+    return {"boxes": torch.cat(kb), "scores": torch.cat(ks), "labels": torch.cat(kl)}
+
+
+def decouple_output(output, bs=2):
+    """engine_loc.py:99-124."""
+    out = {}
+    for k, v in output.items():
+        if k == "aux_outputs":
+            out[k] = [decouple_output(a, bs) for a in v]
+        elif k in ("x_logits", "x_cls_logits"):
+            out[k] = torch.maximum(v[:bs], v[bs:2 * bs])
+        elif k in ("pred_logits", "pred_boxes", "cams_cls"):
+            pos = v[bs:2 * bs].clone()
+            if k == "pred_boxes":
+                pos[:, :, 0] = 1 - pos[:, :, 0]
+            out[k] = torch.cat((v[:bs], pos), dim=1)
+        else:
+            out[k] = v
+    return out

@@ -286,3 +286,50 @@ extern "C" int spe_box_loss_bwd(const long* srow, const int* lidx, const float* 
     SPE_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Per-class greedy NMS of one image's detections (reference engine_loc.py:154-174:
+// for every predicted class, torchvision.ops.nms(boxes, scores, 0.5) and concatenation in ascending class order).
+// Input: n detections ALREADY ordered by (label ascending, score descending) - exactly the order the reference's
+// concatenated result has.  keep[i] = 1 iff detection i survives: it is visited in order and suppresses every later
+// detection of the same class with IoU > thr (areas (x1-x0)*(y1-y0), intersection extents clamped at 0 - the
+// arithmetic of torchvision's nms kernel).  One workgroup per image: thread j owns detection j (+256k), the visit
+// order is serial, each visit is one parallel step.
+// ------------------------------------------------------------------------------------------
+#define NMS_MAXN 4096
+__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ boxes, const long* __restrict__ labels,
+                                                  const int* __restrict__ counts, unsigned char* __restrict__ keep, int nmax, float thr) {
+    __shared__ unsigned char dead[NMS_MAXN];
+    const int img = blockIdx.x;
+    const int n = counts ? counts[img] : nmax;
+    const float* bx = boxes + (long)img * nmax * 4;
+    const long* lb = labels + (long)img * nmax;
+    unsigned char* kp = keep + (long)img * nmax;
+    for (int j = threadIdx.x; j < n; j += 256) dead[j] = 0;
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        if (dead[i]) continue;                               // uniform: every thread reads the same LDS byte
+        const float x0 = bx[i * 4], y0 = bx[i * 4 + 1], x1 = bx[i * 4 + 2], y1 = bx[i * 4 + 3];
+        const float ai = (x1 - x0) * (y1 - y0);
+        const long li = lb[i];
+        for (int j = i + 1 + threadIdx.x; j < n && lb[j] == li; j += 256) {
+            const float u0 = bx[j * 4], v0 = bx[j * 4 + 1], u1 = bx[j * 4 + 2], v1 = bx[j * 4 + 3];
+            const float w = fmaxf(fminf(x1, u1) - fmaxf(x0, u0), 0.f), h = fmaxf(fminf(y1, v1) - fmaxf(y0, v0), 0.f);
+            const float inter = w * h, aj = (u1 - u0) * (v1 - v0);
+            if (inter / (ai + aj - inter) > thr) dead[j] = 1;
+        }
+        __syncthreads();
+    }
+    for (int j = threadIdx.x; j < nmax; j += 256) kp[j] = (j < n && !dead[j]) ? 1 : 0;
+}
+
+// C-ABI: see include/spe_hip.h (spe_nms_sorted).  -2: more than NMS_MAXN detections per image.
+extern "C" int spe_nms_sorted(const float* boxes, const long* labels, const int* counts, unsigned char* keep, int nimg, int nmax,
+                              float iou_threshold, hipStream_t st) {
+    if (nimg <= 0 || nmax <= 0) return 0;
+    if (nmax > NMS_MAXN) return -2;
+    hipLaunchKernelGGL(nms_kernel, dim3(nimg), dim3(256), 0, st, boxes, labels, counts, keep, nmax, iou_threshold);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}

@@ -551,3 +551,14 @@ def adamw_flat(p, g, m, v, seg_end_i64, seg_lr, seg_wd, beta1, beta2, eps, bias_
     _call("spe_adamw_flat", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(seg_end_i64), _p(seg_lr), _p(seg_wd), seg_end_i64.numel(),
           float(beta1), float(beta2), float(eps), float(bias_c1), float(bias_c2), _p(partials), partials.numel(),
           float(max_norm), int(bool(write_grad)), _st())
+
+
+# ---- inference post-processing -----------------------------------------------------------------
+def nms_sorted(boxes, labels, iou_threshold, counts=None):
+    """boxes [I,n,4] fp32 xyxy, labels [I,n] int64, per image ordered by (label asc, score desc) -> keep mask [I,n] bool."""
+    _chk(boxes)
+    I, n, _ = boxes.shape
+    assert labels.dtype == torch.int64 and labels.is_contiguous()
+    keep = torch.empty((I, n), device=boxes.device, dtype=torch.uint8)
+    _call("spe_nms_sorted", _p(boxes), _p(labels), _p(counts), _p(keep), I, n, float(iou_threshold), _st())
+    return keep.bool()

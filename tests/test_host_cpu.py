@@ -125,3 +125,31 @@ def test_registry_has_baseline_backbones():
     from spe_amd.models.cait import _REGISTRY
     for n in ("TSCAM_cait_XXS24", "TSCAM_cait_XXS36", "TSCAM_cait_XXS36_Two_Branch", "TSCAM_cait_S24", "TSCAM_cait_S36"):
         assert n in _REGISTRY
+
+
+def test_deit_checkpoint_interop(tmp_path):
+    """a DeiT-style CaiT checkpoint ('model' dict, 'module.'-prefixed keys, classifier heads of
+    another shape) loads the way cait.py:1639-1663 does, and init_blocks_det_weight (cait.py:724-726) copies the last
+    backbone blocks into the detection branch."""
+    import torch
+    from spe_amd.models import cait
+    torch.manual_seed(0)
+    factory, kw = cait.TSCAM_cait_XXS36_Two_Branch, {"num_classes": 20, "layer_to_det": 33}
+    src, _ = factory(pretrained=False, **kw)
+    sd = {"module." + k: torch.randn_like(v) if v.dtype.is_floating_point else v.clone() for k, v in src.state_dict().items()
+          if not k.startswith("blocks_det")}
+    sd["module.head.weight"] = torch.randn(1000, 192)      # ImageNet classifier of the released file: must be skipped
+    path = tmp_path / "deit_cait.pth"
+    torch.save({"model": sd}, path)
+    dst, width = factory(pretrained=True, checkpoint_path=str(path), **kw)
+    assert width == 192
+    own = dst.state_dict()
+    for k, v in sd.items():
+        k = k[len("module."):]
+        if k in own and own[k].shape == v.shape:
+            assert torch.equal(own[k], v), k
+    nb = len(dst.blocks_det)
+    assert nb > 0
+    for i in range(1, nb + 1):
+        for (ka, a), (kb, b) in zip(dst.blocks[-i].state_dict().items(), dst.blocks_det[-i].state_dict().items()):
+            assert ka == kb and torch.equal(a, b)

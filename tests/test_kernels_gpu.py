@@ -616,3 +616,41 @@ def test_flat_adamw_matches_torch(dev):
         assert rel(opt.state[y]["exp_avg"], ref.state[x]["exp_avg"]) < 2e-6
         # v accumulates (clip * g)^2: twice the relative rounding difference of the two global-norm reductions
         assert rel(opt.state[y]["exp_avg_sq"], ref.state[x]["exp_avg_sq"]) < 5e-5
+
+
+def test_per_class_nms_and_flip_merge_vs_oracle(dev):
+    """spe_amd.infer (HIP NMS kernel, one launch per batch) == the oracle's restatement of engine_loc.py:99-124,150-174."""
+    from oracle import spe_oracle as O
+    from spe_amd import infer
+    g = torch.Generator().manual_seed(33)
+    results = []
+    for i in range(3):
+        n = 300
+        c = torch.rand(n, 2, generator=g) * 600 + 100
+        wh = torch.rand(n, 2, generator=g) * 200 + 20
+        # clusters of near-duplicates so that suppression actually happens
+        c[50:150] = c[:100].clone() + torch.randn(100, 2, generator=g) * 4
+        wh[50:150] = wh[:100].clone() * (1 + 0.05 * torch.randn(100, 2, generator=g))
+        boxes = torch.cat([c - wh / 2, c + wh / 2], 1)
+        labels = torch.randint(0, 6, (n,), generator=g)
+        labels[50:150] = labels[:100].clone()
+        scores = torch.rand(n, generator=g)
+        results.append({"scores": scores, "labels": labels, "boxes": boxes})
+    got = infer.per_class_nms([{k: v.to(dev) for k, v in r.items()} for r in results], 0.5)
+    for r, o in zip(results, got):
+        ref = O.per_class_nms(r, 0.5)
+        assert 0 < ref["scores"].numel() < 300
+        assert torch.equal(o["labels"].cpu(), ref["labels"]) and torch.equal(o["scores"].cpu(), ref["scores"])
+        assert torch.equal(o["boxes"].cpu(), ref["boxes"])
+    # flip test-time-augmentation merge
+    bs, Q, Kc = 2, 7, 5
+    mk = lambda *s: torch.randn(*s, generator=g)
+    outp = {"pred_logits": mk(2 * bs, Q, Kc), "pred_boxes": torch.rand(2 * bs, Q, 4, generator=g), "x_logits": mk(2 * bs, Kc),
+            "x_cls_logits": mk(2 * bs, Kc), "cams_cls": mk(2 * bs, Kc, 3, 4),
+            "aux_outputs": [{"pred_logits": mk(2 * bs, Q, Kc), "pred_boxes": torch.rand(2 * bs, Q, 4, generator=g)}]}
+    ref = O.decouple_output(outp, bs)
+    cp = {k: ([dict((kk, vv.to(dev)) for kk, vv in a.items()) for a in v] if k == "aux_outputs" else v.to(dev)) for k, v in outp.items()}
+    got = infer.decouple_output(cp, bs)
+    for k in ("pred_logits", "pred_boxes", "x_logits", "x_cls_logits", "cams_cls"):
+        assert torch.equal(got[k].cpu(), ref[k]), k
+    assert torch.equal(got["aux_outputs"][0]["pred_boxes"].cpu(), ref["aux_outputs"][0]["pred_boxes"])
