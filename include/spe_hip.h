@@ -35,7 +35,8 @@ int spe_abi_version(void);
  * act: 0 none, 1 ReLU, 2 exact-erf GELU; C2 (optional) receives the pre-activation.
  * splitk>1: K is split over workgroups and atomically accumulated into a PRE-ZEROED C
  * (bias/act/C2 must be null/0).  splitk<-1: |splitk| splits, split z stores its partial result into the
- * private slab C + z*M*ldc (no atomics); the caller sums the slabs (spe_colsum over |splitk| rows of M*ldc).  precision: 0 = bf16 MFMA operands, fp32 accumulate;
+ * private slab C + z*S (no atomics); the caller sums the slabs (spe_colsum over |splitk| rows of S floats), S = M*ldc
+ * for a single matrix, else the extent of the batched C: ((batch0-1)*sC0 + (batch1-1)*sC1 + (M-1)*ldc + N) rounded up to 4.  precision: 0 = bf16 MFMA operands, fp32 accumulate;
  * 1 = 3-term bf16 split (~fp32 accuracy).
  * Replaces nn.Linear / torch.bmm / `@` at reference models/cait.py:376-390 (qkv, QK^T, PV, proj),
  * :114-133 (class attention), timm Mlp fc1/fc2 (cait.py:409), Conv2d patch embed (cait.py:526),

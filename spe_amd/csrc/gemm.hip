@@ -480,8 +480,10 @@ extern "C" int spe_gemm_ex(const void* A, int a_bf16, const float* B, float* C, 
     p.nb1 = batch1; p.sA0 = sA0; p.sA1 = sA1; p.sB0 = sB0; p.sB1 = sB1; p.sC0 = sC0; p.sC1 = sC1;
     p.alpha = alpha; p.act = act; p.slab = 0;
     const int ktiles = (K + BK - 1) / BK;
-    if (splitk < 0) {           // slab mode: C must hold |splitk| slabs of M*ldc floats
-        splitk = -splitk; p.slab = (long)M * ldc;
+    if (splitk < 0) {           // slab mode: C must hold |splitk| slabs (M*ldc floats; batched: the extent of all batches)
+        splitk = -splitk;
+        p.slab = (batch0 * batch1 == 1) ? (long)M * ldc
+                                        : ((((long)(batch0 - 1) * sC0 + (long)(batch1 - 1) * sC1 + (long)(M - 1) * ldc + N) + 3) & ~3L);
         if (splitk > ktiles) return -5;
     }
     if (splitk < 1) splitk = 1;

@@ -183,6 +183,23 @@ def weight16(W):
     return W16, W16T
 
 
+def gemm_splitk_into(A, B, out, M, N, K, lda, ldb, ldc, transA, transB, batch0, batch1, sA, sB, sC, alpha=1.0):
+    """Batched GEMM with a long contraction and few output tiles (decoder cross-attention P.V / dS.K: 64 workgroups
+    looping 130 K-steps): split K into private slabs and sum them into the contiguous `out` whose layout the batch
+    strides sC describe.  Falls back to the plain launch when splitting does not pay."""
+    sk = auto_splitk(M, N, K, batch0 * batch1)
+    if sk <= 1:
+        return gemm(A, B, out, M, N, K, lda, ldb, ldc, transA, transB, batch0=batch0, batch1=batch1, sA=sA, sB=sB, sC=sC, alpha=alpha)
+    extent = (((batch0 - 1) * sC[0] + (batch1 - 1) * sC[1] + (M - 1) * ldc + N) + 3) & ~3
+    assert out.is_contiguous() and extent <= out.numel() + 3
+    ws = torch.empty((sk, extent), device=out.device, dtype=torch.float32)
+    gemm(A, B, ws, M, N, K, lda, ldb, ldc, transA, transB, batch0=batch0, batch1=batch1, sA=sA, sB=sB, sC=sC, alpha=alpha, splitk=-sk)
+    out.zero_()
+    n = out.numel()
+    _call("spe_colsum", _p(ws), _p(out), sk, n, extent, _st())
+    return out
+
+
 def gemm16(A16, B16, C, M, N, K, lda, ldb, ldc, bias=None, C2=None, alpha=1.0, act=0, splitk=1):
     """C = act(alpha * A16 @ B16.T + bias) on bf16 operands (both k-contiguous); splitk < 0: slabs."""
     _call("spe_gemm_bf16nt", _p(A16), _p(B16), _p(C), _p(bias), _p(C2), M, N, K, lda, ldb, ldc, float(alpha), int(act),

@@ -290,8 +290,8 @@ class _Attention(Function):
         seed, off = K.next_rng() if p_drop > 0 else (0, 0)
         P, Pd = K.softmax_fwd(S, mask_u8, B, H, Lq, Lk, ld, p_drop, seed, off)
         O = torch.empty((B, Lq, H * dv), device=q.device, dtype=torch.float32)
-        K.gemm(Pd if Pd is not None else P, v, O, Lq, dv, Lk, ld, ldv, H * dv, False, False, batch0=B, batch1=H,
-               sA=sS, sB=sV, sC=(Lq * H * dv, dv))
+        K.gemm_splitk_into(Pd if Pd is not None else P, v, O, Lq, dv, Lk, ld, ldv, H * dv, False, False, B, H, sS, sV,
+                           (Lq * H * dv, dv))
         ctx.meta = (B, Lq, Lk, H, dk, dv, ld, scale, p_drop, seed, off)
         ctx.save_for_backward(q, k, v, P, Pd)
         if need_map:
@@ -318,8 +318,7 @@ class _Attention(Function):
         K.gemm(Pd if Pd is not None else P, dO, dv_, Lk, dv, Lq, ld, H * dv, H * dv, True, False, batch0=B, batch1=H,
                sA=sS, sB=sO, sC=(Lk * H * dv, dv))
         dS = K.softmax_bwd(dP, P, B, H, Lq, Lk, ld, p_drop, seed, off)
-        K.gemm(dS, k, dq, Lq, dk, Lk, ld, ldk, H * dk, False, False, batch0=B, batch1=H, sA=sS, sB=sK,
-               sC=(Lq * H * dk, dk), alpha=scale)
+        K.gemm_splitk_into(dS, k, dq, Lq, dk, Lk, ld, ldk, H * dk, False, False, B, H, sS, sK, (Lq * H * dk, dk), alpha=scale)
         K.gemm(dS, q, dk_, Lk, dk, Lq, ld, ldq, H * dk, True, False, batch0=B, batch1=H, sA=sS, sB=sQ,
                sC=(Lk * H * dk, dk), alpha=scale)
         return dq, dk_, dv_, None, None, None, None

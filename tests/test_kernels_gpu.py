@@ -215,10 +215,11 @@ def test_talking_heads_dropout_consistency(dev):
     K.set_precision("bf16")
 
 
-def test_attention_generic(dev, prec):
+@pytest.mark.parametrize("Lq,Lk,H,dk,dv", [(10, 77, 4, 48, 24), (100, 2100, 8, 96, 48)])     # second: split-K slab path (long Lk)
+def test_attention_generic(dev, prec, Lq, Lk, H, dk, dv):
     from spe_amd import ops
     g = torch.Generator().manual_seed(21)
-    B, Lq, Lk, H, dk, dv = 2, 10, 77, 4, 48, 24
+    B = 2
     q = torch.randn(B, Lq, H, dk, generator=g).to(dev).requires_grad_()
     k = torch.randn(B, Lk, H, dk, generator=g).to(dev).requires_grad_()
     v = torch.randn(B, Lk, H, dv, generator=g).to(dev).requires_grad_()
