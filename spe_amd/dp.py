@@ -38,6 +38,13 @@ class GradAllReducer:
         if cur:
             self._make_bucket(cur)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        # Parameters that received no gradient in the first step (e.g. `backbone.0.body.head.*`) are treated as
+        # statically unused afterwards (cf. DDP static_graph): their bucket no longer waits for them, so it - and,
+        # because collectives go out strictly in bucket order, every later bucket - can start during backward
+        # instead of in finish().  Every rank runs the same model, so every rank learns the same set.
+        self.learn_unused = True
+        self._fired = set()
+        self._static_unused = None
         self.reset()
 
     def _make_bucket(self, plist):
@@ -68,14 +75,16 @@ class GradAllReducer:
         the .grad views.  With .grad = None autograd adopts the first incoming gradient tensor instead of adding
         it: kernels that wrote into the bucket view (kernels.grad_buffer) cost nothing extra, any other gradient is
         moved into the bucket by `_on_grad`; a parameter that gets no gradient keeps its zeros in the bucket."""
+        skip = self._static_unused or ()
         for b in self.buckets:
             b["flat"].zero_()
-            b["pending"] = len(b["params"])
+            b["pending"] = sum(1 for p in b["params"] if p not in skip)
             b["work"] = None
             for p in b["params"]:
                 p.grad = None
                 p._spe_grad_fresh = True
         self._next = 0
+        self._fired = set()
 
     def zero_grad(self):
         self.reset()
@@ -89,12 +98,19 @@ class GradAllReducer:
     def _on_grad(self, p):
         b = self.buckets[self._bucket_of[p]]
         view = self._views[p]
+        if self._static_unused and p in self._static_unused:
+            if b["work"] is not None:
+                raise RuntimeError("GradAllReducer: a parameter that got no gradient in the first step received one "
+                                   "after its bucket was reduced; construct the reducer with learn_unused = False")
+            self._static_unused = self._static_unused - {p}      # used after all: count it from the next step on
+            b["pending"] += 1
         if p.grad.data_ptr() != view.data_ptr():
             # the gradient was produced outside the bucket (torch op, or a parameter used twice whose contributions
             # autograd summed into a temporary): AccumulateGrad runs once per backward with the TOTAL, so copy it in
             view.copy_(p.grad)
             p._spe_grad_fresh = False
             p.grad = view
+        self._fired.add(p)
         b["pending"] -= 1
         # collectives are issued strictly in bucket order so every rank enqueues the same sequence
         while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
@@ -106,6 +122,8 @@ class GradAllReducer:
         while self._next < len(self.buckets):
             self._launch(self.buckets[self._next])
             self._next += 1
+        if self.learn_unused and self._static_unused is None:
+            self._static_unused = frozenset(p for p in self.params if p not in self._fired)
         for b in self.buckets:
             if b["work"] not in (None, "local"):
                 b["work"].wait()

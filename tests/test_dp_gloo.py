@@ -27,13 +27,15 @@ def _worker(rank, world, port, out):
     assert len(red.buckets) > 2
     g = torch.Generator().manual_seed(100 + rank)           # different data per rank
     results = []
-    for it in range(2):                                     # two iterations: reset() must clear the buckets
+    launched_in_backward = []
+    for it in range(3):                                     # iterations: reset() must clear the buckets
         x = torch.randn(5, 8, generator=g)
         red.reset()
         y = net(x)
         # the first layer is used twice in the graph (like the decoder weights over two passes)
         loss = y.pow(2).sum() + net[0](x).sum()
         loss.backward()
+        launched_in_backward.append(red._next)              # buckets whose all-reduce started before finish()
         red.finish()
         results.append([p.grad.clone() for p in params])
         # local reference gradient of this rank
@@ -44,6 +46,9 @@ def _worker(rank, world, port, out):
         got = torch.cat([p.grad.flatten() for p in net.parameters()])
         assert torch.allclose(got, mean, atol=1e-6), (rank, it)
         assert all(float(p.grad.abs().max()) == 0.0 for p in unused.parameters())
+    # after the first step the never-used parameters are known: every bucket is reduced during backward
+    assert launched_in_backward[0] < len(red.buckets) and launched_in_backward[1] == len(red.buckets), launched_in_backward
+    assert set(red._static_unused) == set(unused.parameters())
     # scalar collective used by SetCriterion (num_boxes, conditional_detr.py:436-440)
     nb = torch.tensor([float(3 + 4 * rank)])
     dist.all_reduce(nb)
