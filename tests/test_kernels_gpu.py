@@ -371,7 +371,7 @@ def test_matcher_cost_and_losses(dev):
     assert rel(dp, refd) < 1e-4
 
 
-@pytest.mark.parametrize("H,N,dh,B", [(4, 50, 8, 2), (8, 131, 48, 2), (4, 200, 48, 1), (8, 330, 48, 1), (8, 1100, 48, 2), (4, 1031, 32, 1)])
+@pytest.mark.parametrize("H,N,dh,B", [(4, 50, 8, 2), (8, 131, 48, 2), (4, 200, 48, 1), (8, 330, 48, 1), (8, 1100, 48, 2), (4, 1031, 32, 1), (4, 100, 64, 1), (8, 70, 40, 1), (4, 90, 20, 2)])
 def test_talking_heads_attention_fused(dev, H, N, dh, B):
     """Fused score kernels (bf16 operands, bf16 P'd/dS storage) vs the fp64 restatement; tail tiles, several
     segments per workgroup and several workgroups per q-tile are all exercised by these shapes."""
