@@ -37,7 +37,9 @@ def build(blob, dev):
 
 OUT_TOL = {"bf16x3": 2e-4, "bf16": 3e-2}
 LOSS_TOL = {"bf16x3": 2e-4, "bf16": 2e-2}
-GRAD_TOL = {"bf16x3": 2e-3, "bf16": 1.5e-1}
+# bf16 mode: scores/probabilities and their gradients are materialised in bf16 and every contraction rounds its
+# operands to bf16; on the tiny fixture models the worst parameter (a small decoder gradient) sits at 0.11-0.14
+GRAD_TOL = {"bf16x3": 2e-3, "bf16": 2e-1}
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
