@@ -75,12 +75,14 @@ int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const
  *   y = x W^T: (x16, W16) ; dx = dy W: (dy16, W16T) ; dW = dy^T x: (dy16T, x16T), contraction zero padded.
  * spe_cvt_bf16: out[R][ldo] = bf16(x) (round to nearest even, the rounding spe_gemm_f32 applies while staging)
  * and/or outT[C][ldt] = transpose, columns R..ldt-1 zero filled; colsum[c] += sum_r x[r][c] (fp32; the bias gradient
- * of the Linear, from the same read).  Any of the three outputs may be NULL. */
+ * of the Linear, from the same read).  Any of the three outputs may be NULL.  aux != NULL: x is first multiplied by the
+ * activation derivative at aux (act 1: ReLU with aux = forward output, 2: erf-GELU with aux = pre-activation; same
+ * layout and leading dimension as x) - the backward of a fused Linear+activation without an fp32 intermediate. */
 int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const float* bias, float* C2,
                     int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int splitk,
                     spe_stream_t stream);
 int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, long ldo, void* outT, long ldt, float* colsum,
-                 spe_stream_t stream);
+                 const float* aux, int act, spe_stream_t stream);
 
 /* ---- masked softmax over scores[B,H,Nq,ld] (Nk valid columns per row).
  * mask[B,Nk] (1 = padded key, -inf) or null; P = softmax; Pd = dropout(P) written only when

@@ -256,9 +256,13 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const
 // ---- fp32 -> bf16 (round to nearest even) copies of a [R, C] matrix: out[R][ldo] (row-major) and/or the
 // transpose outT[C][ldt] whose columns R..ldt-1 are zero filled (the contraction padding of the dW GEMM).
 // colsum (optional): colsum[c] += sum_r x[r][c] in fp32 - the bias gradient of a Linear, taken from the same read of dy.
+// aux (optional, same layout as x): the activation backward of the fused Linear+activation is applied while reading,
+// x := x * act'(aux) (act 1: ReLU, aux = forward output; act 2: exact-erf GELU, aux = pre-activation; the
+// arithmetic of act_bwd_kernel in rowops.hip) - the fp32 gradient w.r.t. the pre-activation never reaches HBM.
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ x, long ldx, int R, int C,
                                                        unsigned short* __restrict__ out, long ldo,
-                                                       unsigned short* __restrict__ outT, long ldt, float* __restrict__ colsum) {
+                                                       unsigned short* __restrict__ outT, long ldt, float* __restrict__ colsum,
+                                                       const float* __restrict__ aux, int act) {
     __shared__ unsigned short tile[64][66];
     __shared__ float csum[16][64];
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -275,6 +279,19 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (c + j < C) v[j] = x[(long)r * ldx + c + j];
+            }
+            if (aux) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (c + j >= C) continue;
+                    const float h = aux[(long)r * ldx + c + j];
+                    if (act == 1) v[j] = h > 0.f ? v[j] : 0.f;
+                    else {
+                        const float cdf = 0.5f * (1.f + erff(h * 0.70710678118654752f));
+                        const float pdf = 0.3989422804014327f * __expf(-0.5f * h * h);
+                        v[j] = v[j] * (cdf + h * pdf);
+                    }
+                }
             }
         }
         cs[0] += v[0]; cs[1] += v[1]; cs[2] += v[2]; cs[3] += v[3];
@@ -329,7 +346,7 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
 
 // C-ABI: see include/spe_hip.h (spe_cvt_bf16).
 extern "C" int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, long ldo, void* outT, long ldt, float* colsum,
-                            hipStream_t stream) {
+                            const float* aux, int act, hipStream_t stream) {
     if (R <= 0 || C <= 0) return 0;
     if (!out && !outT && !colsum) return 0;
     if (outT && ldt < R) return -2;
@@ -337,7 +354,7 @@ extern "C" int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, l
     const long rows = outT ? ((ldt > R) ? ldt : R) : R;
     dim3 grid((C + 63) / 64, (unsigned)((rows + 63) / 64));
     hipLaunchKernelGGL(cvt_bf16_kernel, grid, dim3(256), 0, stream, x, ldx, R, C, reinterpret_cast<unsigned short*>(out), ldo,
-                       reinterpret_cast<unsigned short*>(outT), ldt, colsum);
+                       reinterpret_cast<unsigned short*>(outT), ldt, colsum, aux, act);
     SPE_CHECK_LAUNCH();
     return 0;
 }

@@ -154,7 +154,7 @@ def _lin16_ok(R, N, K):
     return LINEAR16 and _PRECISION == 0 and R >= LINEAR16_MIN_ROWS and N % 8 == 0 and K % 8 == 0
 
 
-def cvt_bf16(x2, want=True, wantT=False, ldt=None, colsum_out=None):
+def cvt_bf16(x2, want=True, wantT=False, ldt=None, colsum_out=None, act_aux=None, act=0):
     """bf16 (RNE) copies of a contiguous fp32 [R, C]: row-major [R, C] and/or the transpose [C, ldt] (zero padded);
     colsum_out (zeroed or running fp32 [C]) += column sums of x2 from the same pass."""
     _chk(x2)
@@ -164,7 +164,7 @@ def cvt_bf16(x2, want=True, wantT=False, ldt=None, colsum_out=None):
     if wantT:
         ldt = ldt or ((R + 63) // 64) * 64
         outT = torch.empty((C, ldt), device=x2.device, dtype=torch.bfloat16)
-    _call("spe_cvt_bf16", _p(x2), x2.stride(0), R, C, _p(out), C, _p(outT), ldt or 0, _p(colsum_out), _st())
+    _call("spe_cvt_bf16", _p(x2), x2.stride(0), R, C, _p(out), C, _p(outT), ldt or 0, _p(colsum_out), _p(act_aux), int(act), _st())
     return out, outT
 
 
@@ -223,9 +223,10 @@ def linear_fwd(x2, W, b, act=0, want_pre=False, save_for_dw=True):
     return y, pre, x2
 
 
-def linear_bwd(dy2, xsave, W, need_dx=True, need_dw=True, need_db=True, dW_out=None, db_out=None):
+def linear_bwd(dy2, xsave, W, need_dx=True, need_dw=True, need_db=True, dW_out=None, db_out=None, act=0, act_aux=None):
     """dx = dy @ W ; dW = dy.T @ x ; db = colsum(dy).  xsave: third result of linear_fwd.
-    dW_out / db_out: zeroed destination buffers (grad_buffer)."""
+    dW_out / db_out: zeroed destination buffers (grad_buffer).  act/act_aux: dy is the gradient w.r.t. the OUTPUT of
+    a fused activation (1 ReLU: aux = output, 2 GELU: aux = pre-activation); its backward is applied on the fly."""
     _chk(dy2, W)
     R, N = dy2.shape
     K = W.shape[1]
@@ -235,7 +236,7 @@ def linear_bwd(dy2, xsave, W, need_dx=True, need_dw=True, need_db=True, dW_out=N
         Rp = xsave.shape[1] if x16 else None
         if need_db:                     # the bias gradient rides on the conversion pass over dy
             db = _zeros_or(db_out, N, dy2.device)
-        dy16, dy16T = cvt_bf16(dy2, need_dx, need_dw and x16, ldt=Rp, colsum_out=db)
+        dy16, dy16T = cvt_bf16(dy2, need_dx, need_dw and x16, ldt=Rp, colsum_out=db, act_aux=act_aux if act else None, act=act)
         need_db = False
         if need_dx:
             dx = torch.empty((R, K), device=dy2.device, dtype=torch.float32)
@@ -252,6 +253,8 @@ def linear_bwd(dy2, xsave, W, need_dx=True, need_dw=True, need_db=True, dW_out=N
     else:
         if x16:
             raise RuntimeError("linear_bwd: bf16 activations were saved but the bf16 GEMM path is disabled now")
+        if act:
+            dy2 = act_bwd(dy2, act_aux, act)
         x2 = xsave
         if need_dx:
             dx = torch.empty((R, K), device=dy2.device, dtype=torch.float32)

@@ -38,13 +38,11 @@ class _Linear(Function):
         dy2 = dy.reshape(-1, W.shape[0])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        if ctx.act != ACT_NONE:
-            dy2 = K.act_bwd(dy2, aux, ctx.act)
         Wp, bp = ctx.params
         need_dw, need_db = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dx, dW, db = K.linear_bwd(dy2, x2, W, ctx.needs_input_grad[0], need_dw, need_db,
                                   dW_out=K.grad_buffer(Wp) if need_dw and Wp.is_contiguous() else None,
-                                  db_out=K.grad_buffer(bp) if need_db else None)
+                                  db_out=K.grad_buffer(bp) if need_db else None, act=ctx.act, act_aux=aux)
         if dx is not None:
             dx = dx.view(*dy.shape[:-1], W.shape[1])
         return dx, dW, db, None
