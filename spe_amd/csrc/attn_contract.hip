@@ -25,7 +25,9 @@
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4c_t __attribute__((ext_vector_type(4)));
 
+#ifndef CONTRACT_R
 #define CONTRACT_R 4
+#endif
 #ifndef CONTRACT_PD
 #define CONTRACT_PD 2
 #endif
