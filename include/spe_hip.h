@@ -214,6 +214,18 @@ int spe_box_loss_bwd(const long* srow, const int* lidx, const float* g_l1, const
 int spe_nms_sorted(const float* boxes, const long* labels, const int* counts, unsigned char* keep, int nimg, int nmax,
                    float iou_threshold, spe_stream_t stream);
 
+/* ---- CAM -> pseudo boxes (reference cams_deit.py:9-13 resize_cam, :61-96 get_multi_bboxes; engine.py:356-398).
+ * spe_cam_prepare (device): M class maps cams[M][h][w] -> thresholded uint8 images out[M][rows][cols]: bilinear resize
+ * (cv2.INTER_LINEAR convention), min-max normalisation, (x*255) truncated to uint8, THRESH_TOZERO at
+ * int(cam_thr * max).  minmax: 2*M floats of workspace.  Synchronises the stream once (workspace initialisation).
+ * spe_cam_contour_boxes (HOST function, host pointers): borders of the non-zero pixels of one image (Suzuki-Abe border
+ * following, 8-connected, outer and hole borders = cv2.findContours RETR_TREE), polygon areas (cv2.contourArea) and the
+ * boxes [x, y, x+w, y+h] (cv2.boundingRect) of every border with area >= area_ratio * largest, largest first;
+ * [0,0,1,1] when there is none.  -5: more than max_boxes boxes. */
+int spe_cam_prepare(const float* cams, int M, int h, int w, int rows, int cols, float cam_thr, float* minmax,
+                    void* out, spe_stream_t stream);
+int spe_cam_contour_boxes(const void* img, int rows, int cols, float area_ratio, int* boxes, int max_boxes, int* nboxes);
+
 /* ---- optimiser step on flat buffers (reference engine.py:161-165: clip_grad_norm_(params, 0.1) + AdamW.step(),
  * parameter groups of main.py:177-191).  spe_sqnorm_partials: partials[b] = sum g^2 over the b-th of nblocks chunks.
  * spe_adamw_flat: clip = min(1, max_norm / (sqrt(sum partials) + 1e-6)) (max_norm <= 0: no clipping), g *= clip,

@@ -582,3 +582,25 @@ def nms_sorted(boxes, labels, iou_threshold, counts=None):
     keep = torch.empty((I, n), device=boxes.device, dtype=torch.uint8)
     _call("spe_nms_sorted", _p(boxes), _p(labels), _p(counts), _p(keep), I, n, float(iou_threshold), _st())
     return keep.bool()
+
+
+# ---- CAM -> pseudo boxes -------------------------------------------------------------------------
+def cam_prepare(maps, rows, cols, cam_thr):
+    """maps [M,h,w] fp32 (device) -> thresholded uint8 images [M,rows,cols] (device); see csrc/cambox.hip."""
+    _chk(maps)
+    M, h, w = maps.shape
+    out = torch.empty((M, rows, cols), device=maps.device, dtype=torch.uint8)
+    mm = torch.empty((2 * M,), device=maps.device, dtype=torch.float32)
+    _call("spe_cam_prepare", _p(maps), M, h, w, rows, cols, float(cam_thr), _p(mm), _p(out), _st())
+    return out
+
+
+def cam_contour_boxes(img_u8_host, area_ratio, max_boxes=256):
+    """One thresholded uint8 image on the HOST ([rows, cols], contiguous) -> int32 [n,4] boxes [x, y, x+w, y+h]."""
+    assert img_u8_host.device.type == "cpu" and img_u8_host.dtype == torch.uint8 and img_u8_host.is_contiguous()
+    rows, cols = img_u8_host.shape
+    boxes = torch.empty((max_boxes, 4), dtype=torch.int32)
+    n = ctypes.c_int(0)
+    lib.call("spe_cam_contour_boxes", ctypes.c_void_p(img_u8_host.data_ptr()), rows, cols, float(area_ratio),
+             ctypes.c_void_p(boxes.data_ptr()), max_boxes, ctypes.byref(n))
+    return boxes[:n.value].clone()

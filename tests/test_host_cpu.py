@@ -153,3 +153,54 @@ def test_deit_checkpoint_interop(tmp_path):
     for i in range(1, nb + 1):
         for (ka, a), (kb, b) in zip(dst.blocks[-i].state_dict().items(), dst.blocks_det[-i].state_dict().items()):
             assert ka == kb and torch.equal(a, b)
+
+
+def _blob_images():
+    import numpy as np
+    rng = np.random.RandomState(7)
+    imgs = []
+    z = np.zeros((12, 16), np.uint8); imgs.append(("empty", z.copy()))
+    a = z.copy(); a[3:9, 4:13] = 200; imgs.append(("rect", a))                      # 9 wide x 6 high
+    a = z.copy(); a[2:11, 2:14] = 9; a[5:8, 6:10] = 0; imgs.append(("ring", a))       # a hole
+    a = z.copy(); a[6, 7] = 1; imgs.append(("pixel", a))
+    a = z.copy(); a[4, 2:12] = 5; a[4:10, 11] = 5; imgs.append(("thin", a))
+    a = z.copy(); a[0, :] = 3; a[:, 0] = 3; a[-1, -1] = 3; imgs.append(("edges", a))
+    for k in range(6):
+        n = rng.rand(40, 56)
+        for _ in range(3):                                                          # smooth -> blobs with holes
+            n = (n + np.roll(n, 1, 0) + np.roll(n, -1, 0) + np.roll(n, 1, 1) + np.roll(n, -1, 1)) / 5
+        imgs.append((f"noise{k}", ((n > np.percentile(n, 55 + 5 * k)) * 255).astype(np.uint8)))
+    return imgs
+
+
+def test_cam_contour_boxes_vs_oracle_and_ndimage():
+    """Native border following (csrc/cambox.hip, host code) == the NumPy restatement, plus checks that do not share
+    its algorithm: outer borders <-> 8-connected components, hole borders <-> enclosed 4-connected background regions
+    (scipy.ndimage), and known answers (filled w x h rectangle: area (w-1)(h-1), box [x, y, x+w, y+h])."""
+    import numpy as np
+    import torch
+    from scipy import ndimage
+    from oracle import cam_oracle as CO
+    from spe_amd import kernels as K
+    for name, img in _blob_images():
+        t = torch.from_numpy(img.copy())
+        for ratio in (0.5, 0.0):
+            got = K.cam_contour_boxes(t, ratio, max_boxes=4096).tolist()
+            assert got == CO.multi_bboxes_from_image(img, ratio), (name, ratio)
+        allb = K.cam_contour_boxes(t, 0.0, max_boxes=4096).tolist()
+        if name == "empty":
+            assert allb == [[0, 0, 1, 1]]
+            continue
+        fg = img != 0
+        lab, n = ndimage.label(fg, structure=np.ones((3, 3)))
+        comp = sorted([[s[1].start, s[0].start, s[1].stop, s[0].stop] for s in ndimage.find_objects(lab)])
+        bg = np.pad(~fg, 1, constant_values=True)
+        labb, nb = ndimage.label(bg)                                                # 4-connected background
+        outside = labb[0, 0]
+        holes = []
+        for k, s in enumerate(ndimage.find_objects(labb), start=1):
+            if k != outside:
+                holes.append([s[1].start - 1 - 1, s[0].start - 1 - 1, s[1].stop - 1 + 1, s[0].stop - 1 + 1])   # un-pad, grow by 1
+        assert sorted(allb) == sorted(comp + holes), name
+    rect = [b for n_, im in _blob_images() if n_ == "rect" for b in CO.find_borders(im)]
+    assert rect == [(8.0 * 5.0, 4, 3, 12, 8)]

@@ -655,3 +655,44 @@ def test_per_class_nms_and_flip_merge_vs_oracle(dev):
     for k in ("pred_logits", "pred_boxes", "x_logits", "x_cls_logits", "cams_cls"):
         assert torch.equal(got[k].cpu(), ref[k]), k
     assert torch.equal(got["aux_outputs"][0]["pred_boxes"].cpu(), ref["aux_outputs"][0]["pred_boxes"])
+
+
+def test_cam_to_boxes_vs_oracle(dev):
+    """device resize/normalise/quantise/threshold == the NumPy restatement (pixels that sit on a
+    uint8 truncation boundary may differ by rounding: <= 0.05 % tolerated), and the whole driver
+    (spe_amd.camboxes.get_pseudo_label_multi_boxes) == the reference's loop run on the oracle functions."""
+    import argparse
+    import numpy as np
+    from oracle import cam_oracle as CO
+    from spe_amd import camboxes, kernels as K
+    g = torch.Generator().manual_seed(12)
+    B, Kc, h, w, H, W = 2, 5, 9, 13, 144, 208
+    cams = torch.zeros(B, Kc, h, w)
+    for b in range(B):
+        for c in range(Kc):
+            for _ in range(2):                                          # two bumps per map
+                cy, cx = torch.rand(2, generator=g) * torch.tensor([h - 1.0, w - 1.0])
+                yy, xx = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+                cams[b, c] += torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * (1.0 + 2 * torch.rand(1, generator=g)) ** 2))
+    cams += 0.05 * torch.randn(cams.shape, generator=g)
+    rows, cols = W, H                                                   # the reference's (H, W) -> dsize quirk
+    got = K.cam_prepare(cams.view(-1, h, w).to(dev), rows, cols, 0.2).cpu().numpy()
+    for m in range(B * Kc):
+        ref = CO.threshold_image(cams.view(-1, h, w)[m].numpy(), rows, cols, 0.2)
+        assert (got[m] != ref).mean() <= 5e-4, m
+    labels = torch.zeros(B, Kc, dtype=torch.int64); labels[0, [0, 3]] = 1; labels[1, [1, 2, 4]] = 1
+    targets = [{"img_label": labels[b].to(dev)} for b in range(B)]
+    args = argparse.Namespace(num_classes=Kc, cam_thr=0.2, multi_box_ratio=0.5)
+    samples = torch.zeros(B, 3, H, W, device=dev)
+    res = camboxes.get_pseudo_label_multi_boxes({"cams_cls": cams.to(dev)}, samples, targets, args)
+    for b in range(B):
+        eb, el = [], []
+        for c in range(Kc):
+            if labels[b, c] > 0:
+                img = got[b * Kc + c]                                   # same thresholded image: isolates the box logic
+                bx = torch.tensor(CO.multi_bboxes_from_image(img, 0.5))
+                x0, y0, x1, y1 = bx[..., 0], bx[..., 1], bx[..., 2], bx[..., 3]
+                eb.append(torch.stack([(x0 + x1) / 2, (y0 + y1) / 2, x1 - x0, y1 - y0], -1))
+                el += [c + 1] * bx.shape[0]
+        eb = torch.cat(eb).float() / torch.tensor([W, H, W, H], dtype=torch.float32)
+        assert torch.equal(res[b]["labels"].cpu(), torch.tensor(el)) and torch.allclose(res[b]["boxes"].cpu(), eb)
