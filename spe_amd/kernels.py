@@ -147,7 +147,16 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
 # fp32-operand kernel.
 LINEAR16 = os.environ.get("SPE_LINEAR16", "1") != "0"
 LINEAR16_MIN_ROWS = int(os.environ.get("SPE_LINEAR16_MIN_ROWS", "128"))
-_W16 = {}        # id(W) -> (weakref, version, data_ptr, W16 [N,K], W16T [K,N])
+_W16 = {}        # id(W) -> (weakref, version, data_ptr, epoch, W16 [N,K], W16T [K,N])
+_W16_EPOCH = 0   # bumped by writers that bypass autograd's version counters (spe_amd.optim.FlatAdamW)
+
+
+def weights_changed():
+    """Invalidate the cached bf16 weight copies.  torch optimisers bump `Tensor._version`, which the cache checks; a
+    kernel that updates parameters through raw pointers (FlatAdamW) must call this after every step."""
+    global _W16_EPOCH
+    _W16_EPOCH += 1
+
 
 
 def _lin16_ok(R, N, K):
@@ -173,13 +182,13 @@ def weight16(W):
     import weakref
     key = id(W)
     ent = _W16.get(key)
-    if ent is not None and ent[0]() is W and ent[1] == W._version and ent[2] == W.data_ptr():
-        return ent[3], ent[4]
+    if ent is not None and ent[0]() is W and ent[1] == W._version and ent[2] == W.data_ptr() and ent[3] == _W16_EPOCH:
+        return ent[4], ent[5]
     with torch.no_grad():
         W16, W16T = cvt_bf16(W.detach(), True, True, ldt=W.shape[0])
     if len(_W16) > 4096:
         _W16.clear()
-    _W16[key] = (weakref.ref(W), W._version, W.data_ptr(), W16, W16T)
+    _W16[key] = (weakref.ref(W), W._version, W.data_ptr(), _W16_EPOCH, W16, W16T)
     return W16, W16T
 
 

@@ -83,6 +83,7 @@ class FlatAdamW(torch.optim.Optimizer):
                 e["tab_key"] = key
             K.adamw_flat(e["b"]["flat_p"], e["b"]["flat"], e["m"], e["v"], e["seg_end"], e["tab"][0], e["tab"][1],
                          b1, b2, eps, bc1, bc2, self._partials, clip, self.write_clipped_grads)
+        K.weights_changed()            # the update bypassed autograd's version counters: drop cached bf16 weight copies
         for grp in self.param_groups:
             for p in grp["params"]:
                 self.state[p]["step"] += 1

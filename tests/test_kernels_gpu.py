@@ -696,3 +696,50 @@ def test_cam_to_boxes_vs_oracle(dev):
                 el += [c + 1] * bx.shape[0]
         eb = torch.cat(eb).float() / torch.tensor([W, H, W, H], dtype=torch.float32)
         assert torch.equal(res[b]["labels"].cpu(), torch.tensor(el)) and torch.allclose(res[b]["boxes"].cpu(), eb)
+
+
+def test_weight_cache_follows_flat_optimizer(dev):
+    """The bf16 weight copies cached for the Linear GEMMs are refreshed after FlatAdamW (which writes parameters through
+    raw pointers, without bumping Tensor._version) as well as after a torch optimiser step."""
+    from spe_amd import kernels as K
+    from spe_amd import ops
+    from spe_amd.dp import GradAllReducer
+    from spe_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(8)
+    W = torch.nn.Parameter((torch.randn(64, 32, generator=g) * 0.1).to(dev))
+    b = torch.nn.Parameter(torch.zeros(64, device=dev))
+    x = torch.randn(300, 32, generator=g).to(dev)                    # >= LINEAR16_MIN_ROWS: bf16-copy path
+    red = GradAllReducer([W, b], flatten_params=True)
+    opt = FlatAdamW([W, b], red, lr=0.05, weight_decay=0.0)
+    ref = lambda: x.to(torch.bfloat16).double() @ W.detach().to(torch.bfloat16).double().t() + b.detach().double()
+    for it in range(3):
+        red.reset()
+        y = ops.linear(x, W, b)
+        assert rel(y, ref()) < 1e-5, it                              # uses the CURRENT weights
+        y.square().sum().backward()
+        red.finish()
+        opt.step()
+    sgd = torch.optim.SGD([W, b], lr=0.1)
+    red.reset()
+    y = ops.linear(x, W, b)
+    y.sum().backward()
+    red.finish()
+    sgd.step()
+    assert rel(ops.linear(x, W, b), ref()) < 1e-5
+
+
+def test_patch_embed_large(dev):
+    """Patch embedding with >= LINEAR16_MIN_ROWS patches: the dW-only backward of the bf16-copy Linear path."""
+    from spe_amd import kernels as K
+    from spe_amd import ops
+    g = torch.Generator().manual_seed(4)
+    img = torch.randn(2, 3, 192, 256, generator=g).to(dev)
+    W = (torch.randn(48, 3, 16, 16, generator=g) * 0.05).to(dev).requires_grad_()
+    b = torch.randn(48, generator=g).to(dev).requires_grad_()
+    y = ops.patch_embed(img, W, b, 16)
+    go = torch.randn(y.shape, generator=g).to(dev)
+    gW, gb = torch.autograd.grad(y, (W, b), go)
+    Wd, bd = W.detach().double().requires_grad_(), b.detach().double().requires_grad_()
+    ref = torch.nn.functional.conv2d(img.double(), Wd, bd, stride=16).flatten(2).transpose(1, 2)
+    rW, rb = torch.autograd.grad(ref, (Wd, bd), go.double())
+    assert rel(y, ref) < 6e-3 and rel(gW, rW) < 1.2e-2 and rel(gb, rb) < 1e-5
