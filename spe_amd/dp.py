@@ -19,7 +19,9 @@ import torch.distributed as dist
 class GradAllReducer:
     def __init__(self, params, bucket_bytes=64 << 20, average=True, group=None, flatten_params=False):
         """flatten_params: also move the parameters themselves into flat per-bucket buffers with the gradient layout
-        (param.data becomes a view) - what spe_amd.optim.FlatAdamW steps in one launch per bucket."""
+        (param.data becomes a view) - what spe_amd.optim.FlatAdamW steps in one launch per bucket.  Construct the
+        reducer AFTER the model is on its device: `module.to(...)` / `.cuda()` re-allocates parameters and would
+        detach them from the flat buffers (load_state_dict and in-place updates are fine)."""
         self.params = [p for p in params if p.requires_grad]
         self.flatten_params = flatten_params
         self.group = group
