@@ -11,6 +11,11 @@ __global__ __launch_bounds__(256) void rd(const float4* __restrict__ x, float* o
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) { const float4 v = x[i]; acc += v.x + v.y + v.z + v.w; }
     if (acc == 12345.678f) out[0] = acc;
 }
+__global__ __launch_bounds__(256) void rd8(const float2* __restrict__ x, float* out, long n2) {   // 8 B per lane, like the score blocks
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256) { const float2 v = x[i]; acc += v.x + v.y; }
+    if (acc == 12345.678f) out[0] = acc;
+}
 __global__ __launch_bounds__(256) void wr(float4* __restrict__ y, long n4) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) y[i] = make_float4(1.f, 2.f, 3.f, 4.f);
 }
@@ -47,6 +52,8 @@ int main() {
     for (int g : {2048, 8192, 32768}) {
         float t = timeit([&] { hipLaunchKernelGGL(rd, dim3(g), dim3(256), 0, 0, x, out, n4); }, 5);
         printf("HBM read   2 GiB grid %6d: %7.0f GB/s\n", g, bytes / (t * 1e-3) / 1e9);
+        t = timeit([&] { hipLaunchKernelGGL(rd8, dim3(g), dim3(256), 0, 0, (const float2*)x, out, n4 * 2); }, 5);
+        printf("HBM read8  2 GiB grid %6d: %7.0f GB/s (8 B per lane)\n", g, bytes / (t * 1e-3) / 1e9);
         t = timeit([&] { hipLaunchKernelGGL(wr, dim3(g), dim3(256), 0, 0, y, n4); }, 5);
         printf("HBM write  2 GiB grid %6d: %7.0f GB/s\n", g, bytes / (t * 1e-3) / 1e9);
         t = timeit([&] { hipLaunchKernelGGL(cp, dim3(g), dim3(256), 0, 0, x, y, n4); }, 5);
