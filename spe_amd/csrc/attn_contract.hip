@@ -29,7 +29,7 @@ typedef __bf16 bf16x4c_t __attribute__((ext_vector_type(4)));
 #define CONTRACT_R 4
 #endif
 #ifndef CONTRACT_PD
-#define CONTRACT_PD 2
+#define CONTRACT_PD 4
 #endif
 
 template <int DT, bool TRANS>
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
 #pragma unroll
     for (int r = 0; r < R; ++r) tr[r] = min(t0 + r, nt - 1);
 
-    // PD contraction steps are in flight per wave (register ring; loads are unconditional with clamped indices - a
-    // branch around a load costs a full vmcnt(0) drain); a step's registers are re-armed right after its MFMAs issued
+    // PD contraction steps are requested together (loads are unconditional with clamped indices - a branch around a
+    // load costs a full vmcnt(0) drain)
     constexpr int PD = CONTRACT_PD;
     uint2 tb[PD][R], xf[PD][DT];
 #define LOAD_STEP(c_, tb_, xf_)                                                                         \
@@ -70,9 +70,12 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
         _Pragma("unroll") for (int r = 0; r < R; ++r)                                                   \
             tb_[r] = TRANS ? Tb[((long)cc * nt + tr[r]) * 64 + lane] : Tb[((long)tr[r] * nt + cc) * 64 + lane]; \
     }
-#pragma unroll
-    for (int s = 0; s < PD; ++s) LOAD_STEP(wave + 4 * s, tb[s], xf[s]);
+    // hipcc drains vmcnt(0) at the head of a loop whose loads are carried across the back edge, so a register ring
+    // gives no overlap; instead every iteration requests PD steps at once and then consumes them in order (the
+    // waits inside the straight-line body are exact: vmcnt(7*(PD-1)), ..., vmcnt(0)).
     for (int c0 = wave; c0 < nt; c0 += 4 * PD) {
+#pragma unroll
+        for (int s = 0; s < PD; ++s) LOAD_STEP(c0 + 4 * s, tb[s], xf[s]);
 #pragma unroll
         for (int s = 0; s < PD; ++s) {
             const int c = c0 + 4 * s;
@@ -94,7 +97,6 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
                         acc[r][d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, xf[s][d]), bt, acc[r][d], 0, 0, 0);
                 }
             }
-            LOAD_STEP(c + 4 * PD, tb[s], xf[s]);
         }
     }
 #undef LOAD_STEP
