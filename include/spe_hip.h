@@ -207,6 +207,11 @@ int spe_box_loss(const float* pred_boxes, const long* srow, const float* tbox, c
 int spe_box_loss_bwd(const long* srow, const int* lidx, const float* g_l1, const float* g_giou, const float* c1,
                      const float* c2, float* dpred, long n, spe_stream_t stream);
 
+/* ---- sine position embedding of the padded feature map (reference models/position_encoding.py:37-57):
+ * mask [B,h,w] uint8 (1 = padded), dim_t[npf] = temperature^(2*(k/2)/npf), out [B,h,w,2*npf] fp32 (row features first). */
+int spe_pos_sine(const void* mask_u8, const float* dim_t, float* out, int B, int h, int w, int npf, float scale,
+                 float eps, int normalize, spe_stream_t stream);
+
 /* ---- per-class greedy NMS (reference engine_loc.py:154-174: torchvision.ops.nms(boxes, scores, 0.5) per predicted
  * class, results concatenated in ascending class order).  boxes [nimg, nmax, 4] xyxy and labels [nimg, nmax] (int64)
  * ALREADY ordered by (label ascending, score descending) per image; counts[img] valid detections (NULL: nmax).

@@ -118,3 +118,46 @@ extern "C" int spe_bicubic(const float* src, float* dst, int gh, int gw, int h, 
 }
 
 extern "C" int spe_abi_version(void) { return 1; }
+
+
+// ------------------------------------------------------------------------------------------
+// Sine position embedding of the padded feature map (reference models/position_encoding.py:37-57, normalize = True):
+// out[b][y][x][k] for k < npf encodes the row coordinate, k >= npf the column coordinate:
+//   e = (count of non-padded cells up to and including this one along the axis) / (count along the whole axis + eps) * scale
+//   value = sin(e / dim_t[k']) for even k', cos(e / dim_t[k']) for odd k'   (dim_t = temperature^(2*(k'/2)/npf), passed in)
+// One thread per (b, y, x, feature pair); the two prefix counts are recomputed from the mask (<= h + w byte loads).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pos_sine_kernel(const unsigned char* __restrict__ mask, const float* __restrict__ dim_t,
+                                                       float* __restrict__ out, int B, int h, int w, int npf, float scale, float eps,
+                                                       int normalize) {
+    const int half = npf / 2;
+    const long total = (long)B * h * w * half;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int kp = (int)(i % half); long t = i / half;
+        const int x = (int)(t % w); t /= w;
+        const int y = (int)(t % h); const int b = (int)(t / h);
+        const unsigned char* m = mask + (long)b * h * w;
+        int cy = 0, ty = 0, cx = 0, tx = 0;
+        for (int yy = 0; yy < h; ++yy) { const int v = m[yy * w + x] ? 0 : 1; ty += v; if (yy <= y) cy += v; }
+        for (int xx = 0; xx < w; ++xx) { const int v = m[y * w + xx] ? 0 : 1; tx += v; if (xx <= x) cx += v; }
+        float ey = (float)cy, ex = (float)cx;
+        if (normalize) { ey = ey / ((float)ty + eps) * scale; ex = ex / ((float)tx + eps) * scale; }
+        const float d0 = dim_t[2 * kp], d1 = dim_t[2 * kp + 1];
+        float* o = out + (((long)b * h + y) * w + x) * (2 * npf);
+        o[2 * kp] = sinf(ey / d0); o[2 * kp + 1] = cosf(ey / d1);
+        o[npf + 2 * kp] = sinf(ex / d0); o[npf + 2 * kp + 1] = cosf(ex / d1);
+    }
+}
+
+// C-ABI: see include/spe_hip.h (spe_pos_sine).  npf even.
+extern "C" int spe_pos_sine(const void* mask_u8, const float* dim_t, float* out, int B, int h, int w, int npf, float scale,
+                            float eps, int normalize, hipStream_t st) {
+    if (B <= 0 || h <= 0 || w <= 0 || npf <= 0) return 0;
+    if (npf & 1) return -2;
+    const long total = (long)B * h * w * (npf / 2);
+    long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(pos_sine_kernel, dim3((unsigned)nb), dim3(256), 0, st, reinterpret_cast<const unsigned char*>(mask_u8), dim_t,
+                       out, B, h, w, npf, scale, eps, normalize);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}

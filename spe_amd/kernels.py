@@ -613,3 +613,12 @@ def cam_contour_boxes(img_u8_host, area_ratio, max_boxes=256):
     lib.call("spe_cam_contour_boxes", ctypes.c_void_p(img_u8_host.data_ptr()), rows, cols, float(area_ratio),
              ctypes.c_void_p(boxes.data_ptr()), max_boxes, ctypes.byref(n))
     return boxes[:n.value].clone()
+
+
+def pos_sine(mask_bool, dim_t, npf, scale, eps, normalize):
+    """mask [B,h,w] bool (True = padded) -> [B,h,w,2*npf] fp32 sine position features (csrc/misc.hip)."""
+    B, h, w = mask_bool.shape
+    m8 = mask_bool.to(torch.uint8).contiguous()
+    out = torch.empty((B, h, w, 2 * npf), device=mask_bool.device, dtype=torch.float32)
+    _call("spe_pos_sine", _p(m8), _p(dim_t), _p(out), B, h, w, npf, float(scale), float(eps), int(bool(normalize)), _st())
+    return out

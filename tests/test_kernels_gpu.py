@@ -743,3 +743,19 @@ def test_patch_embed_large(dev):
     ref = torch.nn.functional.conv2d(img.double(), Wd, bd, stride=16).flatten(2).transpose(1, 2)
     rW, rb = torch.autograd.grad(ref, (Wd, bd), go.double())
     assert rel(y, ref) < 6e-3 and rel(gW, rW) < 1.2e-2 and rel(gb, rb) < 1e-5
+
+
+def test_position_embedding_sine_vs_reference_golden(dev):
+    """pos_sine_kernel through the module vs the vector captured from the reference (padded mask) and a large unpadded grid
+    vs the oracle."""
+    import os
+    from types import SimpleNamespace
+    from oracle import spe_oracle as O
+    from spe_amd.models.position_encoding import PositionEmbeddingSine
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ops.pt"), weights_only=False)["pos_sine"]
+    pe = PositionEmbeddingSine(16, normalize=True).to(dev)
+    out = pe(SimpleNamespace(tensors=None, mask=g["mask"].to(dev)))
+    assert out.shape == g["out"].shape and rel(out, g["out"]) < 2e-6
+    mask = torch.zeros(2, 50, 83, dtype=torch.bool); mask[1, 40:, :] = True; mask[1, :, 70:] = True
+    pe = PositionEmbeddingSine(192, normalize=True).to(dev)
+    assert rel(pe(SimpleNamespace(tensors=None, mask=mask.to(dev))), O.position_embedding_sine(mask, 192)) < 2e-6
