@@ -138,11 +138,11 @@ int spe_attn_merge(const float* ws, float* out0, float* out1, int B, int H, int 
  * (x element strides sb, sn, sh; 0 outside).  out element strides ob (batch), on (row), oh (head), unit d stride.
  * Head dim <= 64, returns -2 otherwise. */
 int spe_attn_pack16(const float* x, long sb, long sn, long sh, int B, int N, int H, int dh, void* out, spe_stream_t stream);
-/* njobs <= 6 packs of same-shape [B,N,H,dh] views in one launch: job i reads xs[i] (element strides strides[3i..3i+2] =
- * batch, row, head), multiplies by scales[i] and writes the spe_attn_pack (kinds[i] = 0) or spe_attn_pack16 (1) layout
- * to outs[i].  The pointer/stride tables are HOST arrays (copied into the kernel arguments). */
+/* njobs <= 6 packs of [B,Ns[i],H,dhs[i]] views in one launch: job i reads xs[i] (element strides strides[3i..3i+2] =
+ * batch, row, head), multiplies by scales[i] and writes the spe_attn_pack (kinds[i] = 0), spe_attn_pack16 (1) or
+ * full-32-steps-only (2: ceil(dh/32) steps of [lane][8], no tail step; spe_mha_*) layout to outs[i].  The pointer/stride tables are HOST arrays (copied into the kernel arguments). */
 int spe_attn_pack_multi(int njobs, const float* const* xs, const long* strides, const float* scales, const int* kinds,
-                        void* const* outs, int B, int N, int H, int dh, spe_stream_t stream);
+                        void* const* outs, const int* Ns, const int* dhs, int B, int H, spe_stream_t stream);
 int spe_attn_contract(const void* T, const void* X16, float* out, long ob, long on, long oh, int B, int H, int N, int dh,
                       int trans, float alpha, spe_stream_t stream);
 
@@ -206,6 +206,26 @@ int spe_box_loss(const float* pred_boxes, const long* srow, const float* tbox, c
                  float* sums, float* g_l1, float* g_giou, long n, spe_stream_t stream);
 int spe_box_loss_bwd(const long* srow, const int* lidx, const float* g_l1, const float* g_giou, const float* c1,
                      const float* c2, float* dpred, long n, spe_stream_t stream);
+
+/* ---- flash-style multi-head attention (reference models/attention.py:277-383; nn.MultiheadAttention core of the
+ * encoder, models/transformer.py:275-277): softmax(scale q k^T + key_padding_mask), dropout, . v, forward and backward
+ * without the [B,H,Lq,Lk] score tensor.  Operands are fragments from spe_attn_pack_multi: kind 2 (32-wide steps) of
+ * q*scale*log2(e), k, v, dO -> Qf, Kf, Vf, dOf ; kind 1 (16-wide) of v, k, q*scale*log2(e), dO -> V16, K16, Q16, dO16.
+ * q/k head dim <= 96, v head dim <= 64; mask [B,Lk] uint8 (1 = padded) or NULL; Philox dropout on element index
+ * ((b*H+h)*Lq + q)*ld4 + key, ld4 = Lk rounded up to 4 (the stream spe_softmax_fwd draws from); the forward records the
+ * keep flags in keepbits (B*H*ntq*ntk*4 64-bit words, needed when p_drop > 0) and the backward reads them.
+ * spe_mha_plan: number of key chunks the forward / dQ kernels split the keys into (few query tiles -> many chunks).
+ * spe_mha_fwd: Opart [B*H*ntq*nch][ceil(dv/16)][64][4] and ML [B*H*ntq*nch][16][2] floats of workspace ->
+ *   O [B,Lq,H*dv], LSE [B,H,Lq] (log2 domain).  spe_mha_bwd: D [B,H,Lq] = rowsum(dO.O); dq [B,Lq,H,dk] must be
+ *   zero-initialised when nch > 1 (atomic accumulation over chunks); dk [B,Lk,H,dk], dv [B,Lk,H,dv] are overwritten. */
+int spe_mha_plan(int B, int H, int Lq, int Lk, int* nch);
+int spe_mha_fwd(const void* Qf, const void* Kf, const void* V16, const void* mask, float* Opart, float* ML, float* O,
+                float* LSE, void* keepbits, int B, int H, int Lq, int Lk, int dk, int dv, int nch, float p_drop,
+                uint64_t seed, uint64_t offset, spe_stream_t stream);
+int spe_mha_bwd(const void* Qf, const void* Kf, const void* Vf, const void* dOf, const void* K16, const void* Q16,
+                const void* dO16, const void* mask, const float* LSE, const float* D, const void* keepbits, float* dq,
+                float* dk, float* dv, int B, int H, int Lq, int Lk, int dk_dim, int dv_dim, int nch, float scale,
+                float p_drop, spe_stream_t stream);
 
 /* ---- sine position embedding of the padded feature map (reference models/position_encoding.py:37-57):
  * mask [B,h,w] uint8 (1 = padded), dim_t[npf] = temperature^(2*(k/2)/npf), out [B,h,w,2*npf] fp32 (row features first). */

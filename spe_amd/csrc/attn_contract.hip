@@ -182,15 +182,16 @@ extern "C" int spe_attn_pack16(const float* x, long sb, long sn, long sh, int B,
 // Several packs of one attention call in ONE launch (forward: q, k -> 32-wide fragments, v -> 16-wide; backward: v, dO
 // -> 32-wide, dO, k, q -> 16-wide): the packs are ~10 us each and launch-latency bound.  blockIdx.y = job.
 #define PACK_MAXJOBS 6
-struct PackJob { const float* x; long sb, sn, sh; float scale; int kind; void* out; };   // kind 0: spe_attn_pack layout, 1: spe_attn_pack16
-struct PackJobs { PackJob j[PACK_MAXJOBS]; int B, N, H, dh, nt; };
+struct PackJob { const float* x; long sb, sn, sh; float scale; int kind; void* out; int N, dh; };   // kind 0: spe_attn_pack layout, 1: spe_attn_pack16, 2: spe_attn_pack layout without the tail step
+struct PackJobs { PackJob j[PACK_MAXJOBS]; int B, H; };
 __global__ __launch_bounds__(256) void attn_pack_multi_kernel(PackJobs a) {
     const PackJob jb = a.j[blockIdx.y];
-    const int nt = a.nt, N = a.N, H = a.H, dh = a.dh;
-    if (jb.kind == 0) {
-        const long total = attn_pack_units(a.B, N, H, dh);
+    const int N = jb.N, H = a.H, dh = jb.dh, nt = (N + 15) / 16;
+    if (jb.kind == 0 || jb.kind == 2) {
+        const int notail = jb.kind == 2;
+        const long total = attn_pack_units(a.B, N, H, dh, notail);
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
-            attn_pack_unit(jb.x, jb.sb, jb.sn, jb.sh, N, H, dh, nt, jb.scale, i, reinterpret_cast<uint2*>(jb.out));
+            attn_pack_unit(jb.x, jb.sb, jb.sn, jb.sh, N, H, dh, nt, jb.scale, i, reinterpret_cast<uint2*>(jb.out), notail);
     } else {
         const int DT = (dh + 15) / 16;
         const long total = (long)a.B * H * nt * DT * 64;
@@ -213,18 +214,21 @@ __global__ __launch_bounds__(256) void attn_pack_multi_kernel(PackJobs a) {
     }
 }
 
-// C-ABI: see include/spe_hip.h (spe_attn_pack_multi).  xs/outs/scales/kinds: njobs entries; common strides.
+// C-ABI: see include/spe_hip.h (spe_attn_pack_multi).  xs/outs/scales/kinds/Ns/dhs: njobs entries (host arrays).
 extern "C" int spe_attn_pack_multi(int njobs, const float* const* xs, const long* strides, const float* scales, const int* kinds,
-                                   void* const* outs, int B, int N, int H, int dh, hipStream_t st) {
-    if (njobs <= 0 || B <= 0 || N <= 0) return 0;
+                                   void* const* outs, const int* Ns, const int* dhs, int B, int H, hipStream_t st) {
+    if (njobs <= 0 || B <= 0) return 0;
     if (njobs > PACK_MAXJOBS) return -2;
     PackJobs a;
+    long total = 0;
     for (int i = 0; i < njobs; ++i) {
         a.j[i].x = xs[i]; a.j[i].sb = strides[3 * i]; a.j[i].sn = strides[3 * i + 1]; a.j[i].sh = strides[3 * i + 2];
-        a.j[i].scale = scales[i]; a.j[i].kind = kinds[i]; a.j[i].out = outs[i];
+        a.j[i].scale = scales[i]; a.j[i].kind = kinds[i]; a.j[i].out = outs[i]; a.j[i].N = Ns[i]; a.j[i].dh = dhs[i];
+        if (Ns[i] <= 0 || dhs[i] <= 0) return -2;
+        const long t = (long)B * H * ((Ns[i] + 15) / 16) * ((dhs[i] + 31) / 32) * 128;    // the largest item count of the layouts
+        if (t > total) total = t;
     }
-    a.B = B; a.N = N; a.H = H; a.dh = dh; a.nt = (N + 15) / 16;
-    const long total = (long)B * H * a.nt * ((dh + 15) / 16) * 64;        // the larger (16-wide) item count
+    a.B = B; a.H = H;
     long nb = (total + 255) / 256; if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(attn_pack_multi_kernel, dim3((unsigned)nb, njobs), dim3(256), 0, st, a);
     SPE_CHECK_LAUNCH();

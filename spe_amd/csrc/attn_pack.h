@@ -4,8 +4,9 @@
 #include "common.h"
 
 __device__ __forceinline__ void attn_pack_unit(const float* __restrict__ x, long sb, long sn, long sh, int N, int H, int dh, int nt,
-                                               float scale, long i, uint2* __restrict__ out) {
-    const int rem = dh % 32, full = dh / 32 + (rem > 16 ? 1 : 0), tail = (rem > 0 && rem <= 16) ? 1 : 0;
+                                               float scale, long i, uint2* __restrict__ out, int notail = 0) {
+    // notail: ceil(dh/32) full steps and no 16-wide tail step (the layout of mha_flash.hip)
+    const int rem = dh % 32, full = notail ? (dh + 31) / 32 : dh / 32 + (rem > 16 ? 1 : 0), tail = (!notail && rem > 0 && rem <= 16) ? 1 : 0;
     const int rec8 = full * 128 + tail * 64;
     const long rec = i / rec8; const int u = (int)(i % rec8);
     const int tile = (int)(rec % nt); const int h = (int)((rec / nt) % H); const int b = (int)(rec / ((long)nt * H));
@@ -22,8 +23,8 @@ __device__ __forceinline__ void attn_pack_unit(const float* __restrict__ x, long
 }
 
 // 8-B units of a packed tensor [B, H, nt] records
-__host__ __device__ static inline long attn_pack_units(int B, int N, int H, int dh) {
-    const int nt = (N + 15) / 16, rem = dh % 32, full = dh / 32 + (rem > 16 ? 1 : 0), tail = (rem > 0 && rem <= 16) ? 1 : 0;
+__host__ __device__ static inline long attn_pack_units(int B, int N, int H, int dh, int notail = 0) {
+    const int nt = (N + 15) / 16, rem = dh % 32, full = notail ? (dh + 31) / 32 : dh / 32 + (rem > 16 ? 1 : 0), tail = (!notail && rem > 0 && rem <= 16) ? 1 : 0;
     return (long)B * H * nt * (full * 128 + tail * 64);
 }
 

@@ -82,4 +82,14 @@ __device__ __forceinline__ float spe_drop_scale(uint64_t seed, uint64_t offset, 
     return (spe_uniform(seed, offset, idx) >= p) ? 1.0f / (1.0f - p) : 0.0f;
 }
 
+// keep-scales of the 4 consecutive elements idx0 .. idx0+3, idx0 a multiple of 4: ONE Philox call
+__device__ __forceinline__ void spe_drop_scale4(uint64_t seed, uint64_t offset, uint64_t idx0, float p, float out[4]) {
+    uint32_t o[4];
+    const uint64_t blk = idx0 >> 2;
+    spe_philox4((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    const float inv = 1.0f / (1.0f - p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = ((float)(o[i] >> 8) * (1.0f / 16777216.0f) >= p) ? inv : 0.0f;
+}
+
 #define SPE_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -138,7 +138,8 @@ extern "C" int spe_layernorm_bwd(const float* dy, const float* x, const float* g
 // ------------------------------------------------------------------------------------------
 // Masked softmax over the last axis of scores[B,H,Nq,ld] (Nk valid columns), one wave per row.
 // key-padding mask [B,Nk] (1 = padded key -> -inf), reference models/attention.py:363-371.
-// P = softmax(S) is written for backward; Pd = dropout(P) (reference :373) only when p_drop > 0.
+// P = softmax(S) is written for backward; Pd = dropout(P) (reference :373) only when p_drop > 0.  The dropout element
+// index is row*ld + k (ld = padded row stride): the same stream mha_flash.hip draws from, 4 keys per Philox block.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, const unsigned char* __restrict__ mask,
                                                           float* __restrict__ P, float* __restrict__ Pd,
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
         if (mk && mk[k]) v = -INFINITY;
         const float pr = __expf(v - M) * inv;
         p[k] = pr;
-        if (pd) pd[k] = pr * spe_drop_scale(seed, offset, (uint64_t)(row * (long)Nk + k), p_drop);
+        if (pd) pd[k] = pr * spe_drop_scale(seed, offset, (uint64_t)(row * ld + k), p_drop);
     }
 }
 
@@ -182,14 +183,14 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
     float acc = 0.f;
     for (int k = lane; k < Nk; k += 64) {
         float g = d[k];
-        if (p_drop > 0.f) g *= spe_drop_scale(seed, offset, (uint64_t)(row * (long)Nk + k), p_drop);
+        if (p_drop > 0.f) g *= spe_drop_scale(seed, offset, (uint64_t)(row * ld + k), p_drop);
         acc += g * p[k];
     }
     acc = spe_wave_sum(acc);
     float* o = dS + row * ld;
     for (int k = lane; k < Nk; k += 64) {
         float g = d[k];
-        if (p_drop > 0.f) g *= spe_drop_scale(seed, offset, (uint64_t)(row * (long)Nk + k), p_drop);
+        if (p_drop > 0.f) g *= spe_drop_scale(seed, offset, (uint64_t)(row * ld + k), p_drop);
         o[k] = p[k] * (g - acc);
     }
 }

@@ -516,23 +516,64 @@ def frag_record_elems(dh):
 
 
 def attn_pack_multi(jobs):
-    """jobs: list of (x4 [B,N,H,dh] fp32 view with unit last stride, scale, kind) with kind 32 -> attn_pack layout,
-    16 -> attn_pack16 layout; all views the same shape.  One launch; -> list of packed bf16 tensors."""
-    B, N, H, dh = jobs[0][0].shape
-    nt = (N + 15) // 16
+    """jobs: list of (x4 [B,N,H,dh] fp32 view with unit last stride, scale, kind): kind 32 -> attn_pack layout (32-wide
+    steps + 16-wide tail), 16 -> attn_pack16 layout, 322 -> 32-wide steps only (mha_flash).  N and dh may differ between
+    jobs (same B and H).  One launch; -> list of packed bf16 tensors."""
+    B, _, H, _ = jobs[0][0].shape
     n = len(jobs)
     outs = []
     for x4, scale, kind in jobs:
-        assert x4.shape == (B, N, H, dh) and x4.stride(3) == 1 and x4.dtype == torch.float32
-        shape = (B, H, nt, frag_record_elems(dh)) if kind == 32 else (B, H, nt, (dh + 15) // 16, 64, 4)
+        Bn, N, Hn, dh = x4.shape
+        assert Bn == B and Hn == H and x4.stride(3) == 1 and x4.dtype == torch.float32
+        nt = (N + 15) // 16
+        if kind == 32:
+            shape = (B, H, nt, frag_record_elems(dh))
+        elif kind == 322:
+            shape = (B, H, nt, (dh + 31) // 32, 64, 8)
+        else:
+            shape = (B, H, nt, (dh + 15) // 16, 64, 4)
         outs.append(torch.empty(shape, device=x4.device, dtype=torch.bfloat16))
     xs = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs])
     strides = (ctypes.c_long * (3 * n))(*[s for j in jobs for s in (j[0].stride(0), j[0].stride(1), j[0].stride(2))])
     scales = (ctypes.c_float * n)(*[float(j[1]) for j in jobs])
-    kinds = (ctypes.c_int * n)(*[0 if j[2] == 32 else 1 for j in jobs])
+    kinds = (ctypes.c_int * n)(*[{32: 0, 16: 1, 322: 2}[j[2]] for j in jobs])
     optr = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
-    _call("spe_attn_pack_multi", n, xs, strides, scales, kinds, optr, B, N, H, dh, _st())
+    Ns = (ctypes.c_int * n)(*[j[0].shape[1] for j in jobs])
+    dhs = (ctypes.c_int * n)(*[j[0].shape[3] for j in jobs])
+    _call("spe_attn_pack_multi", n, xs, strides, scales, kinds, optr, Ns, dhs, B, H, _st())
     return outs
+
+
+def mha_plan(B, H, Lq, Lk):
+    nch = ctypes.c_int(0)
+    lib.call("spe_mha_plan", B, H, Lq, Lk, ctypes.byref(nch))
+    return nch.value
+
+
+def mha_fwd(Qf, Kf, V16, mask_u8, B, H, Lq, Lk, dk, dv, nch, p_drop, seed, offset):
+    """-> O [B,Lq,H*dv] fp32, LSE [B,H,Lq] (log2 domain), keepbits (dropout keep flags, None when p_drop = 0); see
+    csrc/mha_flash.hip."""
+    dev = Qf.device
+    ntq, ntk, dvt = (Lq + 15) // 16, (Lk + 15) // 16, (dv + 15) // 16
+    items = B * H * ntq * nch
+    opart = torch.empty((items, dvt, 64, 4), device=dev, dtype=torch.float32)
+    ml = torch.empty((items, 16, 2), device=dev, dtype=torch.float32)
+    O = torch.empty((B, Lq, H * dv), device=dev, dtype=torch.float32)
+    lse = torch.empty((B, H, Lq), device=dev, dtype=torch.float32)
+    keep = torch.empty((B * H * ntq * ntk * 4,), device=dev, dtype=torch.int64) if p_drop > 0 else None
+    _call("spe_mha_fwd", _p(Qf), _p(Kf), _p(V16), _p(mask_u8), _p(opart), _p(ml), _p(O), _p(lse), _p(keep), B, H, Lq, Lk, dk, dv,
+          nch, float(p_drop), seed, offset, _st())
+    return O, lse, keep
+
+
+def mha_bwd(Qf, Kf, Vf, dOf, K16, Q16, dO16, mask_u8, lse, D, keep, B, H, Lq, Lk, dk, dv, nch, scale, p_drop):
+    dev = Qf.device
+    dq = torch.zeros((B, Lq, H, dk), device=dev, dtype=torch.float32) if nch > 1 else torch.empty((B, Lq, H, dk), device=dev, dtype=torch.float32)
+    dk_ = torch.empty((B, Lk, H, dk), device=dev, dtype=torch.float32)
+    dv_ = torch.empty((B, Lk, H, dv), device=dev, dtype=torch.float32)
+    _call("spe_mha_bwd", _p(Qf), _p(Kf), _p(Vf), _p(dOf), _p(K16), _p(Q16), _p(dO16), _p(mask_u8), _p(lse), _p(D), _p(keep), _p(dq),
+          _p(dk_), _p(dv_), B, H, Lq, Lk, dk, dv, nch, float(scale), float(p_drop), _st())
+    return dq, dk_, dv_
 
 
 def attn_contract(T, X16, out4, trans, alpha=1.0):

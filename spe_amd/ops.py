@@ -322,11 +322,55 @@ class _Attention(Function):
         return dq, dk_, dv_, None, None, None, None
 
 
+class _AttentionFlash(Function):
+    """Same operator without the [B,H,Lq,Lk] tensors (csrc/mha_flash.hip): online-softmax forward, two-kernel backward.
+    Used in bf16 mode when no attention map is requested and the head dims fit (q/k <= 96, v <= 64)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask_u8, scale, p_drop):
+        B, Lq, H, dk = q.shape
+        Lk, dv = k.shape[1], v.shape[3]
+        sc = scale * K.LOG2E
+        need_bwd = any(ctx.needs_input_grad[:3])
+        jobs = [(q, sc, 322), (k, 1.0, 322), (v, 1.0, 16)]
+        if need_bwd:
+            jobs += [(q, sc, 16), (k, 1.0, 16), (v, 1.0, 322)]
+        packs = K.attn_pack_multi(jobs)
+        Qf, Kf, V16 = packs[:3]
+        nch = K.mha_plan(B, H, Lq, Lk)
+        seed, off = K.next_rng() if p_drop > 0 else (0, 0)
+        O, lse, keep = K.mha_fwd(Qf, Kf, V16, mask_u8, B, H, Lq, Lk, dk, dv, nch, p_drop, seed, off)
+        ctx.meta = (B, Lq, Lk, H, dk, dv, nch, scale, p_drop)
+        if need_bwd:
+            ctx.save_for_backward(Qf, Kf, packs[3], packs[4], packs[5], O, lse, mask_u8, keep)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        Qf, Kf, Q16, K16, Vf, O, lse, mask_u8, keep = ctx.saved_tensors
+        B, Lq, Lk, H, dk, dv, nch, scale, p_drop = ctx.meta
+        dO = dO.contiguous()
+        dO4 = dO.view(B, Lq, H, dv)
+        D = (dO4 * O.view(B, Lq, H, dv)).sum(-1).permute(0, 2, 1).contiguous()          # [B,H,Lq] = rowsum(dO . O)
+        dOf, dO16 = K.attn_pack_multi([(dO4, 1.0, 322), (dO4, 1.0, 16)])
+        dq, dk_, dv_ = K.mha_bwd(Qf, Kf, Vf, dOf, K16, Q16, dO16, mask_u8, lse, D, keep, B, H, Lq, Lk, dk, dv, nch, scale, p_drop)
+        return dq, dk_, dv_, None, None, None
+
+
+FLASH_MHA = __import__("os").environ.get("SPE_FLASH_MHA", "1") != "0"
+FLASH_MIN_KEYS = 512
+
+
 def attention(q, k, v, key_padding_mask=None, scale=1.0, p_drop=0.0, need_map=False):
     """key_padding_mask: bool/uint8 [B,Lk], True = padded key."""
     m = None
     if key_padding_mask is not None:
         m = key_padding_mask.to(torch.uint8).contiguous()
+    # flash kernels when no map is wanted and the key axis is long (decoder self-attention over 100 queries is cheaper
+    # through the three small materialising launches)
+    if (FLASH_MHA and not need_map and K.get_precision() == "bf16" and q.is_cuda and q.shape[3] <= 96 and v.shape[3] <= 64
+            and k.shape[1] >= FLASH_MIN_KEYS and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1):
+        return _AttentionFlash.apply(q, k, v, m, float(scale), float(p_drop)), None
     return _Attention.apply(q, k, v, m, float(scale), float(p_drop), need_map)
 
 

@@ -759,3 +759,45 @@ def test_position_embedding_sine_vs_reference_golden(dev):
     mask = torch.zeros(2, 50, 83, dtype=torch.bool); mask[1, 40:, :] = True; mask[1, :, 70:] = True
     pe = PositionEmbeddingSine(192, normalize=True).to(dev)
     assert rel(pe(SimpleNamespace(tensors=None, mask=mask.to(dev))), O.position_embedding_sine(mask, 192)) < 2e-6
+
+
+@pytest.mark.parametrize("Lq,Lk,H,dk,dv", [(10, 77, 4, 48, 24), (200, 2100, 8, 96, 48), (333, 333, 4, 48, 48), (7, 20, 4, 8, 8), (50, 1000, 2, 16, 64)])
+def test_attention_flash(dev, Lq, Lk, H, dk, dv):
+    """mha_flash kernels (no score tensor) vs an fp64 restatement, with a key-padding mask; and, with dropout, vs the
+    materialising path run with the same Philox (seed, offset) - identical masks, so the results agree."""
+    from spe_amd import kernels as K
+    from spe_amd import ops
+    g = torch.Generator().manual_seed(Lq + Lk)
+    B = 2
+    q = torch.randn(B, Lq, H, dk, generator=g).to(dev).requires_grad_()
+    k = torch.randn(B, Lk, H, dk, generator=g).to(dev).requires_grad_()
+    v = torch.randn(B, Lk, H, dv, generator=g).to(dev).requires_grad_()
+    mask = torch.zeros(B, Lk, dtype=torch.bool); mask[1, (3 * Lk) // 4:] = True
+    scale = dk ** -0.5
+    assert ops.FLASH_MHA
+    old_min = ops.FLASH_MIN_KEYS
+    ops.FLASH_MIN_KEYS = 1                      # force the flash kernels for the small shapes too
+    out, pmap = ops.attention(q, k, v, mask.to(dev), scale=scale, p_drop=0.0, need_map=False)
+    assert pmap is None and out.grad_fn.__class__.__name__.startswith("_AttentionFlash")
+    go = torch.randn(out.shape, generator=g).to(dev)
+    gq, gk, gv = torch.autograd.grad(out, (q, k, v), go)
+    qd, kd, vd = (t.detach().double().requires_grad_() for t in (q, k, v))
+    s = torch.einsum("bqhd,bkhd->bhqk", qd * scale, kd).masked_fill(mask.to(dev)[:, None, None], float("-inf"))
+    ref = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), vd).reshape(B, Lq, H * dv)
+    rq, rk, rv = torch.autograd.grad(ref, (qd, kd, vd), go.double())
+    assert rel(out, ref) < TOL["bf16"]
+    assert rel(gq, rq) < 2 * TOL["bf16"] and rel(gk, rk) < 2 * TOL["bf16"] and rel(gv, rv) < 2 * TOL["bf16"]
+    # dropout: same (seed, offset) stream in both implementations
+    res = {}
+    old = ops.FLASH_MHA
+    try:
+        for flash in (True, False):
+            ops.FLASH_MHA = flash
+            K.manual_seed(77)
+            o, _ = ops.attention(q, k, v, mask.to(dev), scale=scale, p_drop=0.1, need_map=False)
+            res[flash] = (o,) + torch.autograd.grad(o, (q, k, v), go)
+    finally:
+        ops.FLASH_MHA = old
+        ops.FLASH_MIN_KEYS = old_min
+    for a_, b_ in zip(res[True], res[False]):
+        assert rel(a_, b_) < 2 * TOL["bf16"]
