@@ -83,6 +83,12 @@ int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const float* bia
                     spe_stream_t stream);
 int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, long ldo, void* outT, long ldt, float* colsum,
                  const float* aux, int act, spe_stream_t stream);
+/* spe_cvt_bf16_multi: the row-major and transposed bf16 copies of njobs contiguous fp32 matrices in ONE launch (every
+ * Linear weight after an optimizer step).  jobs_dev: device array of njobs records of 48 bytes
+ *   { const float* x; void* out; void* outT; long ldt; int R, C, tile0, tiles_c; }     out [R][C], outT [C][ldt], ldt >= R;
+ * tiles_c = ceil(C/64), tile0 = running sum of tiles_c * ceil(max(R, ldt)/64) over the preceding jobs; total_tiles = that
+ * sum over all jobs.  out or outT may be NULL per job. */
+int spe_cvt_bf16_multi(const void* jobs_dev, int njobs, int total_tiles, spe_stream_t stream);
 
 /* ---- masked softmax over scores[B,H,Nq,ld] (Nk valid columns per row).
  * mask[B,Nk] (1 = padded key, -inf) or null; P = softmax; Pd = dropout(P) written only when
@@ -116,7 +122,7 @@ int spe_talking_softmax_bwd(const float* dPd, const float* P, const float* S, co
  *   3: backward pass 2: dS' = P(dP - D), dWl/dbl partials -> ws_w, dS = bf16(proj_l^T dS') -> outT (blocks)
  * spe_attn_merge reduces ws_stats to M/IL (mode 0: row max, 1/row sum) or D (mode 2).
  * ws_stats: B*nt*8*H*32 floats (nt = ceil(N/16)); ws_w: nwg_used rows of 2*(H*H+H) = [dWl|dbl|dWw|dbw]
- * (column-sum them with spe_colsum); outT: bf16 16x16 blocks [B,H,nt,nt][64][4], lane l of block (qt,kt) =
+ * (column-sum them with spe_colsum, or spe_talking_wgrad_reduce: the four sums written to four gradient buffers); outT: bf16 16x16 blocks [B,H,nt,nt][64][4], lane l of block (qt,kt) =
  * query qt*16+(l&15), keys kt*16+4*(l>>4)+i.  The Q fragments must be packed with scale*log2(e) (the kernels
  * work in the log2 domain; M is the log2-domain row max).
  * Supported: H in {4,8}, head dim <= 64.  Returns -2 otherwise (use the materialised path). */
@@ -130,6 +136,8 @@ int spe_talking_fused(int mode, const void* Qf, const void* Kf, const void* Vf, 
                       spe_stream_t stream);
 int spe_attn_merge(const float* ws, float* out0, float* out1, int B, int H, int N, int steps_per_wg, int mode,
                    spe_stream_t stream);
+int spe_talking_wgrad_reduce(const float* ws_w, int nwg, int H, float* dWl, float* dbl, float* dWw, float* dbw,
+                             spe_stream_t stream);
 
 /* ---- streaming contractions of a blocked bf16 score tensor T (written by spe_talking_fused modes 1/3):
  *   trans = 0: out[b, q, h, :]   = alpha * sum_key T[b,h][q,key] x[b, key, h, :]   (`attn @ v`, cait.py:388; dQ)

@@ -682,6 +682,35 @@ extern "C" int spe_attn_merge(const float* ws, float* out0, float* out1, int B, 
     return 0;
 }
 
+// Sum of the per-workgroup weight-gradient partials ws_w[nwg][2*(H*H+H)] (row layout [dWl | dbl | dWw | dbw]) written
+// straight into the four parameter gradients (their all-reduce bucket views): one wave per column, fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws_w, int nwg, int H, float* __restrict__ dWl,
+                                                           float* __restrict__ dbl, float* __restrict__ dWw, float* __restrict__ dbw) {
+    const int hh = H * H, nw = 2 * (hh + H);
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (col >= nw) return;
+    float s = 0.f;
+    for (int r = lane; r < nwg; r += 64) s += ws_w[(long)r * nw + col];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+        if (col < hh) dWl[col] = s;
+        else if (col < hh + H) dbl[col - hh] = s;
+        else if (col < 2 * hh + H) dWw[col - hh - H] = s;
+        else dbw[col - 2 * hh - H] = s;
+    }
+}
+
+// C-ABI: see include/spe_hip.h (spe_talking_wgrad_reduce).
+extern "C" int spe_talking_wgrad_reduce(const float* ws_w, int nwg, int H, float* dWl, float* dbl, float* dWw, float* dbw,
+                                        hipStream_t st) {
+    if (nwg <= 0 || H <= 0) return 0;
+    const int nw = 2 * (H * H + H);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, ws_w, nwg, H, dWl, dbl, dWw, dbw);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
 // steps per workgroup of a chunk: even split over the chunk's workgroups, but the chunk's part of a q-tile may
 // spread over at most FUSED_MAXSLOT / nch workgroups (its slots in the statistics workspace)
 static void make_plan(int B, int nt, int nwg, int* spw_out, int* nwg_out) {

@@ -259,14 +259,13 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const
 // aux (optional, same layout as x): the activation backward of the fused Linear+activation is applied while reading,
 // x := x * act'(aux) (act 1: ReLU, aux = forward output; act 2: exact-erf GELU, aux = pre-activation; the
 // arithmetic of act_bwd_kernel in rowops.hip) - the fp32 gradient w.r.t. the pre-activation never reaches HBM.
-__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ x, long ldx, int R, int C,
-                                                       unsigned short* __restrict__ out, long ldo,
-                                                       unsigned short* __restrict__ outT, long ldt, float* __restrict__ colsum,
-                                                       const float* __restrict__ aux, int act) {
+__device__ __forceinline__ void cvt_bf16_tile(const float* __restrict__ x, long ldx, int R, int C,
+                                              unsigned short* __restrict__ out, long ldo,
+                                              unsigned short* __restrict__ outT, long ldt, float* __restrict__ colsum,
+                                              const float* __restrict__ aux, int act, const int r0, const int c0) {
     __shared__ unsigned short tile[64][66];
     __shared__ float csum[16][64];
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;        // 16 column quads x 16 row lanes
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -342,6 +341,39 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
             for (int j = 0; j < 4; ++j) if (r + j < ldt) outT[(long)c * ldt + r + j] = e[j];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ x, long ldx, int R, int C,
+                                                       unsigned short* __restrict__ out, long ldo,
+                                                       unsigned short* __restrict__ outT, long ldt, float* __restrict__ colsum,
+                                                       const float* __restrict__ aux, int act) {
+    cvt_bf16_tile(x, ldx, R, C, out, ldo, outT, ldt, colsum, aux, act, blockIdx.y * 64, blockIdx.x * 64);
+}
+
+// Many contiguous matrices in one launch (the bf16 copies of every Linear weight after an optimizer step: ~190
+// launch-bound conversions of 0.1-0.6 M elements otherwise).  jobs (device memory, built once by the host side):
+// tile0 = first 64x64 tile of the job in the launch, ascending; a workgroup finds its job by bisection.
+struct CvtJob { const float* x; unsigned short* out; unsigned short* outT; long ldt; int R, C, tile0, tiles_c; };
+static_assert(sizeof(CvtJob) == 48, "spe_cvt_job_t layout");
+__global__ __launch_bounds__(256) void cvt_bf16_multi_kernel(const CvtJob* __restrict__ jobs, int njobs) {
+    const int t = blockIdx.x;
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].tile0 <= t) lo = mid; else hi = mid - 1;
+    }
+    const CvtJob j = jobs[lo];
+    const int lt = t - j.tile0;
+    cvt_bf16_tile(j.x, j.C, j.R, j.C, j.out, j.C, j.outT, j.ldt, nullptr, nullptr, 0, (lt / j.tiles_c) * 64, (lt % j.tiles_c) * 64);
+}
+
+// C-ABI: see include/spe_hip.h (spe_cvt_bf16_multi).
+extern "C" int spe_cvt_bf16_multi(const void* jobs_dev, int njobs, int total_tiles, hipStream_t stream) {
+    if (njobs <= 0 || total_tiles <= 0) return 0;
+    hipLaunchKernelGGL(cvt_bf16_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, stream,
+                       reinterpret_cast<const CvtJob*>(jobs_dev), njobs);
+    SPE_CHECK_LAUNCH();
+    return 0;
 }
 
 // C-ABI: see include/spe_hip.h (spe_cvt_bf16).

@@ -56,19 +56,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // dx per row; dgamma/dbeta accumulated per wave in registers over a grid-stride row loop,
 // combined through LDS, then one atomicAdd per column per block into pre-zeroed buffers.
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      long R, int C) {
-    __shared__ float red[2][4][1024 + 4];
+    extern __shared__ float red_raw[];                 // [2][NW][C + 4]
+    const int ldr = C + 4;
+    auto red = [&](int k, int wv, int c) -> float& { return red_raw[((long)k * NW + wv) * ldr + c]; };
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int C4 = C >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     float4 ag[LN_MAXV], ab[LN_MAXV];
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
-    for (long row = (long)blockIdx.x * 4 + w; row < R; row += (long)gridDim.x * 4) {
+    for (long row = (long)blockIdx.x * NW + w; row < R; row += (long)gridDim.x * NW) {
         const float4* xr = reinterpret_cast<const float4*>(x + row * C);
         const float4* dr = reinterpret_cast<const float4*>(dy + row * C);
         const float mu = mean[row], rs = rstd[row];
@@ -105,14 +108,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int i = 0; i < LN_MAXV; ++i) {
         const int c = lane + 64 * i;
         if (c < C4) {
-            red[0][w][4 * c + 0] = ag[i].x; red[0][w][4 * c + 1] = ag[i].y; red[0][w][4 * c + 2] = ag[i].z; red[0][w][4 * c + 3] = ag[i].w;
-            red[1][w][4 * c + 0] = ab[i].x; red[1][w][4 * c + 1] = ab[i].y; red[1][w][4 * c + 2] = ab[i].z; red[1][w][4 * c + 3] = ab[i].w;
+            red(0, w, 4 * c + 0) = ag[i].x; red(0, w, 4 * c + 1) = ag[i].y; red(0, w, 4 * c + 2) = ag[i].z; red(0, w, 4 * c + 3) = ag[i].w;
+            red(1, w, 4 * c + 0) = ab[i].x; red(1, w, 4 * c + 1) = ab[i].y; red(1, w, 4 * c + 2) = ab[i].z; red(1, w, 4 * c + 3) = ab[i].w;
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    for (int c = threadIdx.x; c < 2 * C; c += NW * 64) {
+        const int k = c >= C, cc = k ? c - C : c;
+        float t = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) t += red(k, wv, cc);
+        atomicAdd((k ? dbeta : dgamma) + cc, t);
     }
 }
 
@@ -129,8 +135,19 @@ extern "C" int spe_layernorm_bwd(const float* dy, const float* x, const float* g
                                  hipStream_t st) {
     if (R <= 0) return 0;
     if ((C & 3) || C > 256 * LN_MAXV) return -2;
-    long nb = (R + 3) / 4; if (nb > 512) nb = 512;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C);
+    // 16 waves per workgroup, at most 256 workgroups: every workgroup ends with 2*C atomics on the same addresses, and
+    // those serialise (512 x 4 waves: 21 us per call at cfg2; 2048 x 4: 42 us; 256 x 16: 15 us)
+    constexpr int NW = 16;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           2 * NW * (256 * LN_MAXV + 4) * (int)sizeof(float));
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    long nb = (R + NW - 1) / NW; if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(ln_bwd_kernel<NW>, dim3((unsigned)nb), dim3(NW * 64), 2 * NW * (C + 4) * (int)sizeof(float), st, dy, x, gamma, mean,
+                       rstd, dx, dgamma, dbeta, R, C);
     SPE_CHECK_LAUNCH();
     return 0;
 }
@@ -323,6 +340,54 @@ __global__ __launch_bounds__(256) void lsres_bwd_kernel(const float* __restrict_
     __syncthreads();
     if (rl == 0 && c < C) atomicAdd(dgamma + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
+// The same, one wave per row with 16-B accesses and per-lane column accumulators (C % 4 == 0, C <= 256 * LN_MAXV):
+// NW = 16 waves per workgroup so that few workgroups (few atomics per column) still fill the SIMDs.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void lsres_bwd_rows_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ sample_scale,
+                                                                 float* __restrict__ dy, float* __restrict__ dgamma, long R, int C,
+                                                                 long rows_per_sample) {
+    extern __shared__ float red_raw[];                 // [NW][C + 4]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int C4 = C >> 2, ldr = C + 4;
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    float4 acc[LN_MAXV], g[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        acc[i] = make_float4(0, 0, 0, 0);
+        const int c = lane + 64 * i;
+        g[i] = c < C4 ? g4[c] : make_float4(0, 0, 0, 0);
+    }
+    for (long row = (long)blockIdx.x * NW + w; row < R; row += (long)gridDim.x * NW) {
+        const float sc = sample_scale ? sample_scale[row / rows_per_sample] : 1.f;
+        const float4* dr = reinterpret_cast<const float4*>(dout + row * C);
+        const float4* yr = reinterpret_cast<const float4*>(y + row * C);
+        float4* o = reinterpret_cast<float4*>(dy + row * C);
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C4) {
+                float4 d = dr[c];
+                const float4 yv = yr[c];
+                d.x *= sc; d.y *= sc; d.z *= sc; d.w *= sc;
+                acc[i].x += d.x * yv.x; acc[i].y += d.y * yv.y; acc[i].z += d.z * yv.z; acc[i].w += d.w * yv.w;
+                o[c] = make_float4(d.x * g[i].x, d.y * g[i].y, d.z * g[i].z, d.w * g[i].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C4) *reinterpret_cast<float4*>(red_raw + (long)w * ldr + 4 * c) = acc[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += NW * 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) t += red_raw[(long)wv * ldr + c];
+        atomicAdd(dgamma + c, t);
+    }
+}
 extern "C" int spe_layerscale_residual_fwd(const float* x, const float* y, const float* gamma, const float* sample_scale,
                                            float* out, long R, int C, long rows_per_sample, hipStream_t st) {
     if (R <= 0) return 0;
@@ -337,7 +402,15 @@ extern "C" int spe_layerscale_residual_fwd(const float* x, const float* y, const
 extern "C" int spe_layerscale_residual_bwd(const float* dout, const float* y, const float* gamma, const float* sample_scale,
                                            float* dy, float* dgamma, long R, int C, long rows_per_sample, hipStream_t st) {
     if (R <= 0) return 0;
-    long ry = (R + 127) / 128; if (ry > 128) ry = 128; if (ry < 1) ry = 1;
+    if ((C & 3) == 0 && C <= 256 * LN_MAXV && ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(y) |
+                                                           reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(gamma)) & 15) == 0) {
+        long nb = (R + 15) / 16; if (nb > 128) nb = 128;
+        hipLaunchKernelGGL(lsres_bwd_rows_kernel<16>, dim3((unsigned)nb), dim3(1024), 16 * (C + 4) * (int)sizeof(float), st, dout, y,
+                           gamma, sample_scale, dy, dgamma, R, C, rows_per_sample);
+        SPE_CHECK_LAUNCH();
+        return 0;
+    }
+    long ry = (R + 63) / 64; if (ry > 256) ry = 256; if (ry < 1) ry = 1;
     hipLaunchKernelGGL(lsres_bwd_kernel, dim3((C + 63) / 64, (unsigned)ry), dim3(256), 0, st, dout, y, gamma, sample_scale,
                        dy, dgamma, R, C, rows_per_sample);
     SPE_CHECK_LAUNCH();

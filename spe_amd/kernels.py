@@ -177,18 +177,79 @@ def cvt_bf16(x2, want=True, wantT=False, ldt=None, colsum_out=None, act_aux=None
     return out, outT
 
 
+_W16_TABLE = None      # (signature, device job table, njobs, total tiles) of the last batched refresh
+_W16_REFRESHED = -1    # epoch of the last batched refresh
+_W16_BATCH = os.environ.get("SPE_W16_BATCH", "1") != "0"
+
+
+def _refresh_weights16():
+    """Re-convert every cached weight copy in ONE launch (spe_cvt_bf16_multi) into its existing buffers: after an
+    optimizer step ~190 weights are stale at once and each conversion alone is launch-latency bound."""
+    global _W16_TABLE, _W16_REFRESHED
+    import numpy as np
+    live = []
+    for key, ent in list(_W16.items()):
+        owner = ent[0]()
+        if owner is None or not _owns(owner, key[0]):
+            del _W16[key]
+            continue
+        live.append((key, owner, ent))
+    _W16_REFRESHED = _W16_EPOCH
+    if not live:
+        return
+    sig = tuple(_W16)
+    if _W16_TABLE is None or _W16_TABLE[0] != sig:
+        rec = np.zeros(len(live), dtype=np.dtype([("x", "<u8"), ("out", "<u8"), ("outT", "<u8"), ("ldt", "<i8"), ("R", "<i4"),
+                                                   ("C", "<i4"), ("tile0", "<i4"), ("tiles_c", "<i4")]))
+        t0 = 0
+        for i, ((ptr, R, C), _, e) in enumerate(live):
+            tc = (C + 63) // 64
+            rec[i] = (ptr, e[3].data_ptr(), e[4].data_ptr(), e[4].shape[1], R, C, t0, tc)
+            t0 += tc * ((max(R, e[4].shape[1]) + 63) // 64)
+        table = host_table(rec.view(np.uint8), live[0][2][3].device)
+        _W16_TABLE = (sig, table, len(live), t0)
+    _, table, n, tiles = _W16_TABLE
+    _call("spe_cvt_bf16_multi", _p(table), n, tiles, _st())
+    for key, owner, e in live:
+        _W16[key] = (e[0], owner._version, _W16_EPOCH, e[3], e[4])
+
+
+def _owns(owner, ptr):
+    """The storage `owner` holds now still covers the address a cache entry was made for."""
+    base = owner.data_ptr()
+    return base <= ptr < base + max(1, owner.numel()) * owner.element_size()
+
+
+def host_table(bytes_np, device):
+    """Small host-built table -> device through a pinned staging buffer (no pageable-copy pipeline drain)."""
+    pin = torch.from_numpy(bytes_np.copy()).pin_memory()
+    dev = torch.empty(pin.shape, dtype=torch.uint8, device=device)
+    dev.copy_(pin, non_blocking=True)
+    dev._spe_pin = pin            # keep the staging buffer alive until the copy has certainly run
+    return dev
+
+
 def weight16(W):
-    """(W16 [N,K], W16T [K,N]) of a weight, cached until the optimizer (or a state-dict load) changes it."""
+    """(W16 [N,K], W16T [K,N]) of a contiguous 2-D weight (or 2-D view of one: the patch-embedding filter), cached until
+    the optimizer (or a state-dict load) changes it.  Cache key: (address, shape); an entry lives as long as the tensor
+    that owns the storage.  The first lookup after weights_changed() refreshes every cached copy in one launch."""
     import weakref
-    key = id(W)
+    key = (W.data_ptr(), W.shape[0], W.shape[1])
     ent = _W16.get(key)
-    if ent is not None and ent[0]() is W and ent[1] == W._version and ent[2] == W.data_ptr() and ent[3] == _W16_EPOCH:
-        return ent[4], ent[5]
+    if ent is not None:
+        owner = ent[0]()
+        if owner is not None and _owns(owner, key[0]):
+            if _W16_BATCH and ent[2] != _W16_EPOCH and _W16_REFRESHED != _W16_EPOCH:
+                _refresh_weights16()
+                ent = _W16.get(key, ent)
+            if ent[1] == owner._version and ent[2] == _W16_EPOCH:
+                return ent[3], ent[4]
+    owner = W._base if W._base is not None else W
     with torch.no_grad():
         W16, W16T = cvt_bf16(W.detach(), True, True, ldt=W.shape[0])
     if len(_W16) > 4096:
         _W16.clear()
-    _W16[key] = (weakref.ref(W), W._version, W.data_ptr(), _W16_EPOCH, W16, W16T)
+    _W16[key] = (weakref.ref(owner), owner._version, _W16_EPOCH, W16, W16T)
     return W16, W16T
 
 
@@ -591,6 +652,18 @@ def attn_merge(ws_stats, B, H, N, spw, mode):
     out1 = torch.empty_like(out0) if mode == 0 else None
     _call("spe_attn_merge", _p(ws_stats), _p(out0), _p(out1), B, H, N, spw, mode, _st())
     return out0, out1
+
+
+def talking_wgrad_reduce(ws_w, H, params):
+    """Column sums of the weight-gradient partials [nwg, 2*(H*H+H)] as (dWl [H,H], dbl [H], dWw [H,H], dbw [H]), written
+    into the parameters' all-reduce bucket views when those are still unclaimed this step (params = Wl, bl, Ww, bw)."""
+    shapes = ((H, H), (H,), (H, H), (H,))
+    outs = []
+    for prm, shp in zip(params, shapes):
+        buf = grad_buffer(prm)
+        outs.append(buf.view(shp) if buf is not None else torch.empty(shp, device=ws_w.device, dtype=torch.float32))
+    _call("spe_talking_wgrad_reduce", _p(ws_w), ws_w.shape[0], H, _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), _st())
+    return outs
 
 
 def gemm_bf16a(A16, B, C, M, N, K, lda, ldb, ldc, transA, transB, batch0, batch1, sA, sB, sC, alpha=1.0):

@@ -216,6 +216,7 @@ class _TalkingHeadsAttentionFused(Function):
         O = torch.empty((B, N, C), device=qkv.device, dtype=torch.float32)
         K.attn_contract(Pd, V16, O.view(B, N, H, dh), False)
         ctx.meta = (B, N, C, H, dh, nt, scale, p_drop, seed, off)
+        ctx.wparams = (Wl, bl, Ww, bw)      # leaves: looked up in backward for their gradient buckets
         ctx.save_for_backward(qkv, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw)
         return O
 
@@ -232,8 +233,6 @@ class _TalkingHeadsAttentionFused(Function):
         dq, dk, dv = d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]
         dO4 = dO.view(B, N, H, dh)
         Vf, dOf, dO16, K16, Q16 = K.attn_pack_multi([(v, 1.0, 32), (dO4, 1.0, 32), (dO4, 1.0, 16), (k, 1.0, 16), (q, 1.0, 16)])
-        # dV[key,d] = sum_q P'd[q,key] dO[q,d]
-        K.attn_contract(Pd, dO16, dv, True)
         nw = 2 * (H * H + H)
         ws_stats = torch.empty((B * nt * 8 * H * 32,), device=qkv.device, dtype=torch.float32)
         ws_w = torch.empty((nwg, nw), device=qkv.device, dtype=torch.float32)
@@ -241,9 +240,10 @@ class _TalkingHeadsAttentionFused(Function):
         D, _ = K.attn_merge(ws_stats, B, H, N, spw, 2)
         dS = K.score_blocks(B, H, N, qkv.device)
         K.talking_fused(3, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, None, ws_w, dS, B, H, N, dh, p_drop, seed, off)
-        g = K.colsum(ws_w)
-        hh = H * H
-        dWl, dbl, dWw, dbw = g[:hh].view(H, H), g[hh:hh + H], g[hh + H:2 * hh + H].view(H, H), g[2 * hh + H:]
+        # dV[key,d] = sum_q P'd[q,key] dO[q,d] - issued here, between backward pass 2 and the contractions that re-read
+        # its 554 MB of dS: a streaming read right after a pass that wrote that much runs ~20 % slower (measured)
+        K.attn_contract(Pd, dO16, dv, True)
+        dWl, dbl, dWw, dbw = K.talking_wgrad_reduce(ws_w, H, ctx.wparams)
         # dQ[q,d] = scale * sum_key dS[q,key] K[key,d] ; dK[key,d] = scale * sum_q dS[q,key] Q[q,d]
         K.attn_contract(dS, K16, dq, False, alpha=scale)
         K.attn_contract(dS, Q16, dk, True, alpha=scale)

@@ -728,6 +728,43 @@ def test_weight_cache_follows_flat_optimizer(dev):
     assert rel(ops.linear(x, W, b), ref()) < 1e-5
 
 
+def test_weight_copies_batched_refresh(dev):
+    """After weights_changed() the first lookup re-converts EVERY cached weight copy in one spe_cvt_bf16_multi launch:
+    bit-identical to the single-matrix conversion, for shapes with partial 64x64 tiles, and dead weights are dropped."""
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(21)
+    shapes = [(384, 384), (1536, 384), (384, 1536), (72, 200), (8, 8), (1000, 24), (65, 129)]
+    Ws = [torch.randn(s, generator=g).to(dev) for s in shapes]
+    for W in Ws:
+        K.weight16(W)
+    dead = torch.randn(40, 40, generator=g).to(dev)
+    K.weight16(dead)
+    del dead
+    with torch.no_grad():
+        for W in Ws:
+            W.view(-1).copy_(torch.randn(W.numel(), generator=g).to(dev) * 3)          # raw update (copy_ bumps _version too)
+    K.weights_changed()
+    first = K.weight16(Ws[3])
+    # all copies are current now (no further conversion launches needed) and equal the single-matrix kernel's output
+    key = lambda W: (W.data_ptr(), W.shape[0], W.shape[1])
+    for W in Ws:
+        ent = K._W16[key(W)]
+        assert ent[2] == K._W16_EPOCH
+        W16, W16T = K.cvt_bf16(W, True, True, ldt=W.shape[0])
+        assert torch.equal(ent[3], W16) and torch.equal(ent[4], W16T), W.shape
+        assert torch.equal(W16.float(), W.to(torch.bfloat16).float()) and torch.equal(W16T, W16.t())
+    assert first[0] is K._W16[key(Ws[3])][3]
+    assert K._W16_TABLE[2] == len(K._W16)                                                # the dead weight left the table
+    # a 2-D view of a 4-D filter (the patch embedding) is cached under its address: no new entry per call
+    conv = torch.randn(64, 3, 4, 4, generator=g).to(dev)
+    a16 = K.weight16(conv.view(64, -1))[0]
+    assert K.weight16(conv.view(64, -1))[0] is a16
+    # an in-place torch update of one weight (version bump, same epoch) converts just that one
+    with torch.no_grad():
+        Ws[0].mul_(0.5)
+    assert torch.equal(K.weight16(Ws[0])[0].float(), Ws[0].to(torch.bfloat16).float())
+
+
 def test_patch_embed_large(dev):
     """Patch embedding with >= LINEAR16_MIN_ROWS patches: the dW-only backward of the bf16-copy Linear path."""
     from spe_amd import kernels as K

@@ -70,7 +70,11 @@ def run16(name, M, N, Kd, splitk=1):
     t = timeit(f)
     fl = 2.0 * M * N * Kd
     by = 2.0 * (M * Kd + N * Kd) + 4.0 * M * N * abs(splitk)
-    print(f"{name:34s} M={M:5d} N={N:5d} K={Kd:5d} sk={splitk:3d} {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.0f} GB/s")
+    # vendor library on the same operands (bf16 output, i.e. half the C traffic): a yardstick, not a code path
+    Bt = B.t()
+    tv = timeit(lambda: torch.mm(A, Bt))
+    print(f"{name:34s} M={M:5d} N={N:5d} K={Kd:5d} sk={splitk:3d} {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e9:7.0f} GB/s"
+          f"   | torch.mm bf16->bf16 {tv*1e6:7.1f} us")
 
 
 def main16():

@@ -61,6 +61,12 @@ def main():
             d = dict(zip(names[name], args))
             key = "gemm M=%d N=%d K=%d %s%s b=%dx%d sk=%d" % (d["M"], d["N"], d["K"], "T" if d["transA"] else "N",
                                                               "T" if d["transB"] else "N", d["batch0"], d["batch1"], d["splitk"])
+        elif name == "spe_gemm_bf16nt":
+            d = dict(zip(names[name], args))
+            key = "gemm16 M=%d N=%d K=%d act=%s bias=%d" % (d["M"], d["N"], d["K"], d.get("act"), int(bool(d.get("bias"))))
+        elif name == "spe_cvt_bf16":
+            d = dict(zip(names[name], args))
+            key = "cvt R=%d C=%d T=%d cs=%d aux=%d" % (d["R"], d["C"], int(bool(d["outT"])), int(bool(d["colsum"])), int(bool(d["aux"])))
         elif name == "spe_talking_fused":
             key = name + ":" + str(args[0])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -4,7 +4,7 @@ import torch
 from spe_amd import kernels as K
 dev = torch.device("cuda:0")
 import os
-H, N, dh, B = 8, 4150, int(os.environ.get("DH", "48")), 2
+H, N, dh, B = 8, int(os.environ.get("N", "4150")), int(os.environ.get("DH", "48")), int(os.environ.get("B", "2"))
 g = torch.Generator().manual_seed(1)
 C = H * dh
 qkv = torch.randn(B, N, 3 * C, generator=g).to(dev)
@@ -45,3 +45,9 @@ print("PV  contract   %.3f ms" % t(lambda: K.attn_contract(PT, V16, O.view(B, N,
 print("dV  contract^T %.3f ms" % t(lambda: K.attn_contract(PT, dO16, d5[:, :, 2], True)))
 print("dQ  contract   %.3f ms" % t(lambda: K.attn_contract(dST, V16, d5[:, :, 0], False, alpha=scale)))
 print("dK  contract^T %.3f ms" % t(lambda: K.attn_contract(dST, dO16, d5[:, :, 1], True, alpha=scale)))
+mb = PT.numel() * 2 / 1e6
+print("score tensor %.0f MB" % mb)
+tp = t(lambda: (f(1, PT), K.attn_contract(PT, V16, O.view(B, N, H, dh), False)))
+print("mode1 + PV contract pair %.3f ms" % tp)
+tp = t(lambda: (f(3, dST), K.attn_contract(dST, V16, d5[:, :, 0], False, alpha=scale), K.attn_contract(dST, dO16, d5[:, :, 1], True, alpha=scale)))
+print("mode3 + dQ + dK contract triple %.3f ms" % tp)
