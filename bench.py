@@ -250,7 +250,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "talking_fused_kernel<8,2,3> (attention backward pass 2)", "launches": launches,
                          "avg_ms": mean_ms, "achieved": ach, "peak": 2500.0, "peak_measured": 1240.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
                          "traffic": 1.54e9,   # bytes/launch, profiles/r01_pmc_fetch_write_v2.txt (2*FETCH_SIZE + WRITE_SIZE)
-                         "note": "issue-bound on the fp32 head mixes (no MFMA form)", "valu_achieved": valu, "valu_peak": 157.3,
+                         "note": "not MFMA-bound: fp32 head mixes (no MFMA form), fragment loads and MFMA phases serialise at 2 waves/SIMD", "valu_achieved": valu, "valu_peak": 157.3,
                          "valu_frac": valu / 157.3,
                          "hbm_kernel": {"bound": "hbm", "kernel": "attn_contract_kernel<3,*> (PV / dV / dQ / dK over blocked bf16 scores)",
                                         "launches": c_launch, "avg_ms": c_ms, "achieved": c_bw, "peak": 8000.0, "peak_measured": 6200.0, "unit": "GB/s",
