@@ -81,6 +81,15 @@ int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const
 int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const float* bias, float* C2,
                     int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int splitk,
                     spe_stream_t stream);
+/* spe_gemm_bf16nt_ex: the same product with an epilogue that feeds the NEXT GEMMs directly (no fp32 round trip, no
+ * separate conversion launch):  v = alpha A16 B16^T + bias ; C2 = v (optional) ; v = act(v), or with aux != NULL
+ * v = v * act'(aux) (aux [M][ldc]: act 1 = ReLU with the forward output, act 2 = erf-GELU with the pre-activation) ;
+ * C = v (optional fp32) ; out16[M][ld16] = bf16(v) ; out16T[N][ld16t] = bf16(v)^T with columns M..ld16t-1 zero
+ * (ld16t <= M rounded up to 64) ; colsum[n] += sum_m v.  Any output may be NULL.  Used by the fused MLP of the backbone
+ * block (reference models/cait.py:405-412 = timm Mlp fc1 -> GELU -> fc2, and its autograd). */
+int spe_gemm_bf16nt_ex(const void* A16, const void* B16, float* C, const float* bias, float* C2,
+                       void* out16, long ld16, void* out16T, long ld16t, float* colsum, const float* aux,
+                       int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, spe_stream_t stream);
 int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, long ldo, void* outT, long ldt, float* colsum,
                  const float* aux, int act, spe_stream_t stream);
 /* spe_cvt_bf16_multi: the row-major and transposed bf16 copies of njobs contiguous fp32 matrices in ONE launch (every

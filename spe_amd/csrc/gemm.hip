@@ -236,7 +236,7 @@ __device__ __forceinline__ void stage_rc(unsigned short* hi, unsigned short* lo,
     }
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + spe_erff(x * 0.70710678118654752f)); }
 
 // TA: opA(m,k) = A[k*lda+m] (else A[m*lda+k]).  TB: opB(k,n) = B[n*ldb+k] (else B[k*ldb+n]).
 template <int T, bool TA, bool TB, bool SPLIT>

@@ -30,9 +30,15 @@ struct Gemm16Args {
     int act;                   // 0 none, 1 relu, 2 gelu(erf)
     int splitk; long slab; int kt_per_split;
     int xcd_bind;              // 0: plain tile order, 1: M-panels bound to XCDs, 2: N-panels bound to XCDs
+    // extended epilogue (spe_gemm_bf16nt_ex): bf16 copies of the result for the NEXT GEMMs, column sums, and the
+    // derivative of a fused activation applied from its saved argument
+    unsigned short* out16; long ld16;      // [M][ld16]  bf16(v)
+    unsigned short* out16T; long ld16t;    // [N][ld16t] bf16(v) transposed, columns M..ld16t-1 zero
+    float* colsum;                         // [N] += sum_m v
+    const float* aux;                      // [M][ldc]: v *= act'(aux) (act 1: aux = forward output, 2: pre-activation)
 };
 
-__device__ __forceinline__ float gelu_erf16(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf16(float x) { return 0.5f * x * (1.0f + spe_erff(x * 0.70710678118654752f)); }
 
 // thread t fetches 16-B chunk (t & 7) of rows (t >> 3) + 32*i ; rows are clamped (never stored), chunks past K zeroed
 template <int R>
@@ -57,7 +63,7 @@ __device__ __forceinline__ void g16_stage(unsigned short* lds, const u32x4g_t (&
         *reinterpret_cast<u32x4g_t*>(lds + ((t >> 3) + 32 * i) * GB_LDR + (t & 7) * 8) = v[i];
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool EX>
 __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     constexpr int NFM = BM / 32, NFN = BN / 32;        // 16x16 MFMA tiles per wave (wave tile BM/2 x BN/2)
@@ -146,6 +152,154 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
         }
     }
 
+    if constexpr (EX) {
+        // ---- extended epilogue.  v = alpha*acc + bias ; C2 = v ; v = act(v) or v * act'(aux) ; C = v (optional);
+        // the bf16 copies go through LDS (the operand buffers are free now) so that both the row-major and the
+        // transposed copy leave as 16-B stores of full rows; column sums: 16-lane DPP reduction + one atomic per
+        // column and wave row.
+        constexpr int LR = BN + 8, LT = BM + 8;            // bf16 per LDS row of the two staged tiles
+        unsigned short* sR = smem16;                         // [BM][LR]  row-major tile
+        unsigned short* sT = smem16 + BM * LR;               // [BN][LT]  transposed tile
+        static_assert((BM * LR + BN * LT) <= 2 * (BM + BN) * GB_LDR, "staged tiles must fit the operand buffers");
+        __syncthreads();
+        typedef short s16x4i_t __attribute__((ext_vector_type(4)));
+        s16x4i_t ident;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ident[e] = ((lane & 15) == 4 * (lane >> 4) + e) ? (short)0x3F80 : (short)0;
+        const bool vst = ((p.ldc & 3) == 0) && (!p.C || (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                         (!p.C2 || (reinterpret_cast<uintptr_t>(p.C2) & 15) == 0) && (!p.aux || (reinterpret_cast<uintptr_t>(p.aux) & 15) == 0);
+        // interior tiles request the whole aux tile up front (the operand staging registers are free now): 16 loads in
+        // flight per lane instead of one exposed round trip per 16x16 block
+        const bool interior = vst && (m0 + BM <= p.M) && (n0 + BN <= p.N);
+        float4 hq[NFN][NFM];
+        if (p.aux && interior) {
+#pragma unroll
+            for (int j = 0; j < NFN; ++j)
+#pragma unroll
+                for (int i = 0; i < NFM; ++i)
+                    hq[j][i] = *reinterpret_cast<const float4*>(p.aux + (long)(m0 + wm * WM + i * 16 + fr) * p.ldc + n0 + wn * WN + j * 16 + (lane >> 4) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NFN; ++j) {
+            const int nl = wn * WN + j * 16 + (lane >> 4) * 4, n = n0 + nl;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[r] = p.bias[min(n + r, p.N - 1)];
+            }
+            float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NFM; ++i) {
+                const int ml = wm * WM + i * 16 + fr, m = m0 + ml;
+                const bool rowv = m < p.M;
+                const long off = (long)min(m, p.M - 1) * p.ldc + min(n, p.N - 1);
+                const bool full = vst && rowv && (n + 3 < p.N);
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha + bv[r];
+                if (p.C2 && rowv) {
+                    if (full) *reinterpret_cast<float4*>(p.C2 + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) p.C2[(long)m * p.ldc + n + r] = v[r];
+                    }
+                }
+                if (p.aux) {
+                    float h[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (interior) { h[0] = hq[j][i].x; h[1] = hq[j][i].y; h[2] = hq[j][i].z; h[3] = hq[j][i].w; }
+                    else if (full) { const float4 q = *reinterpret_cast<const float4*>(p.aux + off); h[0] = q.x; h[1] = q.y; h[2] = q.z; h[3] = q.w; }
+                    else if (rowv) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) h[r] = p.aux[(long)m * p.ldc + n + r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (p.act == 1) v[r] = h[r] > 0.f ? v[r] : 0.f;
+                        else if (p.act == 2) {          // the arithmetic of cvt_bf16_kernel / act_bwd_kernel
+                            const float cdf = 0.5f * (1.f + spe_erff(h[r] * 0.70710678118654752f));
+                            const float pdf = 0.3989422804014327f * __expf(-0.5f * h[r] * h[r]);
+                            v[r] = v[r] * (cdf + h[r] * pdf);
+                        }
+                    }
+                } else if (p.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                } else if (p.act == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf16(v[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (rowv && n + r < p.N) ? v[r] : 0.f;      // padding rows / columns stage zeros
+                if (p.C && rowv) {
+                    if (full) *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) p.C[(long)m * p.ldc + n + r] = v[r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cs[r] += v[r];
+                typedef __bf16 bf16x4v_t __attribute__((ext_vector_type(4)));
+                bf16x4v_t hb;
+                hb[0] = (__bf16)v[0]; hb[1] = (__bf16)v[1]; hb[2] = (__bf16)v[2]; hb[3] = (__bf16)v[3];
+                const uint2 u = __builtin_bit_cast(uint2, hb);
+                *reinterpret_cast<uint2*>(sR + ml * LR + nl) = u;
+                // transposed copy: one MFMA against the identity moves the lane ownership from (row m, 4 columns) to
+                // (column n, 4 rows) - exact in bf16 - so the transposed tile is staged with 8-B writes as well
+                {
+                    typedef short s16x4e_t __attribute__((ext_vector_type(4)));
+                    const f32x4_t t = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4e_t, u), ident,
+                                                                                  (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    bf16x4v_t tb;
+                    tb[0] = (__bf16)t[0]; tb[1] = (__bf16)t[1]; tb[2] = (__bf16)t[2]; tb[3] = (__bf16)t[3];
+                    *reinterpret_cast<uint2*>(sT + (wn * WN + j * 16 + fr) * LT + wm * WM + i * 16 + (lane >> 4) * 4) = __builtin_bit_cast(uint2, tb);
+                }
+            }
+            if (p.colsum) {
+                // 4 column sums over the 16 row lanes in 5 exchanges: lane pairs split the columns (xor 1: even lanes keep
+                // columns 0,1, odd lanes 2,3), then lane pairs of pairs (xor 2), then plain sums over xor 4 and 8
+                const bool o1 = lane & 1, o2 = lane & 2;
+                const float r0 = __shfl_xor(o1 ? cs[0] : cs[2], 1, 64), r1 = __shfl_xor(o1 ? cs[1] : cs[3], 1, 64);
+                const float b0 = (o1 ? cs[2] : cs[0]) + r0, b1 = (o1 ? cs[3] : cs[1]) + r1;
+                float c = (o2 ? b1 : b0) + __shfl_xor(o2 ? b0 : b1, 2, 64);
+                c += __shfl_xor(c, 4, 64);
+                c += __shfl_xor(c, 8, 64);
+                const int col = 2 * (fr & 1) + ((fr >> 1) & 1);          // the column this lane ended up with
+                if (fr < 4 && n + col < p.N) atomicAdd(p.colsum + n + col, c);
+            }
+        }
+        __syncthreads();
+        if (p.out16) {       // [BM][BN] row-major: 16 B = 8 columns per thread and pass
+            constexpr int CH = BN / 8;
+            for (int idx = threadIdx.x; idx < BM * CH; idx += 256) {
+                const int ml = idx / CH, ch = idx % CH, m = m0 + ml, n = n0 + ch * 8;
+                if (m >= p.M || n >= p.N) continue;
+                const u32x4g_t q = *reinterpret_cast<const u32x4g_t*>(sR + ml * LR + ch * 8);
+                unsigned short* dst = p.out16 + (long)m * p.ld16 + n;
+                if (n + 7 < p.N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<u32x4g_t*>(dst) = q;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (n + e < p.N) dst[e] = sR[ml * LR + ch * 8 + e];
+                }
+            }
+        }
+        if (p.out16T) {      // [BN][BM] transposed: 16 B = 8 rows of the result per thread and pass; zero columns up to ld16t
+            constexpr int CH = BM / 8;
+            for (int idx = threadIdx.x; idx < BN * CH; idx += 256) {
+                const int nl = idx / CH, ch = idx % CH, n = n0 + nl, m = m0 + ch * 8;
+                if (n >= p.N || m >= p.ld16t) continue;
+                const u32x4g_t q = *reinterpret_cast<const u32x4g_t*>(sT + nl * LT + ch * 8);
+                unsigned short* dst = p.out16T + (long)n * p.ld16t + m;
+                if (m + 7 < p.ld16t && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<u32x4g_t*>(dst) = q;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (m + e < p.ld16t) dst[e] = sT[nl * LT + ch * 8 + e];
+                }
+            }
+        }
+        return;
+    }
+
     // ---- epilogue (same ownership as spe_gemm_kernel: MFMAs issued as (B-frag, A-frag), so
     // acc[i][j][r] = C[m0 + wm*WM + i*16 + (lane&15)][n0 + wn*WN + j*16 + (lane>>4)*4 + r]: one 16-B store per tile)
     float* C2 = p.C2;
@@ -197,12 +351,12 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool EX = false>
 static int launch_gemm16(const Gemm16Args& p, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * GB_LDR * (int)sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16nt_kernel<BM, BN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16nt_kernel<BM, BN, EX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -218,7 +372,7 @@ static int launch_gemm16(const Gemm16Args& p, hipStream_t stream) {
     if (q.xcd_bind == 1) tiles = 8 * ((tiles_m + 7) / 8) * tiles_n;
     if (q.xcd_bind == 2) tiles = 8 * ((tiles_n + 7) / 8) * tiles_m;
     dim3 grid(tiles, 1, p.splitk);
-    hipLaunchKernelGGL((gemm_bf16nt_kernel<BM, BN>), grid, dim3(256), smem, stream, q);
+    hipLaunchKernelGGL((gemm_bf16nt_kernel<BM, BN, EX>), grid, dim3(256), smem, stream, q);
     SPE_CHECK_LAUNCH();
     return 0;
 }
@@ -236,6 +390,7 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const
     p.A = reinterpret_cast<const unsigned short*>(A16); p.B = reinterpret_cast<const unsigned short*>(B16);
     p.C = C; p.C2 = C2; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.act = act; p.slab = 0;
+    p.out16 = nullptr; p.out16T = nullptr; p.colsum = nullptr; p.aux = nullptr; p.ld16 = 0; p.ld16t = 0;
     const int ktiles = (K + GB_BK - 1) / GB_BK;
     if (splitk < 0) {           // slab mode: C holds |splitk| slabs of M*ldc floats
         splitk = -splitk; p.slab = (long)M * ldc;
@@ -251,6 +406,35 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const
     const long t64n = (long)((M + 127) / 128) * ((N + 63) / 64) * splitk;
     if (t64n >= 256 && M > 64) return launch_gemm16<128, 64>(p, stream);
     return launch_gemm16<64, 64>(p, stream);
+}
+
+// C-ABI: see include/spe_hip.h (spe_gemm_bf16nt_ex).  -2: unsupported alignment / leading dimensions.
+extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, float* C, const float* bias, float* C2,
+                                  void* out16, long ld16, void* out16T, long ld16t, float* colsum, const float* aux,
+                                  int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, hipStream_t stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0) return -4;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al16(A16) || !al16(B16) || (lda & 7) || (ldb & 7) || (K & 7)) return -2;
+    if (out16T && ld16t < M) return -2;
+    if (aux && act != 1 && act != 2) return -2;
+    Gemm16Args p;
+    p.A = reinterpret_cast<const unsigned short*>(A16); p.B = reinterpret_cast<const unsigned short*>(B16);
+    p.C = C; p.C2 = C2; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.alpha = alpha; p.act = act; p.slab = 0; p.splitk = 1;
+    p.kt_per_split = (K + GB_BK - 1) / GB_BK;
+    p.out16 = reinterpret_cast<unsigned short*>(out16); p.ld16 = ld16;
+    p.out16T = reinterpret_cast<unsigned short*>(out16T); p.ld16t = ld16t;
+    p.colsum = colsum; p.aux = aux;
+    // the transposed copy's zero columns M..ld16t-1 are written by the last row tile: it must reach ld16t
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const bool reach128 = !out16T || ld16t <= (long)((M + 127) / 128) * 128;
+    const bool reach64 = !out16T || ld16t <= (long)((M + 63) / 64) * 64;
+    if (!reach128 && !reach64) return -2;
+    if (reach128 && t128 >= 384 && N > 64) return launch_gemm16<128, 128, true>(p, stream);
+    const long t64n = (long)((M + 127) / 128) * ((N + 63) / 64);
+    if (reach128 && ((t64n >= 256 && M > 64) || !reach64)) return launch_gemm16<128, 64, true>(p, stream);
+    return launch_gemm16<64, 64, true>(p, stream);
 }
 
 // ---- fp32 -> bf16 (round to nearest even) copies of a [R, C] matrix: out[R][ldo] (row-major) and/or the
@@ -286,7 +470,7 @@ __device__ __forceinline__ void cvt_bf16_tile(const float* __restrict__ x, long 
                     const float h = aux[(long)r * ldx + c + j];
                     if (act == 1) v[j] = h > 0.f ? v[j] : 0.f;
                     else {
-                        const float cdf = 0.5f * (1.f + erff(h * 0.70710678118654752f));
+                        const float cdf = 0.5f * (1.f + spe_erff(h * 0.70710678118654752f));
                         const float pdf = 0.3989422804014327f * __expf(-0.5f * h * h);
                         v[j] = v[j] * (cdf + h * pdf);
                     }

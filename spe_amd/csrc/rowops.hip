@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float4* __restrict__
             if (mode == 1) o[j] = av[j] > 0.f ? dv[j] : 0.f;
             else {
                 const float h = av[j];
-                const float cdf = 0.5f * (1.f + erff(h * 0.70710678118654752f));
+                const float cdf = 0.5f * (1.f + spe_erff(h * 0.70710678118654752f));
                 const float pdf = 0.3989422804014327f * __expf(-0.5f * h * h);
                 o[j] = dv[j] * (cdf + h * pdf);
             }

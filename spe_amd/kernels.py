@@ -277,6 +277,76 @@ def gemm16(A16, B16, C, M, N, K, lda, ldb, ldc, bias=None, C2=None, alpha=1.0, a
     return C
 
 
+def gemm16_ex(A16, B16, M, N, K, lda, ldb, bias=None, C=None, C2=None, out16=None, out16T=None, colsum=None, aux=None,
+              alpha=1.0, act=0):
+    """spe_gemm_bf16nt_ex: v = alpha * A16 @ B16.T + bias; C2 = v; v = act(v) or v * act'(aux); optional fp32 C [M,N], bf16
+    out16 [M,N], bf16 transposed out16T [N, ldt] (zero padded), colsum [N] += column sums.  All fp32 tensors have ld = N."""
+    _call("spe_gemm_bf16nt_ex", _p(A16), _p(B16), _p(C), _p(bias), _p(C2), _p(out16), N, _p(out16T),
+          out16T.shape[1] if out16T is not None else 0, _p(colsum), _p(aux), M, N, K, lda, ldb, N, float(alpha), int(act), _st())
+
+
+def mlp16_ok(R, K, Hd, N):
+    """The fused bf16 MLP path (spe_amd.ops.mlp_gelu): both Linears on the bf16-copy GEMMs."""
+    return _lin16_ok(R, Hd, K) and _lin16_ok(R, N, Hd)
+
+
+def mlp_gelu_fwd(x2, W1, b1, W2, b2):
+    """y = fc2(gelu(fc1(x2))) with every intermediate that the next GEMM needs emitted as bf16 by the producing GEMM's
+    epilogue: fc1 writes the fp32 pre-activation (for the backward) and the bf16 activation h16 / h16T, never the fp32
+    activation.  -> (y [R,N] fp32, saved = (x16T, pre, h16T))."""
+    R, K = x2.shape
+    Hd, N = W1.shape[0], W2.shape[0]
+    dev = x2.device
+    x16, x16T = cvt_bf16(x2, True, True)
+    Rp = x16T.shape[1]
+    pre = torch.empty((R, Hd), device=dev, dtype=torch.float32)
+    h16 = torch.empty((R, Hd), device=dev, dtype=torch.bfloat16)
+    h16T = torch.empty((Hd, Rp), device=dev, dtype=torch.bfloat16)
+    gemm16_ex(x16, weight16(W1)[0], R, Hd, K, K, K, bias=b1, C2=pre, out16=h16, out16T=h16T, act=2)
+    y = torch.empty((R, N), device=dev, dtype=torch.float32)
+    gemm16(h16, weight16(W2)[0], y, R, N, Hd, Hd, Hd, N, bias=b2)
+    return y, (x16T, pre, h16T)
+
+
+def _dw16(dy16T, x16T, N, K, Rp, dW_out):
+    """dW [N,K] = dy16T [N,Rp] @ x16T[K,Rp]^T, split-K slabs summed into dW_out (zeroed bucket view) when given."""
+    dev = dy16T.device
+    sk = min(auto_splitk(N, K, Rp, 1), Rp // 64)
+    if sk > 1:
+        ws = torch.empty((sk, N * K), device=dev, dtype=torch.float32)
+        gemm16(dy16T, x16T, ws, N, K, Rp, Rp, Rp, K, splitk=-sk)
+        return colsum(ws, out=None if dW_out is None else dW_out.view(-1)).view(N, K)
+    dW = dW_out if dW_out is not None else torch.empty((N, K), device=dev, dtype=torch.float32)
+    gemm16(dy16T, x16T, dW, N, K, Rp, Rp, Rp, K)
+    return dW
+
+
+def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, None)):
+    """Backward of mlp_gelu_fwd.  dy2 [R,N] fp32.  -> (dx, dW1, db1, dW2, db2).  The gradient w.r.t. the pre-activation
+    exists only as the bf16 copies (row-major for dx, transposed for dW1) written by the dh GEMM's epilogue, which also
+    applies gelu' and accumulates db1.  grad_bufs: zeroed bucket views for (dW1, db1, dW2, db2) or None."""
+    x16T, pre, h16T = saved
+    R, N = dy2.shape
+    Hd, K = W1.shape
+    Rp = x16T.shape[1]
+    dev = dy2.device
+    gW1, gb1, gW2, gb2 = grad_bufs
+    db2 = _zeros_or(gb2, N, dev)
+    dy16, dy16T = cvt_bf16(dy2, True, True, ldt=Rp, colsum_out=db2)
+    dW2 = _dw16(dy16T, h16T, N, Hd, Rp, gW2)
+    # dpre = (dy @ W2) * gelu'(pre): bf16 only
+    db1 = _zeros_or(gb1, Hd, dev)
+    dp16 = torch.empty((R, Hd), device=dev, dtype=torch.bfloat16) if need_dx else None
+    dp16T = torch.empty((Hd, Rp), device=dev, dtype=torch.bfloat16)
+    gemm16_ex(dy16, weight16(W2)[1], R, Hd, N, N, N, out16=dp16, out16T=dp16T, colsum=db1, aux=pre, act=2)
+    dW1 = _dw16(dp16T, x16T, Hd, K, Rp, gW1)
+    dx = None
+    if need_dx:
+        dx = torch.empty((R, K), device=dev, dtype=torch.float32)
+        gemm16(dp16, weight16(W1)[1], dx, R, K, Hd, Hd, Hd, K)
+    return dx, dW1, db1, dW2, db2
+
+
 def linear_fwd(x2, W, b, act=0, want_pre=False, save_for_dw=True):
     """y = act(x2 @ W.T + b); x2 [R,K] contiguous, W [N,K].  -> (y, pre-activation or None, xsave): xsave is what
     linear_bwd needs of x - x2 itself, or on the bf16 path the padded bf16 transpose x16T [K, Rp]."""

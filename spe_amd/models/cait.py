@@ -44,6 +44,8 @@ class Mlp(nn.Module):
         self.drop = Dropout(drop)
 
     def forward(self, x):
+        if not (self.training and self.drop.p > 0.0):
+            return ops.mlp_gelu(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
         x = self.drop(self.fc1(x, ops.ACT_GELU))
         return self.drop(self.fc2(x))
 

@@ -250,6 +250,43 @@ class _TalkingHeadsAttentionFused(Function):
         return dqkv, dWl, dbl, dWw, dbw, None, None, None
 
 
+class _MlpGelu(Function):
+    """fc2(gelu(fc1(x))) of the backbone block (reference models/cait.py:405-412: timm Mlp with drop = 0) as ONE autograd
+    node on the bf16-copy GEMMs: the activation and the gradient w.r.t. the pre-activation never exist in fp32 - the
+    producing GEMM epilogues write the bf16 (and transposed bf16) operands of the following GEMMs and the bias gradient."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        y, saved = K.mlp_gelu_fwd(x2, W1, b1, W2, b2)
+        ctx.params = (W1, b1, W2, b2)
+        ctx.save_for_backward(*saved, W1, W2)
+        return y.view(*shp[:-1], W2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16T, pre, h16T, W1, W2 = ctx.saved_tensors
+        dy2 = dy.reshape(-1, W2.shape[0])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        bufs = tuple(K.grad_buffer(p) for p in ctx.params)
+        dx, dW1, db1, dW2, db2 = K.mlp_gelu_bwd(dy2, (x16T, pre, h16T), W1, W2, ctx.needs_input_grad[0], bufs)
+        return (dx.view(*dy.shape[:-1], W1.shape[1]) if dx is not None else None), dW1, db1, dW2, db2
+
+
+def mlp_gelu(x, W1, b1, W2, b2):
+    """Fused MLP when both Linears take the bf16-copy path (benchmark precision, >= LINEAR16_MIN_ROWS rows, contiguous
+    weights with biases); otherwise the two Linear nodes (same arithmetic, fp32 intermediates)."""
+    R = x.numel() // x.shape[-1]
+    if (b1 is not None and b2 is not None and W1.is_contiguous() and W2.is_contiguous()
+            and K.mlp16_ok(R, W1.shape[1], W1.shape[0], W2.shape[0])):
+        return _MlpGelu.apply(x, W1, b1, W2, b2)
+    return linear(linear(x, W1, b1, ACT_GELU), W2, b2)
+
+
 def talking_heads_attention(qkv, Wl, bl, Ww, bw, num_heads, scale, p_drop=0.0, fused=None):
     """fused=None: use the fused kernels in bf16 mode when the head geometry is supported; the 3-term
     (bf16x3) parity mode keeps the fp32 materialised path."""

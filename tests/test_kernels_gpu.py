@@ -499,6 +499,72 @@ def test_gemm_bf16nt(dev, M, N, K_):
         assert rel(ws.sum(0).view(M, N), ref) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K_", [(300, 384, 384), (8300, 1536, 384), (130, 72, 64), (77, 200, 136), (1000, 64, 256)])
+@pytest.mark.parametrize("mode", ["gelu_fwd", "gelu_bwd", "relu_fwd", "relu_bwd", "plain"])
+def test_gemm_bf16nt_extended_epilogue(dev, M, N, K_, mode):
+    """spe_gemm_bf16nt_ex: fp32 / pre-activation / bf16 / transposed-bf16 / column-sum outputs against the plain kernel
+    followed by spe_cvt_bf16 (bit-identical values), for full, ragged and single-tile shapes."""
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(M + N + K_)
+    A16 = torch.randn(M, K_, generator=g).to(dev).to(torch.bfloat16)
+    B16 = (torch.randn(N, K_, generator=g) * 0.2).to(dev).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(dev) if mode.endswith("fwd") else None
+    aux = torch.randn(M, N, generator=g).to(dev) if mode.endswith("bwd") else None
+    act = {"g": 2, "r": 1, "p": 0}[mode[0]]
+    Rp = ((M + 63) // 64) * 64
+    # reference: plain kernel -> fp32, then the conversion kernel (which also applies act' from aux and sums columns)
+    C = torch.empty(M, N, device=dev); C2 = torch.empty(M, N, device=dev) if bias is not None else None
+    K.gemm16(A16, B16, C, M, N, K_, K_, K_, N, bias=bias, C2=C2, act=act if aux is None else 0)
+    cs_ref = torch.zeros(N, device=dev)
+    r16, r16T = K.cvt_bf16(C, True, True, ldt=Rp, colsum_out=cs_ref, act_aux=aux, act=act if aux is not None else 0)
+    # extended epilogue, all outputs at once
+    Cx = torch.full((M, N), float("nan"), device=dev); C2x = torch.full((M, N), float("nan"), device=dev) if bias is not None else None
+    o16 = torch.full((M, N), float("nan"), device=dev).to(torch.bfloat16)
+    o16T = torch.full((N, Rp), float("nan"), device=dev).to(torch.bfloat16)
+    cs = torch.zeros(N, device=dev)
+    K.gemm16_ex(A16, B16, M, N, K_, K_, K_, bias=bias, C=Cx, C2=C2x, out16=o16, out16T=o16T, colsum=cs, aux=aux, act=act)
+    if aux is None:
+        assert torch.equal(Cx, C)
+    if C2 is not None:
+        assert torch.equal(C2x, C2)
+    assert torch.equal(o16, r16)
+    assert torch.equal(o16T, r16T)                       # includes the zero padding columns M..Rp-1
+    assert torch.equal(Cx.to(torch.bfloat16), o16)
+    assert rel(cs, cs_ref) < 1e-5
+    # outputs are individually optional
+    o16b = torch.empty_like(o16)
+    K.gemm16_ex(A16, B16, M, N, K_, K_, K_, bias=bias, out16=o16b, aux=aux, act=act)
+    assert torch.equal(o16b, r16)
+
+
+def test_fused_mlp_matches_two_linears(dev):
+    """ops.mlp_gelu (one autograd node, bf16 intermediates emitted by the GEMM epilogues) against linear(gelu) + linear on
+    the same bf16-copy GEMMs: identical forward, identical weight/bias/input gradients up to summation order."""
+    from spe_amd import kernels as K, ops
+    K.set_precision("bf16")
+    g = torch.Generator().manual_seed(5)
+    R, C, Hd = 1000, 384, 1536
+    x = torch.randn(2, R // 2, C, generator=g).to(dev).requires_grad_()
+    W1 = (torch.randn(Hd, C, generator=g) * 0.05).to(dev).requires_grad_(); b1 = (torch.randn(Hd, generator=g) * 0.1).to(dev).requires_grad_()
+    W2 = (torch.randn(C, Hd, generator=g) * 0.05).to(dev).requires_grad_(); b2 = (torch.randn(C, generator=g) * 0.1).to(dev).requires_grad_()
+    go = torch.randn(2, R // 2, C, generator=g).to(dev)
+    y = ops.mlp_gelu(x, W1, b1, W2, b2)
+    assert y.grad_fn.name().startswith("_MlpGelu")
+    gr = torch.autograd.grad(y, (x, W1, b1, W2, b2), go)
+    y0 = ops.linear(ops.linear(x, W1, b1, ops.ACT_GELU), W2, b2)
+    g0 = torch.autograd.grad(y0, (x, W1, b1, W2, b2), go)
+    assert torch.equal(y, y0)
+    for a, b, nm in zip(gr, g0, ["x", "W1", "b1", "W2", "b2"]):
+        assert rel(a, b) < 2e-6, (nm, rel(a, b))
+    # and against fp64 on the bf16-rounded operands of the first GEMM only (sanity of the whole chain)
+    xd, W1d, W2d = x.detach().double(), W1.detach().double(), W2.detach().double()
+    ref = torch.nn.functional.gelu(xd @ W1d.t() + b1.detach().double()) @ W2d.t() + b2.detach().double()
+    assert rel(y, ref) < 1e-2
+    # small inputs fall back to the two-node path
+    xs = torch.randn(1, 7, C, generator=g).to(dev)
+    assert torch.allclose(ops.mlp_gelu(xs, W1, b1, W2, b2), ops.linear(ops.linear(xs, W1, b1, ops.ACT_GELU), W2, b2))
+
+
 def test_linear_bf16_path_matches_fp32_operand_path(dev):
     """ops.linear on the bf16-copy GEMMs == the fp32-operand kernel in bf16 mode (same roundings), fwd and bwd."""
     from spe_amd import kernels as K

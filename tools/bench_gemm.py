@@ -57,7 +57,7 @@ def main():
       run("dec proj NT", 200, 384, 384, False, True)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "bf16nt"):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("bf16nt", "epi")):
     main()
 
 
@@ -99,3 +99,36 @@ def main16():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "bf16nt":
     main16()
+
+
+def main_epi():
+    """Epilogue cost breakdown on the fc1 shape."""
+    M, N, Kd = 8300, 1536, 384
+    A = torch.randn(M, Kd, device=dev).to(torch.bfloat16)
+    B = torch.randn(N, Kd, device=dev).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev)
+    C = torch.empty(M, N, device=dev); C2 = torch.empty(M, N, device=dev); aux = torch.randn(M, N, device=dev)
+    o16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16); o16T = torch.empty(N, 8320, device=dev, dtype=torch.bfloat16)
+    cs = torch.zeros(N, device=dev)
+    us = lambda f: timeit(f) * 1e6
+    print("plain C                 %.1f us" % us(lambda: K.gemm16(A, B, C, M, N, Kd, Kd, Kd, N)))
+    print("plain C + bias          %.1f us" % us(lambda: K.gemm16(A, B, C, M, N, Kd, Kd, Kd, N, bias=bias)))
+    print("plain C + C2            %.1f us" % us(lambda: K.gemm16(A, B, C, M, N, Kd, Kd, Kd, N, bias=bias, C2=C2)))
+    print("plain C + C2 + relu     %.1f us" % us(lambda: K.gemm16(A, B, C, M, N, Kd, Kd, Kd, N, bias=bias, C2=C2, act=1)))
+    print("plain C + C2 + gelu     %.1f us" % us(lambda: K.gemm16(A, B, C, M, N, Kd, Kd, Kd, N, bias=bias, C2=C2, act=2)))
+    print("plain C + gelu          %.1f us" % us(lambda: K.gemm16(A, B, C, M, N, Kd, Kd, Kd, N, bias=bias, act=2)))
+    print("ex o16                  %.1f us" % us(lambda: K.gemm16_ex(A, B, M, N, Kd, Kd, Kd, out16=o16)))
+    print("ex o16T                 %.1f us" % us(lambda: K.gemm16_ex(A, B, M, N, Kd, Kd, Kd, out16T=o16T)))
+    print("ex o16 + o16T           %.1f us" % us(lambda: K.gemm16_ex(A, B, M, N, Kd, Kd, Kd, out16=o16, out16T=o16T)))
+    print("ex o16 + o16T + C2      %.1f us" % us(lambda: K.gemm16_ex(A, B, M, N, Kd, Kd, Kd, bias=bias, C2=C2, out16=o16, out16T=o16T)))
+    print("ex o16 + o16T + C2+gelu %.1f us" % us(lambda: K.gemm16_ex(A, B, M, N, Kd, Kd, Kd, bias=bias, C2=C2, out16=o16, out16T=o16T, act=2)))
+    print("ex o16 + o16T + cs      %.1f us" % us(lambda: K.gemm16_ex(A, B, M, N, Kd, Kd, Kd, out16=o16, out16T=o16T, colsum=cs)))
+    print("ex o16 + o16T + cs+relu'%.1f us" % us(lambda: K.gemm16_ex(A, B, M, N, Kd, Kd, Kd, out16=o16, out16T=o16T, colsum=cs, aux=aux, act=1)))
+    print("ex o16 + o16T + cs+gelu'%.1f us" % us(lambda: K.gemm16_ex(A, B, M, N, Kd, Kd, Kd, out16=o16, out16T=o16T, colsum=cs, aux=aux, act=2)))
+    x = torch.randn(M, N, device=dev)
+    print("cvt out+outT+cs+gelu'   %.1f us" % us(lambda: K.cvt_bf16(x, True, True, colsum_out=cs, act_aux=aux, act=2)))
+    print("cvt out+outT            %.1f us" % us(lambda: K.cvt_bf16(x, True, True)))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "epi":
+    main_epi()

@@ -64,6 +64,11 @@ def main():
         elif name == "spe_gemm_bf16nt":
             d = dict(zip(names[name], args))
             key = "gemm16 M=%d N=%d K=%d act=%s bias=%d" % (d["M"], d["N"], d["K"], d.get("act"), int(bool(d.get("bias"))))
+        elif name == "spe_gemm_bf16nt_ex":
+            d = dict(zip(names[name], args))
+            key = "gemm16ex M=%d N=%d K=%d act=%s aux=%d C=%d C2=%d o16=%d o16T=%d cs=%d" % (
+                d["M"], d["N"], d["K"], d.get("act"), int(bool(d["aux"])), int(bool(d["C"])), int(bool(d["C2"])), int(bool(d["out16"])),
+                int(bool(d["out16T"])), int(bool(d["colsum"])))
         elif name == "spe_cvt_bf16":
             d = dict(zip(names[name], args))
             key = "cvt R=%d C=%d T=%d cs=%d aux=%d" % (d["R"], d["C"], int(bool(d["outT"])), int(bool(d["colsum"])), int(bool(d["aux"])))
