@@ -154,6 +154,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    # the HIP library is built in-tree by __graft_entry__.build(); if this checkout has none (or a stale one), local
+    # rank 0 builds it once and the other ranks wait for the file - there is no CPU fallback to run instead
+    from spe_amd import build as _build
+    if local == 0 and _build.needs_build():
+        _build.build(verbose=(rank == 0))
+    if world > 1:
+        dist.barrier()
     from spe_amd import kernels as K
     from spe_amd import lib
     from spe_amd.dp import GradAllReducer
