@@ -85,11 +85,13 @@ int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const float* bia
  * separate conversion launch):  v = alpha A16 B16^T + bias ; C2 = v (optional) ; v = act(v), or with aux != NULL
  * v = v * act'(aux) (aux [M][ldc]: act 1 = ReLU with the forward output, act 2 = erf-GELU with the pre-activation) ;
  * C = v (optional fp32) ; out16[M][ld16] = bf16(v) ; out16T[N][ld16t] = bf16(v)^T with columns M..ld16t-1 zero
- * (ld16t <= M rounded up to 64) ; colsum[n] += sum_m v.  Any output may be NULL.  Used by the fused MLP of the backbone
- * block (reference models/cait.py:405-412 = timm Mlp fc1 -> GELU -> fc2, and its autograd). */
+ * (ld16t <= M rounded up to 64) ; colsum[n] += sum_m v.  Any output may be NULL.  res/rgamma != NULL (act 0, no aux):
+ * the LayerScale residual of the block is applied by the epilogue, C = res[m][n] + rgamma[n] * v (res [M][ldc]), while C2
+ * keeps v for the gamma gradient.  Used by the fused MLP of the backbone block (reference models/cait.py:405-416 = timm
+ * Mlp fc1 -> GELU -> fc2 inside x + gamma_2 * mlp(norm2(x)), and its autograd). */
 int spe_gemm_bf16nt_ex(const void* A16, const void* B16, float* C, const float* bias, float* C2,
                        void* out16, long ld16, void* out16T, long ld16t, float* colsum, const float* aux,
-                       int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, spe_stream_t stream);
+                       const float* res, const float* rgamma, int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, spe_stream_t stream);
 int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, long ldo, void* outT, long ldt, float* colsum,
                  const float* aux, int act, spe_stream_t stream);
 /* spe_cvt_bf16_multi: the row-major and transposed bf16 copies of njobs contiguous fp32 matrices in ONE launch (every
@@ -172,6 +174,12 @@ int spe_layerscale_residual_fwd(const float* x, const float* y, const float* gam
                                 float* out, long R, int C, long rows_per_sample, spe_stream_t stream);
 int spe_layerscale_residual_bwd(const float* dout, const float* y, const float* gamma, const float* sample_scale,
                                 float* dy, float* dgamma, long R, int C, long rows_per_sample, spe_stream_t stream);
+/* spe_layerscale_residual_bwd16: the same backward when the branch ends in a Linear on the bf16-copy GEMMs (proj / fc2 of
+ * the backbone block, cait.py:390,412): dy = gamma * dout is emitted only as the bf16 operands of that Linear's backward
+ * GEMMs - dy16 [R][C] and dy16T [C][ldt] (ldt = R rounded up to 64, padding zero) - with db[c] += sum_r dy (the Linear's
+ * bias gradient, fp32 before rounding) and dgamma[c] += sum_r dout * y.  No per-sample scale (drop_path = 0). */
+int spe_layerscale_residual_bwd16(const float* dout, const float* y, const float* gamma, void* dy16, void* dy16T, long ldt,
+                                  float* db, float* dgamma, long R, int C, spe_stream_t stream);
 
 /* ---- activation backward: mode 1 ReLU (aux = forward output), mode 2 GELU (aux = pre-activation);
  * autograd of F.relu (transformer.py:32,287,424) and nn.GELU (timm Mlp). n % 4 == 0. */

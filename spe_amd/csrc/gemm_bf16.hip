@@ -36,6 +36,7 @@ struct Gemm16Args {
     unsigned short* out16T; long ld16t;    // [N][ld16t] bf16(v) transposed, columns M..ld16t-1 zero
     float* colsum;                         // [N] += sum_m v
     const float* aux;                      // [M][ldc]: v *= act'(aux) (act 1: aux = forward output, 2: pre-activation)
+    const float* res; const float* rgamma; // LayerScale residual: C = res[m][n] + rgamma[n] * v  (C2 still gets v)
 };
 
 __device__ __forceinline__ float gelu_erf16(float x) { return 0.5f * x * (1.0f + spe_erff(x * 0.70710678118654752f)); }
@@ -167,17 +168,20 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) ident[e] = ((lane & 15) == 4 * (lane >> 4) + e) ? (short)0x3F80 : (short)0;
         const bool vst = ((p.ldc & 3) == 0) && (!p.C || (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
-                         (!p.C2 || (reinterpret_cast<uintptr_t>(p.C2) & 15) == 0) && (!p.aux || (reinterpret_cast<uintptr_t>(p.aux) & 15) == 0);
+                         (!p.C2 || (reinterpret_cast<uintptr_t>(p.C2) & 15) == 0) && (!p.aux || (reinterpret_cast<uintptr_t>(p.aux) & 15) == 0) &&
+                         (!p.res || (reinterpret_cast<uintptr_t>(p.res) & 15) == 0);
         // interior tiles request the whole aux tile up front (the operand staging registers are free now): 16 loads in
         // flight per lane instead of one exposed round trip per 16x16 block
+        const bool stage = p.out16 || p.out16T || p.colsum;      // bf16 copies / column sums wanted at all
         const bool interior = vst && (m0 + BM <= p.M) && (n0 + BN <= p.N);
         float4 hq[NFN][NFM];
-        if (p.aux && interior) {
+        const float* pre_src = p.aux ? p.aux : p.res;              // aux and res are mutually exclusive
+        if (pre_src && interior) {
 #pragma unroll
             for (int j = 0; j < NFN; ++j)
 #pragma unroll
                 for (int i = 0; i < NFM; ++i)
-                    hq[j][i] = *reinterpret_cast<const float4*>(p.aux + (long)(m0 + wm * WM + i * 16 + fr) * p.ldc + n0 + wn * WN + j * 16 + (lane >> 4) * 4);
+                    hq[j][i] = *reinterpret_cast<const float4*>(pre_src + (long)(m0 + wm * WM + i * 16 + fr) * p.ldc + n0 + wn * WN + j * 16 + (lane >> 4) * 4);
         }
 #pragma unroll
         for (int j = 0; j < NFN; ++j) {
@@ -186,6 +190,11 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
             if (p.bias) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bv[r] = p.bias[min(n + r, p.N - 1)];
+            }
+            float gv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.rgamma) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gv[r] = p.rgamma[min(n + r, p.N - 1)];
             }
             float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -231,12 +240,25 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = (rowv && n + r < p.N) ? v[r] : 0.f;      // padding rows / columns stage zeros
                 if (p.C && rowv) {
-                    if (full) *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    float o[4] = {v[0], v[1], v[2], v[3]};
+                    if (p.res) {
+                        float xr[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (interior) { xr[0] = hq[j][i].x; xr[1] = hq[j][i].y; xr[2] = hq[j][i].z; xr[3] = hq[j][i].w; }
+                        else if (full) { const float4 q = *reinterpret_cast<const float4*>(p.res + off); xr[0] = q.x; xr[1] = q.y; xr[2] = q.z; xr[3] = q.w; }
+                        else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) if (n + r < p.N) xr[r] = p.res[(long)m * p.ldc + n + r];
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = xr[r] + gv[r] * v[r];
+                    }
+                    if (full) *reinterpret_cast<float4*>(p.C + off) = make_float4(o[0], o[1], o[2], o[3]);
                     else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) if (n + r < p.N) p.C[(long)m * p.ldc + n + r] = v[r];
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) p.C[(long)m * p.ldc + n + r] = o[r];
                     }
                 }
+                if (!stage) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cs[r] += v[r];
                 typedef __bf16 bf16x4v_t __attribute__((ext_vector_type(4)));
@@ -390,7 +412,7 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const
     p.A = reinterpret_cast<const unsigned short*>(A16); p.B = reinterpret_cast<const unsigned short*>(B16);
     p.C = C; p.C2 = C2; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.act = act; p.slab = 0;
-    p.out16 = nullptr; p.out16T = nullptr; p.colsum = nullptr; p.aux = nullptr; p.ld16 = 0; p.ld16t = 0;
+    p.out16 = nullptr; p.out16T = nullptr; p.colsum = nullptr; p.aux = nullptr; p.ld16 = 0; p.ld16t = 0; p.res = nullptr; p.rgamma = nullptr;
     const int ktiles = (K + GB_BK - 1) / GB_BK;
     if (splitk < 0) {           // slab mode: C holds |splitk| slabs of M*ldc floats
         splitk = -splitk; p.slab = (long)M * ldc;
@@ -411,6 +433,7 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const
 // C-ABI: see include/spe_hip.h (spe_gemm_bf16nt_ex).  -2: unsupported alignment / leading dimensions.
 extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, float* C, const float* bias, float* C2,
                                   void* out16, long ld16, void* out16T, long ld16t, float* colsum, const float* aux,
+                                  const float* res, const float* rgamma,
                                   int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, hipStream_t stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0) return -4;
@@ -418,6 +441,7 @@ extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, float* C, co
     if (!al16(A16) || !al16(B16) || (lda & 7) || (ldb & 7) || (K & 7)) return -2;
     if (out16T && ld16t < M) return -2;
     if (aux && act != 1 && act != 2) return -2;
+    if ((res != nullptr) != (rgamma != nullptr) || (res && (!C || act != 0 || aux))) return -2;
     Gemm16Args p;
     p.A = reinterpret_cast<const unsigned short*>(A16); p.B = reinterpret_cast<const unsigned short*>(B16);
     p.C = C; p.C2 = C2; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -425,7 +449,7 @@ extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, float* C, co
     p.kt_per_split = (K + GB_BK - 1) / GB_BK;
     p.out16 = reinterpret_cast<unsigned short*>(out16); p.ld16 = ld16;
     p.out16T = reinterpret_cast<unsigned short*>(out16T); p.ld16t = ld16t;
-    p.colsum = colsum; p.aux = aux;
+    p.colsum = colsum; p.aux = aux; p.res = res; p.rgamma = rgamma;
     // the transposed copy's zero columns M..ld16t-1 are written by the last row tile: it must reach ld16t
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const bool reach128 = !out16T || ld16t <= (long)((M + 127) / 128) * 128;

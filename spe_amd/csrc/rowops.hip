@@ -388,6 +388,117 @@ __global__ __launch_bounds__(NW * 64) void lsres_bwd_rows_kernel(const float* __
         atomicAdd(dgamma + c, t);
     }
 }
+// LayerScale backward feeding a Linear backward directly: dy = gamma * dout is never written in fp32 - the kernel emits
+// what the weight / input gradient GEMMs of the preceding Linear consume, dy16 [R][C] and dy16T [C][ldt] (zero padded
+// to ldt = R rounded up to 64), plus db[c] += sum_r dy (that Linear's bias gradient) and dgamma[c] += sum_r dout * y.
+// A workgroup of 16 waves owns 64-row tiles: wave w converts rows w, w+16, w+32, w+48 of the tile (16-B loads, 8-B bf16
+// stores) and stages them in LDS, then the tile leaves transposed as 16-B stores of 8 consecutive rows per column.
+__global__ __launch_bounds__(1024) void lsres_bwd16_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                           const float* __restrict__ gamma, unsigned short* __restrict__ dy16,
+                                                           unsigned short* __restrict__ dy16T, long ldt, float* __restrict__ db,
+                                                           float* __restrict__ dgamma, long R, int C) {
+    extern __shared__ unsigned short lsT[];            // [64][C + 8] bf16 tile ; reused as float [16][C + 4] x 2 at the end
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int C4 = C >> 2, ldl = C + 8;
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    float4 ag[LN_MAXV], ab[LN_MAXV], g[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0);
+        const int c = lane + 64 * i;
+        g[i] = c < C4 ? g4[c] : make_float4(0, 0, 0, 0);
+    }
+    typedef __bf16 bf16x4r_t __attribute__((ext_vector_type(4)));
+    const long ntiles = (ldt + 63) / 64;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long r0 = tile * 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int rl = w + 16 * k;
+            const long row = r0 + rl;
+            const bool rv = row < R;
+            const float4* dr = reinterpret_cast<const float4*>(dout + (rv ? row : 0) * C);
+            const float4* yr = reinterpret_cast<const float4*>(y + (rv ? row : 0) * C);
+#pragma unroll
+            for (int i = 0; i < LN_MAXV; ++i) {
+                const int c = lane + 64 * i;
+                if (c < C4) {
+                    float4 d = make_float4(0, 0, 0, 0), yv = d;
+                    if (rv) { d = dr[c]; yv = yr[c]; }
+                    ag[i].x += d.x * yv.x; ag[i].y += d.y * yv.y; ag[i].z += d.z * yv.z; ag[i].w += d.w * yv.w;
+                    const float4 o = make_float4(d.x * g[i].x, d.y * g[i].y, d.z * g[i].z, d.w * g[i].w);
+                    ab[i].x += o.x; ab[i].y += o.y; ab[i].z += o.z; ab[i].w += o.w;
+                    bf16x4r_t h;
+                    h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
+                    const uint2 u = __builtin_bit_cast(uint2, h);
+                    if (rv && dy16) *reinterpret_cast<uint2*>(dy16 + row * C + 4 * c) = u;
+                    *reinterpret_cast<uint2*>(lsT + rl * ldl + 4 * c) = u;        // rows past R stage zeros
+                }
+            }
+        }
+        __syncthreads();
+        if (dy16T) {
+            for (int item = threadIdx.x; item < C * 8; item += 1024) {
+                const int c = item >> 3, ch = item & 7;
+                const long rr = r0 + ch * 8;
+                if (rr >= ldt) continue;
+                unsigned short e[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e[k] = lsT[(ch * 8 + k) * ldl + c];
+                uint4 q;
+                q.x = (unsigned)e[0] | ((unsigned)e[1] << 16); q.y = (unsigned)e[2] | ((unsigned)e[3] << 16);
+                q.z = (unsigned)e[4] | ((unsigned)e[5] << 16); q.w = (unsigned)e[6] | ((unsigned)e[7] << 16);
+                *reinterpret_cast<uint4*>(dy16T + (long)c * ldt + rr) = q;       // ldt % 64 == 0: aligned, in range
+            }
+        }
+        __syncthreads();
+    }
+    // column sums of the 16 waves through LDS, one atomic per column and workgroup
+    float* red = reinterpret_cast<float*>(lsT);
+    const int ldr = C + 4;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C4) {
+            *reinterpret_cast<float4*>(red + (long)w * ldr + 4 * c) = ag[i];
+            *reinterpret_cast<float4*>(red + (long)(16 + w) * ldr + 4 * c) = ab[i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += 1024) {
+        const int k = c >= C, cc = k ? c - C : c;
+        float t = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 16; ++wv) t += red[(long)(16 * k + wv) * ldr + cc];
+        float* dst = k ? db : dgamma;
+        if (dst) atomicAdd(dst + cc, t);
+    }
+}
+
+// C-ABI: see include/spe_hip.h (spe_layerscale_residual_bwd16).  -2: C % 4 != 0, C > 1024, ldt not a multiple of 64
+// or smaller than R, misaligned pointers.
+extern "C" int spe_layerscale_residual_bwd16(const float* dout, const float* y, const float* gamma, void* dy16, void* dy16T, long ldt,
+                                             float* db, float* dgamma, long R, int C, hipStream_t st) {
+    if (R <= 0) return 0;
+    if ((C & 3) || C > 256 * LN_MAXV || (ldt & 63) || ldt < R) return -2;
+    if ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) |
+         reinterpret_cast<uintptr_t>(dy16) | reinterpret_cast<uintptr_t>(dy16T)) & 15) return -2;
+    const int tile_bytes = 64 * (C + 8) * 2, red_bytes = 32 * (C + 4) * 4;
+    const int smem = tile_bytes > red_bytes ? tile_bytes : red_bytes;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lsres_bwd16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           64 * (256 * LN_MAXV + 8) * 2 > 32 * (256 * LN_MAXV + 4) * 4 ? 64 * (256 * LN_MAXV + 8) * 2 : 32 * (256 * LN_MAXV + 4) * 4);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    long nb = (ldt + 63) / 64; if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(lsres_bwd16_kernel, dim3((unsigned)nb), dim3(1024), smem, st, dout, y, gamma,
+                       reinterpret_cast<unsigned short*>(dy16), reinterpret_cast<unsigned short*>(dy16T), ldt, db, dgamma, R, C);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int spe_layerscale_residual_fwd(const float* x, const float* y, const float* gamma, const float* sample_scale,
                                            float* out, long R, int C, long rows_per_sample, hipStream_t st) {
     if (R <= 0) return 0;

@@ -278,11 +278,12 @@ def gemm16(A16, B16, C, M, N, K, lda, ldb, ldc, bias=None, C2=None, alpha=1.0, a
 
 
 def gemm16_ex(A16, B16, M, N, K, lda, ldb, bias=None, C=None, C2=None, out16=None, out16T=None, colsum=None, aux=None,
-              alpha=1.0, act=0):
+              alpha=1.0, act=0, res=None, rgamma=None):
     """spe_gemm_bf16nt_ex: v = alpha * A16 @ B16.T + bias; C2 = v; v = act(v) or v * act'(aux); optional fp32 C [M,N], bf16
     out16 [M,N], bf16 transposed out16T [N, ldt] (zero padded), colsum [N] += column sums.  All fp32 tensors have ld = N."""
     _call("spe_gemm_bf16nt_ex", _p(A16), _p(B16), _p(C), _p(bias), _p(C2), _p(out16), N, _p(out16T),
-          out16T.shape[1] if out16T is not None else 0, _p(colsum), _p(aux), M, N, K, lda, ldb, N, float(alpha), int(act), _st())
+          out16T.shape[1] if out16T is not None else 0, _p(colsum), _p(aux), _p(res), _p(rgamma), M, N, K, lda, ldb, N,
+          float(alpha), int(act), _st())
 
 
 def mlp16_ok(R, K, Hd, N):
@@ -290,7 +291,20 @@ def mlp16_ok(R, K, Hd, N):
     return _lin16_ok(R, Hd, K) and _lin16_ok(R, N, Hd)
 
 
-def mlp_gelu_fwd(x2, W1, b1, W2, b2):
+def layerscale_residual_bwd16(dout2, y2, gamma, Rp, db_out=None, dg_out=None, want_rowmajor=True):
+    """Backward of out = x + gamma * y when y is the output of a Linear on the bf16-copy GEMMs: -> (dy16 [R,C], dy16T
+    [C,Rp], db [C], dgamma [C]); dy = gamma * dout exists only as those bf16 operands."""
+    R, C = dout2.shape
+    dev = dout2.device
+    dy16 = torch.empty((R, C), device=dev, dtype=torch.bfloat16) if want_rowmajor else None
+    dy16T = torch.empty((C, Rp), device=dev, dtype=torch.bfloat16)
+    db = _zeros_or(db_out, C, dev)
+    dg = _zeros_or(dg_out, C, dev)
+    _call("spe_layerscale_residual_bwd16", _p(dout2), _p(y2), _p(gamma), _p(dy16), _p(dy16T), Rp, _p(db), _p(dg), R, C, _st())
+    return dy16, dy16T, db, dg
+
+
+def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None):
     """y = fc2(gelu(fc1(x2))) with every intermediate that the next GEMM needs emitted as bf16 by the producing GEMM's
     epilogue: fc1 writes the fp32 pre-activation (for the backward) and the bf16 activation h16 / h16T, never the fp32
     activation.  -> (y [R,N] fp32, saved = (x16T, pre, h16T))."""
@@ -304,8 +318,13 @@ def mlp_gelu_fwd(x2, W1, b1, W2, b2):
     h16T = torch.empty((Hd, Rp), device=dev, dtype=torch.bfloat16)
     gemm16_ex(x16, weight16(W1)[0], R, Hd, K, K, K, bias=b1, C2=pre, out16=h16, out16T=h16T, act=2)
     y = torch.empty((R, N), device=dev, dtype=torch.float32)
-    gemm16(h16, weight16(W2)[0], y, R, N, Hd, Hd, Hd, N, bias=b2)
-    return y, (x16T, pre, h16T)
+    if res is None:
+        gemm16(h16, weight16(W2)[0], y, R, N, Hd, Hd, Hd, N, bias=b2)
+        return y, (x16T, pre, h16T)
+    # LayerScale residual in the fc2 epilogue: out = res + gamma * y ; y is kept for the gamma gradient
+    out = torch.empty((R, N), device=dev, dtype=torch.float32)
+    gemm16_ex(h16, weight16(W2)[0], R, N, Hd, Hd, Hd, bias=b2, C=out, C2=y, res=res, rgamma=gamma)
+    return out, (x16T, pre, h16T, y)
 
 
 def _dw16(dy16T, x16T, N, K, Rp, dW_out):
@@ -321,18 +340,22 @@ def _dw16(dy16T, x16T, N, K, Rp, dW_out):
     return dW
 
 
-def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, None)):
+def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, None), gamma=None, dg_out=None):
     """Backward of mlp_gelu_fwd.  dy2 [R,N] fp32.  -> (dx, dW1, db1, dW2, db2).  The gradient w.r.t. the pre-activation
     exists only as the bf16 copies (row-major for dx, transposed for dW1) written by the dh GEMM's epilogue, which also
     applies gelu' and accumulates db1.  grad_bufs: zeroed bucket views for (dW1, db1, dW2, db2) or None."""
-    x16T, pre, h16T = saved
+    x16T, pre, h16T = saved[:3]
     R, N = dy2.shape
     Hd, K = W1.shape
     Rp = x16T.shape[1]
     dev = dy2.device
     gW1, gb1, gW2, gb2 = grad_bufs
-    db2 = _zeros_or(gb2, N, dev)
-    dy16, dy16T = cvt_bf16(dy2, True, True, ldt=Rp, colsum_out=db2)
+    dg = None
+    if gamma is not None:        # residual form: dy2 is d(out); the branch gradient gamma * dout only exists in bf16
+        dy16, dy16T, db2, dg = layerscale_residual_bwd16(dy2, saved[3], gamma, Rp, db_out=gb2, dg_out=dg_out)
+    else:
+        db2 = _zeros_or(gb2, N, dev)
+        dy16, dy16T = cvt_bf16(dy2, True, True, ldt=Rp, colsum_out=db2)
     dW2 = _dw16(dy16T, h16T, N, Hd, Rp, gW2)
     # dpre = (dy @ W2) * gelu'(pre): bf16 only
     db1 = _zeros_or(gb1, Hd, dev)
@@ -344,6 +367,8 @@ def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, 
     if need_dx:
         dx = torch.empty((R, K), device=dev, dtype=torch.float32)
         gemm16(dp16, weight16(W1)[1], dx, R, K, Hd, Hd, Hd, K)
+    if gamma is not None:
+        return dx, dW1, db1, dW2, db2, dg
     return dx, dW1, db1, dW2, db2
 
 

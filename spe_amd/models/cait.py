@@ -103,9 +103,11 @@ class LayerScale_Block(nn.Module):
         B = x.shape[0]
         x = ops.layerscale_residual(x, self.attn(self.norm1(x)), self.gamma_1,
                                     ops.drop_path_scale(B, self.drop_path, self.training, x.device))
-        x = ops.layerscale_residual(x, self.mlp(self.norm2(x)), self.gamma_2,
-                                    ops.drop_path_scale(B, self.drop_path, self.training, x.device))
-        return x
+        ss = ops.drop_path_scale(B, self.drop_path, self.training, x.device)
+        if isinstance(self.mlp, Mlp) and not (self.training and self.mlp.drop.p > 0.0):
+            return ops.mlp_gelu_residual(self.norm2(x), self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight,
+                                         self.mlp.fc2.bias, x, self.gamma_2, ss)
+        return ops.layerscale_residual(x, self.mlp(self.norm2(x)), self.gamma_2, ss)
 
 
 class Multi_Class_Attention(nn.Module):

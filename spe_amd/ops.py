@@ -277,6 +277,50 @@ class _MlpGelu(Function):
         return (dx.view(*dy.shape[:-1], W1.shape[1]) if dx is not None else None), dW1, db1, dW2, db2
 
 
+class _MlpGeluRes(Function):
+    """xres + gamma * fc2(gelu(fc1(x))) - the MLP half of the backbone block after its LayerNorm (reference
+    models/cait.py:405-416, drop_path = 0) as one node: _MlpGelu plus the LayerScale residual in the fc2 epilogue, and in
+    the backward the branch gradient gamma * dout emitted directly as the bf16 operands of the fc2 gradient GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, xres, gamma):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        r2 = xres.reshape(-1, xres.shape[-1])
+        if not r2.is_contiguous():
+            r2 = r2.contiguous()
+        out, saved = K.mlp_gelu_fwd(x2, W1, b1, W2, b2, res=r2, gamma=gamma)
+        ctx.params = (W1, b1, W2, b2, gamma)
+        ctx.save_for_backward(*saved, W1, W2, gamma)
+        return out.view(xres.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x16T, pre, h16T, y, W1, W2, gamma = ctx.saved_tensors
+        d2 = dout.reshape(-1, W2.shape[0])
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        W1p, b1p, W2p, b2p, gp = ctx.params
+        bufs = tuple(K.grad_buffer(p) for p in (W1p, b1p, W2p, b2p))
+        dx, dW1, db1, dW2, db2, dg = K.mlp_gelu_bwd(d2, (x16T, pre, h16T, y), W1, W2, ctx.needs_input_grad[0], bufs,
+                                                     gamma=gamma, dg_out=K.grad_buffer(gp))
+        return ((dx.view(*dout.shape[:-1], W1.shape[1]) if dx is not None else None), dW1, db1, dW2, db2, dout,
+                dg.view_as(gamma))
+
+
+def mlp_gelu_residual(x, W1, b1, W2, b2, xres, gamma, sample_scale=None):
+    """xres + s * gamma * mlp(x).  One fused node when the MLP takes the bf16-copy path and there is no per-sample DropPath
+    scale; otherwise mlp_gelu followed by layerscale_residual (same arithmetic)."""
+    R = x.numel() // x.shape[-1]
+    if (sample_scale is None and b1 is not None and b2 is not None and W1.is_contiguous() and W2.is_contiguous()
+            and gamma.is_contiguous() and W2.shape[0] % 4 == 0 and W2.shape[0] <= 1024
+            and K.mlp16_ok(R, W1.shape[1], W1.shape[0], W2.shape[0])):
+        return _MlpGeluRes.apply(x, W1, b1, W2, b2, xres, gamma)
+    return layerscale_residual(xres, mlp_gelu(x, W1, b1, W2, b2), gamma, sample_scale)
+
+
 def mlp_gelu(x, W1, b1, W2, b2):
     """Fused MLP when both Linears take the bf16-copy path (benchmark precision, >= LINEAR16_MIN_ROWS rows, contiguous
     weights with biases); otherwise the two Linear nodes (same arithmetic, fp32 intermediates)."""

@@ -565,6 +565,59 @@ def test_fused_mlp_matches_two_linears(dev):
     assert torch.allclose(ops.mlp_gelu(xs, W1, b1, W2, b2), ops.linear(ops.linear(xs, W1, b1, ops.ACT_GELU), W2, b2))
 
 
+@pytest.mark.parametrize("R,C", [(1000, 384), (8300, 384), (130, 64), (77, 1024)])
+def test_layerscale_residual_bwd16(dev, R, C):
+    """spe_layerscale_residual_bwd16 against layerscale_residual_bwd + spe_cvt_bf16: identical bf16 copies (incl. the zero
+    padding of the transpose), column sums within summation order."""
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(R + C)
+    dout = torch.randn(R, C, generator=g).to(dev); y = torch.randn(R, C, generator=g).to(dev)
+    gamma = (torch.randn(C, generator=g) * 0.3).to(dev)
+    Rp = ((R + 63) // 64) * 64
+    dy, dg_ref = K.layerscale_residual_bwd(dout, y, gamma, None, R)
+    db_ref = torch.zeros(C, device=dev)
+    r16, r16T = K.cvt_bf16(dy, True, True, ldt=Rp, colsum_out=db_ref)
+    dy16, dy16T, db, dg = K.layerscale_residual_bwd16(dout, y, gamma, Rp)
+    assert torch.equal(dy16, r16) and torch.equal(dy16T, r16T)
+    assert rel(db, db_ref) < 1e-5 and rel(dg, dg_ref) < 1e-5
+
+
+def test_fused_mlp_residual_matches_composite(dev):
+    """ops.mlp_gelu_residual (fc2 epilogue applies x + gamma * y; backward emits gamma * dout as bf16 operands) against
+    layerscale_residual(x, mlp_gelu(...)), including gradient placement into all-reduce bucket views."""
+    from spe_amd import kernels as K, ops
+    from spe_amd.dp import GradAllReducer
+    K.set_precision("bf16")
+    g = torch.Generator().manual_seed(6)
+    R, C, Hd = 1100, 384, 1536
+    mk = lambda *s, sc=1.0: torch.nn.Parameter((torch.randn(*s, generator=g) * sc).to(dev))
+    W1, b1, W2, b2, gamma = mk(Hd, C, sc=0.05), mk(Hd, sc=0.1), mk(C, Hd, sc=0.05), mk(C, sc=0.1), mk(C, sc=0.5)
+    params = [W1, b1, W2, b2, gamma]
+    xn = torch.randn(2, R // 2, C, generator=g).to(dev).requires_grad_()
+    xr = torch.randn(2, R // 2, C, generator=g).to(dev).requires_grad_()
+    go = torch.randn(2, R // 2, C, generator=g).to(dev)
+    out = ops.mlp_gelu_residual(xn, W1, b1, W2, b2, xr, gamma)
+    assert out.grad_fn.name().startswith("_MlpGeluRes")
+    gr = torch.autograd.grad(out, [xn, xr] + params, go)
+    ref = ops.layerscale_residual(xr, ops.mlp_gelu(xn, W1, b1, W2, b2), gamma)
+    g0 = torch.autograd.grad(ref, [xn, xr] + params, go)
+    assert rel(out, ref) < 1e-6
+    for a, b, nm in zip(gr, g0, ["xn", "xres", "W1", "b1", "W2", "b2", "gamma"]):
+        assert rel(a, b) < 5e-6, (nm, rel(a, b))
+    # with a reducer: every parameter gradient lands in its bucket view without a copy
+    red = GradAllReducer(params, flatten_params=False)
+    red.reset()
+    ops.mlp_gelu_residual(xn, W1, b1, W2, b2, xr, gamma).backward(go)
+    red.finish()
+    for p, b in zip(params, g0[2:]):
+        assert p.grad.data_ptr() == red._views[p].data_ptr() and rel(p.grad, b) < 5e-6
+    # DropPath scale present -> composite path
+    ss = torch.tensor([1.25, 0.0], device=dev)
+    o2 = ops.mlp_gelu_residual(xn, W1, b1, W2, b2, xr, gamma, ss)
+    assert not o2.grad_fn.name().startswith("_MlpGeluRes")
+    assert rel(o2, ops.layerscale_residual(xr, ops.mlp_gelu(xn, W1, b1, W2, b2), gamma, ss)) < 1e-6
+
+
 def test_linear_bf16_path_matches_fp32_operand_path(dev):
     """ops.linear on the bf16-copy GEMMs == the fp32-operand kernel in bf16 mode (same roundings), fwd and bwd."""
     from spe_amd import kernels as K
