@@ -242,14 +242,16 @@ int spe_box_loss_bwd(const long* srow, const int* lidx, const float* g_l1, const
  * spe_mha_plan: number of key chunks the forward / dQ kernels split the keys into (few query tiles -> many chunks).
  * spe_mha_fwd: Opart [B*H*ntq*nch][ceil(dv/16)][64][4] and ML [B*H*ntq*nch][16][2] floats of workspace ->
  *   O [B,Lq,H*dv], LSE [B,H,Lq] (log2 domain).  spe_mha_bwd: D [B,H,Lq] = rowsum(dO.O); dq [B,Lq,H,dk] must be
- *   zero-initialised when nch > 1 (atomic accumulation over chunks); dk [B,Lk,H,dk], dv [B,Lk,H,dv] are overwritten. */
+ *   zero-initialised when nch > 1 and dq_ws == NULL (atomic accumulation over chunks); with dq_ws [nch][B*Lq*H*dk] every
+ *   chunk writes its own partial slab instead (sum them with spe_colsum: no atomics, fixed order) and dq is not touched;
+ *   dk [B,Lk,H,dk], dv [B,Lk,H,dv] are overwritten. */
 int spe_mha_plan(int B, int H, int Lq, int Lk, int* nch);
 int spe_mha_fwd(const void* Qf, const void* Kf, const void* V16, const void* mask, float* Opart, float* ML, float* O,
                 float* LSE, void* keepbits, int B, int H, int Lq, int Lk, int dk, int dv, int nch, float p_drop,
                 uint64_t seed, uint64_t offset, spe_stream_t stream);
 int spe_mha_bwd(const void* Qf, const void* Kf, const void* Vf, const void* dOf, const void* K16, const void* Q16,
                 const void* dO16, const void* mask, const float* LSE, const float* D, const void* keepbits, float* dq,
-                float* dk, float* dv, int B, int H, int Lq, int Lk, int dk_dim, int dv_dim, int nch, float scale,
+                float* dq_ws, float* dk, float* dv, int B, int H, int Lq, int Lk, int dk_dim, int dv_dim, int nch, float scale,
                 float p_drop, spe_stream_t stream);
 
 /* ---- sine position embedding of the padded feature map (reference models/position_encoding.py:37-57):

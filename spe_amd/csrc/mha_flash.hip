@@ -34,7 +34,8 @@ struct MhaArgs {
     const unsigned char* mask;                 // [B, Lk] key padding (1 = padded) or null
     float* Opart; float* ML;                   // forward partials: [item][dvt][64][4], [item][16][2]
     const float* LSE; const float* Dd;         // [B,H,Lq] log2-domain log-sum-exp, D = rowsum(dO . O)
-    float* dq; float* dk; float* dv;           // [B,L,H,d] fp32 (dq zero-initialised: atomics)
+    float* dq; float* dk; float* dv;           // [B,L,H,d] fp32 (dq zero-initialised when chunks add into it atomically)
+    float* dq_ws;                              // optional [nch][B,Lq,H,dk] slabs: one private partial dq per key chunk
     unsigned long long* keepbits;              // dropout keep flags [B*H*ntq*ntk][4] (written by the forward, p_drop > 0)
     int B, H, Lq, Lk, dk_dim, dv_dim, ntq, ntk, nch, ch_len;
     float scale, p_drop; uint64_t seed, offset;
@@ -71,6 +72,9 @@ __device__ __forceinline__ float mha_keep_plain(const unsigned long long* kb, in
 }
 
 // ---- forward ---------------------------------------------------------------------------------------
+// TDK / TDV: head dims fixed at compile time (0: taken from the arguments - every step guard is then a branch around an
+// MFMA; the instantiated pairs fold them away: 131 -> 12 branches, 192 -> ~120 registers in the dK/dV kernel)
+template <int TDK, int TDV>
 __global__ __launch_bounds__(256) void mha_fwd_kernel(MhaArgs a) {
     __shared__ u32x4m_t sK[2][MHA_DSK * 64];
     __shared__ uint2 sV[2][MHA_DVT * 64];
@@ -78,7 +82,8 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(MhaArgs a) {
     const int nqg = (a.ntq + 3) / 4;
     const int ch = blockIdx.x % a.nch; const int qg = (blockIdx.x / a.nch) % nqg; const long bh = blockIdx.x / ((long)a.nch * nqg);
     const int b = (int)(bh / a.H);
-    const int dsk = (a.dk_dim + 31) / 32, dvt = (a.dv_dim + 15) / 16;
+    const int dkd = TDK ? TDK : a.dk_dim, dvd = TDV ? TDV : a.dv_dim;
+    const int dsk = (dkd + 31) / 32, dvt = (dvd + 15) / 16;
     const int qt = qg * 4 + wave;
     const bool active = qt < a.ntq;
     const int qtc = min(qt, a.ntq - 1);
@@ -196,6 +201,7 @@ __global__ __launch_bounds__(256) void mha_merge_kernel(const float* __restrict_
 }
 
 // ---- backward: dQ ------------------------------------------------------------------------------------
+template <int TDK, int TDV>
 __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaArgs a) {
     __shared__ u32x4m_t sK[2][MHA_DSK * 64];
     __shared__ u32x4m_t sV[2][MHA_DSV * 64];
@@ -204,7 +210,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaArgs a) {
     const int nqg = (a.ntq + 3) / 4;
     const int ch = blockIdx.x % a.nch; const int qg = (blockIdx.x / a.nch) % nqg; const long bh = blockIdx.x / ((long)a.nch * nqg);
     const int b = (int)(bh / a.H), h = (int)(bh % a.H);
-    const int dsk = (a.dk_dim + 31) / 32, dsv = (a.dv_dim + 31) / 32, dkt = (a.dk_dim + 15) / 16;
+    const int dkd = TDK ? TDK : a.dk_dim, dvd = TDV ? TDV : a.dv_dim;
+    const int dsk = (dkd + 31) / 32, dsv = (dvd + 31) / 32, dkt = (dkd + 15) / 16;
     const int qt = qg * 4 + wave;
     const bool active = qt < a.ntq;
     const int qtc = min(qt, a.ntq - 1);
@@ -271,20 +278,26 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaArgs a) {
     }
     if (!qv) return;
     // dq[b, q, h, d] += scale * g ; lane = (query, 4 consecutive d)
-    float* dst = a.dq + (((long)b * a.Lq + q) * a.H + h) * a.dk_dim;
+    const bool slab = a.nch > 1 && a.dq_ws;     // private slab per chunk (summed by the caller): no atomics, fixed order
+    float* dst = (slab ? a.dq_ws + (long)ch * a.B * a.Lq * a.H * dkd : a.dq) + (((long)b * a.Lq + q) * a.H + h) * dkd;
 #pragma unroll
     for (int d = 0; d < MHA_DKT; ++d)
         if (d < dkt) {
             const int dc = d * 16 + 4 * (lane >> 4);
+            if ((slab || a.nch == 1) && dc + 3 < dkd && (dkd & 3) == 0) {
+                *reinterpret_cast<float4*>(dst + dc) = make_float4(g[d][0] * a.scale, g[d][1] * a.scale, g[d][2] * a.scale, g[d][3] * a.scale);
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (dc + r < a.dk_dim) {
-                    if (a.nch > 1) atomicAdd(dst + dc + r, g[d][r] * a.scale); else dst[dc + r] = g[d][r] * a.scale;
+                if (dc + r < dkd) {
+                    if (a.nch > 1 && !slab) atomicAdd(dst + dc + r, g[d][r] * a.scale); else dst[dc + r] = g[d][r] * a.scale;
                 }
         }
 }
 
 // ---- backward: dK, dV ----------------------------------------------------------------------------------
+template <int TDK, int TDV>
 __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(MhaArgs a) {
     __shared__ u32x4m_t sQ[2][MHA_DSK * 64];
     __shared__ u32x4m_t sdO[2][MHA_DSV * 64];
@@ -295,7 +308,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(MhaArgs a) {
     const int nkg = (a.ntk + 3) / 4;
     const int kg = blockIdx.x % nkg; const long bh = blockIdx.x / nkg;
     const int b = (int)(bh / a.H), h = (int)(bh % a.H);
-    const int dsk = (a.dk_dim + 31) / 32, dsv = (a.dv_dim + 31) / 32, dkt = (a.dk_dim + 15) / 16, dvt = (a.dv_dim + 15) / 16;
+    const int dkd = TDK ? TDK : a.dk_dim, dvd = TDV ? TDV : a.dv_dim;
+    const int dsk = (dkd + 31) / 32, dsv = (dvd + 31) / 32, dkt = (dkd + 15) / 16, dvt = (dvd + 15) / 16;
     const int kt = kg * 4 + wave;
     const bool active = kt < a.ntk;
     const int ktc = min(kt, a.ntk - 1);
@@ -372,22 +386,24 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(MhaArgs a) {
         __syncthreads();
     }
     if (!active || key >= a.Lk) return;
-    float* dk_ = a.dk + (((long)b * a.Lk + key) * a.H + h) * a.dk_dim;
-    float* dv_ = a.dv + (((long)b * a.Lk + key) * a.H + h) * a.dv_dim;
+    float* dk_ = a.dk + (((long)b * a.Lk + key) * a.H + h) * dkd;
+    float* dv_ = a.dv + (((long)b * a.Lk + key) * a.H + h) * dvd;
     // the Q fragments carry scale * log2(e): dK = dS^T (scale q) = dS^T Qpacked * ln 2
 #pragma unroll
     for (int d = 0; d < MHA_DKT; ++d)
         if (d < dkt) {
             const int dc = d * 16 + 4 * (lane >> 4);
+            if (dc + 3 < dkd && (dkd & 3) == 0) { *reinterpret_cast<float4*>(dk_ + dc) = make_float4(gk[d][0] * MHA_LN2, gk[d][1] * MHA_LN2, gk[d][2] * MHA_LN2, gk[d][3] * MHA_LN2); continue; }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (dc + r < a.dk_dim) dk_[dc + r] = gk[d][r] * MHA_LN2;
+            for (int r = 0; r < 4; ++r) if (dc + r < dkd) dk_[dc + r] = gk[d][r] * MHA_LN2;
         }
 #pragma unroll
     for (int d = 0; d < MHA_DVT; ++d)
         if (d < dvt) {
             const int dc = d * 16 + 4 * (lane >> 4);
+            if (dc + 3 < dvd && (dvd & 3) == 0) { *reinterpret_cast<float4*>(dv_ + dc) = make_float4(gv[d][0], gv[d][1], gv[d][2], gv[d][3]); continue; }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (dc + r < a.dv_dim) dv_[dc + r] = gv[d][r];
+            for (int r = 0; r < 4; ++r) if (dc + r < dvd) dv_[dc + r] = gv[d][r];
         }
 }
 
@@ -406,7 +422,10 @@ static int mha_fill(MhaArgs& a, int B, int H, int Lq, int Lk, int dk, int dv, in
 extern "C" int spe_mha_plan(int B, int H, int Lq, int Lk, int* nch) {
     const int ntq = (Lq + 15) / 16, ntk = (Lk + 15) / 16;
     long items = (long)B * H * ((ntq + 3) / 4);                // workgroups of 4 query tiles
-    int c = (int)((1024 + items - 1) / items);                 // ~4 workgroups per CU
+#ifndef MHA_TARGET
+#define MHA_TARGET 1024                                         // developer knob (tools/ab.py): workgroups the plan aims at
+#endif
+    int c = (int)((MHA_TARGET + items - 1) / items);           // ~4 workgroups per CU
     if (c > ntk / 4) c = ntk / 4;                              // at least 4 key tiles per chunk
     if (c < 1) c = 1;
     const int len = (ntk + c - 1) / c;
@@ -426,7 +445,9 @@ extern "C" int spe_mha_fwd(const void* Qf, const void* Kf, const void* V16, cons
     a.keepbits = (unsigned long long*)keepbits;
     if (p_drop > 0.f && !keepbits) return -2;
     const long wgs = (long)B * H * ((a.ntq + 3) / 4) * a.nch;
-    hipLaunchKernelGGL(mha_fwd_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a);
+    if (dk == 96 && dv == 48) hipLaunchKernelGGL((mha_fwd_kernel<96, 48>), dim3((unsigned)wgs), dim3(256), 0, st, a);
+    else if (dk == 48 && dv == 48) hipLaunchKernelGGL((mha_fwd_kernel<48, 48>), dim3((unsigned)wgs), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((mha_fwd_kernel<0, 0>), dim3((unsigned)wgs), dim3(256), 0, st, a);
     SPE_CHECK_LAUNCH();
     const long total = (long)B * H * a.ntq * ((dv + 15) / 16) * 64;
     hipLaunchKernelGGL(mha_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Opart, ML, O, LSE, B, H, Lq, a.ntq,
@@ -436,7 +457,7 @@ extern "C" int spe_mha_fwd(const void* Qf, const void* Kf, const void* V16, cons
 }
 extern "C" int spe_mha_bwd(const void* Qf, const void* Kf, const void* Vf, const void* dOf, const void* K16, const void* Q16,
                            const void* dO16, const void* mask, const float* LSE, const float* D, const void* keepbits, float* dq,
-                           float* dk_, float* dv_, int B, int H, int Lq, int Lk, int dk, int dv, int nch, float scale, float p_drop,
+                           float* dq_ws, float* dk_, float* dv_, int B, int H, int Lq, int Lk, int dk, int dv, int nch, float scale, float p_drop,
                            hipStream_t st) {
     if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
     MhaArgs a = {};
@@ -444,15 +465,19 @@ extern "C" int spe_mha_bwd(const void* Qf, const void* Kf, const void* Vf, const
     if (rc) return rc;
     a.Qf = (const u32x4m_t*)Qf; a.Kf = (const u32x4m_t*)Kf; a.Vf = (const u32x4m_t*)Vf; a.dOf = (const u32x4m_t*)dOf;
     a.K16 = (const uint2*)K16; a.Q16 = (const uint2*)Q16; a.dO16 = (const uint2*)dO16; a.mask = (const unsigned char*)mask;
-    a.LSE = LSE; a.Dd = D; a.dq = dq; a.dk = dk_; a.dv = dv_;
+    a.LSE = LSE; a.Dd = D; a.dq = dq; a.dq_ws = dq_ws; a.dk = dk_; a.dv = dv_;
     a.scale = scale; a.p_drop = p_drop;
     a.keepbits = (unsigned long long*)const_cast<void*>(keepbits);
     if (p_drop > 0.f && !keepbits) return -2;
     long wgs = (long)B * H * ((a.ntq + 3) / 4) * a.nch;
-    hipLaunchKernelGGL(mha_bwd_dq_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a);
+    if (dk == 96 && dv == 48) hipLaunchKernelGGL((mha_bwd_dq_kernel<96, 48>), dim3((unsigned)wgs), dim3(256), 0, st, a);
+    else if (dk == 48 && dv == 48) hipLaunchKernelGGL((mha_bwd_dq_kernel<48, 48>), dim3((unsigned)wgs), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((mha_bwd_dq_kernel<0, 0>), dim3((unsigned)wgs), dim3(256), 0, st, a);
     SPE_CHECK_LAUNCH();
     wgs = (long)B * H * ((a.ntk + 3) / 4);
-    hipLaunchKernelGGL(mha_bwd_dkv_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a);
+    if (dk == 96 && dv == 48) hipLaunchKernelGGL((mha_bwd_dkv_kernel<96, 48>), dim3((unsigned)wgs), dim3(256), 0, st, a);
+    else if (dk == 48 && dv == 48) hipLaunchKernelGGL((mha_bwd_dkv_kernel<48, 48>), dim3((unsigned)wgs), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((mha_bwd_dkv_kernel<0, 0>), dim3((unsigned)wgs), dim3(256), 0, st, a);
     SPE_CHECK_LAUNCH();
     return 0;
 }

@@ -724,11 +724,17 @@ def mha_fwd(Qf, Kf, V16, mask_u8, B, H, Lq, Lk, dk, dv, nch, p_drop, seed, offse
 
 def mha_bwd(Qf, Kf, Vf, dOf, K16, Q16, dO16, mask_u8, lse, D, keep, B, H, Lq, Lk, dk, dv, nch, scale, p_drop):
     dev = Qf.device
-    dq = torch.zeros((B, Lq, H, dk), device=dev, dtype=torch.float32) if nch > 1 else torch.empty((B, Lq, H, dk), device=dev, dtype=torch.float32)
+    dq = torch.empty((B, Lq, H, dk), device=dev, dtype=torch.float32)
+    # key chunks write private dq slabs that one column-sum launch adds up (atomics on the same 0.3 M addresses from 16
+    # chunks cost more than the whole kernel: cross-attention backward 0.21 -> 0.14 ms)
+    ws = torch.empty((nch, dq.numel()), device=dev, dtype=torch.float32) if nch > 1 else None
     dk_ = torch.empty((B, Lk, H, dk), device=dev, dtype=torch.float32)
     dv_ = torch.empty((B, Lk, H, dv), device=dev, dtype=torch.float32)
     _call("spe_mha_bwd", _p(Qf), _p(Kf), _p(Vf), _p(dOf), _p(K16), _p(Q16), _p(dO16), _p(mask_u8), _p(lse), _p(D), _p(keep), _p(dq),
-          _p(dk_), _p(dv_), B, H, Lq, Lk, dk, dv, nch, float(scale), float(p_drop), _st())
+          _p(ws), _p(dk_), _p(dv_), B, H, Lq, Lk, dk, dv, nch, float(scale), float(p_drop), _st())
+    if ws is not None:
+        dq.zero_()
+        colsum(ws, out=dq.view(-1))
     return dq, dk_, dv_
 
 
