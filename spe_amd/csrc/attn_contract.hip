@@ -184,34 +184,40 @@ extern "C" int spe_attn_pack16(const float* x, long sb, long sn, long sh, int B,
 #define PACK_MAXJOBS 6
 struct PackJob { const float* x; long sb, sn, sh; float scale; int kind; void* out; int N, dh; };   // kind 0: spe_attn_pack layout, 1: spe_attn_pack16, 2: spe_attn_pack layout without the tail step
 struct PackJobs { PackJob j[PACK_MAXJOBS]; int B, H; };
-__global__ __launch_bounds__(256) void attn_pack_multi_kernel(PackJobs a) {
-    const PackJob jb = a.j[blockIdx.y];
-    const int N = jb.N, H = a.H, dh = jb.dh, nt = (N + 15) / 16;
+template <typename IT>
+__device__ __forceinline__ void attn_pack_job(const PackJob& jb, int B, int H) {
+    const int N = jb.N, dh = jb.dh, nt = (N + 15) / 16;
+    const IT stride = (IT)gridDim.x * 256;
     if (jb.kind == 0 || jb.kind == 2) {
         const int notail = jb.kind == 2;
-        const long total = attn_pack_units(a.B, N, H, dh, notail);
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
-            attn_pack_unit(jb.x, jb.sb, jb.sn, jb.sh, N, H, dh, nt, jb.scale, i, reinterpret_cast<uint2*>(jb.out), notail);
+        const IT total = (IT)attn_pack_units(B, N, H, dh, notail);
+        for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < total; i += stride)
+            attn_pack_unit_t<IT>(jb.x, jb.sb, jb.sn, jb.sh, N, H, dh, nt, jb.scale, i, reinterpret_cast<uint2*>(jb.out), notail);
     } else {
         const int DT = (dh + 15) / 16;
-        const long total = (long)a.B * H * nt * DT * 64;
+        const IT total = (IT)((long)B * H * nt * DT * 64);
         uint2* out = reinterpret_cast<uint2*>(jb.out);
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-            const int ln = (int)(i & 63); long t = i >> 6;
-            const int dt = (int)(t % DT); t /= DT;
-            const int tile = (int)(t % nt); t /= nt;
-            const int h = (int)(t % H); const int b = (int)(t / H);
+        for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+            const int ln = (int)(i & 63); IT t = i >> 6;
+            const IT t1 = t / (IT)DT; const int dt = (int)(t - t1 * (IT)DT);
+            const IT t2 = t1 / (IT)nt; const int tile = (int)(t1 - t2 * (IT)nt);
+            const int b = (int)(t2 / (IT)H), h = (int)(t2 - (IT)b * (IT)H);
             const int d = dt * 16 + (ln & 15), r0 = tile * 16 + 4 * (ln >> 4);
+            const float* src = jb.x + b * jb.sb + h * jb.sh + min(d, dh - 1);
             bf16x4c_t o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = r0 + j;
-                const float f = jb.x[b * jb.sb + (long)min(row, N - 1) * jb.sn + h * jb.sh + min(d, dh - 1)];
+                const float f = src[(long)min(row, N - 1) * jb.sn];
                 o[j] = (__bf16)((row < N && d < dh) ? f * jb.scale : 0.f);
             }
             out[i] = __builtin_bit_cast(uint2, o);
         }
     }
+}
+__global__ __launch_bounds__(256) void attn_pack_multi_kernel(PackJobs a, int narrow) {
+    const PackJob jb = a.j[blockIdx.y];
+    if (narrow) attn_pack_job<unsigned>(jb, a.B, a.H); else attn_pack_job<long>(jb, a.B, a.H);
 }
 
 // C-ABI: see include/spe_hip.h (spe_attn_pack_multi).  xs/outs/scales/kinds/Ns/dhs: njobs entries (host arrays).
@@ -230,7 +236,8 @@ extern "C" int spe_attn_pack_multi(int njobs, const float* const* xs, const long
     }
     a.B = B; a.H = H;
     long nb = (total + 255) / 256; if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(attn_pack_multi_kernel, dim3((unsigned)nb, njobs), dim3(256), 0, st, a);
+    const int narrow = total + 2048L * 256 < (1L << 31);          // unit indices (and one grid stride beyond) fit 32 bits
+    hipLaunchKernelGGL(attn_pack_multi_kernel, dim3((unsigned)nb, njobs), dim3(256), 0, st, a, narrow);
     SPE_CHECK_LAUNCH();
     return 0;
 }
