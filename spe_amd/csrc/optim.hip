@@ -60,8 +60,9 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(AdamwArgs a) {
         clip = fminf(a.max_norm / (tot + 1e-6f), 1.f);
     }
     __syncthreads();
-    const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 >= a.n) return;
+    // grid-stride over float4 chunks: the prologue above (segment table, clip factor from the norm partials) is paid once
+    // per workgroup, not once per 1024 elements (26 K workgroups for the 27 M parameters of cfg2: 0.41 -> 0.2x ms)
+    for (long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i0 < a.n; i0 += (long)gridDim.x * 1024) {
     int lo = 0, hi = a.nseg - 1;                         // first segment whose end is > i0
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_end[mid] > i0) hi = mid; else lo = mid + 1; }
     int seg = lo;
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(AdamwArgs a) {
         for (int j = 0; j < 4; ++j)
             if (i0 + j < a.n) { a.p[i0 + j] = pv[j]; a.m[i0 + j] = mv[j]; a.v[i0 + j] = vv[j]; if (a.write_grad) a.g[i0 + j] = gv[j]; }
     }
+    }
 }
 
 // C-ABI: see include/spe_hip.h (spe_adamw_flat).  All flat buffers 16-B aligned, n elements.
@@ -114,7 +116,7 @@ extern "C" int spe_adamw_flat(float* p, float* g, float* m, float* v, long n, co
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.seg_end = seg_end; a.seg_lr = seg_lr; a.seg_wd = seg_wd; a.nseg = nseg;
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.bc1 = bias_c1; a.bc2sqrt = sqrtf(bias_c2);
     a.partials = partials; a.npartials = npartials; a.max_norm = max_norm; a.write_grad = write_grad;
-    const long nb = (n + 1023) / 1024;
+    long nb = (n + 1023) / 1024; if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)nb), dim3(256), 0, st, a);
     SPE_CHECK_LAUNCH();
     return 0;
