@@ -304,18 +304,19 @@ def layerscale_residual_bwd16(dout2, y2, gamma, Rp, db_out=None, dg_out=None, wa
     return dy16, dy16T, db, dg
 
 
-def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None):
+def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True):
     """y = fc2(gelu(fc1(x2))) with every intermediate that the next GEMM needs emitted as bf16 by the producing GEMM's
     epilogue: fc1 writes the fp32 pre-activation (for the backward) and the bf16 activation h16 / h16T, never the fp32
     activation.  -> (y [R,N] fp32, saved = (x16T, pre, h16T))."""
     R, K = x2.shape
     Hd, N = W1.shape[0], W2.shape[0]
     dev = x2.device
-    x16, x16T = cvt_bf16(x2, True, True)
-    Rp = x16T.shape[1]
-    pre = torch.empty((R, Hd), device=dev, dtype=torch.float32)
+    # save = False (no gradient wanted: inference): none of the tensors that only the backward reads is produced
+    x16, x16T = cvt_bf16(x2, True, save)
+    Rp = ((R + 63) // 64) * 64
+    pre = torch.empty((R, Hd), device=dev, dtype=torch.float32) if save else None
     h16 = torch.empty((R, Hd), device=dev, dtype=torch.bfloat16)
-    h16T = torch.empty((Hd, Rp), device=dev, dtype=torch.bfloat16)
+    h16T = torch.empty((Hd, Rp), device=dev, dtype=torch.bfloat16) if save else None
     gemm16_ex(x16, weight16(W1)[0], R, Hd, K, K, K, bias=b1, C2=pre, out16=h16, out16T=h16T, act=2)
     y = torch.empty((R, N), device=dev, dtype=torch.float32)
     if res is None:
@@ -323,7 +324,7 @@ def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None):
         return y, (x16T, pre, h16T)
     # LayerScale residual in the fc2 epilogue: out = res + gamma * y ; y is kept for the gamma gradient
     out = torch.empty((R, N), device=dev, dtype=torch.float32)
-    gemm16_ex(h16, weight16(W2)[0], R, N, Hd, Hd, Hd, bias=b2, C=out, C2=y, res=res, rgamma=gamma)
+    gemm16_ex(h16, weight16(W2)[0], R, N, Hd, Hd, Hd, bias=b2, C=out, C2=y if save else None, res=res, rgamma=gamma)
     return out, (x16T, pre, h16T, y)
 
 

@@ -261,9 +261,11 @@ class _MlpGelu(Function):
         x2 = x.reshape(-1, shp[-1])
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        y, saved = K.mlp_gelu_fwd(x2, W1, b1, W2, b2)
+        train = any(ctx.needs_input_grad)
+        y, saved = K.mlp_gelu_fwd(x2, W1, b1, W2, b2, save=train)
         ctx.params = (W1, b1, W2, b2)
-        ctx.save_for_backward(*saved, W1, W2)
+        if train:
+            ctx.save_for_backward(*saved, W1, W2)
         return y.view(*shp[:-1], W2.shape[0])
 
     @staticmethod
@@ -291,9 +293,11 @@ class _MlpGeluRes(Function):
         r2 = xres.reshape(-1, xres.shape[-1])
         if not r2.is_contiguous():
             r2 = r2.contiguous()
-        out, saved = K.mlp_gelu_fwd(x2, W1, b1, W2, b2, res=r2, gamma=gamma)
+        train = any(ctx.needs_input_grad)
+        out, saved = K.mlp_gelu_fwd(x2, W1, b1, W2, b2, res=r2, gamma=gamma, save=train)
         ctx.params = (W1, b1, W2, b2, gamma)
-        ctx.save_for_backward(*saved, W1, W2, gamma)
+        if train:
+            ctx.save_for_backward(*saved, W1, W2, gamma)
         return out.view(xres.shape)
 
     @staticmethod

@@ -611,6 +611,10 @@ def test_fused_mlp_residual_matches_composite(dev):
     red.finish()
     for p, b in zip(params, g0[2:]):
         assert p.grad.data_ptr() == red._views[p].data_ptr() and rel(p.grad, b) < 5e-6
+    # no gradient wanted (inference): same output, nothing saved
+    with torch.no_grad():
+        oi = ops.mlp_gelu_residual(xn.detach(), W1.detach(), b1.detach(), W2.detach(), b2.detach(), xr.detach(), gamma.detach())
+    assert torch.equal(oi, out.detach())
     # DropPath scale present -> composite path
     ss = torch.tensor([1.25, 0.0], device=dev)
     o2 = ops.mlp_gelu_residual(xn, W1, b1, W2, b2, xr, gamma, ss)
