@@ -64,7 +64,11 @@ __device__ __forceinline__ void g16_stage(unsigned short* lds, const u32x4g_t (&
         *reinterpret_cast<u32x4g_t*>(lds + ((t >> 3) + 32 * i) * GB_LDR + (t & 7) * 8) = v[i];
 }
 
-template <int BM, int BN, bool EX>
+// NTS > 0 ("small" variant, decoder-size problems: 400 x 384 x 384 is 42 workgroups of 6 K tiles, bound by the chain of
+// load round trips of the pipelined loop - 10 us for 0.1 GFLOP): all NTS K tiles of the workgroup are requested at once
+// (NTS * (BM + BN) / 32 16-B registers per thread), staged into NTS LDS slots behind ONE wait and barrier, then multiplied
+// back to back.  K tiles past the contraction length load zeros.
+template <int BM, int BN, bool EX, int NTS = 0>
 __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     constexpr int NFM = BM / 32, NFN = BN / 32;        // 16x16 MFMA tiles per wave (wave tile BM/2 x BN/2)
@@ -104,13 +108,47 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
 #pragma unroll
         for (int j = 0; j < NFN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (NTS > 0) {
+        u32x4g_t ra[NTS][BM / 32], rb[NTS][BN / 32];
+#pragma unroll
+        for (int t = 0; t < NTS; ++t) {
+            g16_load<BM>(p.A, p.lda, m0, p.M, t * GB_BK, p.K, ra[t]);
+            g16_load<BN>(p.B, p.ldb, n0, p.N, t * GB_BK, p.K, rb[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < NTS; ++t) {
+            g16_stage<BM>(sA(0) + t * (TA_ + TB_), ra[t]);
+            g16_stage<BN>(sA(0) + t * (TA_ + TB_) + TA_, rb[t]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NTS; ++t) {
+            const unsigned short* tA = sA(0) + t * (TA_ + TB_);
+            const unsigned short* tB = tA + TA_;
+#pragma unroll
+            for (int ks = 0; ks < GB_BK / 32; ++ks) {
+                bf16x8_t a[NFM], b[NFN];
+#pragma unroll
+                for (int i = 0; i < NFM; ++i)
+                    a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(tA + (wm * WM + i * 16 + fr) * GB_LDR + ks * 32 + fk));
+#pragma unroll
+                for (int j = 0; j < NFN; ++j)
+                    b[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(tB + (wn * WN + j * 16 + fr) * GB_LDR + ks * 32 + fk));
+#pragma unroll
+                for (int i = 0; i < NFM; ++i)
+#pragma unroll
+                    for (int j = 0; j < NFN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
     u32x4g_t ca[BM / 32], cb[BN / 32];     // tile t+1 (landed or landing)
     u32x4g_t na[BM / 32], nb[BN / 32];     // tile t+2 (being fetched)
 #pragma unroll
     for (int i = 0; i < BM / 32; ++i) na[i] = (u32x4g_t){0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i) nb[i] = (u32x4g_t){0u, 0u, 0u, 0u};
-    if (nt > 0) {
+    if (NTS == 0 && nt > 0) {
         g16_load<BM>(p.A, p.lda, m0, p.M, kt_begin * GB_BK, p.K, ca);
         g16_load<BN>(p.B, p.ldb, n0, p.N, kt_begin * GB_BK, p.K, cb);
         g16_stage<BM>(sA(0), ca);
@@ -373,12 +411,12 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
     }
 }
 
-template <int BM, int BN, bool EX = false>
+template <int BM, int BN, bool EX = false, int NTS = 0>
 static int launch_gemm16(const Gemm16Args& p, hipStream_t stream) {
-    constexpr int smem = 2 * (BM + BN) * GB_LDR * (int)sizeof(unsigned short);
+    constexpr int smem = (NTS > 0 ? NTS : 2) * (BM + BN) * GB_LDR * (int)sizeof(unsigned short);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16nt_kernel<BM, BN, EX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16nt_kernel<BM, BN, EX, NTS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -394,7 +432,7 @@ static int launch_gemm16(const Gemm16Args& p, hipStream_t stream) {
     if (q.xcd_bind == 1) tiles = 8 * ((tiles_m + 7) / 8) * tiles_n;
     if (q.xcd_bind == 2) tiles = 8 * ((tiles_n + 7) / 8) * tiles_m;
     dim3 grid(tiles, 1, p.splitk);
-    hipLaunchKernelGGL((gemm_bf16nt_kernel<BM, BN, EX>), grid, dim3(256), smem, stream, q);
+    hipLaunchKernelGGL((gemm_bf16nt_kernel<BM, BN, EX, NTS>), grid, dim3(256), smem, stream, q);
     SPE_CHECK_LAUNCH();
     return 0;
 }
@@ -427,6 +465,9 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const
     if (t128 >= 384 && N > 64) return launch_gemm16<128, 128>(p, stream);
     const long t64n = (long)((M + 127) / 128) * ((N + 63) / 64) * splitk;
     if (t64n >= 256 && M > 64) return launch_gemm16<128, 64>(p, stream);
+    // decoder-size problems (few workgroups, short contraction): every K tile in flight at once
+    if (splitk == 1 && ktiles <= 6) return launch_gemm16<64, 64, false, 6>(p, stream);
+    if (splitk == 1 && ktiles == 7) return launch_gemm16<64, 64, false, 7>(p, stream);
     return launch_gemm16<64, 64>(p, stream);
 }
 
