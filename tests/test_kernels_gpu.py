@@ -471,7 +471,8 @@ def test_grad_buffer_direct_placement(dev):
         K.set_precision("bf16")
 
 
-@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (300, 384, 384), (8300, 1536, 384), (8300, 384, 1536), (77, 136, 4152), (65, 72, 8), (1000, 64, 200)])
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (300, 384, 384), (8300, 1536, 384), (8300, 384, 1536), (77, 136, 4152), (65, 72, 8), (1000, 64, 200),
+                                    (384, 384, 448), (400, 2048, 384), (91, 40, 392), (200, 384, 512)])
 def test_gemm_bf16nt(dev, M, N, K_):
     """bf16-operand NT GEMM: exact products of the bf16-rounded operands (fp32 accumulate) + epilogues + slabs."""
     from spe_amd import kernels as K
