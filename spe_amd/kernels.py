@@ -128,7 +128,9 @@ def auto_splitk(M, N, K, batch):
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
     if tiles >= 256 or K < 1024:
         return 1
-    return max(1, min((512 + tiles - 1) // tiles, K // 512, 16))
+    # tiles * splits must FIT the 512 resident workgroup slots (2 per CU): 36 tiles x 15 = 540 leaves 28 workgroups for a
+    # second, nearly empty round (fc1 / fc2 dW: 29 -> 24 us with 14 splits)
+    return max(1, min(512 // tiles, K // 512, 16))
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, C2=None,

@@ -57,7 +57,7 @@ def main():
       run("dec proj NT", 200, 384, 384, False, True)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("bf16nt", "epi")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("bf16nt", "epi", "dw")):
     main()
 
 
@@ -132,3 +132,14 @@ def main_epi():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "epi":
     main_epi()
+
+
+def main_dw():
+    """Split-K factor of the fc dW GEMMs: 36 output tiles x splits against the 512 resident workgroup slots."""
+    for M, N in ((1536, 384), (384, 1536), (1152, 384), (384, 384)):
+        for sk in (8, 10, 12, 13, 14, 15, 16):
+            run16("dW %dx%d" % (M, N), M, N, 8320, splitk=-sk)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "dw":
+    main_dw()
