@@ -15,6 +15,7 @@
 // Block = 256 threads = 4 waves (2x2); block tile BM x BN x 64 (BM, BN in {128, 64}); v_mfma_f32_16x16x32_bf16.
 // Pipeline per workgroup: tile t is multiplied out of LDS buffer t&1 while tile t+1 waits in registers and tile
 // t+2 is being fetched (16-B loads of 8 elements, no conversion work).
+#include <cstdlib>
 #include "common.h"
 
 #define GB_BK 64
@@ -460,6 +461,12 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const
     p.kt_per_split = (ktiles + splitk - 1) / splitk;
     p.splitk = splitk;
     if (splitk > 1 && (act != 0 || C2 != nullptr || bias != nullptr)) return -3;
+    {   // developer knob (tools/bench_gemm.py): SPE_GEMM16_TILE = 1 / 2 / 3 forces 128x128 / 128x64 / 64x64
+        static const int forced = getenv("SPE_GEMM16_TILE") ? atoi(getenv("SPE_GEMM16_TILE")) : 0;
+        if (forced == 1) return launch_gemm16<128, 128>(p, stream);
+        if (forced == 2) return launch_gemm16<128, 64>(p, stream);
+        if (forced == 3) return launch_gemm16<64, 64>(p, stream);
+    }
     // tile: 128x128 when that already fills the chip, else narrower tiles (more workgroups in flight)
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splitk;
     if (t128 >= 384 && N > 64) return launch_gemm16<128, 128>(p, stream);
