@@ -375,7 +375,22 @@ def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, 
     return dx, dW1, db1, dW2, db2
 
 
-def linear_fwd(x2, W, b, act=0, want_pre=False, save_for_dw=True):
+def act16(x2, wantT, src=None):
+    """bf16 copies (row-major, and transposed when wantT) of an activation [R,K].  `src`: the tensor object the caller
+    holds (x2 is a reshape of it) - the copies are remembered ON that object (attribute, checked against its version
+    counter), so an activation that feeds several Linears (the decoder's memory, positional embedding, tgt, query_pos;
+    q / k / v of the class attention) is converted once; they die with the tensor."""
+    if src is not None:
+        ent = getattr(src, "_spe16", None)
+        if ent is not None and ent[0] == src._version and ent[1].shape == x2.shape and (ent[2] is not None or not wantT):
+            return ent[1], ent[2]
+    x16, x16T = cvt_bf16(x2, True, wantT)
+    if src is not None:
+        src._spe16 = (src._version, x16, x16T)
+    return x16, x16T
+
+
+def linear_fwd(x2, W, b, act=0, want_pre=False, save_for_dw=True, src=None):
     """y = act(x2 @ W.T + b); x2 [R,K] contiguous, W [N,K].  -> (y, pre-activation or None, xsave): xsave is what
     linear_bwd needs of x - x2 itself, or on the bf16 path the padded bf16 transpose x16T [K, Rp]."""
     _chk(x2, W, b)
@@ -384,7 +399,7 @@ def linear_fwd(x2, W, b, act=0, want_pre=False, save_for_dw=True):
     y = torch.empty((R, N), device=x2.device, dtype=torch.float32)
     pre = torch.empty_like(y) if want_pre else None
     if _lin16_ok(R, N, K) and W.is_contiguous():
-        x16, x16T = cvt_bf16(x2, True, save_for_dw)
+        x16, x16T = act16(x2, save_for_dw, src)
         gemm16(x16, weight16(W)[0], y, R, N, K, K, K, N, bias=b, C2=pre, act=act)
         return y, pre, (x16T if save_for_dw else x2)
     gemm(x2, W, y, R, N, K, K, K, N, False, True, bias=b, C2=pre, act=act)

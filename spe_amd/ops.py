@@ -24,7 +24,7 @@ class _Linear(Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         Wc = W if W.is_contiguous() else W.contiguous()
-        y, pre, xsave = K.linear_fwd(x2, Wc, b, act, want_pre=(act == ACT_GELU), save_for_dw=ctx.needs_input_grad[1])
+        y, pre, xsave = K.linear_fwd(x2, Wc, b, act, want_pre=(act == ACT_GELU), save_for_dw=ctx.needs_input_grad[1], src=x)
         aux = pre if act == ACT_GELU else (y if act == ACT_RELU else None)
         ctx.act = act
         ctx.has_bias = b is not None
