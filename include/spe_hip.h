@@ -155,7 +155,10 @@ int spe_talking_wgrad_reduce(const float* ws_w, int nwg, int H, float* dWl, floa
  *   trans = 1: out[b, key, h, :] = alpha * sum_q   T[b,h][q,key] x[b, q, h, :]     (dV, dK of the same autograd)
  * X16 = spe_attn_pack16(x): bf16 [B,H,nt,ceil(dh/16)][64][4] = x[b, tile*16+4*(lane>>4)+i, h, dtile*16+(lane&15)]
  * (x element strides sb, sn, sh; 0 outside).  out element strides ob (batch), on (row), oh (head), unit d stride.
- * Head dim <= 64, returns -2 otherwise. */
+ * Head dim <= 64, returns -2 otherwise.  ws / counters (optional, both or neither): ws_floats floats of scratch and zero-
+ * initialised 32-bit counters (at least B*H*2; left zero again by every launch) that let the launcher cut the groups of
+ * output tiles beyond the last full round of resident workgroups into quarters of the contraction range, combined by the
+ * last arriver in fixed order - without them every group is one workgroup.  One workspace serves all launches of a stream. */
 int spe_attn_pack16(const float* x, long sb, long sn, long sh, int B, int N, int H, int dh, void* out, spe_stream_t stream);
 /* njobs <= 6 packs of [B,Ns[i],H,dhs[i]] views in one launch: job i reads xs[i] (element strides strides[3i..3i+2] =
  * batch, row, head), multiplies by scales[i] and writes the spe_attn_pack (kinds[i] = 0), spe_attn_pack16 (1) or
@@ -163,7 +166,7 @@ int spe_attn_pack16(const float* x, long sb, long sn, long sh, int B, int N, int
 int spe_attn_pack_multi(int njobs, const float* const* xs, const long* strides, const float* scales, const int* kinds,
                         void* const* outs, const int* Ns, const int* dhs, int B, int H, spe_stream_t stream);
 int spe_attn_contract(const void* T, const void* X16, float* out, long ob, long on, long oh, int B, int H, int N, int dh,
-                      int trans, float alpha, spe_stream_t stream);
+                      int trans, float alpha, float* ws, unsigned int* counters, long ws_floats, spe_stream_t stream);
 
 /* ---- out[c] += sum_r in[r*ld + c] (bias gradients; autograd of nn.Linear bias). */
 int spe_colsum(const float* in, float* out, long R, int C, long ld, spe_stream_t stream);

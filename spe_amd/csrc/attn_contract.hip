@@ -35,12 +35,25 @@ typedef __bf16 bf16x4c_t __attribute__((ext_vector_type(4)));
 template <int DT, bool TRANS>
 __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restrict__ T, const uint2* __restrict__ X,
                                                             float* __restrict__ out, long ob, long on, long oh,
-                                                            int H, int N, int nt, int dh, int ngrp, float alpha) {
+                                                            int H, int N, int nt, int dh, int ngrp, float alpha,
+                                                            int bhn, int nfull, float* ws, unsigned* counters) {
     constexpr int R = CONTRACT_R;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4_t* red = reinterpret_cast<f32x4_t*>(smem_raw);          // [2 waves][R][DT][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int grp = blockIdx.x % ngrp, bh = blockIdx.x / ngrp;
+    // Workgroups [0, bhn*nfull): one group of R output tiles over the whole contraction range.  The ngrp - nfull
+    // left-over groups per (b, h) come LAST in the grid, each as 4 workgroups over a quarter of the range: they start
+    // when the first full workgroups retire and run alone, so their length is the tail of the launch (see the launcher).
+    int grp, bh, quarter = -1;
+    if ((int)blockIdx.x < bhn * nfull) { grp = blockIdx.x % nfull; bh = blockIdx.x / nfull; }
+    else {
+        int li = blockIdx.x - bhn * nfull;
+        quarter = li & 3; li >>= 2;
+        const int nlo = ngrp - nfull;
+        grp = nfull + li % nlo; bh = li / nlo;
+    }
+    const int clen = (nt + 3) / 4;
+    const int cbeg = quarter < 0 ? 0 : quarter * clen, cend = quarter < 0 ? nt : min(nt, cbeg + clen);
     const int t0 = grp * R;
     const uint2* Tb = T + (long)bh * nt * nt * 64;
     const uint2* Xb = X + (long)bh * nt * DT * 64;
@@ -73,13 +86,13 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
     // hipcc drains vmcnt(0) at the head of a loop whose loads are carried across the back edge, so a register ring
     // gives no overlap; instead every iteration requests PD steps at once and then consumes them in order (the
     // waits inside the straight-line body are exact: vmcnt(7*(PD-1)), ..., vmcnt(0)).
-    for (int c0 = wave; c0 < nt; c0 += 4 * PD) {
+    for (int c0 = cbeg + wave; c0 < cend; c0 += 4 * PD) {
 #pragma unroll
         for (int s = 0; s < PD; ++s) LOAD_STEP(c0 + 4 * s, tb[s], xf[s]);
 #pragma unroll
         for (int s = 0; s < PD; ++s) {
             const int c = c0 + 4 * s;
-            if (c < nt) {
+            if (c < cend) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     s16x4_t bt;
@@ -123,6 +136,40 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
             for (int d = 0; d < DT; ++d) red[(r * DT + d) * 64 + lane] = acc[r][d];
     }
     __syncthreads();
+    if (wave == 0 && quarter >= 0) {
+        // ---- quarter of a left-over group: publish the partial tiles; the workgroup that arrives last adds the four
+        // partials in fixed order and writes the rows (device-scope fences: the quarters run on different XCDs)
+        const int slot = bh * (ngrp - nfull) + (grp - nfull);
+        float* wsp = ws + ((long)slot * 4 + quarter) * (R * DT * 256);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                acc[r][d] += red[(r * DT + d) * 64 + lane];
+                *reinterpret_cast<f32x4_t*>(wsp + ((r * DT + d) * 64 + lane) * 4) = acc[r][d];
+            }
+        __threadfence();
+        unsigned old = 0;
+        if (lane == 0) old = atomicAdd(counters + slot, 1u);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != 3u) return;
+        __threadfence();
+        const float* w0 = ws + (long)slot * 4 * (R * DT * 256);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const int o = ((r * DT + d) * 64 + lane) * 4;
+                // plain loads: the fence above orders them after the counter (volatile ones would be issued one by one)
+                f32x4_t v = *reinterpret_cast<const f32x4_t*>(w0 + o);
+                v += *reinterpret_cast<const f32x4_t*>(w0 + 1 * (R * DT * 256) + o);
+                v += *reinterpret_cast<const f32x4_t*>(w0 + 2 * (R * DT * 256) + o);
+                v += *reinterpret_cast<const f32x4_t*>(w0 + 3 * (R * DT * 256) + o);
+                acc[r][d] = v;
+                red[(r * DT + d) * 64 + lane] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            }
+        if (lane == 0) counters[slot] = 0u;            // ready for the next launch on this stream
+    }
     if (wave == 0) {
         const int b = bh / H, h = bh % H;
 #pragma unroll
@@ -242,27 +289,43 @@ extern "C" int spe_attn_pack_multi(int njobs, const float* const* xs, const long
     return 0;
 }
 
+// The launch lasts as long as its most loaded CU (a CU streams ~19 GB/s of blocks whatever its resident waves), and
+// workgroups beyond the resident slots run alone after the rest, latency-bound: 1040 workgroups on 1024 slots cost
+// 0.136 ms against 0.117 ms for the first 1024 (cfg2).  With a workspace the groups beyond the last full round are
+// therefore split into quarters of the contraction range (4x shorter) and combined by the last arriver.
 template <int DT, bool TRANS>
 static int launch_contract(const void* T, const void* X, float* out, long ob, long on, long oh, int B, int H, int N, int nt, int dh,
-                           float alpha, hipStream_t st) {
+                           float alpha, float* ws, unsigned* counters, long ws_floats, hipStream_t st) {
     const int ngrp = (nt + CONTRACT_R - 1) / CONTRACT_R;
+    const long bhn = (long)B * H, full = bhn * ngrp;
+    int nlo = 0;
+    if (ws && counters && full > 1024) {
+        const long over = full - (full / 1024) * 1024;                     // workgroups past the last full round
+        const long l = (over + bhn - 1) / bhn;
+        if (over > 0 && l <= 2 && l < ngrp && bhn * l * 4 <= 256 && bhn * l * 4 * (CONTRACT_R * DT * 256) <= ws_floats) nlo = (int)l;
+    }
+    const int nfull = ngrp - nlo;
     const int smem = 2 * CONTRACT_R * DT * 64 * 16;
-    hipLaunchKernelGGL((attn_contract_kernel<DT, TRANS>), dim3((unsigned)((long)B * H * ngrp)), dim3(256), smem, st,
-                       reinterpret_cast<const uint2*>(T), reinterpret_cast<const uint2*>(X), out, ob, on, oh, H, N, nt, dh, ngrp, alpha);
+    hipLaunchKernelGGL((attn_contract_kernel<DT, TRANS>), dim3((unsigned)(bhn * nfull + bhn * nlo * 4)), dim3(256), smem, st,
+                       reinterpret_cast<const uint2*>(T), reinterpret_cast<const uint2*>(X), out, ob, on, oh, H, N, nt, dh, ngrp, alpha,
+                       (int)bhn, nfull, ws, counters);
     SPE_CHECK_LAUNCH();
     return 0;
 }
 
 // C-ABI: see include/spe_hip.h (spe_attn_contract).  Returns -2 for head dims above 64.
 extern "C" int spe_attn_contract(const void* T, const void* X16, float* out, long ob, long on, long oh, int B, int H, int N, int dh,
-                                 int trans, float alpha, hipStream_t st) {
+                                 int trans, float alpha, float* ws, unsigned int* counters, long ws_floats, hipStream_t st) {
     const int nt = (N + 15) / 16, DT = (dh + 15) / 16;
     if (B <= 0 || H <= 0 || N <= 0) return 0;
+#define SPE_CONTRACT_CASE(D) case D: return trans ? launch_contract<D, true>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, ws, counters, ws_floats, st) \
+                                                  : launch_contract<D, false>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, ws, counters, ws_floats, st);
     switch (DT) {
-        case 1: return trans ? launch_contract<1, true>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st) : launch_contract<1, false>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st);
-        case 2: return trans ? launch_contract<2, true>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st) : launch_contract<2, false>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st);
-        case 3: return trans ? launch_contract<3, true>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st) : launch_contract<3, false>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st);
-        case 4: return trans ? launch_contract<4, true>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st) : launch_contract<4, false>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, st);
+        SPE_CONTRACT_CASE(1)
+        SPE_CONTRACT_CASE(2)
+        SPE_CONTRACT_CASE(3)
+        SPE_CONTRACT_CASE(4)
     }
+#undef SPE_CONTRACT_CASE
     return -2;
 }

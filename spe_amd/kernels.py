@@ -756,13 +756,26 @@ def mha_bwd(Qf, Kf, Vf, dOf, K16, Q16, dO16, mask_u8, lse, D, keep, B, H, Lq, Lk
     return dq, dk_, dv_
 
 
+_CONTRACT_WS = {}      # device -> (scratch floats, zeroed counters) shared by every contraction launch of the stream
+
+
+def _contract_ws(device):
+    ent = _CONTRACT_WS.get(device)
+    if ent is None:
+        ent = (torch.empty(256 * 4 * 4 * 256, device=device, dtype=torch.float32),       # 256 quarter workgroups x R*DT*256 floats (DT <= 4)
+               torch.zeros(1024, device=device, dtype=torch.int32))
+        _CONTRACT_WS[device] = ent
+    return ent
+
+
 def attn_contract(T, X16, out4, trans, alpha=1.0):
     """out4[b, row, h, :] = alpha * sum T[b,h][q,key] x[.., :]  (trans=False: rows = q, sum over keys; True: rows = keys,
     sum over q).  out4: [B,N,H,dh] fp32 view with unit last stride."""
     B, N, H, dh = out4.shape
     assert out4.stride(3) == 1
+    ws, cnt = _contract_ws(out4.device)
     _call("spe_attn_contract", _p(T), _p(X16), _p(out4), out4.stride(0), out4.stride(1), out4.stride(2), B, H, N, dh,
-          int(trans), float(alpha), _st())
+          int(trans), float(alpha), _p(ws), _p(cnt), ws.numel(), _st())
     return out4
 
 

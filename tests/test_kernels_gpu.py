@@ -623,6 +623,39 @@ def test_fused_mlp_residual_matches_composite(dev):
     assert rel(o2, ops.layerscale_residual(xr, ops.mlp_gelu(xn, W1, b1, W2, b2), gamma, ss)) < 1e-6
 
 
+@pytest.mark.parametrize("B,H,N,dh", [(2, 8, 4150, 48), (1, 8, 8200, 48), (2, 4, 300, 32), (3, 8, 2100, 64)])
+def test_attn_contract_blocked_scores(dev, B, H, N, dh):
+    """Streaming contractions of a blocked bf16 score tensor against a dense fp64 product, both orientations; the first two
+    shapes put a few groups of output tiles past the last full round of workgroups (cut into quarters of the contraction
+    range and combined by the last arriver), launched repeatedly to check that the counters are left clean."""
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(B * N + dh)
+    torch.manual_seed(B * N + dh)
+    nt = (N + 15) // 16
+    T = K.score_blocks(B, H, N, dev)
+    T.normal_(0.0, 0.5)
+    x = torch.randn(B, N, H, dh, generator=g).to(dev)
+    X16 = K.attn_pack16(x)
+    # dense [B,H,q,key] from the blocks: lane l of block (qt,kt) = query qt*16+(l&15), keys kt*16+4*(l>>4)+i
+    blk = T.view(B, H, nt, nt, 4, 16, 4)
+    dense = blk.permute(0, 1, 2, 5, 3, 4, 6).reshape(B, H, nt * 16, nt * 16)[:, :, :N, :N]
+    xb = x.to(torch.bfloat16)
+    for trans in (False, True):
+        ref = torch.empty(B, N, H, dh, device=dev)
+        for b in range(B):                                  # per batch element: bounded fp32 temporaries
+            d = dense[b].float()
+            ref[b] = torch.einsum("hkq,khd->qhd" if trans else "hqk,khd->qhd", d, xb[b].float()) * 0.37
+        for rep in range(3):
+            out = torch.full((B, N, H, dh), float("nan"), device=dev)
+            K.attn_contract(T, X16, out, trans, alpha=0.37)
+            assert rel(out, ref) < 2e-5, (trans, rep, rel(out, ref))
+        # a different shape in between must not disturb the shared workspace
+        T2 = K.score_blocks(1, H, 100, dev); T2.zero_()
+        o2 = torch.full((1, 100, H, dh), float("nan"), device=dev)
+        K.attn_contract(T2, K.attn_pack16(x[:1, :100].contiguous()), o2, trans)
+        assert float(o2.abs().max()) == 0.0
+
+
 def test_linear_bf16_path_matches_fp32_operand_path(dev):
     """ops.linear on the bf16-copy GEMMs == the fp32-operand kernel in bf16 mode (same roundings), fwd and bwd."""
     from spe_amd import kernels as K
