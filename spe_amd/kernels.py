@@ -306,6 +306,34 @@ def layerscale_residual_bwd16(dout2, y2, gamma, Rp, db_out=None, dg_out=None, wa
     return dy16, dy16T, db, dg
 
 
+def linear_res_fwd(x2, W, b, res, gamma, save=True, src=None):
+    """out = res + gamma * (x2 @ W.T + b) on the bf16-copy GEMM with the residual in its epilogue.  -> (out, (x16T, y))."""
+    R, K = x2.shape
+    N = W.shape[0]
+    dev = x2.device
+    x16, x16T = act16(x2, save, src)
+    out = torch.empty((R, N), device=dev, dtype=torch.float32)
+    y = torch.empty((R, N), device=dev, dtype=torch.float32) if save else None
+    gemm16_ex(x16, weight16(W)[0], R, N, K, K, K, bias=b, C=out, C2=y, res=res, rgamma=gamma)
+    return out, (x16T, y)
+
+
+def linear_res_bwd(dout2, saved, W, gamma, need_dx=True, grad_bufs=(None, None, None)):
+    """Backward of linear_res_fwd: (dx, dW, db, dgamma); gamma * dout only exists as the bf16 operands of the two GEMMs."""
+    x16T, y = saved
+    R, N = dout2.shape
+    K = W.shape[1]
+    Rp = x16T.shape[1]
+    gW, gb, gg = grad_bufs
+    dy16, dy16T, db, dg = layerscale_residual_bwd16(dout2, y, gamma, Rp, db_out=gb, dg_out=gg, want_rowmajor=need_dx)
+    dW = _dw16(dy16T, x16T, N, K, Rp, gW)
+    dx = None
+    if need_dx:
+        dx = torch.empty((R, K), device=dout2.device, dtype=torch.float32)
+        gemm16(dy16, weight16(W)[1], dx, R, K, N, N, N, K)
+    return dx, dW, db, dg
+
+
 def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True):
     """y = fc2(gelu(fc1(x2))) with every intermediate that the next GEMM needs emitted as bf16 by the producing GEMM's
     epilogue: fc1 writes the fp32 pre-activation (for the backward) and the bf16 activation h16 / h16T, never the fp32

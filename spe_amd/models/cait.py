@@ -77,12 +77,15 @@ class Attention_talking_head(nn.Module):
         self.proj_w = nn.Linear(num_heads, num_heads)
         self.proj_drop = Dropout(proj_drop)
 
-    def forward(self, x):
+    def context(self, x):
+        """Attention output before the output projection."""
         qkv = self.qkv(x)
-        o = ops.talking_heads_attention(qkv, self.proj_l.weight, self.proj_l.bias, self.proj_w.weight,
-                                        self.proj_w.bias, self.num_heads, self.scale,
-                                        self.attn_drop if self.training else 0.0)
-        return self.proj_drop(self.proj(o))
+        return ops.talking_heads_attention(qkv, self.proj_l.weight, self.proj_l.bias, self.proj_w.weight,
+                                           self.proj_w.bias, self.num_heads, self.scale,
+                                           self.attn_drop if self.training else 0.0)
+
+    def forward(self, x):
+        return self.proj_drop(self.proj(self.context(x)))
 
 
 class LayerScale_Block(nn.Module):
@@ -101,8 +104,13 @@ class LayerScale_Block(nn.Module):
 
     def forward(self, x):
         B = x.shape[0]
-        x = ops.layerscale_residual(x, self.attn(self.norm1(x)), self.gamma_1,
-                                    ops.drop_path_scale(B, self.drop_path, self.training, x.device))
+        ss1 = ops.drop_path_scale(B, self.drop_path, self.training, x.device)
+        if isinstance(self.attn, Attention_talking_head) and not (self.training and self.attn.proj_drop.p > 0.0):
+            # output projection + LayerScale residual as one node (same arithmetic)
+            x = ops.linear_residual(self.attn.context(self.norm1(x)), self.attn.proj.weight, self.attn.proj.bias, x,
+                                    self.gamma_1, ss1)
+        else:
+            x = ops.layerscale_residual(x, self.attn(self.norm1(x)), self.gamma_1, ss1)
         ss = ops.drop_path_scale(B, self.drop_path, self.training, x.device)
         if isinstance(self.mlp, Mlp) and not (self.training and self.mlp.drop.p > 0.0):
             return ops.mlp_gelu_residual(self.norm2(x), self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight,

@@ -279,6 +279,53 @@ class _MlpGelu(Function):
         return (dx.view(*dy.shape[:-1], W1.shape[1]) if dx is not None else None), dW1, db1, dW2, db2
 
 
+FUSE_LINEAR_RES = __import__("os").environ.get("SPE_FUSE_LINEAR_RES", "1") != "0"
+
+
+class _LinearRes(Function):
+    """xres + gamma * linear(x) - the attention half of the backbone block after the attention itself (reference
+    models/cait.py:390 `proj` inside x + gamma_1 * attn(norm1(x)), :404-405; drop_path = proj_drop = 0) as one node: the
+    LayerScale residual rides on the projection GEMM's epilogue and the backward emits gamma * dout directly as the bf16
+    operands of the projection's gradient GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, xres, gamma):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        r2 = xres.reshape(-1, xres.shape[-1])
+        if not r2.is_contiguous():
+            r2 = r2.contiguous()
+        train = any(ctx.needs_input_grad)
+        out, saved = K.linear_res_fwd(x2, W, b, r2, gamma, save=train, src=x)
+        ctx.params = (W, b, gamma)
+        if train:
+            ctx.save_for_backward(*saved, W, gamma)
+        return out.view(xres.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x16T, y, W, gamma = ctx.saved_tensors
+        d2 = dout.reshape(-1, W.shape[0])
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        bufs = tuple(K.grad_buffer(p) for p in ctx.params)
+        dx, dW, db, dg = K.linear_res_bwd(d2, (x16T, y), W, gamma, ctx.needs_input_grad[0], bufs)
+        return (dx.view(*dout.shape[:-1], W.shape[1]) if dx is not None else None), dW, db, dout, dg.view_as(gamma)
+
+
+def linear_residual(x, W, b, xres, gamma, sample_scale=None):
+    """xres + s * gamma * linear(x): one fused node on the bf16-copy GEMM path without a per-sample DropPath scale, else
+    linear followed by layerscale_residual."""
+    R = x.numel() // x.shape[-1]
+    N, Kd = W.shape
+    if (FUSE_LINEAR_RES and sample_scale is None and b is not None and W.is_contiguous() and gamma.is_contiguous() and N % 4 == 0 and N <= 1024
+            and K._lin16_ok(R, N, Kd)):
+        return _LinearRes.apply(x, W, b, xres, gamma)
+    return layerscale_residual(xres, linear(x, W, b), gamma, sample_scale)
+
+
 class _MlpGeluRes(Function):
     """xres + gamma * fc2(gelu(fc1(x))) - the MLP half of the backbone block after its LayerNorm (reference
     models/cait.py:405-416, drop_path = 0) as one node: _MlpGelu plus the LayerScale residual in the fc2 epilogue, and in

@@ -656,6 +656,31 @@ def test_attn_contract_blocked_scores(dev, B, H, N, dh):
         assert float(o2.abs().max()) == 0.0
 
 
+def test_fused_linear_residual_matches_composite(dev):
+    """ops.linear_residual (projection + LayerScale residual as one node) against layerscale_residual(x, linear(...))."""
+    from spe_amd import kernels as K, ops
+    K.set_precision("bf16")
+    g = torch.Generator().manual_seed(9)
+    R, C = 1100, 384
+    mk = lambda *s, sc=1.0: torch.nn.Parameter((torch.randn(*s, generator=g) * sc).to(dev))
+    W, b, gamma = mk(C, C, sc=0.05), mk(C, sc=0.1), mk(C, sc=0.5)
+    xa = torch.randn(2, R // 2, C, generator=g).to(dev).requires_grad_()
+    xr = torch.randn(2, R // 2, C, generator=g).to(dev).requires_grad_()
+    go = torch.randn(2, R // 2, C, generator=g).to(dev)
+    out = ops.linear_residual(xa, W, b, xr, gamma)
+    assert out.grad_fn.name().startswith("_LinearRes")
+    gr = torch.autograd.grad(out, [xa, xr, W, b, gamma], go)
+    ref = ops.layerscale_residual(xr, ops.linear(xa, W, b), gamma)
+    g0 = torch.autograd.grad(ref, [xa, xr, W, b, gamma], go)
+    assert rel(out, ref) < 1e-6
+    for a, c, nm in zip(gr, g0, ["x", "xres", "W", "b", "gamma"]):
+        assert rel(a, c) < 5e-6, (nm, rel(a, c))
+    with torch.no_grad():
+        assert torch.equal(ops.linear_residual(xa.detach(), W.detach(), b.detach(), xr.detach(), gamma.detach()), out.detach())
+    ss = torch.tensor([1.25, 0.0], device=dev)
+    assert not ops.linear_residual(xa, W, b, xr, gamma, ss).grad_fn.name().startswith("_LinearRes")
+
+
 def test_linear_bf16_path_matches_fp32_operand_path(dev):
     """ops.linear on the bf16-copy GEMMs == the fp32-operand kernel in bf16 mode (same roundings), fwd and bwd."""
     from spe_amd import kernels as K
