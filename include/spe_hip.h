@@ -60,12 +60,14 @@ int spe_gemm_tile(int M, int N, int nbatch);
 
 /* ---- LayerNorm (nn.LayerNorm; reference models/cait.py:403,407 eps 1e-6,
  * models/transformer.py:264-265,342-344 eps 1e-5).  C % 4 == 0, C <= 1024.
- * bwd: dgamma/dbeta are ACCUMULATED into (pre-zeroed or running) buffers. */
+ * bwd: dgamma/dbeta are ACCUMULATED into (pre-zeroed or running) buffers; add (optional, [R][C]; may alias dx) is added to
+ * dx - the gradient arriving over the residual path around the normalised branch (x feeds both: cait.py:404-405), which
+ * autograd would otherwise sum with one more elementwise launch. */
 int spe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                       float* rstd, long R, int C, float eps, spe_stream_t stream);
 int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                       const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,
-                      spe_stream_t stream);
+                      const float* add, spe_stream_t stream);
 
 /* ---- bf16-operand Linear GEMM (benchmark precision mode): C = act(alpha * A16 B16^T + bias), both operands
  * k-contiguous bf16 (lda, ldb, K multiples of 8; 16-B aligned bases), fp32 C / C2 (pre-activation) / bias.

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     long R, int C) {
+                                                     long R, int C, const float* __restrict__ add) {
     extern __shared__ float red_raw[];                 // [2][NW][C + 4]
     const int ldr = C + 4;
     auto red = [&](int k, int wv, int c) -> float& { return red_raw[((long)k * NW + wv) * ldr + c]; };
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict
         s1 = spe_wave_sum(s1) / (float)C;
         s2 = spe_wave_sum(s2) / (float)C;
         float4* dxr = reinterpret_cast<float4*>(dx + row * C);
+        const float4* ar = add ? reinterpret_cast<const float4*>(add + row * C) : nullptr;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + 64 * i;
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict
                 float4 o;
                 o.x = rs * (dg[i].x - s1 - xh[i].x * s2); o.y = rs * (dg[i].y - s1 - xh[i].y * s2);
                 o.z = rs * (dg[i].z - s1 - xh[i].z * s2); o.w = rs * (dg[i].w - s1 - xh[i].w * s2);
+                if (ar) { const float4 a4 = ar[c]; o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w; }   // + gradient of the skip path
                 dxr[c] = o;
             }
         }
@@ -132,7 +134,7 @@ extern "C" int spe_layernorm_fwd(const float* x, const float* gamma, const float
 }
 extern "C" int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                  const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,
-                                 hipStream_t st) {
+                                 const float* add, hipStream_t st) {
     if (R <= 0) return 0;
     if ((C & 3) || C > 256 * LN_MAXV) return -2;
     // 16 waves per workgroup, at most 256 workgroups: every workgroup ends with 2*C atomics on the same addresses, and
@@ -147,7 +149,7 @@ extern "C" int spe_layernorm_bwd(const float* dy, const float* x, const float* g
     }
     long nb = (R + NW - 1) / NW; if (nb > 256) nb = 256;
     hipLaunchKernelGGL(ln_bwd_kernel<NW>, dim3((unsigned)nb), dim3(NW * 64), 2 * NW * (C + 4) * (int)sizeof(float), st, dy, x, gamma, mean,
-                       rstd, dx, dgamma, dbeta, R, C);
+                       rstd, dx, dgamma, dbeta, R, C, add);
     SPE_CHECK_LAUNCH();
     return 0;
 }

@@ -513,13 +513,14 @@ def layernorm_fwd(x2, g, b, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy2, x2, g, mean, rstd, dg_out=None, db_out=None):
+def layernorm_bwd(dy2, x2, g, mean, rstd, dg_out=None, db_out=None, add=None):
+    """add [R,C]: gradient of the skip path around the normalised branch, summed into dx by the same kernel."""
     _chk(dy2, x2, g)
     R, C = x2.shape
     dx = torch.empty_like(x2)
     dg = _zeros_or(dg_out, C, x2.device)
     db = _zeros_or(db_out, C, x2.device)
-    _call("spe_layernorm_bwd", _p(dy2), _p(x2), _p(g), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), R, C, _st())
+    _call("spe_layernorm_bwd", _p(dy2), _p(x2), _p(g), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), R, C, _p(add), _st())
     return dx, dg, db
 
 

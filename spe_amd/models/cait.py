@@ -104,18 +104,22 @@ class LayerScale_Block(nn.Module):
 
     def forward(self, x):
         B = x.shape[0]
+        # norm.skip(x) -> (LN(x), x): the residual operand comes back through the LayerNorm node, whose backward kernel
+        # adds the skip-path gradient to the normalisation's (one launch less per branch than autograd's sum)
+        skip = isinstance(self.norm1, LayerNorm) and isinstance(self.norm2, LayerNorm)
         ss1 = ops.drop_path_scale(B, self.drop_path, self.training, x.device)
+        y, xs = self.norm1.skip(x) if skip else (self.norm1(x), x)
         if isinstance(self.attn, Attention_talking_head) and not (self.training and self.attn.proj_drop.p > 0.0):
             # output projection + LayerScale residual as one node (same arithmetic)
-            x = ops.linear_residual(self.attn.context(self.norm1(x)), self.attn.proj.weight, self.attn.proj.bias, x,
-                                    self.gamma_1, ss1)
+            x = ops.linear_residual(self.attn.context(y), self.attn.proj.weight, self.attn.proj.bias, xs, self.gamma_1, ss1)
         else:
-            x = ops.layerscale_residual(x, self.attn(self.norm1(x)), self.gamma_1, ss1)
+            x = ops.layerscale_residual(xs, self.attn(y), self.gamma_1, ss1)
         ss = ops.drop_path_scale(B, self.drop_path, self.training, x.device)
+        y, xs = self.norm2.skip(x) if skip else (self.norm2(x), x)
         if isinstance(self.mlp, Mlp) and not (self.training and self.mlp.drop.p > 0.0):
-            return ops.mlp_gelu_residual(self.norm2(x), self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight,
-                                         self.mlp.fc2.bias, x, self.gamma_2, ss)
-        return ops.layerscale_residual(x, self.mlp(self.norm2(x)), self.gamma_2, ss)
+            return ops.mlp_gelu_residual(y, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight,
+                                         self.mlp.fc2.bias, xs, self.gamma_2, ss)
+        return ops.layerscale_residual(xs, self.mlp(y), self.gamma_2, ss)
 
 
 class Multi_Class_Attention(nn.Module):

@@ -17,6 +17,10 @@ class LayerNorm(nn.LayerNorm):
     def forward(self, x):
         return ops.layer_norm(x, self.weight, self.bias, self.eps)
 
+    def skip(self, x):
+        """(LN(x), x) for a pre-norm residual branch: pass the second result to the residual add (ops._LayerNormSkip)."""
+        return ops.layer_norm_skip(x, self.weight, self.bias, self.eps)
+
 
 class Dropout(nn.Module):
     """nn.Dropout semantics with a counter-based (Philox) mask regenerated in backward."""

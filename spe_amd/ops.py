@@ -79,6 +79,44 @@ def layer_norm(x, g, b, eps):
     return _LayerNorm.apply(x, g, b, eps)
 
 
+class _LayerNormSkip(Function):
+    """(LN(x), x) for a pre-norm residual branch x + f(LN(x)) (reference models/cait.py:404-405): the second output is x
+    itself, to be used as the residual operand, so that the two gradients of x - through the normalisation and over the
+    skip path - meet in THIS node and are summed inside the LayerNorm backward kernel instead of by an extra autograd add."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        y, mean, rstd = K.layernorm_fwd(x2, g, b, eps)
+        ctx.params = (g, b)
+        ctx.save_for_backward(x2, g, mean, rstd)
+        return y.view(x.shape), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x2, g, mean, rstd = ctx.saved_tensors
+        gp, bp = ctx.params
+        if dy is None:                       # only the skip path was used
+            return dskip, None, None, None
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        add = None
+        if dskip is not None:
+            add = dskip.reshape(-1, dskip.shape[-1])
+            if not add.is_contiguous():
+                add = add.contiguous()
+        dx, dg, db = K.layernorm_bwd(dy2, x2, g, mean, rstd, dg_out=K.grad_buffer(gp), db_out=K.grad_buffer(bp), add=add)
+        return dx.view(dy.shape), dg.view_as(gp), db.view_as(bp), None
+
+
+def layer_norm_skip(x, g, b, eps):
+    """-> (LN(x), x): use the second result as the residual operand of the branch (see _LayerNormSkip)."""
+    return _LayerNormSkip.apply(x, g, b, eps)
+
+
 # ---------------------------------------------------------------------------------------------
 class _LayerScaleResidual(Function):
     """out = x + s_b * gamma * y   (cait.py:413-416; s_b = DropPath keep-scale per sample)."""

@@ -681,6 +681,28 @@ def test_fused_linear_residual_matches_composite(dev):
     assert not ops.linear_residual(xa, W, b, xr, gamma, ss).grad_fn.name().startswith("_LinearRes")
 
 
+def test_layer_norm_skip_sums_both_gradients(dev):
+    """ops.layer_norm_skip returns (LN(x), x); the gradient over the skip result is added inside the LayerNorm backward kernel."""
+    from spe_amd import ops
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(3, 50, 384, generator=g).to(dev).requires_grad_()
+    w = (1 + 0.1 * torch.randn(384, generator=g)).to(dev).requires_grad_(); b = (0.1 * torch.randn(384, generator=g)).to(dev).requires_grad_()
+    u = torch.randn(3, 50, 384, generator=g).to(dev); v = torch.randn(3, 50, 384, generator=g).to(dev)
+    y, xs = ops.layer_norm_skip(x, w, b, 1e-6)
+    assert torch.equal(xs, x) and torch.equal(y, ops.layer_norm(x, w, b, 1e-6))
+    gr = torch.autograd.grad((y * u).sum() + (xs * v).sum(), (x, w, b))
+    xd = x.detach().double().requires_grad_(); wd = w.detach().double().requires_grad_(); bd = b.detach().double().requires_grad_()
+    ref = torch.nn.functional.layer_norm(xd, (384,), wd, bd, 1e-6)
+    g0 = torch.autograd.grad((ref * u.double()).sum() + (xd * v.double()).sum(), (xd, wd, bd))
+    for a, c in zip(gr, g0):
+        assert rel(a, c) < 1e-5
+    # only one of the two results used
+    y, xs = ops.layer_norm_skip(x, w, b, 1e-6)
+    assert rel(torch.autograd.grad((xs * v).sum(), x)[0], v) < 1e-7
+    y, xs = ops.layer_norm_skip(x, w, b, 1e-6)
+    assert rel(torch.autograd.grad((y * u).sum(), x)[0], torch.autograd.grad((ops.layer_norm(x, w, b, 1e-6) * u).sum(), x)[0]) < 1e-6
+
+
 def test_linear_bf16_path_matches_fp32_operand_path(dev):
     """ops.linear on the bf16-copy GEMMs == the fp32-operand kernel in bf16 mode (same roundings), fwd and bwd."""
     from spe_amd import kernels as K
