@@ -334,7 +334,7 @@ def linear_res_bwd(dout2, saved, W, gamma, need_dx=True, grad_bufs=(None, None, 
     return dx, dW, db, dg
 
 
-def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True):
+def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True, src=None):
     """y = fc2(gelu(fc1(x2))) with every intermediate that the next GEMM needs emitted as bf16 by the producing GEMM's
     epilogue: fc1 writes the fp32 pre-activation (for the backward) and the bf16 activation h16 / h16T, never the fp32
     activation.  -> (y [R,N] fp32, saved = (x16T, pre, h16T))."""
@@ -342,7 +342,7 @@ def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True):
     Hd, N = W1.shape[0], W2.shape[0]
     dev = x2.device
     # save = False (no gradient wanted: inference): none of the tensors that only the backward reads is produced
-    x16, x16T = cvt_bf16(x2, True, save)
+    x16, x16T = act16(x2, save, src)
     Rp = ((R + 63) // 64) * 64
     pre = torch.empty((R, Hd), device=dev, dtype=torch.float32) if save else None
     h16 = torch.empty((R, Hd), device=dev, dtype=torch.bfloat16)

@@ -90,9 +90,10 @@ class _LayerNormSkip(Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         y, mean, rstd = K.layernorm_fwd(x2, g, b, eps)
+        yv = y.view(x.shape)
         ctx.params = (g, b)
         ctx.save_for_backward(x2, g, mean, rstd)
-        return y.view(x.shape), x.view_as(x)
+        return yv, x.view_as(x)
 
     @staticmethod
     def backward(ctx, dy, dskip):
@@ -300,7 +301,7 @@ class _MlpGelu(Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         train = any(ctx.needs_input_grad)
-        y, saved = K.mlp_gelu_fwd(x2, W1, b1, W2, b2, save=train)
+        y, saved = K.mlp_gelu_fwd(x2, W1, b1, W2, b2, save=train, src=x)
         ctx.params = (W1, b1, W2, b2)
         if train:
             ctx.save_for_backward(*saved, W1, W2)
@@ -379,7 +380,7 @@ class _MlpGeluRes(Function):
         if not r2.is_contiguous():
             r2 = r2.contiguous()
         train = any(ctx.needs_input_grad)
-        out, saved = K.mlp_gelu_fwd(x2, W1, b1, W2, b2, res=r2, gamma=gamma, save=train)
+        out, saved = K.mlp_gelu_fwd(x2, W1, b1, W2, b2, res=r2, gamma=gamma, save=train, src=x)
         ctx.params = (W1, b1, W2, b2, gamma)
         if train:
             ctx.save_for_backward(*saved, W1, W2, gamma)
