@@ -256,7 +256,7 @@ def main():
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": loss_val},
             "roofline": {"bound": "mfma", "kernel": "talking_fused_kernel<8,2,3> (attention backward pass 2)", "launches": launches,
                          "avg_ms": mean_ms, "achieved": ach, "peak": 2500.0, "peak_measured": 1240.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
-                         "traffic": 1.54e9,   # bytes/launch, profiles/r01_pmc_fetch_write_v2.txt (2*FETCH_SIZE + WRITE_SIZE)
+                         "traffic": 9.95e8,   # bytes/launch, profiles/r01_pmc_fetch_write_v3.txt (2*FETCH_SIZE + WRITE_SIZE)
                          "note": "not MFMA-bound: fp32 head mixes (no MFMA form), fragment loads and MFMA phases serialise at 2 waves/SIMD", "valu_achieved": valu, "valu_peak": 157.3,
                          "valu_frac": valu / 157.3,
                          "hbm_kernel": {"bound": "hbm", "kernel": "attn_contract_kernel<3,*> (PV / dV / dQ / dK over blocked bf16 scores)",
