@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha + bv[r];
                 if (p.C2 && rowv) {
-                    if (full) *reinterpret_cast<float4*>(p.C2 + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (full) spe_store4_stream(p.C2 + off, v[0], v[1], v[2], v[3]);
                     else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) if (n + r < p.N) p.C2[(long)m * p.ldc + n + r] = v[r];
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = xr[r] + gv[r] * v[r];
                     }
-                    if (full) *reinterpret_cast<float4*>(p.C + off) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (full) spe_store4_stream(p.C + off, o[0], o[1], o[2], o[3]);
                     else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) if (n + r < p.N) p.C[(long)m * p.ldc + n + r] = o[r];
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
                 if (m >= p.M || n >= p.N) continue;
                 const u32x4g_t q = *reinterpret_cast<const u32x4g_t*>(sR + ml * LR + ch * 8);
                 unsigned short* dst = p.out16 + (long)m * p.ld16 + n;
-                if (n + 7 < p.N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<u32x4g_t*>(dst) = q;
+                if (n + 7 < p.N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) spe_store16_stream(dst, q);
                 else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) if (n + e < p.N) dst[e] = sR[ml * LR + ch * 8 + e];
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
                 if (n >= p.N || m >= p.ld16t) continue;
                 const u32x4g_t q = *reinterpret_cast<const u32x4g_t*>(sT + nl * LT + ch * 8);
                 unsigned short* dst = p.out16T + (long)n * p.ld16t + m;
-                if (m + 7 < p.ld16t && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) *reinterpret_cast<u32x4g_t*>(dst) = q;
+                if (m + 7 < p.ld16t && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) spe_store16_stream(dst, q);
                 else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) if (m + e < p.ld16t) dst[e] = sT[nl * LT + ch * 8 + e];
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += bv[r];
                 if (C2) {
-                    if (full) *reinterpret_cast<float4*>(C2 + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (full) spe_store4_stream(C2 + off, v[0], v[1], v[2], v[3]);
                     else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) if (n + r < p.N) C2[off + r] = v[r];
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
                 }
             }
             // split-K: the private slab of this split (zeros if the split was empty), summed by the caller
-            if (full) *reinterpret_cast<float4*>(C + off) = make_float4(v[0], v[1], v[2], v[3]);
+            if (full) spe_store4_stream(C + off, v[0], v[1], v[2], v[3]);
             else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (n + r < p.N) C[off + r] = v[r];
