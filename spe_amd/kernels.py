@@ -104,11 +104,18 @@ def _zeros_or(buf, n, device):
 
 
 def _p(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    # a plain int: ctypes converts it for a c_void_p argtype itself (no Python-side c_void_p object per argument)
+    return None if t is None else t.data_ptr()
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def _st():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Current HIP stream handle of the current device (the raw-handle query skips building a torch.cuda.Stream object)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _chk(*ts):

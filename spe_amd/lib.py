@@ -66,8 +66,14 @@ def load():
     return lib
 
 
+_fn = {}
+
+
 def call(name, *args):
     """Invoke an entry point; raise on a non-zero status."""
-    rc = getattr(load(), name)(*args)
+    f = _fn.get(name)
+    if f is None:
+        f = _fn[name] = getattr(load(), name)
+    rc = f(*args)
     if rc != 0:
         raise SpeLibraryError(f"{name} failed with status {rc}")

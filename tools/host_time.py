@@ -1,0 +1,54 @@
+"""Host time to ENQUEUE one cfg2 training step (no synchronisation inside the loop) against the GPU time of the step: the
+margin by which the host stays ahead of the GPU.  Run on the GPU box."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from spe_amd import kernels as K, lib
+from spe_amd.dp import GradAllReducer
+from spe_amd.optim import FlatAdamW
+from spe_amd.models import build_model
+from spe_amd.util.misc import NestedTensor
+
+dev = torch.device("cuda", 0)
+lib.load(); K.set_precision("bf16"); K.manual_seed(1234)
+args = bench.model_args()
+torch.manual_seed(0)
+model, crit, crit_r, pp, rpp = build_model(args)
+model.to(dev).train(); crit.to(dev).train(); crit_r.to(dev).train()
+params = [p for p in model.parameters() if p.requires_grad]
+reducer = GradAllReducer(params, flatten_params=True)
+opt = FlatAdamW(params, reducer, lr=1e-4, weight_decay=1e-4, max_grad_norm=0.1)
+img, mask, targets = bench.synth_batch(1234, dev)
+samples = NestedTensor(img, mask)
+
+
+def step():
+    reducer.reset()
+    out = model(samples)
+    l0 = crit(out[0], targets)
+    with torch.no_grad():
+        ps = bench.pseudo_labels(rpp, out[0], targets)
+    l1 = crit_r(out[1], ps)
+    bench.weighted_total(l0, l1, crit.weight_dict).backward()
+    reducer.finish(); opt.step()
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+n = 10
+t0 = time.perf_counter()
+for _ in range(n):
+    step()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("host enqueue %.1f ms/step ; wall %.1f ms/step (GPU-bound when the second is larger)" % ((t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3))
+# host-only cost: the same loop while the GPU queue is allowed to run dry between steps
+hs = []
+for _ in range(5):
+    torch.cuda.synchronize()
+    a = time.perf_counter(); step(); hs.append(time.perf_counter() - a)
+torch.cuda.synchronize()
+print("host enqueue with an empty queue: %.1f ms/step" % (sum(hs) / len(hs) * 1e3))
