@@ -181,12 +181,15 @@ class TransformerDecoder(nn.Module):
         output = tgt
         reference_points = self.ref_point_head(query_pos).sigmoid()            # [B,RQ,2]
         intermediate = []
+        # the reference points do not change from layer to layer (transformer.py:187-193 recomputes the embedding in every
+        # layer): one evaluation, ~25 small launches of sin / cos / stack / cat and their backward saved per further layer
+        sine0 = gen_sineembed_for_position(reference_points[..., :2], self.d_model)
         for layer_id, layer in enumerate(self.layers):
             if layer_id not in mem_cache:
                 mem_cache[layer_id] = layer.memory_side(memory, pos, layer_id == 0)
-            sine = gen_sineembed_for_position(reference_points[..., :2], self.d_model)
+            sine = sine0
             if layer_id > 0:
-                sine = sine * self.query_scale(output)
+                sine = sine0 * self.query_scale(output)
             output = layer(output, mem_cache[layer_id], memory_key_padding_mask, query_pos, sine, layer_id == 0,
                            n_stages=n_stages)
             intermediate.append(self.norm(output))
