@@ -113,29 +113,39 @@ class _BoxLoss(Function):
 def jitter_targets(targets, ratio, jitter):
     """One-to-many targets (conditional_detr.py:409-431): each GT box -> `ratio` rows: up to ratio-1
     multiplicatively jittered copies (first of 1000 candidates with IoU>0.7), original box last; labels
-    and scores repeated.  Vectorised over the boxes of an image; RNG = torch's generator on the device."""
+    and scores repeated.  Vectorised over ALL boxes of the batch and over the ratio-1 picks (the reference loops over
+    images, boxes and attempts): a dozen small launches per call whatever the number of images; RNG = torch's generator
+    on the device."""
     out = copy.deepcopy(targets)
-    for t in out:
-        box = t["boxes"]
+    counts = [t["boxes"].shape[0] for t in out]
+    if sum(counts) > 0:
+        box = torch.cat([t["boxes"] for t in out if t["boxes"].shape[0] > 0])
         M = box.shape[0]
-        if M > 0:
-            scale = torch.empty((M, 1000, 4), dtype=box.dtype, device=box.device).uniform_(1 - jitter, 1 + jitter)
-            cand = scale * box[:, None, :]
-            a = box_ops.box_cxcywh_to_xyxy(cand)
-            b = box_ops.box_cxcywh_to_xyxy(box)[:, None, :]
-            wh = (torch.min(a[..., 2:], b[..., 2:]) - torch.max(a[..., :2], b[..., :2])).clamp(min=0)
-            inter = wh[..., 0] * wh[..., 1]
-            area = lambda z: (z[..., 2] - z[..., 0]) * (z[..., 3] - z[..., 1])
-            iou = inter / (area(a) + area(b) - inter)
-            keep = iou > 0.7
-            rank = keep.cumsum(1)
-            rep = box[:, None, :].repeat(1, ratio, 1)
-            for s in range(ratio - 1):
-                hit = keep & (rank == s + 1)
-                has = hit.any(1)
-                idx = hit.float().argmax(1)
-                rep[:, s] = torch.where(has[:, None], cand[torch.arange(M, device=box.device), idx], box)
-            t["boxes"] = rep.reshape(M * ratio, 4)
+        scale = torch.empty((M, 1000, 4), dtype=box.dtype, device=box.device).uniform_(1 - jitter, 1 + jitter)
+        cand = scale * box[:, None, :]
+        a = box_ops.box_cxcywh_to_xyxy(cand)
+        b = box_ops.box_cxcywh_to_xyxy(box)[:, None, :]
+        wh = (torch.min(a[..., 2:], b[..., 2:]) - torch.max(a[..., :2], b[..., :2])).clamp(min=0)
+        inter = wh[..., 0] * wh[..., 1]
+        area = lambda z: (z[..., 2] - z[..., 0]) * (z[..., 3] - z[..., 1])
+        iou = inter / (area(a) + area(b) - inter)
+        keep = iou > 0.7
+        rank = keep.cumsum(1)
+        rep = box[:, None, :].repeat(1, ratio, 1)
+        if ratio > 1:
+            picks = torch.arange(1, ratio, device=box.device)
+            hit = keep[:, None, :] & (rank[:, None, :] == picks[None, :, None])          # [M, ratio-1, 1000]
+            has = hit.any(2)
+            idx = hit.to(torch.uint8).argmax(2)                                          # the (s+1)-th kept candidate
+            got = cand[torch.arange(M, device=box.device)[:, None], idx]                 # [M, ratio-1, 4]
+            rep[:, :ratio - 1] = torch.where(has[..., None], got, box[:, None, :])
+        rep = rep.reshape(M * ratio, 4)
+        off = 0
+        for t, m in zip(out, counts):
+            if m > 0:
+                t["boxes"] = rep[off * ratio:(off + m) * ratio]
+                off += m
+    for t in out:
         t["labels"] = t["labels"].unsqueeze(1).repeat(1, ratio).reshape(-1)
         if "scores" in t:
             t["scores"] = t["scores"].unsqueeze(1).repeat(1, ratio).reshape(-1)
