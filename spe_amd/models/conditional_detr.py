@@ -250,7 +250,11 @@ class SetCriterion(nn.Module):
         if "boxes" in self.losses:
             w = scores[gidx].contiguous() if self.refine else None
             bl = _BoxLoss.apply(boxes.view(-1, 4), srow, tgt_boxes[gidx].contiguous(), w, lidx, L, 1.0) / num_boxes
-        sizes_t = host_to_device(sizes, torch.float, dev) if "cardinality" in self.losses else None
+        card_err = None
+        if "cardinality" in self.losses:                                        # conditional_detr.py:286-298 (logging), all layers at once
+            sizes_t = host_to_device(sizes, torch.float, dev)
+            card = (amax.view(L, B, Q) != Kc - 1).sum(2).float()                # [L, B] predicted non-background counts
+            card_err = (card - sizes_t[None, :]).abs().mean(1)                  # = F.l1_loss(card[l], sizes) per layer
         for l in range(L):
             sfx = suffix[l]
             if "labels" in self.losses:
@@ -263,9 +267,8 @@ class SetCriterion(nn.Module):
             if "boxes" in self.losses:
                 losses["loss_bbox" + sfx] = bl[l, 0]
                 losses["loss_giou" + sfx] = bl[l, 1]
-            if "cardinality" in self.losses:                                    # conditional_detr.py:286-298 (logging)
-                card = (amax.view(L, B, Q)[l] != Kc - 1).sum(1).float()
-                losses["cardinality_error" + sfx] = F.l1_loss(card, sizes_t)
+            if card_err is not None:
+                losses["cardinality_error" + sfx] = card_err[l]
             if l == 0 and "image_label" in self.losses:
                 losses.update(self.loss_img_label(outputs, targets_cp))
         return losses
