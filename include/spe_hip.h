@@ -218,8 +218,10 @@ int spe_matcher_cost(const float* logits, const float* boxes, const int* tgt_ids
 /* ---- the assignment itself, on the device (reference models/matcher.py:83-86: scipy.optimize.linear_sum_assignment
  * per image on the host).  cost / toff as produced for spe_matcher_cost; every image needs M_b <= Q <= 1024 (-2
  * otherwise: fall back to the host).  Writes, for problem (l, b), M_b triples at offset l*total + toff[b] in ascending
- * query order: srow = (l*B+b)*Q + q, gidx = toff[b] + j (int64 each), lidx = l (int32).  fp64 potentials like SciPy. */
-int spe_hungarian(const float* cost, const int* toff, long* srow, long* gidx, int* lidx, int L, int B, int Q,
+ * query order: srow = (l*B+b)*Q + q, gidx = toff[b] + j (int64 each), lidx = l (int32).  fp64 potentials like SciPy.
+ * err (device int, may be null; the flag word of spe_matcher_cost): bit 1 (value 2) is set when a problem has a row whose
+ * remaining costs are all NaN / infinite (SciPy raises ValueError there); that problem gets the identity assignment. */
+int spe_hungarian(const float* cost, const int* toff, long* srow, long* gidx, int* lidx, int* err, int L, int B, int Q,
                   spe_stream_t stream);
 
 /* ---- weighted sigmoid focal loss (reference models/conditional_detr.py:468-494, 504-535):
@@ -288,11 +290,14 @@ int spe_cam_contour_boxes(const void* img, int rows, int cols, float area_ratio,
  * spe_adamw_flat: clip = min(1, max_norm / (sqrt(sum partials) + 1e-6)) (max_norm <= 0: no clipping), g *= clip,
  * then torch.optim.AdamW's update with bias corrections bias_c1 = 1 - beta1^t, bias_c2 = 1 - beta2^t; element i uses
  * (lr, weight decay) of the segment s with seg_end[s-1] <= i < seg_end[s] (nseg <= 64).  write_grad != 0 stores the
- * clipped gradient back (what clip_grad_norm_ leaves in .grad).  Buffers 16-B aligned. */
+ * clipped gradient back (what clip_grad_norm_ leaves in .grad).  Buffers 16-B aligned.  grad_scale: g is first multiplied
+ * by it (1/world after a SUM all-reduce: DistributedDataParallel's gradient averaging, reference main.py:172, folded into
+ * this launch); the clip norm is that of the scaled gradient. */
 int spe_sqnorm_partials(const float* g, long n, float* partials, int nblocks, spe_stream_t stream);
 int spe_adamw_flat(float* p, float* g, float* m, float* v, long n, const long* seg_end, const float* seg_lr,
                    const float* seg_wd, int nseg, float beta1, float beta2, float eps, float bias_c1, float bias_c2,
-                   const float* partials, int npartials, float max_norm, int write_grad, spe_stream_t stream);
+                   const float* partials, int npartials, float max_norm, int write_grad, float grad_scale,
+                   spe_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,26 +1,40 @@
-"""Build libspe_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libspe_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Each csrc/*.hip is compiled to an object file on its own (in parallel; an object is reused while the content hash of its
+source and of the shared headers is unchanged), then everything is linked into spe_amd/libspe_hip.so."""
 import glob
 import hashlib
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libspe_hip.so")
 STAMP = os.path.join(HERE, "libspe_hip.srchash")     # content hash of the sources the library was built from
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def source_hash():
-    h = hashlib.sha256()
-    for f in sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))):
+def _headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.h")))
+
+
+def _hash(files, extra=b""):
+    h = hashlib.sha256(extra)
+    for f in files:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
+
+
+def source_hash():
+    return _hash(sources() + _headers())
 
 
 def needs_build():
@@ -32,14 +46,37 @@ def needs_build():
         return fh.read().strip() != source_hash()
 
 
+def _compile(src, hipcc, verbose):
+    name = os.path.splitext(os.path.basename(src))[0]
+    obj, tag = os.path.join(OBJ, name + ".o"), os.path.join(OBJ, name + ".hash")
+    want = _hash([src] + _headers(), " ".join(FLAGS).encode())
+    if os.path.exists(obj) and os.path.exists(tag) and open(tag).read().strip() == want:
+        return obj
+    cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    os.replace(obj + ".tmp", obj)
+    with open(tag, "w") as fh:
+        fh.write(want + "\n")
+    return obj
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in glob.glob(os.path.join(OBJ, "*.hash")):
+            os.remove(f)
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, hipcc, verbose), srcs))
     tmp = LIB + ".tmp.%d" % os.getpid()
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", tmp] + sources()
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
     os.replace(tmp, LIB)                      # never leave a half-written library behind
     with open(STAMP, "w") as fh:

@@ -73,7 +73,7 @@ extern "C" int spe_matcher_cost(const float* logits, const float* boxes, const i
 #define HUNG_QMAX 1024
 __global__ __launch_bounds__(64) void hungarian_kernel(const float* __restrict__ cost, const int* __restrict__ toff,
                                                        long* __restrict__ srow, long* __restrict__ gidx, int* __restrict__ lidx,
-                                                       int B, int Q) {
+                                                       int* __restrict__ err, int B, int Q) {
     __shared__ double u[HUNG_QMAX + 1], v[HUNG_QMAX + 1], minv[HUNG_QMAX + 1];
     __shared__ int p[HUNG_QMAX + 1], way[HUNG_QMAX + 1];
     __shared__ unsigned char used[HUNG_QMAX + 1];
@@ -110,6 +110,20 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float* __restrict__
                 if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
             }
             const double delta = best; const int j1 = bj;
+            if (j1 == 0x7fffffff || !(fabs(delta) <= 1.7e308)) {
+                // every remaining cost of this row is NaN / +-inf (diverged logits or boxes): the augmenting-path search
+                // has no column to move to.  SciPy raises ValueError here (matcher.py:86); the device path raises flag
+                // bit 1 (inspected by the host without a stall) and emits the identity assignment so that nothing
+                // indexes out of bounds or spins; the step's loss is non-finite anyway (engine.py:156-159 exits on it).
+                if (err && lane == 0) atomicOr(err, 2);
+                const long ob = (long)l * total + toff[b];
+                for (int i2 = lane; i2 < n; i2 += 64) {
+                    srow[ob + i2] = ((long)l * B + b) * Q + i2;
+                    gidx[ob + i2] = toff[b] + i2;
+                    lidx[ob + i2] = l;
+                }
+                return;
+            }
             __syncthreads();
             for (int j = lane; j <= m; j += 64) {
                 if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
@@ -141,11 +155,11 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float* __restrict__
 }
 
 // C-ABI: see include/spe_hip.h (spe_hungarian).  -2: Q above HUNG_QMAX (callers fall back to the host solver).
-extern "C" int spe_hungarian(const float* cost, const int* toff, long* srow, long* gidx, int* lidx, int L, int B, int Q,
-                             hipStream_t st) {
+extern "C" int spe_hungarian(const float* cost, const int* toff, long* srow, long* gidx, int* lidx, int* err, int L, int B,
+                             int Q, hipStream_t st) {
     if (L <= 0 || B <= 0 || Q <= 0) return 0;
     if (Q > HUNG_QMAX) return -2;
-    hipLaunchKernelGGL(hungarian_kernel, dim3(B, L), dim3(64), 0, st, cost, toff, srow, gidx, lidx, B, Q);
+    hipLaunchKernelGGL(hungarian_kernel, dim3(B, L), dim3(64), 0, st, cost, toff, srow, gidx, lidx, err, B, Q);
     SPE_CHECK_LAUNCH();
     return 0;
 }

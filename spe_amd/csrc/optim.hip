@@ -9,7 +9,7 @@
 __global__ __launch_bounds__(256) void sqnorm_partials_kernel(const float* __restrict__ g, long n, float* __restrict__ partials) {
     __shared__ float red[16];
     const long per = ((n + gridDim.x - 1) / gridDim.x + 3) & ~3L;
-    const long beg = (long)blockIdx.x * per;
+    long beg = (long)blockIdx.x * per; if (beg > n) beg = n;       // chunks past the end are empty (end - beg must not go negative)
     long end = beg + per; if (end > n) end = n;
     float acc = 0.f;
     const bool al = (reinterpret_cast<uintptr_t>(g) & 15) == 0;
@@ -39,7 +39,7 @@ struct AdamwArgs {
     float* p; float* g; float* m; float* v; long n;
     const long* seg_end; const float* seg_lr; const float* seg_wd; int nseg;
     float beta1, beta2, eps, bc1, bc2sqrt;
-    const float* partials; int npartials; float max_norm; int write_grad;
+    const float* partials; int npartials; float max_norm; int write_grad; float gscale;
 };
 
 // torch.optim.AdamW (amsgrad = False, maximize = False):
@@ -56,9 +56,10 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(AdamwArgs a) {
     if (a.max_norm > 0.f) {
         float acc = 0.f;
         for (int i = threadIdx.x; i < a.npartials; i += 256) acc += a.partials[i];
-        const float tot = sqrtf(spe_block_sum(acc, red));
+        const float tot = a.gscale * sqrtf(spe_block_sum(acc, red));
         clip = fminf(a.max_norm / (tot + 1e-6f), 1.f);
     }
+    clip *= a.gscale;
     __syncthreads();
     // grid-stride over float4 chunks: the prologue above (segment table, clip factor from the norm partials) is paid once
     // per workgroup, not once per 1024 elements (26 K workgroups for the 27 M parameters of cfg2: 0.41 -> 0.2x ms)
@@ -108,14 +109,15 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(AdamwArgs a) {
 // C-ABI: see include/spe_hip.h (spe_adamw_flat).  All flat buffers 16-B aligned, n elements.
 extern "C" int spe_adamw_flat(float* p, float* g, float* m, float* v, long n, const long* seg_end, const float* seg_lr,
                               const float* seg_wd, int nseg, float beta1, float beta2, float eps, float bias_c1, float bias_c2,
-                              const float* partials, int npartials, float max_norm, int write_grad, hipStream_t st) {
+                              const float* partials, int npartials, float max_norm, int write_grad, float grad_scale,
+                              hipStream_t st) {
     if (n <= 0) return 0;
     if (nseg < 1 || nseg > ADAMW_MAXSEG) return -2;
     if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) return -2;
     AdamwArgs a;
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.seg_end = seg_end; a.seg_lr = seg_lr; a.seg_wd = seg_wd; a.nseg = nseg;
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.bc1 = bias_c1; a.bc2sqrt = sqrtf(bias_c2);
-    a.partials = partials; a.npartials = npartials; a.max_norm = max_norm; a.write_grad = write_grad;
+    a.partials = partials; a.npartials = npartials; a.max_norm = max_norm; a.write_grad = write_grad; a.gscale = grad_scale;
     long nb = (n + 1023) / 1024; if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)nb), dim3(256), 0, st, a);
     SPE_CHECK_LAUNCH();

@@ -17,16 +17,30 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, params, bucket_bytes=64 << 20, average=True, group=None, flatten_params=False):
+    def __init__(self, params, bucket_bytes=64 << 20, average=True, group=None, flatten_params=False, broadcast=True,
+                 always_reduce=False, wire_dtype=None, buffers=()):
         """flatten_params: also move the parameters themselves into flat per-bucket buffers with the gradient layout
         (param.data becomes a view) - what spe_amd.optim.FlatAdamW steps in one launch per bucket.  Construct the
         reducer AFTER the model is on its device: `module.to(...)` / `.cuda()` re-allocates parameters and would
-        detach them from the flat buffers (load_state_dict and in-place updates are fine)."""
+        detach them from the flat buffers (load_state_dict and in-place updates are fine).
+        broadcast: rank 0's parameters (and `buffers`) overwrite every other rank's at construction, as
+        DistributedDataParallel does (reference main.py:161-172 seeds each rank with seed + rank BEFORE build_model, so
+        everything that is not loaded from a checkpoint starts different per rank).
+        always_reduce: issue the collectives even in a one-rank group (tests of the RCCL path on one GPU).
+        wire_dtype: torch.bfloat16 sends the buckets in bf16 (half the xGMI bytes, one conversion pass each way); the
+        default None keeps DDP's fp32 gradients."""
         self.params = [p for p in params if p.requires_grad]
         self.flatten_params = flatten_params
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.initialised = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.initialised else 1
+        self.collective = self.world > 1 or (always_reduce and self.initialised)
         self.average = average
+        self.average_in_optimizer = False      # FlatAdamW folds the 1/world into its update launch (no div_ per bucket)
+        self.wire_dtype = wire_dtype
+        self.measure = False                   # bench: record events around the waits of finish() (exposed all-reduce time)
+        self.exposed_ms = []
+        self._wait_events = []
         self.buckets = []          # dicts: flat, params, pending, work
         self._bucket_of = {}
         self._views = {}
@@ -39,6 +53,16 @@ class GradAllReducer:
                 cur, cur_bytes = [], 0
         if cur:
             self._make_bucket(cur)
+        if broadcast and self.world > 1:
+            with torch.no_grad():
+                if flatten_params:
+                    for b in self.buckets:
+                        dist.broadcast(b["flat_p"], src=0, group=group)
+                else:
+                    for p in self.params:
+                        dist.broadcast(p.data, src=0, group=group)
+                for t in buffers:
+                    dist.broadcast(t, src=0, group=group)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         # Parameters that received no gradient in the first step (e.g. `backbone.0.body.head.*`) are treated as
         # statically unused afterwards (cf. DDP static_graph): their bucket no longer waits for them, so it - and,
@@ -92,8 +116,12 @@ class GradAllReducer:
         self.reset()
 
     def _launch(self, b):
-        if self.world > 1:
-            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.collective:
+            if self.wire_dtype is not None:
+                b["wire"] = b["flat"].to(self.wire_dtype)
+                b["work"] = dist.all_reduce(b["wire"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             b["work"] = "local"
 
@@ -114,6 +142,9 @@ class GradAllReducer:
             p.grad = view
         self._fired.add(p)
         b["pending"] -= 1
+        if b["pending"] < 0:
+            raise RuntimeError("GradAllReducer: a gradient arrived for a bucket that was not re-armed - call reset() (or the "
+                               "optimizer's zero_grad()) before every backward")
         # collectives are issued strictly in bucket order so every rank enqueues the same sequence
         while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
             self._launch(self.buckets[self._next])
@@ -126,14 +157,32 @@ class GradAllReducer:
             self._next += 1
         if self.learn_unused and self._static_unused is None:
             self._static_unused = frozenset(p for p in self.params if p not in self._fired)
+        ev = None
+        if self.measure and self.collective:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for b in self.buckets:
             if b["work"] not in (None, "local"):
                 b["work"].wait()
-            if self.average and self.world > 1:
-                b["flat"].div_(self.world)
+                if self.wire_dtype is not None:
+                    b["flat"].copy_(b.pop("wire"))
             for p in b["params"]:
                 if p.grad is None:                            # unused this step: zeros, like DDP's unused-parameter path
                     p.grad = self._views[p]
+        if ev is not None:          # compute-stream time between "backward enqueued" and "last collective done"
+            ev[1].record()
+            self._wait_events.append(ev)
+        if self.average and self.world > 1 and not self.average_in_optimizer:
+            torch._foreach_div_([b["flat"] for b in self.buckets], float(self.world))
+
+    def grad_scale(self):
+        """Factor the optimizer still has to apply to the bucket contents (1/world when the averaging is folded in)."""
+        return 1.0 / self.world if (self.average and self.average_in_optimizer and self.world > 1) else 1.0
+
+    def exposed_ms_mean(self):
+        """Mean compute-stream stall of finish() in ms (call after a device synchronisation; needs measure = True)."""
+        ms = [a.elapsed_time(b) for a, b in self._wait_events]
+        return sum(ms) / len(ms) if ms else 0.0
 
     def remove(self):
         for h in self._hooks:

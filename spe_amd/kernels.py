@@ -13,7 +13,9 @@ from . import lib
 # 0 = bf16 MFMA operands / fp32 accumulate (benchmark mode); 1 = 3-term bf16 split (~fp32, parity mode)
 _PRECISION = 0
 # Philox stream for dropout: (seed, running offset).  Each dropout site draws a fresh offset.
-_RNG = {"seed": 0x5EEDC0DE, "offset": 0}
+# seed None = not set by the caller: derived on first use from torch's seed (the reference's main.py:161-164 seeds torch
+# with args.seed + rank and nothing else, so its dropout masks differ per rank and per run; ours then do too).
+_RNG = {"seed": None, "offset": 0}
 
 
 def set_precision(mode):
@@ -32,6 +34,8 @@ def manual_seed(seed):
 
 def next_rng():
     """-> (seed, offset) for one dropout site; offsets never repeat within a process."""
+    if _RNG["seed"] is None:
+        _RNG["seed"] = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x5EEDC0DE) & 0xFFFFFFFFFFFFFFFF
     _RNG["offset"] += 1
     return _RNG["seed"], _RNG["offset"]
 
@@ -52,8 +56,18 @@ def timing_results():
     return {n: (len(ev), (sum(a.elapsed_time(b) for a, b in ev) / len(ev)) if ev else 0.0) for n, ev in _TIMED.items()}
 
 
+# entry point -> positions of (M, N, K) in its argument list: GEMM launches can be timed per problem shape, e.g.
+# enable_timing(["spe_gemm_bf16nt:8300,384,384"])
+_GEMM_DIMS = {"spe_gemm_bf16nt": (5, 6, 7), "spe_gemm_bf16nt_ex": (13, 14, 15)}
+
+
 def _call(name, *args):
+    if not _TIMED:
+        return lib.call(name, *args)
     ev = _TIMED.get(name)
+    if ev is None and name in _GEMM_DIMS:
+        i, j, k = _GEMM_DIMS[name]
+        ev = _TIMED.get("%s:%d,%d,%d" % (name, args[i], args[j], args[k]))
     if ev is None:
         return lib.call(name, *args)
     if name == "spe_talking_fused":          # time the four modes separately
@@ -626,14 +640,15 @@ def matcher_cost(logits, boxes, tgt_ids_i32, tgt_boxes, toff_i32, total_targets,
     return cost, err
 
 
-def hungarian(cost, toff_i32, L, B, Q, total_targets):
+def hungarian(cost, toff_i32, L, B, Q, total_targets, err=None):
     """Device-side linear_sum_assignment of every (layer, image) block of `cost` -> (srow, gidx) int64 and lidx int32,
-    each [L*total_targets] (see csrc/loss.hip: hungarian_kernel)."""
+    each [L*total_targets] (see csrc/loss.hip: hungarian_kernel).  err: the int32 flag word of matcher_cost (bit 1 is
+    raised for a problem with non-finite costs)."""
     dev = cost.device
     srow = torch.empty((L * total_targets,), device=dev, dtype=torch.int64)
     gidx = torch.empty_like(srow)
     lidx = torch.empty((L * total_targets,), device=dev, dtype=torch.int32)
-    _call("spe_hungarian", _p(cost), _p(toff_i32), _p(srow), _p(gidx), _p(lidx), L, B, Q, _st())
+    _call("spe_hungarian", _p(cost), _p(toff_i32), _p(srow), _p(gidx), _p(lidx), _p(err), L, B, Q, _st())
     return srow, gidx, lidx
 
 
@@ -858,10 +873,11 @@ def sqnorm_partials(g_flat, partials):
     _call("spe_sqnorm_partials", _p(g_flat), g_flat.numel(), _p(partials), partials.numel(), _st())
 
 
-def adamw_flat(p, g, m, v, seg_end_i64, seg_lr, seg_wd, beta1, beta2, eps, bias_c1, bias_c2, partials, max_norm, write_grad):
+def adamw_flat(p, g, m, v, seg_end_i64, seg_lr, seg_wd, beta1, beta2, eps, bias_c1, bias_c2, partials, max_norm, write_grad,
+               grad_scale=1.0):
     _call("spe_adamw_flat", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(seg_end_i64), _p(seg_lr), _p(seg_wd), seg_end_i64.numel(),
           float(beta1), float(beta2), float(eps), float(bias_c1), float(bias_c2), _p(partials), partials.numel(),
-          float(max_norm), int(bool(write_grad)), _st())
+          float(max_norm), int(bool(write_grad)), float(grad_scale), _st())
 
 
 # ---- inference post-processing -----------------------------------------------------------------

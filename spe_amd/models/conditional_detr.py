@@ -152,6 +152,10 @@ def jitter_targets(targets, ratio, jitter):
     return out
 
 
+# tests: take the cross-rank `num_boxes` branch (device scalar + all-reduce) even in a one-rank process group
+FORCE_NUM_BOXES_ALLREDUCE = False
+
+
 class SetCriterion(nn.Module):
     """Hungarian matching + focal / L1 / GIoU set loss (+ image-label BCE, cardinality, class_error)."""
 
@@ -203,8 +207,8 @@ class SetCriterion(nn.Module):
                 targets_cp = copy.deepcopy(targets)
         sizes = [int(len(t["labels"])) for t in targets_cp]
         # normaliser: a host number on one GPU; across ranks it stays a device scalar (no .item() stall per step)
-        if is_dist_avail_and_initialized() and get_world_size() > 1:
-            nb = host_to_device([float(sum(sizes))], torch.float, dev)
+        if is_dist_avail_and_initialized() and (get_world_size() > 1 or FORCE_NUM_BOXES_ALLREDUCE):
+            nb = host_to_device([float(sum(sizes))], torch.float, dev)             # conditional_detr.py:436-440
             torch.distributed.all_reduce(nb)
             num_boxes = torch.clamp(nb / get_world_size(), min=1)[0]
         else:

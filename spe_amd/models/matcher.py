@@ -43,7 +43,10 @@ class HungarianMatcher(nn.Module):
         if prev is not None:
             host, ev = prev
             ev.synchronize()            # a step old: already complete
-            assert int(host[0]) == 0, "degenerate box (x1 < x0 or y1 < y0) in matcher inputs"
+            flag = int(host[0])
+            assert not (flag & 1), "degenerate box (x1 < x0 or y1 < y0) in matcher inputs"
+            if flag & 2:      # what scipy.optimize.linear_sum_assignment raises at reference matcher.py:86
+                raise ValueError("matrix contains invalid numeric entries (non-finite matching cost)")
         host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
         host.copy_(err, non_blocking=True)
         ev = torch.cuda.Event()
@@ -61,8 +64,9 @@ class HungarianMatcher(nn.Module):
         if sum(sizes) == 0 or max(sizes) > Q or Q > 1024 or not logits.is_cuda:
             return None
         cost, err, toff_t, sizes, toff = self._costs(logits, boxes, targets)
-        self._check_degenerate_async(err)
-        return K.hungarian(cost, toff_t, L, B, Q, toff[-1])
+        res = K.hungarian(cost, toff_t, L, B, Q, toff[-1], err=err)
+        self._check_degenerate_async(err)           # after the assignment: it raises bit 1 of the same flag word
+        return res
 
     @torch.no_grad()
     def match_many(self, logits, boxes, targets):

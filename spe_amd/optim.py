@@ -25,6 +25,7 @@ class FlatAdamW(torch.optim.Optimizer):
             raise ValueError("FlatAdamW needs GradAllReducer(..., flatten_params=True)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.reducer = reducer
+        reducer.average_in_optimizer = True     # gradient averaging (1/world) rides on the update launch
         self.max_grad_norm = max_grad_norm
         self.write_clipped_grads = write_clipped_grads
         gid = {}
@@ -82,12 +83,18 @@ class FlatAdamW(torch.optim.Optimizer):
                             host_to_device([k[1] for k in key], torch.float32, dev))
                 e["tab_key"] = key
             K.adamw_flat(e["b"]["flat_p"], e["b"]["flat"], e["m"], e["v"], e["seg_end"], e["tab"][0], e["tab"][1],
-                         b1, b2, eps, bc1, bc2, self._partials, clip, self.write_clipped_grads)
+                         b1, b2, eps, bc1, bc2, self._partials, clip, self.write_clipped_grads,
+                         grad_scale=self.reducer.grad_scale())
         K.weights_changed()            # the update bypassed autograd's version counters: drop cached bf16 weight copies
         for grp in self.param_groups:
             for p in grp["params"]:
                 self.state[p]["step"] += 1
         return loss
+
+    def zero_grad(self, set_to_none=True):
+        """The reference loop calls optimizer.zero_grad() before backward (engine.py:161): the gradients live in the
+        reducer's buckets, so this re-arms them (zeroes the buckets, detaches .grad, resets the bucket counters)."""
+        self.reducer.reset()
 
     def load_state_dict(self, state_dict):
         """Standard torch format; the moments are copied INTO the flat buffers (the views must stay views)."""

@@ -1,0 +1,156 @@
+"""BASELINE.json configurations at their OWN dimensions, as reproducible parity cases.
+
+Every case is fully determined by seeds: `build_case(name)` constructs the product's module tree on the CPU (construction
+only - no kernel runs), randomises the parameters whose reference initialisation would hide bugs (SURVEY.md section 4:
+LayerScale gammas of 1e-5, zero-initialised box head, constant class bias, talking-heads mixers), and returns the
+state dict, the images and the targets.  tools/gen_config_golden.py loads that SAME state dict into the REFERENCE
+(imported from /root/reference in the build container; the key names are identical - that is a boundary requirement),
+runs one training iteration's forward + both criteria + backward there and commits the results as data-only fixtures
+under tests/golden/cfg_*.pt: small outputs in full, large tensors and every parameter gradient as (norm, 64-element
+strided sample).  The weights themselves (56 MB for cfg1) are never stored: any box rebuilds them from the seed.
+
+tests/test_config_golden.py then compares  oracle (CPU) vs fixture  and  product (GPU) vs fixture  - i.e. both against
+the reference itself - at cfg1 / cfg2 / cfg5 token counts.
+"""
+import argparse
+
+import torch
+
+# name -> dims.  depth-2 variants keep every per-block dimension of the named configuration (width, heads, token count,
+# decoder) and cut only the number of identical backbone blocks, so the reference finishes in seconds on 8 cores and
+# the fused attention / GEMM kernels run at the configuration's real N.
+CASES = {
+    # BASELINE.json configs[0]: TSCAM_cait_XXS24 (reference models/cait.py:1465-1498), 1-layer decoder, 10 queries
+    "cfg1": dict(backbone="TSCAM_cait_XXS24", width=192, depth=24, heads=4, init_scale=1e-5, layer_to_det=23, enc=0, dec=1,
+                 Q=10, dataset="voc", K=20, sizes_hw=[(224, 224), (192, 208)], n_tgt=[3, 2], seed=101, gamma=0.25),
+    # configs[1] dims (S24: models/cait.py:1860-1866), N = 4150 tokens, 6-layer decoder, 100 queries; 2 of the 24 blocks
+    "cfg2_depth2": dict(backbone="TSCAM_cait_S24_depth2", width=384, depth=2, heads=8, init_scale=1e-5, layer_to_det=1, enc=0,
+                        dec=6, Q=100, dataset="coco", K=90, sizes_hw=[(800, 1333)], n_tgt=[7], seed=202, gamma=1.0),
+    # same with the script's 3 encoder layers (scripts/run_voc0712.py:15-41), smaller image to bound the CPU time
+    "cfg2_enc3_small": dict(backbone="TSCAM_cait_S24_depth2", width=384, depth=2, heads=8, init_scale=1e-5, layer_to_det=1,
+                            enc=3, dec=6, Q=100, dataset="coco", K=90, sizes_hw=[(512, 640), (480, 608)], n_tgt=[7, 4], seed=203,
+                            gamma=1.0),
+    # configs[4] dims (S36: models/cait.py:1882-1888), 1x3x1000x1600 -> N = 6200 tokens; 2 of the 36 blocks
+    "cfg5_depth2": dict(backbone="TSCAM_cait_S36_depth2", width=384, depth=2, heads=8, init_scale=1e-6, layer_to_det=1, enc=0,
+                        dec=6, Q=100, dataset="coco", K=90, sizes_hw=[(1000, 1600)], n_tgt=[7], seed=505, gamma=1.0),
+}
+
+SAMPLE = 64
+
+
+def make_args(c, device="cpu"):
+    """Namespace with every field build_model reads in the reference (main.py:37-146) and in the product."""
+    return argparse.Namespace(
+        dataset_file=c["dataset"], device=device, backbone=c["backbone"], backbone_drop_rate=0.0, drop_path_rate=0.0,
+        drop_block_rate=0.0, drop_attn_rate=0.0, layer_to_det=c["layer_to_det"], lr_backbone=1e-5, masks=False, dilation=False,
+        position_embedding="sine", hidden_dim=256, dropout=0.0, nheads=8, num_queries=c["Q"], dim_feedforward=2048,
+        enc_layers=c["enc"], dec_layers=c["dec"], pre_norm=False, aux_loss=True, num_refines=1, frozen_weights=None,
+        set_cost_class=2, set_cost_bbox=5, set_cost_giou=2, hung_match_ratio=5, hungarian_multi=False, box_jitter=0.1,
+        cls_loss_coef=2, bbox_loss_coef=2, giou_loss_coef=2, img_label_loss_coef=1, img_label_tokens_loss_coef=1,
+        mask_loss_coef=1, dice_loss_coef=1, focal_alpha=0.25, focal_gamma=2, drloc=False)
+
+
+def register_product_backbones():
+    from spe_amd.models import cait
+    for name, c in CASES.items():
+        if c["backbone"] in cait._REGISTRY:
+            continue
+
+        def fac(pretrained=False, _c=c, **kw):
+            return cait._make(cait.TSCAM_cait, _c["width"], _c["depth"], _c["heads"], _c["init_scale"], False, **kw)
+        fac.__name__ = c["backbone"]
+        cait.register_model(fac)
+
+
+def randomise(model, g, gamma):
+    """O(1) values where the reference's initialisation would make a bug invisible (cf. tools/gen_golden.py)."""
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("gamma_1") or n.endswith("gamma_2"):
+                p.copy_((torch.randn(p.shape, generator=g) * 0.3 + 1.0) * gamma)
+            elif "proj_l.weight" in n or "proj_w.weight" in n:
+                p.copy_(torch.eye(p.shape[0]) + 0.3 * torch.randn(p.shape, generator=g))
+            elif "proj_l.bias" in n:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif "proj_w.bias" in n:
+                # added to probabilities of size ~1/N: a bias of 0.1 would swamp them (every token would receive the same
+                # N * 0.1 * mean(V)), so it is drawn at the scale of the probabilities themselves
+                p.copy_(2e-4 * torch.randn(p.shape, generator=g))
+            elif n.startswith("bbox_embed") and ".layers.2." in n:
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+            elif n.startswith("class_embed"):           # logits of O(1) spread around the reference's negative prior
+                if p.dim() == 2:
+                    p.copy_(torch.randn(p.shape, generator=g) / p.shape[1] ** 0.5)
+                else:
+                    p.copy_(0.3 * torch.randn(p.shape, generator=g) - 2.0)
+            elif (".ca_q" in n or ".ca_k" in n) and n.endswith("weight"):
+                # xavier-initialised cross-attention logits are ~1 over thousands of keys: every query would attend almost
+                # uniformly, all queries would get the same class logits (measured: top-2 gap 1e-7) and the argmax over
+                # queries in PostProcessRefine would be a coin flip.  Sharper attention makes the stage-1 pseudo labels
+                # well conditioned.
+                p.mul_(4.0)
+            elif "backbone" in n and p.dim() >= 2 and (".blocks" in n or "patch_embed" in n):
+                # unit-gain weights (the reference's trunc_normal(0.02) attenuates the token-dependent signal ~2.5x per
+                # Linear while the biases stay: after two blocks every token would carry the same vector, measured)
+                p.copy_(torch.randn(p.shape, generator=g) / (p.numel() // p.shape[0]) ** 0.5)
+            elif n.endswith("pos_embed") or n.endswith("cls_token"):
+                p.copy_(0.5 * torch.randn(p.shape, generator=g))
+            elif n.endswith(".bias") and p.dim() == 1:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+
+
+def make_targets(g, K, sizes, orig):
+    ts = []
+    for n, hw in zip(sizes, orig):
+        labels = torch.randint(1, K + 1, (n,), generator=g)
+        c = torch.rand(n, 2, generator=g) * 0.6 + 0.2
+        wh = torch.rand(n, 2, generator=g) * 0.35 + 0.05
+        il = torch.zeros(K, dtype=torch.int64)
+        il[labels - 1] = 1
+        ts.append({"boxes": torch.cat([c, wh], 1), "labels": labels, "img_label": il, "orig_size": torch.tensor(list(hw))})
+    return ts
+
+
+def build_case(name):
+    """-> (args, product model on the CPU carrying the case's weights, padded image tensor, mask, targets)."""
+    from spe_amd.models import build_model
+    from spe_amd.util.misc import nested_tensor_from_tensor_list
+    c = CASES[name]
+    register_product_backbones()
+    args = make_args(c)
+    torch.manual_seed(c["seed"])
+    model, crit, crit_r, pp, rpp = build_model(args)
+    g = torch.Generator().manual_seed(c["seed"] + 1)
+    randomise(model, g, c["gamma"])
+    imgs = [torch.randn(3, h, w, generator=g) for h, w in c["sizes_hw"]]
+    nt = nested_tensor_from_tensor_list(imgs)
+    targets = make_targets(g, c["K"], c["n_tgt"], c["sizes_hw"])
+    return args, (model, crit, crit_r, pp, rpp), nt.tensors, nt.mask, targets
+
+
+def oracle_cfg(name):
+    from oracle import spe_oracle as O
+    c = CASES[name]
+    return O.make_cfg(embed_dim=c["width"], depth=c["depth"], num_heads=c["heads"], num_cls_tokens=c["K"],
+                      layer_to_det=c["layer_to_det"], two_branch=False, pos_grid=(50, 84), nheads=8, enc_layers=c["enc"],
+                      dec_layers=c["dec"], dim_feedforward=2048, num_queries=c["Q"], num_refines=1,
+                      num_det_classes=91 if c["dataset"] == "coco" else 21, aux_loss=True)
+
+
+def sample(t, n=SAMPLE):
+    """(norm, n strided elements) of a tensor: what the fixtures keep of large tensors."""
+    f = t.detach().reshape(-1).double()
+    step = max(1, f.numel() // n)
+    return float(f.norm()), f[::step][:n].float().clone()
+
+
+def sample_err(t, ref):
+    """Error of tensor t against a (norm, samples) record: max of the norm's relative error and the samples' norm-relative
+    error (64 points spread over the tensor)."""
+    nrm, s = ref
+    got_n, got_s = sample(t, s.numel())
+    if nrm == 0.0:
+        return abs(got_n)
+    e_n = abs(got_n - nrm) / nrm
+    e_s = float((got_s.double() - s.double()).norm() / (s.double().norm() + 1e-30))
+    return max(e_n, e_s)

@@ -1,0 +1,161 @@
+"""Parity at BASELINE.json's own dimensions, against the REFERENCE (fixtures tests/golden/cfg_*.pt written by
+tools/gen_config_golden.py from the imported reference; case table and seeded weights: tests/cfg_cases.py).
+
+  CPU  (-m "not gpu"): the oracle against the reference at cfg1 (real TSCAM_cait_XXS24, 24 blocks) and at cfg2 token
+                       counts - the oracle is pinned at real dimensions, not only on the tiny e2e fixtures.
+  GPU  (-m gpu)      : the product against the same reference results, in both precision modes:
+        bf16x3 - 3-term split, the mode that meets north_star's 1e-3 on logits / losses (asserted here at 1e-3);
+        bf16   - single-pass bf16 MFMA operands, THE BENCHMARK MODE (bench.py's headline): this is the test that pins
+                 the benchmarked kernel set (fused talking-heads attention at N = 4150 / 6200, bf16-copy GEMMs, fused MLP
+                 and projection nodes, flash MHA) to the reference at real token counts.  Its tolerances are what bf16
+                 operand rounding (2^-9 per operand) allows through the stack with gamma = O(1); the measured errors are
+                 printed and written to gpurun_out/parity_*.json (copied to profiles/ and quoted in DESIGN.md).
+"""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import cfg_cases as cc  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden")
+LOGGING_ONLY = ("class_error", "cardinality_error")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def err_of(t, ref):
+    """ref: full tensor or (norm, samples)."""
+    return cc.sample_err(t.detach().cpu(), ref) if isinstance(ref, tuple) else rel(t, ref)
+
+
+def compare_outputs(out, blob):
+    errs = {}
+    for st, key in ((0, "out0"), (1, "out1")):
+        g = blob[key]
+        for k in ("pred_logits", "pred_boxes", "x_logits", "x_cls_logits", "cams_cls"):
+            errs[f"{st}.{k}"] = err_of(out[st][k], g[k])
+        xp = out[st]["x_patch"]
+        xt, xm = (xp.tensors, xp.mask) if hasattr(xp, "tensors") else xp
+        errs[f"{st}.x_patch"] = err_of(xt, g["x_patch"][0])
+        assert torch.equal(xm.cpu(), g["x_patch"][1])
+        for i, (a, b) in enumerate(zip(out[st]["aux_outputs"], g["aux_outputs"])):
+            errs[f"{st}.aux{i}.logits"] = err_of(a["pred_logits"], b["pred_logits"])
+            errs[f"{st}.aux{i}.boxes"] = err_of(a["pred_boxes"], b["pred_boxes"])
+    return errs
+
+
+def compare_losses(l0, l1, blob, skip_logging):
+    errs = {}
+    for tag, l, ref in (("0", l0, blob["loss0"]), ("1", l1, blob["loss1"])):
+        assert set(l) == set(ref), set(l) ^ set(ref)
+        for k, v in ref.items():
+            if skip_logging and k.startswith(LOGGING_ONLY):
+                continue
+            errs[f"{tag}.{k}"] = abs(float(l[k].detach()) - float(v)) / max(1.0, abs(float(v)))
+    return errs
+
+
+def compare_grads(named_grads, blob):
+    """-> (worst (name, err), compared count, errors); analytically-zero gradients are checked for smallness only."""
+    errs = {}
+    gmax = max(r[0] for r in blob["grads"].values() if r is not None)
+    for k, g in named_grads:
+        ref = blob["grads"][k]
+        if ref is None:
+            assert g is None or float(g.abs().max()) == 0.0, k
+            continue
+        assert g is not None, k
+        if ref[0] < 1e-6 * gmax:            # softmax shift invariance etc.: exact gradient ~0, only rounding noise remains
+            continue
+        errs[k] = cc.sample_err(g.detach().cpu(), ref)
+    return errs
+
+
+# -------------------------------------------------------------------------------------------------- CPU: oracle
+@pytest.mark.parametrize("name", ["cfg1", "cfg2_enc3_small", "cfg2_depth2"])
+def test_oracle_matches_reference_at_config_dims(name):
+    from oracle import spe_oracle as O
+    blob = torch.load(os.path.join(GOLD, f"cfg_{name}.pt"), weights_only=False)
+    args, (model, *_), tensors, mask, targets = cc.build_case(name)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    chk = float(sum(v.detach().double().abs().sum() for v in sd.values() if v.is_floating_point()))
+    assert abs(chk - blob["sd_checksum"]) <= 1e-9 * blob["sd_checksum"], "seeded weights differ from the ones the fixture was made with"
+    tot, out, l0, l1 = O.total_loss(sd, cc.oracle_cfg(name), tensors, mask, targets)
+    tot.backward()
+    oe = compare_outputs(out, blob)
+    le = compare_losses(l0, l1, blob, skip_logging=False)
+    ge = compare_grads([(k, v.grad) for k, v in sd.items() if k in blob["grads"]], blob)
+    print(f"[oracle {name}] worst output {max(oe.values()):.2e}, loss {max(le.values()):.2e}, grad {max(ge.values()):.2e} over {len(ge)} parameters")
+    assert max(oe.values()) < 1e-5, max(oe.items(), key=lambda kv: kv[1])
+    assert max(le.values()) < 1e-5, max(le.items(), key=lambda kv: kv[1])
+    assert abs(float(tot.detach()) - float(blob["total"])) <= 1e-5 * abs(float(blob["total"]))
+    assert max(ge.values()) < 2e-4 and len(ge) > 100, max(ge.items(), key=lambda kv: kv[1])
+    for p, r in zip(O.postprocess_refine(out[0], targets), blob["pseudo"]):
+        assert torch.equal(p["labels"], r["labels"])
+
+
+# -------------------------------------------------------------------------------------------------- GPU: product
+# norm-relative tolerances: (outputs, losses, parameter gradients).  bf16x3 = north_star's 1e-3 on logits / losses.
+TOL = {"bf16x3": (1e-3, 1e-3, 1e-2), "bf16": (3e-2, 2e-2, 2e-1)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("name", list(cc.CASES))
+def test_product_matches_reference_at_config_dims(dev, name, prec):
+    from spe_amd import kernels as K
+    from spe_amd.util.misc import NestedTensor
+    blob = torch.load(os.path.join(GOLD, f"cfg_{name}.pt"), weights_only=False)
+    args, (model, crit, crit_r, pp, rpp), tensors, mask, targets = cc.build_case(name)
+    K.set_precision(prec)
+    try:
+        model.to(dev).train(); crit.to(dev).eval(); crit_r.to(dev).eval()      # all drop rates 0; eval criteria = no jitter
+        tg = [{k: v.to(dev) for k, v in t.items()} for t in targets]
+        out = model(NestedTensor(tensors.to(dev), mask.to(dev)))
+        l0 = crit(out[0], tg)
+        orig = torch.stack([t["orig_size"] for t in tg])
+        with torch.no_grad():
+            pr = rpp["bbox"](out[0], orig, tg)
+        # stage-1 targets: the reference's pseudo labels (detached inputs of criterion_refine, engine.py:122-130).  Our own
+        # PostProcessRefine output is compared with them below; feeding the reference's keeps an argmax-over-queries flip
+        # between near-tied queries (gaps stored in the fixture) from masquerading as a criterion error.
+        pseudo = [{k: v.to(dev) for k, v in p.items()} for p in blob["pseudo"]]
+        l1 = crit_r(out[1], pseudo)
+        wd = blob["weight_dict"]
+        total = sum(l0[k] * wd[k] for k in l0 if k in wd) + sum(l1[k] * wd[k] for k in l1 if k in wd)
+        total.backward()
+        torch.cuda.synchronize()
+        oe = compare_outputs(out, blob)
+        le = compare_losses(l0, l1, blob, skip_logging=(prec == "bf16"))
+        ge = compare_grads([(k, p.grad) for k, p in model.named_parameters()], blob)
+        te = abs(float(total.detach()) - float(blob["total"])) / abs(float(blob["total"]))
+        wo, wl, wg = (max(d.items(), key=lambda kv: kv[1]) for d in (oe, le, ge))
+        gs = sorted(ge.values())
+        rec = {"case": name, "precision": prec, "tokens": int(out[0]["x_patch"].tensors.shape[2] * out[0]["x_patch"].tensors.shape[3]),
+               "worst_output": wo, "pred_logits": oe["0.pred_logits"], "pred_boxes": oe["0.pred_boxes"], "x_patch": oe["0.x_patch"],
+               "worst_loss": wl, "total_loss_rel_err": te, "worst_grad": wg, "median_grad": gs[len(gs) // 2], "grads_compared": len(ge)}
+        print(f"[{name} {prec}] " + json.dumps(rec))
+        od = os.path.join(os.path.dirname(HERE), "gpurun_out")
+        if os.path.isdir(od):
+            with open(os.path.join(od, f"parity_{name}_{prec}.json"), "w") as fh:
+                json.dump(rec, fh)
+        to, tl, tgr = TOL[prec]
+        assert wo[1] < to, wo
+        assert wl[1] < tl and te < tl, (wl, te)
+        assert wg[1] < tgr and len(ge) > 100, wg
+        for p, r, mg in zip(pr, blob["pseudo"], blob["pseudo_margins"]):
+            assert torch.equal(p["labels"].cpu(), r["labels"])
+            assert rel(p["scores"], r["scores"]) < to
+            clear = torch.tensor(mg) > 20 * to                  # classes whose best query is not nearly tied with the runner-up
+            if clear.any():
+                assert rel(p["boxes"].cpu()[clear], r["boxes"][clear]) < to
+    finally:
+        K.set_precision("bf16")

@@ -19,12 +19,17 @@ def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from spe_amd.dp import GradAllReducer
-    torch.manual_seed(0)                                    # identical replicas
+    torch.manual_seed(rank)                                 # reference main.py:161-164: seed + rank BEFORE build_model
     net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
     unused = torch.nn.Linear(3, 3)                          # never receives a gradient (cf. backbone.0.body.head)
     params = list(net.parameters()) + list(unused.parameters())
     red = GradAllReducer(params, bucket_bytes=64)           # several small buckets
     assert len(red.buckets) > 2
+    # construction broadcast rank 0's parameters (what DistributedDataParallel does): replicas are identical now
+    mine = torch.cat([p.detach().flatten() for p in params])
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    assert torch.equal(both[0], both[1])
     g = torch.Generator().manual_seed(100 + rank)           # different data per rank
     results = []
     launched_in_backward = []
@@ -46,6 +51,13 @@ def _worker(rank, world, port, out):
         got = torch.cat([p.grad.flatten() for p in net.parameters()])
         assert torch.allclose(got, mean, atol=1e-6), (rank, it)
         assert all(float(p.grad.abs().max()) == 0.0 for p in unused.parameters())
+    # a backward without re-arming the buckets must fail loudly instead of silently skipping the all-reduce
+    try:
+        net(torch.randn(5, 8, generator=g)).sum().backward()
+        raise AssertionError("expected RuntimeError")
+    except RuntimeError as e:
+        assert "re-armed" in str(e)
+    red.reset()
     # after the first step the never-used parameters are known: every bucket is reduced during backward
     assert launched_in_backward[0] < len(red.buckets) and launched_in_backward[1] == len(red.buckets), launched_in_backward
     assert set(red._static_unused) == set(unused.parameters())

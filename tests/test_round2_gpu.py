@@ -1,0 +1,399 @@
+"""GPU tests added in round 2 (VERDICT r1 items 1, 2, 6, 7 and the ADVICE findings):
+
+  * the reference's own e2e goldens through the BENCHMARK kernel set (bf16-copy GEMMs, fused MLP / projection nodes,
+    flash MHA forced on for the tiny fixtures);
+  * cfg4: matcher cost + device Hungarian at Q = 300, Kc in {91, 80}, M in {35, 100, 300}, 6 layers x 2 criteria,
+    against fp64 + SciPy;
+  * cfg2 / cfg5: fused talking-heads attention at N = 4150 (B = 2) and N = 6200 against the fp64 restatement on the device;
+  * fused attention with attn_drop > 0 (the script's drop_attn_rate 0.05): mask recovered from the blocked P'd output;
+  * data-parallel path under RCCL in a one-rank group: product model through GradAllReducer + FlatAdamW with the cross-rank
+    num_boxes branch of SetCriterion forced;
+  * Hungarian kernel on non-finite costs; squared-norm partials on sizes that are not multiples of 4.
+"""
+import argparse
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+sys.path.insert(0, HERE)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def to_dev(targets, dev):
+    return [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in t.items()} for t in targets]
+
+
+def build(blob, dev):
+    from spe_amd.models import build_model
+    args = argparse.Namespace(**blob["args"])
+    args.device = "cuda"
+    model, crit, crit_r, pp, rpp = build_model(args)
+    model.load_state_dict(blob["state_dict"], strict=True)
+    return model.to(dev), crit.to(dev), crit_r.to(dev), pp, rpp
+
+
+class bench_kernel_set:
+    """Route even the tiny fixtures (48 token rows, 24 keys) through the kernels that carry the benchmark's time."""
+
+    def __enter__(self):
+        from spe_amd import kernels as K, ops
+        self.old = (K.LINEAR16_MIN_ROWS, ops.FLASH_MIN_KEYS)
+        K.set_precision("bf16")
+        K.LINEAR16_MIN_ROWS, ops.FLASH_MIN_KEYS = 16, 1
+        return self
+
+    def __exit__(self, *a):
+        from spe_amd import kernels as K, ops
+        K.LINEAR16_MIN_ROWS, ops.FLASH_MIN_KEYS = self.old
+        K.set_precision("bf16")
+
+
+@pytest.mark.parametrize("name", ["e2e_single", "e2e_two_branch"])
+def test_reference_goldens_through_benchmark_kernel_set(dev, name):
+    """gemm_bf16nt* (all Linears), _MlpGeluRes, _LinearRes, lsres_bwd16, cvt_bf16*, flash MHA fwd/bwd and the fused
+    talking-heads kernels against the REFERENCE's outputs, losses and every parameter gradient."""
+    from spe_amd import kernels as K, ops
+    from spe_amd.util.misc import NestedTensor
+    blob = torch.load(os.path.join(GOLD, name + ".pt"), weights_only=False)
+    tr, ev = blob["train"], blob["eval"]
+    seen = set()
+    orig_call = K.lib.call
+
+    def spy(nm, *a):
+        seen.add(nm)
+        return orig_call(nm, *a)
+    with bench_kernel_set():
+        K.lib.call = spy
+        try:
+            model, crit, crit_r, pp, rpp = build(blob, dev)
+            model.train(); crit.train(); crit_r.train()
+            out = model(NestedTensor(blob["tensors"].to(dev), blob["mask"].to(dev)))
+            worst_o = 0.0
+            for st, gold in ((0, ev["out0"]), (1, ev["out1"])):           # dropout 0: train-mode outputs = eval-mode outputs
+                for k in ("pred_logits", "pred_boxes", "x_logits", "x_cls_logits", "cams_cls"):
+                    worst_o = max(worst_o, rel(out[st][k], gold[k]))
+                worst_o = max(worst_o, rel(out[st]["x_patch"].tensors, gold["x_patch"][0]))
+            l0 = crit(out[0], to_dev(blob["targets"], dev), targets_cp=to_dev(tr["targets_cp0"], dev))
+            l1 = crit_r(out[1], to_dev(tr["pseudo"], dev), targets_cp=to_dev(tr["targets_cp1"], dev))
+            wd = tr["weight_dict"]
+            worst_l = 0.0
+            for l, ref in ((l0, tr["loss0"]), (l1, tr["loss1"])):
+                for k, v in ref.items():
+                    if k in wd:
+                        worst_l = max(worst_l, abs(float(l[k].detach()) - float(v)) / max(1.0, abs(float(v))))
+            total = sum(l0[k] * wd[k] for k in l0 if k in wd) + sum(l1[k] * wd[k] for k in l1 if k in wd)
+            total.backward()
+        finally:
+            K.lib.call = orig_call
+    worst_g, n = ("", 0.0), 0
+    for k, p in model.named_parameters():
+        gref = tr["grads"][k]
+        if gref is None or float(gref.abs().max()) < 1e-7:
+            continue
+        r = rel(p.grad, gref)
+        n += 1
+        if r > worst_g[1]:
+            worst_g = (k, r)
+    te = abs(float(total.detach()) - float(tr["total"])) / abs(float(tr["total"]))
+    print(f"[{name} bench kernel set] outputs {worst_o:.3e}, losses {worst_l:.3e}, total {te:.3e}, worst grad {worst_g} over {n}")
+    # the kernels that carry the benchmark's GEMM / attention time really ran
+    for nm in ("spe_gemm_bf16nt", "spe_gemm_bf16nt_ex", "spe_cvt_bf16", "spe_layerscale_residual_bwd16", "spe_mha_fwd", "spe_mha_bwd",
+               "spe_talking_fused", "spe_attn_contract"):
+        assert nm in seen, f"{nm} was not launched: the fixture did not reach the benchmark kernel set"
+    assert worst_o < 3e-2 and worst_l < 2e-2 and te < 2e-2, (worst_o, worst_l, te)
+    assert worst_g[1] < 2e-1 and n > 100, worst_g
+
+
+# ---------------------------------------------------------------------------------------------------------------- cfg4
+def _giou(a, b):
+    ax0, ay0, ax1, ay1 = a[:, 0] - a[:, 2] / 2, a[:, 1] - a[:, 3] / 2, a[:, 0] + a[:, 2] / 2, a[:, 1] + a[:, 3] / 2
+    bx0, by0, bx1, by1 = b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2
+    iw = (torch.min(ax1[:, None], bx1) - torch.max(ax0[:, None], bx0)).clamp(min=0)
+    ih = (torch.min(ay1[:, None], by1) - torch.max(ay0[:, None], by0)).clamp(min=0)
+    inter = iw * ih
+    union = ((ax1 - ax0) * (ay1 - ay0))[:, None] + (bx1 - bx0) * (by1 - by0) - inter
+    cw = (torch.max(ax1[:, None], bx1) - torch.min(ax0[:, None], bx0)).clamp(min=0)
+    ch = (torch.max(ay1[:, None], by1) - torch.min(ay0[:, None], by0)).clamp(min=0)
+    area = cw * ch
+    return inter / union - (area - union) / area
+
+
+def _rand_boxes(n, g):
+    c = torch.rand(n, 2, generator=g) * 0.6 + 0.2
+    wh = torch.rand(n, 2, generator=g) * 0.35 + 0.05
+    return torch.cat([c, wh], 1)
+
+
+@pytest.mark.parametrize("Kc", [91, 80])
+@pytest.mark.parametrize("M", [35, 100, 300])
+def test_cfg4_matcher_stress(dev, Kc, M):
+    """BASELINE.json configs[3]: Q = 300, COCO-scale class counts, M targets per image (7 / 20 / 60 ground-truth boxes x
+    hung_match_ratio 5), 6 decoder layers, for both criteria of an iteration: the cost kernel against fp64
+    (reference models/matcher.py:62-83) and the device assignment against SciPy (matcher.py:86), pair for pair."""
+    from scipy.optimize import linear_sum_assignment
+    from spe_amd import kernels as K
+    L, B, Q = 6, 2, 300
+    for crit_id in (0, 1):
+        g = torch.Generator().manual_seed(Kc * 1000 + M + crit_id)
+        logits = (torch.randn(L, B, Q, Kc, generator=g) * 2).to(dev)
+        boxes = torch.stack([torch.stack([_rand_boxes(Q, g) for _ in range(B)]) for _ in range(L)]).to(dev)
+        sizes = [M, M - 5 * crit_id]
+        total = sum(sizes)
+        toff = [0, sizes[0], total]
+        tgt_ids = torch.randint(1, Kc, (total,), generator=g)
+        tgt_boxes = _rand_boxes(total, g)
+        toff_t = torch.tensor(toff, dtype=torch.int32, device=dev)
+        cost, err = K.matcher_cost(logits, boxes, tgt_ids.int().to(dev), tgt_boxes.to(dev), toff_t, total, 2.0, 5.0, 2.0)
+        srow, gidx, lidx = K.hungarian(cost, toff_t, L, B, Q, total, err=err)
+        assert err.item() == 0
+        ch = cost.cpu()
+        es, eg = [], []
+        worst, mean, nblk = 0.0, 0.0, 0
+        for l in range(L):
+            for b in range(B):
+                p = logits[l, b].double().sigmoid().cpu()
+                ids = tgt_ids[toff[b]:toff[b + 1]]
+                tb = tgt_boxes[toff[b]:toff[b + 1]].double()
+                neg = 0.75 * p ** 2 * (-(1 - p + 1e-8).log())
+                pos = 0.25 * (1 - p) ** 2 * (-(p + 1e-8).log())
+                pb = boxes[l, b].double().cpu()
+                ref = 5.0 * torch.cdist(pb, tb, p=1) + 2.0 * (pos[:, ids] - neg[:, ids]) - 2.0 * _giou(pb, tb)
+                blk = ch[l, Q * toff[b]:Q * toff[b + 1]].view(Q, sizes[b])
+                worst = max(worst, float((blk.double() - ref).abs().max()))
+                mean += float((blk.double() - ref).abs().mean()); nblk += 1
+                i, j = linear_sum_assignment(blk.numpy())
+                es.append(torch.as_tensor(i) + (l * B + b) * Q)
+                eg.append(torch.as_tensor(j) + toff[b])
+        # fp32 like the reference (matcher.py:70-73): at |logit| ~ 8 the reference's own `1 - out_prob` cancels to ~3e-4
+        # relative, which the log turns into ~5e-4 absolute on the class cost - the worst element is bounded by that, the mean
+        # error shows there is nothing systematic
+        assert worst < 2e-3 and mean / nblk < 2e-5, (worst, mean / nblk)
+        assert torch.equal(srow.cpu(), torch.cat(es)) and torch.equal(gidx.cpu(), torch.cat(eg))
+
+
+def test_hungarian_non_finite_costs_do_not_hang(dev):
+    """NaN / inf costs (diverged logits) must raise the flag and return, not index LDS out of bounds or spin."""
+    from spe_amd import kernels as K
+    L, B, Q, sizes = 2, 2, 40, [5, 7]
+    total = sum(sizes)
+    toff_t = torch.tensor([0, 5, 12], dtype=torch.int32, device=dev)
+    for bad in (float("nan"), float("inf"), float("-inf")):
+        cost = torch.randn(L, Q * total, device=dev)
+        cost[1, Q * 5:] = bad                                   # layer 1, image 1: every cost non-finite
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        srow, gidx, lidx = K.hungarian(cost, toff_t, L, B, Q, total, err=err)
+        torch.cuda.synchronize()
+        assert err.item() & 2
+        assert int(srow.min()) >= 0 and int(srow.max()) < L * B * Q and int(gidx.max()) < total
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    K.hungarian(torch.randn(L, Q * total, device=dev), toff_t, L, B, Q, total, err=err)
+    assert err.item() == 0
+
+
+@pytest.mark.parametrize("n", [1001, 4097, 64, 3, 1 << 20])
+def test_sqnorm_partials_any_size(dev, n):
+    from spe_amd import kernels as K
+    g = torch.randn(n + 4, device=dev)[:n] if n % 4 else torch.randn(n, device=dev)
+    g = g.contiguous()
+    part = torch.zeros(256, device=dev)
+    K.sqnorm_partials(g, part)
+    assert abs(float(part.double().sum()) - float(g.double().pow(2).sum())) <= 1e-5 * float(g.double().pow(2).sum())
+
+
+# -------------------------------------------------------------------------------------------------- cfg2 / cfg5 attention
+def _talking_ref(qkv, Wl, bl, Ww, bw, H, scale, keep=None):
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    q, k, v = qkv.reshape(B, N, 3, H, C // H).permute(2, 0, 3, 1, 4)
+    attn = (q * scale) @ k.transpose(-2, -1)
+    attn = torch.nn.functional.linear(attn.permute(0, 2, 3, 1), Wl, bl).permute(0, 3, 1, 2)
+    attn = attn.softmax(-1)
+    attn = torch.nn.functional.linear(attn.permute(0, 2, 3, 1), Ww, bw).permute(0, 3, 1, 2)
+    if keep is not None:
+        attn = attn * keep
+    return (attn @ v).transpose(1, 2).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("B,N", [(2, 4150), (1, 6200)])
+def test_fused_attention_at_config_token_counts(dev, B, N):
+    """talking_fused_kernel (4 modes) + attn_contract at the token counts of cfg2 (2 x 4150) and cfg5 (1 x 6200), H = 8,
+    dh = 48, against the fp64 restatement of reference models/cait.py:377-389 evaluated on the device."""
+    from spe_amd import kernels as K, ops
+    K.set_precision("bf16")
+    H, dh = 8, 48
+    g = torch.Generator().manual_seed(N)
+    C = H * dh
+    qkv = torch.randn(B, N, 3 * C, generator=g).to(dev).requires_grad_()
+    Wl = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g)).to(dev).requires_grad_()
+    Ww = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g)).to(dev).requires_grad_()
+    bl = (0.1 * torch.randn(H, generator=g)).to(dev).requires_grad_()
+    bw = (0.1 * torch.randn(H, generator=g)).to(dev).requires_grad_()
+    scale = dh ** -0.5
+    out = ops.talking_heads_attention(qkv, Wl, bl, Ww, bw, H, scale, 0.0, fused=True)
+    go = torch.randn(out.shape, generator=g).to(dev)
+    grads = torch.autograd.grad(out, (qkv, Wl, bl, Ww, bw), go)
+    errs = {}
+    ref_out, ref_g = [], None
+    acc = None
+    for b in range(B):                                     # per image: bounds the fp64 N x N temporaries (~2.5 GB each)
+        dd = [qkv[b:b + 1].detach().double().requires_grad_()] + [t.detach().double().requires_grad_() for t in (Wl, bl, Ww, bw)]
+        ref = _talking_ref(*dd, H, scale)
+        rg = torch.autograd.grad(ref, dd, go[b:b + 1].double())
+        ref_out.append(ref.detach())
+        acc = [rg[0]] if acc is None else acc + [rg[0]]
+        ref_g = list(rg[1:]) if ref_g is None else [x + y for x, y in zip(ref_g, rg[1:])]
+        del ref, rg, dd
+    errs["out"] = rel(out, torch.cat(ref_out))
+    errs["dqkv"] = rel(grads[0], torch.cat(acc))
+    for nm, a, b_ in zip(("dWl", "dbl", "dWw", "dbw"), grads[1:], ref_g):
+        errs[nm] = float(a.abs().max() / grads[1].abs().max()) if nm == "dbl" else rel(a, b_)
+    print(f"[fused attention B={B} N={N}] " + ", ".join(f"{k} {v:.3e}" for k, v in errs.items()))
+    assert torch.isfinite(out).all() and all(torch.isfinite(t).all() for t in grads)
+    assert errs["out"] < 1e-2 and errs["dqkv"] < 2e-2 and errs["dWl"] < 2e-2 and errs["dWw"] < 2e-2 and errs["dbw"] < 2e-2, errs
+    assert errs["dbl"] < 2e-2, errs          # softmax is shift invariant: the exact gradient is 0
+
+
+def _dense_from_blocks(T, N):
+    """[B,H,nt,nt,64,4] blocked scores -> dense [B,H,N,N]: lane l of block (qt,kt) = query qt*16+(l&15), keys
+    kt*16+4*(l>>4)+i (csrc/attn_contract.hip)."""
+    B, H, nt = T.shape[:3]
+    return T.view(B, H, nt, nt, 4, 16, 4).permute(0, 1, 2, 5, 3, 4, 6).reshape(B, H, nt * 16, nt * 16)[:, :, :N, :N]
+
+
+@pytest.mark.parametrize("H,N,dh,B,p", [(8, 131, 48, 2, 0.3), (4, 200, 48, 1, 0.05), (8, 1100, 48, 1, 0.05)])
+def test_fused_attention_with_dropout(dev, H, N, dh, B, p):
+    """The DROP = true instantiation of talking_fused_kernel (reference scripts/run_voc0712.py: drop_attn_rate 0.05;
+    models/cait.py:387 drops the post-softmax mixed probabilities): the keep mask is recovered from the blocked P'd the write
+    pass emits (with / without dropout, same seed and offset the autograd node draws), its rate is checked, and the output
+    and all gradients are compared with the fp64 restatement using THAT mask - so the three backward modes must regenerate
+    it identically."""
+    from spe_amd import kernels as K, ops
+    K.set_precision("bf16")
+    g = torch.Generator().manual_seed(H * N + 7)
+    C = H * dh
+    qkv = torch.randn(B, N, 3 * C, generator=g).to(dev).requires_grad_()
+    Wl = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g)).to(dev).requires_grad_()
+    Ww = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g)).to(dev).requires_grad_()
+    bl = (0.1 * torch.randn(H, generator=g)).to(dev).requires_grad_()
+    bw = (0.2 + 0.05 * torch.randn(H, generator=g)).to(dev).requires_grad_()      # P' stays away from 0: the mask is recoverable
+    scale = dh ** -0.5
+    K.manual_seed(4242)
+    seed, off = 4242, 1                                     # what next_rng() hands to the node below
+    out = ops.talking_heads_attention(qkv, Wl, bl, Ww, bw, H, scale, p, fused=True)
+    go = torch.randn(out.shape, generator=g).to(dev)
+    grads = torch.autograd.grad(out, (qkv, Wl, bl, Ww, bw), go)
+    # --- recover the mask: the write pass with and without dropout on the same statistics
+    with torch.no_grad():
+        v5 = qkv.detach().view(B, N, 3, H, dh)
+        Qf, Kf, _ = K.attn_pack_multi([(v5[:, :, 0], scale * K.LOG2E, 32), (v5[:, :, 1], 1.0, 32), (v5[:, :, 2], 1.0, 16)])
+        nt = (N + 15) // 16
+        spw0, _ = K.fused_plan(B, N, 0)
+        ws = torch.empty((B * nt * 8 * H * 32,), device=dev)
+        args = [t.detach().contiguous() for t in (Wl, bl, Ww, bw)]
+        K.talking_fused(0, Qf, Kf, None, None, *args, None, None, None, ws, None, None, B, H, N, dh, 0.0, 0, 0)
+        M, IL = K.attn_merge(ws, B, H, N, spw0, 0)
+        Pd, P0 = K.score_blocks(B, H, N, dev), K.score_blocks(B, H, N, dev)
+        K.talking_fused(1, Qf, Kf, None, None, *args, M, IL, None, None, None, Pd, B, H, N, dh, p, seed, off)
+        K.talking_fused(1, Qf, Kf, None, None, *args, M, IL, None, None, None, P0, B, H, N, dh, 0.0, 0, 0)
+        dPd, dP0 = _dense_from_blocks(Pd, N).float(), _dense_from_blocks(P0, N).float()
+        ratio = dPd / dP0
+        keepm = ratio.abs() > 0.5
+        rate = 1.0 - float(keepm.float().mean())
+        kept = ratio[keepm]
+        assert abs(rate - p) < 0.02 + 3.0 * (p * (1 - p) / keepm.numel()) ** 0.5, (rate, p)
+        assert float((kept - 1.0 / (1.0 - p)).abs().max()) < 2e-2            # kept entries are scaled by 1 / (1 - p)
+    dd = [t.detach().double().requires_grad_() for t in (qkv, Wl, bl, Ww, bw)]
+    ref = _talking_ref(*dd, H, scale, keep=keepm.double() / (1.0 - p))
+    rg = torch.autograd.grad(ref, dd, go.double())
+    errs = {"out": rel(out, ref)}
+    for nm, a, b_ in zip(("dqkv", "dWl", "dbl", "dWw", "dbw"), grads, rg):
+        errs[nm] = float(a.abs().max() / grads[1].abs().max()) if nm == "dbl" else rel(a, b_)
+    print(f"[fused attention dropout p={p} H={H} N={N}] rate {rate:.4f}, " + ", ".join(f"{k} {v:.3e}" for k, v in errs.items()))
+    assert all(v < 2e-2 for v in errs.values()), errs
+
+
+# ------------------------------------------------------------------------------------------ DP path under RCCL, one rank
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_dp_path_rccl_world1_product_model(dev):
+    """One product-model training step through GradAllReducer (collectives issued through RCCL in a one-rank group, fp32
+    and bf16 wire formats) + FlatAdamW, with the cross-rank `num_boxes` branch of SetCriterion (device scalar +
+    all-reduce, reference conditional_detr.py:436-440) forced - against the plain single-process path: same losses, same
+    updated parameters."""
+    import torch.distributed as dist
+    from spe_amd import kernels as K
+    from spe_amd.dp import GradAllReducer
+    from spe_amd.models import conditional_detr as cd
+    from spe_amd.optim import FlatAdamW
+    from spe_amd.util.misc import NestedTensor
+    blob = torch.load(os.path.join(GOLD, "e2e_single.pt"), weights_only=False)
+    tr = blob["train"]
+
+    def run(mode):
+        model, crit, crit_r, pp, rpp = build(blob, dev)
+        model.train(); crit.train(); crit_r.train()
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        groups = [{"params": [p for n, p in named if "backbone" not in n], "lr": 2e-3},
+                  {"params": [p for n, p in named if "backbone" in n], "lr": 5e-4}]
+        red = GradAllReducer([p for _, p in named], bucket_bytes=1 << 16, flatten_params=True, always_reduce=(mode != "plain"),
+                             wire_dtype=torch.bfloat16 if mode == "rccl_bf16" else None)
+        assert red.collective == (mode != "plain")
+        opt = FlatAdamW(groups, red, weight_decay=1e-2, max_grad_norm=0.1)
+        cd.FORCE_NUM_BOXES_ALLREDUCE = mode != "plain"
+        samples = NestedTensor(blob["tensors"].to(dev), blob["mask"].to(dev))
+        losses = []
+        try:
+            for it in range(3):
+                opt.zero_grad()                                 # the reference loop's call (engine.py:161) re-arms the buckets
+                out = model(samples)
+                l0 = crit(out[0], to_dev(blob["targets"], dev), targets_cp=to_dev(tr["targets_cp0"], dev))
+                l1 = crit_r(out[1], to_dev(tr["pseudo"], dev), targets_cp=to_dev(tr["targets_cp1"], dev))
+                wd = tr["weight_dict"]
+                total = sum(l0[k] * wd[k] for k in l0 if k in wd) + sum(l1[k] * wd[k] for k in l1 if k in wd)
+                total.backward()
+                red.finish()
+                opt.step()
+                losses.append(float(total.detach()))
+        finally:
+            cd.FORCE_NUM_BOXES_ALLREDUCE = False
+            red.remove()
+        return losses, {n: p.detach().clone() for n, p in named}
+
+    K.set_precision("bf16x3")
+    created = False
+    try:
+        la, pa = run("plain")
+        if not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+            created = True
+        lb, pb = run("rccl")
+        lc, pc = run("rccl_bf16")
+    finally:
+        K.set_precision("bf16")
+        if created:
+            dist.destroy_process_group()
+    print("plain", la, "rccl", lb, "rccl bf16 wire", lc)
+    assert abs(la[0] - float(tr["total"])) <= 2e-4 * abs(float(tr["total"]))       # and it is the reference's loss
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 1e-5 * abs(x), (la, lb)
+    errs = sorted(((rel(pb[n], pa[n]), n) for n in pa), reverse=True)
+    assert errs[len(errs) // 10][0] < 1e-5, errs[:3]
+    for x, y in zip(la, lc):                                    # bf16 gradients on the wire: same trajectory within bf16 rounding
+        assert abs(x - y) <= 2e-2 * abs(x), (la, lc)
