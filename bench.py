@@ -98,32 +98,77 @@ def host_cores():
     return n
 
 
-def cpu_baseline(enc_layers):
-    """The oracle (CPU fp32 restatement, parity-pinned to the reference) timed on this box's host cores on a
-    bounded sample of the same workload: ONE 3x800x1333 image, S24 dims, forward + both criteria + backward,
-    with 2 and 6 of the 24 backbone blocks; the per-block time (their difference / 4) is scaled to 24 blocks."""
-    from oracle import spe_oracle as O
-    from spe_amd.models import build_model
-    from spe_amd.models.cait import TSCAM_cait, _make, register_model
-    cores = host_cores()
-    torch.set_num_threads(cores)
-    times = {}
-    for depth in (2, 6):
-        name = f"TSCAM_cait_S24_depth{depth}"
+def host_ram_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / 1e6
+    except Exception:
+        pass
+    return 0.0
 
+
+def _cpu_case(depth, enc_layers):
+    """(model args, oracle cfg) of the bench workload with `depth` of the 24 backbone blocks."""
+    from oracle import spe_oracle as O
+    from spe_amd.models.cait import TSCAM_cait, _make, register_model
+    name = "TSCAM_cait_S24" if depth == 24 else f"TSCAM_cait_S24_depth{depth}"
+    if depth != 24:
         def fac(pretrained=False, _d=depth, **kw):
             return _make(TSCAM_cait, 384, _d, 8, 1e-5, False, **kw)
         fac.__name__ = name
         register_model(fac)
-        a = model_args(backbone=name, enc_layers=enc_layers, layer_to_det=depth - 1)
-        a.device = "cpu"
+    a = model_args(backbone=name, enc_layers=enc_layers, layer_to_det=depth - 1)
+    a.device = "cpu"
+    cfg = O.make_cfg(embed_dim=384, depth=depth, num_heads=8, num_cls_tokens=90, layer_to_det=depth - 1, two_branch=False,
+                     pos_grid=(50, 84), nheads=8, enc_layers=enc_layers, dec_layers=6, dim_feedforward=2048,
+                     num_queries=100, num_refines=1, num_det_classes=91, aux_loss=True)
+    return a, cfg
+
+
+def cpu_baseline(enc_layers, gpu_model=None, gpu_eval=None):
+    """The oracle (CPU fp32 restatement, parity-pinned to the reference) timed on this box's host cores on a bounded
+    sample of the same workload: ONE 3x800x1333 image, S24 dims, forward + both criteria + backward.
+    With >= 100 GB of free host RAM (the eager graph keeps ~2.7 GB per backbone block at N = 4150) all 24 blocks run -
+    a measured number; otherwise 2 and 6 blocks are timed and the per-block time is scaled to 24 ("extrapolated": true).
+    gpu_model / gpu_eval: when given, the oracle runs on the GPU model's CURRENT weights and its total loss is compared
+    with the product's on the same image (BASELINE.json's "loss delta vs ref" of the benchmarked precision mode)."""
+    from oracle import spe_oracle as O
+    from spe_amd.models import build_model
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    img, mask, tg = synth_batch(99, "cpu", batch=1)
+    ram = host_ram_gb()
+    parity = None
+    if ram >= 100.0:
+        a, cfg = _cpu_case(24, enc_layers)
+        if gpu_model is not None:
+            sd = {k: v.detach().to("cpu", copy=True).requires_grad_(v.is_floating_point()) for k, v in gpu_model.state_dict().items()}
+        else:
+            torch.manual_seed(0)
+            model, *_ = build_model(a)
+            sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+        got, pseudo = gpu_eval(img, mask, tg) if gpu_eval is not None else (None, None)
+        t0 = time.perf_counter()
+        # the stage-1 targets (detached inputs of criterion_refine) are the product's: an argmax-over-queries flip between
+        # two nearly tied queries of a randomly initialised decoder must not pass for a loss error
+        tot, *_ = O.total_loss(sd, cfg, img, mask, tg, pseudo=pseudo)
+        tot.backward()
+        t_img = time.perf_counter() - t0
+        if gpu_eval is not None:
+            ref = float(tot.detach())
+            parity = {"loss_gpu": got, "loss_oracle_cpu": ref, "loss_rel_delta": abs(got - ref) / abs(ref),
+                      "sample": "total weighted loss (both criteria, eval mode, no dropout), 1 image 3x800x1333, the benchmarked "
+                                "model's current weights, product in the benchmarked precision mode vs the fp32 CPU oracle"}
+        return ({"value": 1.0 / t_img, "unit": "images/sec", "cores": cores, "kind": "port", "extrapolated": False,
+                 "sample": f"oracle fwd+criteria+bwd, 1 image 3x800x1333, S24 dims, all 24 backbone blocks: {t_img:.1f}s "
+                           f"(host RAM available {ram:.0f} GB)"}, parity)
+    times = {}
+    for depth in (2, 6):
+        a, cfg = _cpu_case(depth, enc_layers)
         torch.manual_seed(0)
         model, *_ = build_model(a)
         sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
-        cfg = O.make_cfg(embed_dim=384, depth=depth, num_heads=8, num_cls_tokens=90, layer_to_det=depth - 1, two_branch=False,
-                         pos_grid=(50, 84), nheads=8, enc_layers=enc_layers, dec_layers=6, dim_feedforward=2048,
-                         num_queries=100, num_refines=1, num_det_classes=91, aux_loss=True)
-        img, mask, tg = synth_batch(99, "cpu", batch=1)
         t0 = time.perf_counter()
         tot, *_ = O.total_loss(sd, cfg, img, mask, tg)
         tot.backward()
@@ -132,9 +177,30 @@ def cpu_baseline(enc_layers):
     per_block = max((times[6] - times[2]) / 4.0, 1e-9)
     rest = max(times[2] - 2 * per_block, 0.0)
     t_img = rest + 24 * per_block
-    return {"value": 1.0 / t_img, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": (f"oracle fwd+criteria+bwd, 1 image 3x800x1333, S24 dims; timed with 2 and 6 backbone blocks "
-                       f"({times[2]:.1f}s, {times[6]:.1f}s), per-block {per_block:.2f}s scaled to 24 blocks + rest {rest:.1f}s")}
+    return ({"value": 1.0 / t_img, "unit": "images/sec", "cores": cores, "kind": "port", "extrapolated": True,
+             "sample": (f"oracle fwd+criteria+bwd, 1 image 3x800x1333, S24 dims; host RAM {ram:.0f} GB < 100 GB, so timed with 2 and 6 "
+                        f"backbone blocks ({times[2]:.1f}s, {times[6]:.1f}s), per-block {per_block:.2f}s scaled to 24 blocks + rest {rest:.1f}s")},
+            parity)
+
+
+def roofline_inputs():
+    """HBM traffic per launch (PMC runs) and the measured peaks: profiles/roofline_inputs.json, written by
+    tools/pmc_to_json.py from the rocprofv3 --pmc runs of this same command."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "roofline_inputs.json")) as fh:
+            return json.load(fh)
+    except Exception:
+        return {}
+
+
+def parity_record():
+    """Measured errors of the benchmarked precision mode against the REFERENCE at cfg2's token count
+    (tests/test_config_golden.py on the GPU box -> profiles/parity_r02.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "parity_r02.json")) as fh:
+            return json.load(fh)
+    except Exception:
+        return {}
 
 
 def main():
@@ -218,33 +284,48 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    # dominant kernel (largest single-shape kernel of the step: backward pass 2 of the fused talking-heads
-    # attention) timed live with HIP events on the launch stream
+    # kernels timed live with HIP events on the launch stream: the dominant kernel (backward pass 2 of the fused
+    # talking-heads attention), the HBM-bound contraction kernel and north_star's decoder cross-attention GEMM (the
+    # memory-side projections ca_kcontent / ca_v / ca_kpos of reference models/transformer.py:389-419:
+    # [B*S, d] x [d, d] = [8300 x 384] x [384 x 384] at cfg2)
     DOM, HBMK = "spe_talking_fused", "spe_attn_contract"
-    K.enable_timing([DOM, HBMK])
+    S_rows, d_model = a.batch * (a.height // 16) * (a.width // 16), 384
+    CAG = f"spe_gemm_bf16nt:{S_rows},{d_model},{d_model}"
+    K.enable_timing([DOM, HBMK, CAG])
+    reducer.measure = True
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         last = step()
     sync()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     K_res = K.timing_results()
     K.enable_timing([])
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    reducer.measure = False
+    per_rank = [dt_local]
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+        tl = torch.tensor([dt_local], device=dev, dtype=torch.float64)
+        gath = [torch.zeros_like(tl) for _ in range(world)]
+        dist.all_gather(gath, tl)
+        per_rank = [float(g.item()) for g in gath]
+    dt = max(per_rank)
     loss_val = float(last.detach())
 
     if rank == 0:
         imgs = a.batch * world * a.steps
         N = (a.height // 16) * (a.width // 16)
         Hh = 8
+        rin = roofline_inputs()
+        kin = rin.get("kernels", {})
+        pk = rin.get("peaks_measured", {})
         # K.timing_results() keys fused launches by mode: "spe_talking_fused:3" = backward pass 2
         launches, mean_ms = K_res.get(DOM + ":3", (0, 0.0))
-        # algorithmic MFMA work of one launch: S = QK^T and dP' = dO V^T for all heads, 2*N*N*dh FLOP each
-        alg_flop = 2 * (2.0 * N * N * 48) * Hh * a.batch
-        ach = alg_flop / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
+        # MFMA work of one launch: S = QK^T (a recomputation: SURVEY 8(d) does not count it) and dP' = dO V^T (algorithmic)
+        # for all heads, 2*N*N*dh FLOP each.  `achieved` counts both (what the matrix pipe executes); `achieved_algorithmic`
+        # only dP'.
+        mf = (2.0 * N * N * 48) * Hh * a.batch
+        ach = 2 * mf / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
+        ach_alg = mf / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
         # the kernel's real limiter is the fp32 head-mix VALU work (3 mixes + the dWl outer product, 2*H FLOP each
         # per score and head): reported alongside against the 157.3 TFLOP/s vector peak
         valu_flop = 4 * (2.0 * Hh * Hh) * N * N * a.batch
@@ -254,6 +335,13 @@ def main():
         c_launch, c_ms = K_res.get(HBMK, (0, 0.0))
         c_bytes = 2.0 * a.batch * Hh * N * N
         c_bw = c_bytes / (c_ms * 1e-3) / 1e9 if c_ms > 0 else 0.0
+        # decoder cross-attention memory-side GEMM: 2*M*N*K FLOP; bytes = bf16 A [M,K] + bf16 W [N,K] + fp32 C [M,N]
+        g_launch, g_ms = K_res.get(CAG, (0, 0.0))
+        g_flop = 2.0 * S_rows * d_model * d_model
+        g_bytes = 2.0 * S_rows * d_model + 2.0 * d_model * d_model + 4.0 * S_rows * d_model
+        g_tf = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        g_bw = g_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+        g_floor_us = max(g_flop / 2.5e15, g_bytes / 8e12) * 1e6
         res = {
             "metric": "images/sec (whole node) at 3x800x1333 bs=2/GPU", "value": imgs / dt, "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -264,18 +352,46 @@ def main():
                                    f"{a.batch}x3x{a.height}x{a.width} per GPU (N={N} tokens), fwd + SetCriterion + "
                                    f"SetCriterionRefine + bwd + grad all-reduce + clip + AdamW",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": loss_val},
+            "per_rank_ms_per_step": [t_ / a.steps * 1e3 for t_ in per_rank],
+            "allreduce_exposed_ms_per_step": reducer.exposed_ms_mean(),
             "roofline": {"bound": "mfma", "kernel": "talking_fused_kernel<8,2,3> (attention backward pass 2)", "launches": launches,
-                         "avg_ms": mean_ms, "achieved": ach, "peak": 2500.0, "peak_measured": 1240.0, "unit": "TFLOP/s", "frac": ach / 2500.0,
-                         "traffic": 9.95e8,   # bytes/launch, profiles/r01_pmc_fetch_write_v3.txt (2*FETCH_SIZE + WRITE_SIZE)
+                         "avg_ms": mean_ms, "achieved": ach, "achieved_algorithmic": ach_alg, "peak": 2500.0,
+                         "peak_measured": pk.get("mfma_bf16_tflops"), "unit": "TFLOP/s", "frac": ach / 2500.0,
+                         "frac_algorithmic": ach_alg / 2500.0,
+                         "traffic": kin.get("talking_fused_mode3", {}).get("traffic_bytes"),   # bytes/launch, PMC (profiles/roofline_inputs.json)
                          "note": "not MFMA-bound: fp32 head mixes (no MFMA form), fragment loads and MFMA phases serialise at 2 waves/SIMD", "valu_achieved": valu, "valu_peak": 157.3,
                          "valu_frac": valu / 157.3,
                          "hbm_kernel": {"bound": "hbm", "kernel": "attn_contract_kernel<3,*> (PV / dV / dQ / dK over blocked bf16 scores)",
-                                        "launches": c_launch, "avg_ms": c_ms, "achieved": c_bw, "peak": 8000.0, "peak_measured": 6200.0, "unit": "GB/s",
-                                        "frac": c_bw / 8000.0, "traffic": 6.14e8}},
+                                        "launches": c_launch, "avg_ms": c_ms, "achieved": c_bw, "peak": 8000.0,
+                                        "peak_measured": pk.get("hbm_read_gbs"), "unit": "GB/s",
+                                        "frac": c_bw / 8000.0, "traffic": kin.get("attn_contract", {}).get("traffic_bytes")},
+                         "decoder_ca_gemm": {"kernel": f"gemm_bf16nt_kernel [{S_rows}x{d_model}]x[{d_model}x{d_model}] (ca_kcontent / ca_v / ca_kpos "
+                                                       "projections of the decoder cross-attention and the equal-shaped dx GEMMs)",
+                                             "launches": g_launch, "avg_us": g_ms * 1e3, "flop": g_flop, "bytes": g_bytes,
+                                             "achieved_tflops": g_tf, "mfma_frac": g_tf / 2500.0, "achieved_gbs": g_bw, "hbm_frac": g_bw / 8000.0,
+                                             "bound": "hbm", "floor_us": g_floor_us,
+                                             "note": "130 FLOP/B < the 312 FLOP/B ridge: HBM-bound; one such GEMM has a 2.4 us HBM floor "
+                                                     "(1.0 PFLOP/s = 41 % of the MFMA peak at best) and sits at the launch/latency floor"}},
+            "precision_contract": parity_record().get(a.precision),
         }
         if world == 1 and not a.no_cpu_baseline:
+            def gpu_eval(img1, mask1, tg1):
+                model.eval(); crit.eval(); crit_r.eval()
+                try:
+                    with torch.no_grad():
+                        tgd = [{k: v.to(dev) for k, v in t.items()} for t in tg1]
+                        o = model(NestedTensor(img1.to(dev), mask1.to(dev)))
+                        e0 = crit(o[0], tgd)
+                        ps = pseudo_labels(rpp, o[0], tgd)
+                        e1 = crit_r(o[1], ps)
+                        keep = ("labels", "boxes", "scores")
+                        return float(weighted_total(e0, e1, wd)), [{k: p[k].detach().cpu() for k in keep} for p in ps]
+                finally:
+                    model.train(); crit.train(); crit_r.train()
             try:
-                res["cpu_baseline"] = cpu_baseline(a.enc_layers)
+                res["cpu_baseline"], par = cpu_baseline(a.enc_layers, gpu_model=model, gpu_eval=gpu_eval)
+                if par is not None:
+                    res["loss_delta_vs_ref"] = par
             except Exception as e:      # the CPU leg must never take the GPU number down with it
                 res["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": host_cores(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}

@@ -546,14 +546,18 @@ def weight_dict(cfg, coef=None):
     return wd
 
 
-def total_loss(sd, cfg, img, mask, targets, targets_refine_scores=None):
+def total_loss(sd, cfg, img, mask, targets, targets_refine_scores=None, pseudo=None):
     """One reference training iteration's scalar (engine.py:116-144 without the cv2 CAM step and the
     epoch curriculum): stage-0 criterion on `targets`, stage-1 (refine) criterion on PostProcessRefine
-    pseudo labels of stage 0.  Eval-mode criterion (no jitter)."""
+    pseudo labels of stage 0.  Eval-mode criterion (no jitter).  `pseudo`: stage-1 targets given by the caller
+    (they are detached inputs of criterion_refine, engine.py:122-130) instead of this function's own."""
     out = model_forward(sd, cfg, img, mask)
     l0 = set_criterion(out[0], targets, refine=False)
-    with torch.no_grad():
-        pseudo = postprocess_refine(out[0], targets)
+    if pseudo is None:
+        with torch.no_grad():
+            pseudo = postprocess_refine(out[0], targets)
+    else:
+        pseudo = [dict(p_) for p_ in pseudo]
     for p_, t_ in zip(pseudo, targets):
         p_["img_label"] = t_["img_label"]
     l1 = set_criterion(out[1], pseudo, refine=True)
