@@ -25,11 +25,11 @@ sys.path.insert(0, ROOT)
 
 
 def model_args(backbone="TSCAM_cait_S24", enc_layers=0, dec_layers=6, num_queries=100, dataset="coco", layer_to_det=23,
-               dropout=0.1, nheads=8, dim_feedforward=2048):
+               dropout=0.1, nheads=8, dim_feedforward=2048, drop_path=0.0, attn_drop=0.0, backbone_drop=0.0):
     """reference main.py:37-146 defaults + BASELINE.json cfg2."""
     return argparse.Namespace(
-        dataset_file=dataset, device="cuda", backbone=backbone, backbone_drop_rate=0.0, drop_path_rate=0.0,
-        drop_block_rate=0.0, drop_attn_rate=0.0, layer_to_det=layer_to_det, lr_backbone=1e-5, masks=False, dilation=False,
+        dataset_file=dataset, device="cuda", backbone=backbone, backbone_drop_rate=backbone_drop, drop_path_rate=drop_path,
+        drop_block_rate=0.0, drop_attn_rate=attn_drop, layer_to_det=layer_to_det, lr_backbone=1e-5, masks=False, dilation=False,
         position_embedding="sine", hidden_dim=256, dropout=dropout, nheads=nheads, num_queries=num_queries,
         dim_feedforward=dim_feedforward, enc_layers=enc_layers, dec_layers=dec_layers, pre_norm=False, aux_loss=True,
         num_refines=1, frozen_weights=None, set_cost_class=2, set_cost_bbox=5, set_cost_giou=2, hung_match_ratio=5,
@@ -215,6 +215,12 @@ def main():
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--queries", type=int, default=100)
+    # the reference's launch scripts (scripts/run_voc0712.py:15-41): --backbone TSCAM_cait_XXS36_Two_Branch --layer-to-det 24
+    # --enc-layers 3 --queries 300 --drop-path 0.2 --attn-drop 0.05 --backbone-drop 0.07 --height 512 --width 512 --batch 1
+    ap.add_argument("--layer-to-det", type=int, default=23)
+    ap.add_argument("--drop-path", type=float, default=0.0)
+    ap.add_argument("--attn-drop", type=float, default=0.0)
+    ap.add_argument("--backbone-drop", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -247,7 +253,8 @@ def main():
     K.set_precision(a.precision)
     K.manual_seed(1234 + rank)
 
-    args = model_args(backbone=a.backbone, enc_layers=a.enc_layers, num_queries=a.queries)
+    args = model_args(backbone=a.backbone, enc_layers=a.enc_layers, num_queries=a.queries, layer_to_det=a.layer_to_det,
+                      drop_path=a.drop_path, attn_drop=a.attn_drop, backbone_drop=a.backbone_drop)
     torch.manual_seed(0)                      # identical replicas
     model, crit, crit_r, pp, rpp = build_model(args)
     model.to(dev).train()
@@ -289,7 +296,8 @@ def main():
     # memory-side projections ca_kcontent / ca_v / ca_kpos of reference models/transformer.py:389-419:
     # [B*S, d] x [d, d] = [8300 x 384] x [384 x 384] at cfg2)
     DOM, HBMK = "spe_talking_fused", "spe_attn_contract"
-    S_rows, d_model = a.batch * (a.height // 16) * (a.width // 16), 384
+    body = model.backbone[0].body
+    S_rows, d_model = a.batch * (a.height // 16) * (a.width // 16), body.embed_dim
     CAG = f"spe_gemm_bf16nt:{S_rows},{d_model},{d_model}"
     K.enable_timing([DOM, HBMK, CAG])
     reducer.measure = True
@@ -314,7 +322,7 @@ def main():
     if rank == 0:
         imgs = a.batch * world * a.steps
         N = (a.height // 16) * (a.width // 16)
-        Hh = 8
+        Hh, dh_ = body.num_heads, body.embed_dim // body.num_heads
         rin = roofline_inputs()
         kin = rin.get("kernels", {})
         pk = rin.get("peaks_measured", {})
@@ -323,7 +331,7 @@ def main():
         # MFMA work of one launch: S = QK^T (a recomputation: SURVEY 8(d) does not count it) and dP' = dO V^T (algorithmic)
         # for all heads, 2*N*N*dh FLOP each.  `achieved` counts both (what the matrix pipe executes); `achieved_algorithmic`
         # only dP'.
-        mf = (2.0 * N * N * 48) * Hh * a.batch
+        mf = (2.0 * N * N * dh_) * Hh * a.batch
         ach = 2 * mf / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
         ach_alg = mf / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
         # the kernel's real limiter is the fp32 head-mix VALU work (3 mixes + the dWl outer product, 2*H FLOP each
@@ -347,11 +355,12 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if a.precision == "bf16" else "bf16x3", "data": "synthetic",
-            "config": {"workload": f"{a.backbone} (C=384, depth 24, 8 heads) + {a.enc_layers}-layer encoder + 6-layer "
+            "config": {"workload": f"{a.backbone} (C={body.embed_dim}, depth {body.depth}, {Hh} heads) + {a.enc_layers}-layer encoder + 6-layer "
                                    f"conditional-DETR decoder x2 stages, {a.queries} queries, COCO heads (91), "
                                    f"{a.batch}x3x{a.height}x{a.width} per GPU (N={N} tokens), fwd + SetCriterion + "
                                    f"SetCriterionRefine + bwd + grad all-reduce + clip + AdamW",
-                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": loss_val},
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": loss_val,
+                       "drop_rates": {"decoder": 0.1, "drop_path": a.drop_path, "attn_drop": a.attn_drop, "backbone_drop": a.backbone_drop}},
             "per_rank_ms_per_step": [t_ / a.steps * 1e3 for t_ in per_rank],
             "allreduce_exposed_ms_per_step": reducer.exposed_ms_mean(),
             "roofline": {"bound": "mfma", "kernel": "talking_fused_kernel<8,2,3> (attention backward pass 2)", "launches": launches,
@@ -374,7 +383,8 @@ def main():
                                                      "(1.0 PFLOP/s = 41 % of the MFMA peak at best) and sits at the launch/latency floor"}},
             "precision_contract": parity_record().get(a.precision),
         }
-        if world == 1 and not a.no_cpu_baseline:
+        default_cfg = (a.backbone == "TSCAM_cait_S24" and a.height == 800 and a.width == 1333 and a.queries == 100 and a.batch == 2)
+        if world == 1 and not a.no_cpu_baseline and default_cfg:
             def gpu_eval(img1, mask1, tg1):
                 model.eval(); crit.eval(); crit_r.eval()
                 try:

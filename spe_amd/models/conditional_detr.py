@@ -326,6 +326,27 @@ class PostProcessRefine(nn.Module):
         return res
 
 
+class PostProcessRefineMulti(nn.Module):
+    """Multi-box variant of PostProcessRefine (reference conditional_detr.py:680-715; built by no script, kept for API
+    parity): for every class present in an image's labels ALL queries whose probability reaches half of the best
+    query's, with their normalised cxcywh boxes; classes ascending, queries ascending within a class."""
+
+    @torch.no_grad()
+    def forward(self, outputs, target_sizes, targets=None):
+        out_logits, out_bbox = outputs["pred_logits"], outputs["pred_boxes"]
+        assert len(out_logits) == len(target_sizes) and target_sizes.shape[1] == 2
+        prob = out_logits.sigmoid()
+        keep = prob >= 0.5 * prob.max(dim=1, keepdim=True)[0]                   # [B,Q,Kc]
+        res = []
+        for b, t in enumerate(targets):
+            lab = torch.unique(t["labels"]).to(out_logits.device)
+            lab = lab[lab < out_logits.shape[2]]
+            cq = keep[b][:, lab].t().nonzero(as_tuple=False)                    # (class position, query), class-major
+            cls, q = lab[cq[:, 0]], cq[:, 1]
+            res.append({"scores": prob[b, q, cls], "labels": cls, "boxes": out_bbox[b, q]})
+        return res
+
+
 def build(args):
     num_classes = 21 if args.dataset_file != "coco" else 91
     if args.dataset_file == "coco_panoptic":

@@ -59,6 +59,33 @@ def get_rank():
     return dist.get_rank() if is_dist_avail_and_initialized() else 0
 
 
+def reduce_dict(input_dict, average=True):
+    """All-reduce a dict of 0-dim loss tensors for logging (reference util/misc.py:139-163, called at engine.py:147):
+    keys sorted so every rank stacks the same order, ONE collective for the whole dict, / world when `average`."""
+    world_size = get_world_size()
+    if world_size < 2:
+        return input_dict
+    with torch.no_grad():
+        names = sorted(input_dict.keys())
+        values = torch.stack([input_dict[k] for k in names], dim=0)
+        dist.all_reduce(values)
+        if average:
+            values /= world_size
+        return dict(zip(names, values))
+
+
+@torch.no_grad()
+def accuracy(output, target, topk=(1,)):
+    """precision@k in percent of [n, classes] scores against [n] labels (reference util/misc.py:439-455); the criterion's
+    `class_error` is 100 - accuracy(...)[0] (inside SetCriterion the top-1 comes out of the focal kernel's pass instead)."""
+    if target.numel() == 0:
+        return [torch.zeros([], device=output.device)]
+    maxk = max(topk)
+    pred = output.topk(maxk, 1, True, True)[1].t()
+    correct = pred.eq(target.view(1, -1).expand_as(pred))
+    return [correct[:k].reshape(-1).float().sum(0) * (100.0 / target.size(0)) for k in topk]
+
+
 def host_to_device(values, dtype, device):
     """Small host list -> device tensor through pinned memory with an asynchronous copy.  `torch.tensor(list,
     device=cuda)` stages through pageable memory and blocks the host until every kernel queued before it has run."""

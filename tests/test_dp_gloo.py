@@ -65,6 +65,10 @@ def _worker(rank, world, port, out):
     nb = torch.tensor([float(3 + 4 * rank)])
     dist.all_reduce(nb)
     assert float(torch.clamp(nb / world, min=1)) == 5.0
+    # logging-only reduction of the loss dict (reference util/misc.py:139-163, engine.py:147)
+    from spe_amd.util.misc import reduce_dict
+    rd = reduce_dict({"b": torch.tensor(float(rank)), "a": torch.tensor(2.0 + rank)})
+    assert float(rd["a"]) == 2.5 and float(rd["b"]) == 0.5
     out[rank] = True
     dist.barrier()
     dist.destroy_process_group()

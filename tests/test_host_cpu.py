@@ -204,3 +204,32 @@ def test_cam_contour_boxes_vs_oracle_and_ndimage():
         assert sorted(allb) == sorted(comp + holes), name
     rect = [b for n_, im in _blob_images() if n_ == "rect" for b in CO.find_borders(im)]
     assert rect == [(8.0 * 5.0, 4, 3, 12, 8)]
+
+
+def test_accuracy_and_postprocess_refine_multi():
+    """util.misc.accuracy (reference util/misc.py:439-455) and PostProcessRefineMulti (conditional_detr.py:680-715) against
+    loop restatements of their semantics."""
+    import torch
+    from spe_amd.models.conditional_detr import PostProcessRefineMulti
+    from spe_amd.util.misc import accuracy
+    g = torch.Generator().manual_seed(3)
+    out = torch.randn(17, 9, generator=g)
+    tgt = torch.randint(0, 9, (17,), generator=g)
+    a1, a3 = accuracy(out, tgt, topk=(1, 3))
+    assert abs(float(a1) - 100.0 * float((out.argmax(1) == tgt).float().mean())) < 1e-4
+    top3 = out.topk(3, 1)[1]
+    assert abs(float(a3) - 100.0 * float((top3 == tgt[:, None]).any(1).float().mean())) < 1e-4
+    assert float(accuracy(out[:0], tgt[:0])[0]) == 0.0
+    B, Q, Kc = 2, 12, 7
+    logits, boxes = torch.randn(B, Q, Kc, generator=g), torch.rand(B, Q, 4, generator=g)
+    targets = [{"labels": torch.tensor([3, 1, 3])}, {"labels": torch.tensor([6])}]
+    res = PostProcessRefineMulti()({"pred_logits": logits, "pred_boxes": boxes}, torch.tensor([[10, 10], [10, 10]]), targets)
+    prob = logits.sigmoid()
+    for b, t in enumerate(targets):
+        labs, scs, bxs = [], [], []
+        for c in range(Kc):
+            if c in t["labels"]:
+                keep = (prob[b, :, c] >= 0.5 * prob[b, :, c].max()).nonzero().reshape(-1)
+                labs += [c] * len(keep); scs.append(prob[b, keep, c]); bxs.append(boxes[b, keep])
+        assert res[b]["labels"].tolist() == labs
+        assert torch.equal(res[b]["scores"], torch.cat(scs)) and torch.equal(res[b]["boxes"], torch.cat(bxs))
