@@ -190,6 +190,17 @@ int spe_layerscale_residual_bwd16(const float* dout, const float* y, const float
  * autograd of F.relu (transformer.py:32,287,424) and nn.GELU (timm Mlp). n % 4 == 0. */
 int spe_act_bwd(const float* dy, const float* aux, float* dx, long n, int mode, spe_stream_t stream);
 
+/* ---- norm(x + dropout(z)): the post-norm residual sites of the DETR encoder / decoder layers (reference
+ * models/transformer.py:279-287, 384-386, 420-421, 426-427) in one pass each way.  fwd: sum = x + z*keepscale(row*C+c) (kept:
+ * it is LayerNorm's input), y / mean / rstd as spe_layernorm_fwd.  bwd: ds = LayerNorm backward (gradient of x and of the sum),
+ * dz = ds*keepscale with the same mask (not written when p == 0: the branch gradient is ds); dgamma / dbeta pre-zeroed. */
+int spe_layernorm_res_fwd(const float* x, const float* z, const float* gamma, const float* beta, float* sum, float* y,
+                          float* mean, float* rstd, long R, int C, float eps, float p, uint64_t seed, uint64_t offset,
+                          spe_stream_t stream);
+int spe_layernorm_res_bwd(const float* dy, const float* sum, const float* gamma, const float* mean, const float* rstd,
+                          float* ds, float* dz, float* dgamma, float* dbeta, long R, int C, float p, uint64_t seed,
+                          uint64_t offset, spe_stream_t stream);
+
 /* ---- dropout y = x*keepscale (nn.Dropout at cait.py:387,391, transformer.py:266-288, timm Mlp);
  * the backward is the same call on dy. */
 int spe_dropout(const float* x, float* y, long n, float p, uint64_t seed, uint64_t offset, spe_stream_t stream);

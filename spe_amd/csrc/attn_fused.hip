@@ -124,9 +124,15 @@ __device__ __forceinline__ f32x4_t frag_mfma(int st, u32x4_t a, u32x4_t b, f32x4
 }
 
 template <int H, int DSTEPS, bool TAIL16, int MODE, bool DROP, int KT>
-__global__ __launch_bounds__(256, 2) void talking_fused_kernel(FusedArgs a) {
+#ifndef SPE_FUSED_MINW
+#define SPE_FUSED_MINW 2
+#endif
+#ifndef SPE_FUSED_JB2
+#define SPE_FUSED_JB2 4
+#endif
+__global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(FusedArgs a) {
     constexpr int NFR = H * DSTEPS;                        // fragments (16 B per lane) per q-tile
-    constexpr int JB = (MODE >= 2) ? ((H >= 4) ? 4 : H) : H;  // MFMA jobs per operand-fragment batch
+    constexpr int JB = (MODE >= 2) ? ((H >= SPE_FUSED_JB2) ? SPE_FUSED_JB2 : H) : H;  // MFMA jobs per operand-fragment batch
     // request the next macro step's first batch before the VALU phases (its registers stay live through them)
 #ifndef SPE_FUSED_PREF1
 #define SPE_FUSED_PREF1 1

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     long R, int C, const float* __restrict__ add) {
+                                                     long R, int C, const float* __restrict__ add, float* __restrict__ dz,
+                                                     float p, uint64_t seed, uint64_t offset) {
     extern __shared__ float red_raw[];                 // [2][NW][C + 4]
     const int ldr = C + 4;
     auto red = [&](int k, int wv, int c) -> float& { return red_raw[((long)k * NW + wv) * ldr + c]; };
@@ -103,6 +104,11 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict
                 o.z = rs * (dg[i].z - s1 - xh[i].z * s2); o.w = rs * (dg[i].w - s1 - xh[i].w * s2);
                 if (ar) { const float4 a4 = ar[c]; o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w; }   // + gradient of the skip path
                 dxr[c] = o;
+                if (dz) {          // gradient of the dropped branch of norm(x + dropout(z)): same mask as ln_res_fwd_kernel
+                    float ks[4];
+                    spe_drop_scale4(seed, offset, (uint64_t)(row * C + 4 * c), p, ks);
+                    reinterpret_cast<float4*>(dz + row * C)[c] = make_float4(o.x * ks[0], o.y * ks[1], o.z * ks[2], o.w * ks[3]);
+                }
             }
         }
     }
@@ -124,6 +130,80 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict
     }
 }
 
+// Post-norm residual site of the DETR encoder / decoder layers, `norm(x + dropout(z))` (reference models/transformer.py:
+// 279-287, 384-386, 420-421, 426-427), as ONE pass: s = x + z * keepscale(row*C + c) is written (LayerNorm's input, kept for
+// the backward), then normalised exactly like ln_fwd_kernel.  The dropout stream is that of dropout_kernel (element index
+// row*C + c), so the fused and the unfused composition draw the same mask.
+__global__ __launch_bounds__(256) void ln_res_fwd_kernel(const float* __restrict__ x, const float* __restrict__ z,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ sum, float* __restrict__ y, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, long R, int C, float eps, float p,
+                                                         uint64_t seed, uint64_t offset) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int C4 = C >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * C);
+    const float4* zr = reinterpret_cast<const float4*>(z + row * C);
+    float4* sr = reinterpret_cast<float4*>(sum + row * C);
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C4) {
+            const float4 a = xr[c];
+            float4 b = zr[c];
+            if (p > 0.f) {
+                float ks[4];
+                spe_drop_scale4(seed, offset, (uint64_t)(row * C + 4 * c), p, ks);
+                b.x *= ks[0]; b.y *= ks[1]; b.z *= ks[2]; b.w *= ks[3];
+            }
+            v[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            sr[c] = v[i];
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    }
+    const float mu = spe_wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C4) {
+            const float a = v[i].x - mu, b = v[i].y - mu, d = v[i].z - mu, e = v[i].w - mu;
+            q += a * a + b * b + d * d + e * e;
+        }
+    }
+    const float rs = rsqrtf(spe_wave_sum(q) / (float)C + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    float4* yr = reinterpret_cast<float4*>(y + row * C);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C4) {
+            const float4 g = g4[c], b = b4[c];
+            float4 o;
+            o.x = (v[i].x - mu) * rs * g.x + b.x; o.y = (v[i].y - mu) * rs * g.y + b.y;
+            o.z = (v[i].z - mu) * rs * g.z + b.z; o.w = (v[i].w - mu) * rs * g.w + b.w;
+            yr[c] = o;
+        }
+    }
+}
+
+// C-ABI: see include/spe_hip.h (spe_layernorm_res_fwd).
+extern "C" int spe_layernorm_res_fwd(const float* x, const float* z, const float* gamma, const float* beta, float* sum, float* y,
+                                     float* mean, float* rstd, long R, int C, float eps, float p, uint64_t seed, uint64_t offset,
+                                     hipStream_t st) {
+    if (R <= 0) return 0;
+    if ((C & 3) || C > 256 * LN_MAXV) return -2;
+    hipLaunchKernelGGL(ln_res_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, z, gamma, beta, sum, y, mean, rstd, R, C,
+                       eps, p, seed, offset);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int spe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                  float* rstd, long R, int C, float eps, hipStream_t st) {
     if (R <= 0) return 0;
@@ -132,9 +212,9 @@ extern "C" int spe_layernorm_fwd(const float* x, const float* gamma, const float
     SPE_CHECK_LAUNCH();
     return 0;
 }
-extern "C" int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
-                                 const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,
-                                 const float* add, hipStream_t st) {
+static int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                         float* dgamma, float* dbeta, long R, int C, const float* add, float* dz, float p, uint64_t seed,
+                         uint64_t offset, hipStream_t st) {
     if (R <= 0) return 0;
     if ((C & 3) || C > 256 * LN_MAXV) return -2;
     // 16 waves per workgroup, at most 256 workgroups: every workgroup ends with 2*C atomics on the same addresses, and
@@ -149,9 +229,21 @@ extern "C" int spe_layernorm_bwd(const float* dy, const float* x, const float* g
     }
     long nb = (R + NW - 1) / NW; if (nb > 256) nb = 256;
     hipLaunchKernelGGL(ln_bwd_kernel<NW>, dim3((unsigned)nb), dim3(NW * 64), 2 * NW * (C + 4) * (int)sizeof(float), st, dy, x, gamma, mean,
-                       rstd, dx, dgamma, dbeta, R, C, add);
+                       rstd, dx, dgamma, dbeta, R, C, add, dz, p, seed, offset);
     SPE_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                 const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,
+                                 const float* add, hipStream_t st) {
+    return ln_bwd_launch(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, add, nullptr, 0.f, 0, 0, st);
+}
+// C-ABI: see include/spe_hip.h (spe_layernorm_res_bwd): backward of spe_layernorm_res_fwd; ds = gradient of the sum (= of x),
+// dz = ds * keepscale (null when p == 0: the branch gradient is ds itself).
+extern "C" int spe_layernorm_res_bwd(const float* dy, const float* sum, const float* gamma, const float* mean, const float* rstd,
+                                     float* ds, float* dz, float* dgamma, float* dbeta, long R, int C, float p, uint64_t seed,
+                                     uint64_t offset, hipStream_t st) {
+    return ln_bwd_launch(dy, sum, gamma, mean, rstd, ds, dgamma, dbeta, R, C, nullptr, (p > 0.f) ? dz : nullptr, p, seed, offset, st);
 }
 
 // ------------------------------------------------------------------------------------------

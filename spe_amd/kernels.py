@@ -545,6 +545,30 @@ def layernorm_bwd(dy2, x2, g, mean, rstd, dg_out=None, db_out=None, add=None):
     return dx, dg, db
 
 
+def layernorm_res_fwd(x2, z2, g, b, eps, p, seed, offset):
+    """norm(x + dropout(z)) -> (y, sum, mean, rstd); see spe_layernorm_res_fwd."""
+    _chk(x2, z2, g, b)
+    R, C = x2.shape
+    y, sm = torch.empty_like(x2), torch.empty_like(x2)
+    mean = torch.empty((R,), device=x2.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    _call("spe_layernorm_res_fwd", _p(x2), _p(z2), _p(g), _p(b), _p(sm), _p(y), _p(mean), _p(rstd), R, C, float(eps), float(p), seed,
+          offset, _st())
+    return y, sm, mean, rstd
+
+
+def layernorm_res_bwd(dy2, sm, g, mean, rstd, p, seed, offset, dg_out=None, db_out=None):
+    """-> (ds, dz, dgamma, dbeta); dz is ds itself when p == 0."""
+    R, C = sm.shape
+    ds = torch.empty_like(sm)
+    dz = torch.empty_like(sm) if p > 0 else None
+    dg = _zeros_or(dg_out, C, sm.device)
+    db = _zeros_or(db_out, C, sm.device)
+    _call("spe_layernorm_res_bwd", _p(dy2), _p(sm), _p(g), _p(mean), _p(rstd), _p(ds), _p(dz), _p(dg), _p(db), R, C, float(p), seed,
+          offset, _st())
+    return ds, (dz if dz is not None else ds), dg, db
+
+
 # ---- LayerScale residual --------------------------------------------------------------------
 def layerscale_residual_fwd(x2, y2, gamma, sample_scale, rows_per_sample):
     _chk(x2, y2, gamma, sample_scale)
@@ -684,7 +708,8 @@ def box_loss_bwd(srow_i64, lidx_i32, g1, g2, c1, c2, shape):
 # ---- fused talking-heads attention (bf16 mode) ----------------------------------------------
 # workgroups per fused pass (256 CUs): the statistics and write passes need <= 168 VGPRs (3 waves per SIMD), the
 # backward passes ~250 (2 per SIMD).  Modes 2 and 3 share ws_w rows, so they use the same count.
-FUSED_NWG = {0: int(os.environ.get("SPE_FUSED_NWG0", 768)), 1: int(os.environ.get("SPE_FUSED_NWG1", 768)), 2: 512, 3: 512}
+FUSED_NWG = {0: int(os.environ.get("SPE_FUSED_NWG0", 768)), 1: int(os.environ.get("SPE_FUSED_NWG1", 768)),
+             2: int(os.environ.get("SPE_FUSED_NWG2", 512)), 3: int(os.environ.get("SPE_FUSED_NWG3", 512))}
 
 
 def fused_supported(H, dh):

@@ -17,6 +17,10 @@ class LayerNorm(nn.LayerNorm):
     def forward(self, x):
         return ops.layer_norm(x, self.weight, self.bias, self.eps)
 
+    def residual(self, x, z, drop):
+        """norm(x + drop(z)) as one kernel (drop: the layer's Dropout module)."""
+        return ops.res_drop_layer_norm(x, z, self.weight, self.bias, self.eps, drop.p, drop.training)
+
     def skip(self, x):
         """(LN(x), x) for a pre-norm residual branch: pass the second result to the residual add (ops._LayerNormSkip)."""
         return ops.layer_norm_skip(x, self.weight, self.bias, self.eps)

@@ -74,9 +74,9 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, src, src_key_padding_mask=None, pos=None):
         qk = src if pos is None else ops.add(src, pos)
         src2 = self.self_attn(qk, src, src_key_padding_mask)
-        src = self.norm1(ops.add(src, self.dropout1(src2)))
+        src = self.norm1.residual(src, src2, self.dropout1)
         src2 = self.linear2(self.dropout(self.linear1(src, ops.ACT_RELU)))
-        return self.norm2(ops.add(src, self.dropout2(src2)))
+        return self.norm2.residual(src, src2, self.dropout2)
 
 
 class TransformerEncoder(nn.Module):
@@ -146,7 +146,7 @@ class TransformerDecoderLayer(nn.Module):
         v = self.sa_v_proj(tgt)
         sa = lambda t: t.view(B * n_stages, Q, d)
         tgt2 = self.self_attn(sa(q), sa(k), sa(v))[0].view(B, RQ, d)
-        tgt = self.norm1(tgt + self.dropout1(tgt2))
+        tgt = self.norm1.residual(tgt, tgt2, self.dropout1)
         # ---- conditional cross attention
         q = self.ca_qcontent_proj(tgt)
         if is_first:
@@ -155,10 +155,10 @@ class TransformerDecoderLayer(nn.Module):
         q = torch.cat([q.view(B, RQ, H, dh), qs.view(B, RQ, H, dh)], dim=3).view(B, RQ, 2 * d)
         k, v = mem_kv
         tgt2 = self.cross_attn(q, k, v, key_padding_mask=memory_key_padding_mask)[0]
-        tgt = self.norm2(tgt + self.dropout2(tgt2))
+        tgt = self.norm2.residual(tgt, tgt2, self.dropout2)
         # ---- FFN
         tgt2 = self.linear2(self.dropout(self.linear1(tgt, ops.ACT_RELU)))
-        return self.norm3(tgt + self.dropout3(tgt2))
+        return self.norm3.residual(tgt, tgt2, self.dropout3)
 
 
 class TransformerDecoder(nn.Module):

@@ -79,6 +79,38 @@ def layer_norm(x, g, b, eps):
     return _LayerNorm.apply(x, g, b, eps)
 
 
+class _ResDropLayerNorm(Function):
+    """norm(x + dropout(z)) - a post-norm residual site of the DETR encoder / decoder layers (reference
+    models/transformer.py:279-287, 384-386, 420-421, 426-427) as one kernel each way instead of dropout, add and LayerNorm."""
+
+    @staticmethod
+    def forward(ctx, x, z, g, b, eps, p):
+        x2 = x.reshape(-1, x.shape[-1])
+        z2 = z.reshape(-1, z.shape[-1])
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        z2 = z2 if z2.is_contiguous() else z2.contiguous()
+        seed, off = K.next_rng() if p > 0 else (0, 0)
+        y, sm, mean, rstd = K.layernorm_res_fwd(x2, z2, g, b, eps, p, seed, off)
+        ctx.params = (g, b)
+        ctx.drop = (p, seed, off)
+        ctx.save_for_backward(sm, g, mean, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        sm, g, mean, rstd = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        gp, bp = ctx.params
+        p, seed, off = ctx.drop
+        ds, dz, dg, db = K.layernorm_res_bwd(dy2, sm, g, mean, rstd, p, seed, off, dg_out=K.grad_buffer(gp), db_out=K.grad_buffer(bp))
+        return ds.view(dy.shape), dz.view(dy.shape), dg.view_as(gp), db.view_as(bp), None, None
+
+
+def res_drop_layer_norm(x, z, g, b, eps, p, training):
+    return _ResDropLayerNorm.apply(x, z, g, b, eps, p if training else 0.0)
+
+
 class _LayerNormSkip(Function):
     """(LN(x), x) for a pre-norm residual branch x + f(LN(x)) (reference models/cait.py:404-405): the second output is x
     itself, to be used as the residual operand, so that the two gradients of x - through the normalisation and over the

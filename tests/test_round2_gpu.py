@@ -397,3 +397,38 @@ def test_dp_path_rccl_world1_product_model(dev):
     assert errs[len(errs) // 10][0] < 1e-5, errs[:3]
     for x, y in zip(la, lc):                                    # bf16 gradients on the wire: same trajectory within bf16 rounding
         assert abs(x - y) <= 2e-2 * abs(x), (la, lc)
+
+
+@pytest.mark.parametrize("R,C,p", [(400, 384, 0.1), (8300, 384, 0.0), (77, 64, 0.3)])
+def test_res_drop_layer_norm(dev, R, C, p):
+    """norm(x + dropout(z)) in one kernel each way (reference models/transformer.py:384-386 etc.) against dropout + add +
+    LayerNorm composed from the separate ops (same Philox stream -> same mask) and, for p = 0, against fp64."""
+    from spe_amd import kernels as K, ops
+    g_ = torch.Generator().manual_seed(R + C)
+    x = torch.randn(2, R // 2 if R % 2 == 0 else R, C, generator=g_).to(dev)
+    if R % 2:
+        x = x[:1]
+    z = torch.randn(x.shape, generator=g_).to(dev)
+    w = (1 + 0.2 * torch.randn(C, generator=g_)).to(dev); b = (0.1 * torch.randn(C, generator=g_)).to(dev)
+    go = torch.randn(x.shape, generator=g_).to(dev)
+    res = {}
+    for fused in (True, False):
+        xs, zs, ws, bs = (t.clone().requires_grad_() for t in (x, z, w, b))
+        K.manual_seed(99)
+        if fused:
+            y = ops.res_drop_layer_norm(xs, zs, ws, bs, 1e-5, p, True)
+        else:
+            y = ops.layer_norm(ops.add(xs, ops.dropout(zs, p, True)), ws, bs, 1e-5)
+        res[fused] = (y,) + torch.autograd.grad(y, (xs, zs, ws, bs), go)
+    for a, c in zip(res[True], res[False]):
+        assert rel(a, c) < 1e-5, rel(a, c)
+    if p == 0.0:
+        xd, zd, wd_, bd = (t.double().requires_grad_() for t in (x, z, w, b))
+        yd = torch.nn.functional.layer_norm(xd + zd, (C,), wd_, bd, 1e-5)
+        gd = torch.autograd.grad(yd, (xd, zd, wd_, bd), go.double())
+        for a, c in zip(res[True], (yd,) + gd):
+            assert rel(a, c) < 1e-5
+    else:
+        dz, dx = res[True][2], res[True][1]
+        dropped = (dz == 0) & (dx != 0)
+        assert abs(float(dropped.float().mean()) - p) < 0.02
