@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libspe_hip.so")
+COMM_LIB = os.path.join(HERE, "libspe_comm.so")      # RCCL collectives behind include/spe_comm.h (csrc/comm/)
 STAMP = os.path.join(HERE, "libspe_hip.srchash")     # content hash of the sources the library was built from
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
@@ -33,14 +34,18 @@ def _hash(files, extra=b""):
     return h.hexdigest()
 
 
+def _comm_sources():
+    return sorted(glob.glob(os.path.join(CSRC, "comm", "*.hip"))) + [os.path.join(os.path.dirname(HERE), "include", "spe_comm.h")]
+
+
 def source_hash():
-    return _hash(sources() + _headers())
+    return _hash(sources() + _headers() + _comm_sources())
 
 
 def needs_build():
     """True when there is no library or it was built from other sources.  Compared by content, not by mtime: a copied
     tree (the GPU box snapshot) does not keep modification times."""
-    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
+    if not (os.path.exists(LIB) and os.path.exists(COMM_LIB) and os.path.exists(STAMP)):
         return True
     with open(STAMP) as fh:
         return fh.read().strip() != source_hash()
@@ -79,6 +84,17 @@ def build(force=False, verbose=False):
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
     os.replace(tmp, LIB)                      # never leave a half-written library behind
+    # the collective layer is its own small library: it needs librccl.so.1 (the process' copy - torch's - is reused when
+    # torch is already imported; otherwise the ROCm one), the kernel library does not
+    import torch
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib")
+    ctmp = COMM_LIB + ".tmp.%d" % os.getpid()
+    ccmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", ctmp,
+            os.path.join(CSRC, "comm", "comm.hip"), "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath," + tl, "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(ccmd), flush=True)
+    subprocess.run(ccmd, check=True, cwd=CSRC)
+    os.replace(ctmp, COMM_LIB)
     with open(STAMP, "w") as fh:
         fh.write(source_hash() + "\n")
     return LIB

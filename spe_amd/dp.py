@@ -16,9 +16,19 @@ import torch
 import torch.distributed as dist
 
 
+class _EventWork:
+    """`work.wait()` of a collective issued through spe_amd.comm: the current stream waits for the collective's event."""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
 class GradAllReducer:
     def __init__(self, params, bucket_bytes=64 << 20, average=True, group=None, flatten_params=False, broadcast=True,
-                 always_reduce=False, wire_dtype=None, buffers=()):
+                 always_reduce=False, wire_dtype=None, buffers=(), comm=None):
         """flatten_params: also move the parameters themselves into flat per-bucket buffers with the gradient layout
         (param.data becomes a view) - what spe_amd.optim.FlatAdamW steps in one launch per bucket.  Construct the
         reducer AFTER the model is on its device: `module.to(...)` / `.cuda()` re-allocates parameters and would
@@ -28,12 +38,15 @@ class GradAllReducer:
         everything that is not loaded from a checkpoint starts different per rank).
         always_reduce: issue the collectives even in a one-rank group (tests of the RCCL path on one GPU).
         wire_dtype: torch.bfloat16 sends the buckets in bf16 (half the xGMI bytes, one conversion pass each way); the
-        default None keeps DDP's fp32 gradients."""
+        default None keeps DDP's fp32 gradients.
+        comm: a spe_amd.comm.RcclComm - the collectives then go through the C ABI of libspe_comm.so (include/spe_comm.h)
+        on its side stream instead of torch.distributed (same RCCL underneath)."""
         self.params = [p for p in params if p.requires_grad]
         self.flatten_params = flatten_params
         self.group = group
-        self.initialised = dist.is_available() and dist.is_initialized()
-        self.world = dist.get_world_size(group) if self.initialised else 1
+        self.comm = comm
+        self.initialised = comm is not None or (dist.is_available() and dist.is_initialized())
+        self.world = comm.world if comm is not None else (dist.get_world_size(group) if self.initialised else 1)
         self.collective = self.world > 1 or (always_reduce and self.initialised)
         self.average = average
         self.average_in_optimizer = False      # FlatAdamW folds the 1/world into its update launch (no div_ per bucket)
@@ -55,14 +68,15 @@ class GradAllReducer:
             self._make_bucket(cur)
         if broadcast and self.world > 1:
             with torch.no_grad():
+                bc = (lambda t: comm.broadcast(t, 0)) if comm is not None else (lambda t: dist.broadcast(t, src=0, group=group))
                 if flatten_params:
                     for b in self.buckets:
-                        dist.broadcast(b["flat_p"], src=0, group=group)
+                        bc(b["flat_p"])
                 else:
                     for p in self.params:
-                        dist.broadcast(p.data, src=0, group=group)
+                        bc(p.data)
                 for t in buffers:
-                    dist.broadcast(t, src=0, group=group)
+                    bc(t)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         # Parameters that received no gradient in the first step (e.g. `backbone.0.body.head.*`) are treated as
         # statically unused afterwards (cf. DDP static_graph): their bucket no longer waits for them, so it - and,
@@ -117,11 +131,13 @@ class GradAllReducer:
 
     def _launch(self, b):
         if self.collective:
+            buf = b["flat"]
             if self.wire_dtype is not None:
-                b["wire"] = b["flat"].to(self.wire_dtype)
-                b["work"] = dist.all_reduce(b["wire"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                buf = b["wire"] = b["flat"].to(self.wire_dtype)
+            if self.comm is not None:
+                b["work"] = _EventWork(self.comm.all_reduce_async(buf))
             else:
-                b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b["work"] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             b["work"] = "local"
 

@@ -23,6 +23,23 @@ def test_library_exports_every_header_symbol():
     assert l.spe_abi_version() == 1
 
 
+def test_comm_library_exports_every_header_symbol():
+    """libspe_comm.so (RCCL collectives, include/spe_comm.h): loads without a GPU, every declared entry point resolves, and
+    calls before spe_comm_init report "not initialised" instead of crashing."""
+    from spe_amd import comm
+    so = comm.load()
+    assert set(comm.PROTOS) == {"spe_comm_unique_id", "spe_comm_init", "spe_comm_world", "spe_comm_allreduce", "spe_comm_broadcast",
+                                "spe_comm_destroy"}
+    for name, sig in comm.PROTOS.items():
+        assert len(getattr(so, name).argtypes) == len(sig)
+    assert so.spe_comm_world(None, None) == -1
+    assert so.spe_comm_allreduce(None, 0, 0, None) == -1
+    assert so.spe_comm_destroy() == 0
+    text = open(comm.HEADER).read()
+    for ref in ("util/misc.py:414-436", "main.py:172", "models/conditional_detr.py:438-440"):
+        assert ref in text, ref
+
+
 def test_header_cites_reference_sites():
     text = open(os.path.join(ROOT, "include", "spe_hip.h")).read()
     for ref in ("models/cait.py", "models/matcher.py", "models/conditional_detr.py", "models/attention.py",

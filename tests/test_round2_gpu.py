@@ -352,7 +352,7 @@ def test_dp_path_rccl_world1_product_model(dev):
         groups = [{"params": [p for n, p in named if "backbone" not in n], "lr": 2e-3},
                   {"params": [p for n, p in named if "backbone" in n], "lr": 5e-4}]
         red = GradAllReducer([p for _, p in named], bucket_bytes=1 << 16, flatten_params=True, always_reduce=(mode != "plain"),
-                             wire_dtype=torch.bfloat16 if mode == "rccl_bf16" else None)
+                             wire_dtype=torch.bfloat16 if mode == "rccl_bf16" else None, comm=comm_obj if mode == "spe_comm" else None)
         assert red.collective == (mode != "plain")
         opt = FlatAdamW(groups, red, weight_decay=1e-2, max_grad_norm=0.1)
         cd.FORCE_NUM_BOXES_ALLREDUCE = mode != "plain"
@@ -377,8 +377,21 @@ def test_dp_path_rccl_world1_product_model(dev):
 
     K.set_precision("bf16x3")
     created = False
+    comm_obj = None
     try:
         la, pa = run("plain")
+        # the C-ABI collective layer (libspe_comm.so, include/spe_comm.h): its own communicator, no torch.distributed
+        from spe_amd.comm import RcclComm
+        comm_obj = RcclComm(rank=0, world=1)
+        t = torch.arange(1000, device=dev, dtype=torch.float32)
+        comm_obj.all_reduce(t); comm_obj.broadcast(t, 0)
+        tb = torch.ones(64, device=dev, dtype=torch.bfloat16)
+        comm_obj.all_reduce(tb)
+        torch.cuda.synchronize()
+        assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float32)) and float(tb.float().sum()) == 64.0
+        ld, pd = run("spe_comm")
+        for x, y in zip(la, ld):
+            assert abs(x - y) <= 1e-5 * abs(x), (la, ld)
         if not dist.is_initialized():
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
@@ -387,6 +400,8 @@ def test_dp_path_rccl_world1_product_model(dev):
         lc, pc = run("rccl_bf16")
     finally:
         K.set_precision("bf16")
+        if comm_obj is not None:
+            comm_obj.destroy()
         if created:
             dist.destroy_process_group()
     print("plain", la, "rccl", lb, "rccl bf16 wire", lc)
