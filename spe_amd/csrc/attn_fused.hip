@@ -100,6 +100,60 @@ __device__ __forceinline__ void mix_rows(const f32x4_t (&s)[H], const float (&w)
     }
 }
 
+// Head mixes on the MATRIX pipe.  The three mixes whose operands the bf16 contract rounds anyway - P' = Ww P + bw (its result is
+// stored as bf16), dP = Ww^T dP' (dP' is an MFMA product of bf16 operands) and dS = Wl^T dS' (stored as bf16) - do not need the
+// fp32 vector FMAs that bound these kernels (H*H v_pk_fma_f32 per lane and tile each; the vector pipe is ~80 % busy, the
+// matrix pipe ~10 %).  One v_mfma_f32_16x16x16_bf16 against a BLOCK-DIAGONAL weight operand mixes 4 input heads into 4 output
+// heads for all 64 lanes at once without moving data between lanes:
+//   B[k = 4j + i][n = q] := x[head 4hh + i] of (query q, key 4j + i0)        - lane (q, j)'s own 4 values (bf16)
+//   A[m = 4j' + g'][k = 4j + i] := (j' == j) ? W[4gh + g'][4hh + i] : 0     - constant per (gh, hh): 2 registers
+//   D[m = 4j + r][n = q] = sum_i W[4gh + r][4hh + i] x[4hh + i]              - lands in lane (q, j): its own key, heads 4gh + r
+// i.e. (H/4)^2 MFMAs per key and 4 * (H/4)^2 per tile (16 at H = 8) instead of H*H/2 * 4 = 128 packed FMAs, plus H/2
+// v_cvt_pk_bf16_f32 per key.  Measured at cfg2 (same box, isolated): write pass 0.218 -> 0.187 ms, backward pass 1 0.385 -> 0.370,
+// backward pass 2 0.424 -> 0.377; errors against fp64 unchanged (out 2.4e-3, dqkv 3.8e-3 -> 4.0e-3).  The softmax-input mix
+// S' = Wl S + bl stays in fp32 on the vector pipe (it feeds exp2); a 3-term bf16 split of it on the matrix pipe (hi*hi + lo*hi +
+// hi*lo, 48 MFMAs per tile, same accuracy) was measured and is NOT faster: the split itself costs what the packed FMAs did.
+#ifndef SPE_FUSED_MFMAMIX
+#define SPE_FUSED_MFMAMIX 1
+#endif
+typedef short s16x4m_t __attribute__((ext_vector_type(4)));
+template <int H, bool TRANSPOSE>
+__device__ __forceinline__ void mixA_build(const float* __restrict__ W, int lane, s16x4m_t (&A)[H / 4][H / 4]) {
+    const bool nz = ((lane & 15) >> 2) == (lane >> 4);
+#pragma unroll
+    for (int gh = 0; gh < H / 4; ++gh)
+#pragma unroll
+        for (int hh = 0; hh < H / 4; ++hh) {
+            bf16x4_t v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int go = 4 * gh + (lane & 3), hi = 4 * hh + i;
+                const float w = TRANSPOSE ? W[hi * H + go] : W[go * H + hi];
+                v[i] = (__bf16)(nz ? w : 0.f);
+            }
+            A[gh][hh] = __builtin_bit_cast(s16x4m_t, v);
+        }
+}
+// out[gh][r] = init[4gh + r] + sum_h A(4gh + r, h) x[h]  for ONE key of the lane (x[h]: the H heads' values at that key)
+template <int H>
+__device__ __forceinline__ void mix_mfma_key(const float (&x)[H], const s16x4m_t (&A)[H / 4][H / 4], const float* init, f32x4_t (&out)[H / 4]) {
+    s16x4m_t bv[H / 4];
+#pragma unroll
+    for (int hh = 0; hh < H / 4; ++hh) {
+        bf16x4_t v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (__bf16)x[4 * hh + i];
+        bv[hh] = __builtin_bit_cast(s16x4m_t, v);
+    }
+#pragma unroll
+    for (int gh = 0; gh < H / 4; ++gh) {
+        f32x4_t d = init ? (f32x4_t){init[4 * gh], init[4 * gh + 1], init[4 * gh + 2], init[4 * gh + 3]} : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int hh = 0; hh < H / 4; ++hh) d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A[gh][hh], bv[hh], d, 0, 0, 0);
+        out[gh] = d;
+    }
+}
+
 // Fragment record of one (b, h, 16-row tile): FULL = DSTEPS - TAIL16 steps of 32 head dims (64 lanes x 16 B) followed,
 // when TAIL16, by one step of 16 dims (64 lanes x 8 B: the v_mfma_f32_16x16x16_bf16 operand).  dh = 48 is 32 + 16:
 // 1.5 KB per record instead of the 2 KB of two padded 32-steps - the score kernels are sensitive to exactly this
@@ -164,6 +218,13 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
     float vbl2[H], vbw[H];
 #pragma unroll
     for (int g = 0; g < H; ++g) { vbl2[g] = a.bl[g] * SPE_LOG2E; vbw[g] = a.bw[g]; }
+    // block-diagonal weight operands of the matrix-pipe mixes (see mix_mfma_key)
+    constexpr bool MM = SPE_FUSED_MFMAMIX && (H % 4 == 0);
+    s16x4m_t Aw[(MM && MODE >= 1) ? H / 4 : 1][(MM && MODE >= 1) ? H / 4 : 1];       // mode 1: Ww ; modes 2, 3: Ww^T
+    s16x4m_t Al[(MM && MODE == 3) ? H / 4 : 1][(MM && MODE == 3) ? H / 4 : 1];       // mode 3: Wl^T
+    if constexpr (MM && MODE == 1) mixA_build<H, false>(a.Ww, lane, Aw);
+    if constexpr (MM && MODE >= 2) mixA_build<H, true>(a.Ww, lane, Aw);
+    if constexpr (MM && MODE == 3) mixA_build<H, true>(a.Wl, lane, Al);
     // weight-gradient accumulators (whole workgroup range)
     // as head pairs: mode 2 gWp[g*(H/2)+hp] = (dWw[g][2hp], dWw[g][2hp+1]) ; mode 3 gWp[gp*H+h] = (dWl[2gp][h], dWl[2gp+1][h])
     f32x2_t gWp[(MODE >= 2) ? H * H / 2 : 1], gb2[(MODE == 3) ? H / 2 : 1];
@@ -366,12 +427,28 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // phase B (Ww): P'd = dropout(Ww P + bw) -> bf16
-                float ww[H][H];
-                load_w<H>(a.Ww, ww);
+                float ww[MM ? 1 : H][MM ? 1 : H];
+                if constexpr (!MM) load_w<H>(a.Ww, ww);
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     f32x2_t lo[H], hi[H];
-                    mix_rows<H>(acc[j], ww, vbw, lo, hi);
+                    if constexpr (MM) {
+                        f32x4_t pr[4][H / 4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float x[H];
+#pragma unroll
+                            for (int h = 0; h < H; ++h) x[h] = acc[j][h][r];
+                            mix_mfma_key<H>(x, Aw, vbw, pr[r]);
+                        }
+#pragma unroll
+                        for (int g = 0; g < H; ++g) {
+                            lo[g] = (f32x2_t){pr[0][g >> 2][g & 3], pr[1][g >> 2][g & 3]};
+                            hi[g] = (f32x2_t){pr[2][g >> 2][g & 3], pr[3][g >> 2][g & 3]};
+                        }
+                    } else {
+                        mix_rows<H>(acc[j], ww, vbw, lo, hi);
+                    }
                     if (DROP) {
 #pragma unroll
                         for (int g = 0; g < H; ++g) {
@@ -433,8 +510,8 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // phase B (Ww): dP' = (dO V^T) keepscale ; dWw += dP' P^T ; dbw += dP' ; D += (Ww^T dP') . P
-                float ww[H][H];
-                load_w<H>(a.Ww, ww);
+                float ww[MM ? 1 : H][MM ? 1 : H];
+                if constexpr (!MM) load_w<H>(a.Ww, ww);
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     // rows q >= N have zero dO fragments and keys >= N zero V fragments, so dP' is already 0 there
@@ -452,8 +529,18 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         f32x2_t mt[H / 2];
+                        if constexpr (MM) {
+                            float x[H];
 #pragma unroll
-                        for (int hp = 0; hp < H / 2; ++hp) mt[hp] = splat2(0.f);
+                            for (int g = 0; g < H; ++g) x[g] = acc2[j][g][r];
+                            f32x4_t m4[H / 4];
+                            mix_mfma_key<H>(x, Aw, nullptr, m4);               // dP = Ww^T dP' of this key
+#pragma unroll
+                            for (int hp = 0; hp < H / 2; ++hp) mt[hp] = (f32x2_t){m4[hp >> 1][2 * (hp & 1)], m4[hp >> 1][2 * (hp & 1) + 1]};
+                        } else {
+#pragma unroll
+                            for (int hp = 0; hp < H / 2; ++hp) mt[hp] = splat2(0.f);
+                        }
 #pragma unroll
                         for (int g = 0; g < H; ++g) {
                             const float dv = acc2[j][g][r];
@@ -462,7 +549,7 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
 #pragma unroll
                             for (int hp = 0; hp < H / 2; ++hp) {
                                 gWp[g * (H / 2) + hp] = fma2(db, PT[j][r][hp], gWp[g * (H / 2) + hp]);
-                                mt[hp] = fma2(db, (f32x2_t){ww[g][2 * hp], ww[g][2 * hp + 1]}, mt[hp]);
+                                if constexpr (!MM) mt[hp] = fma2(db, (f32x2_t){ww[g][2 * hp], ww[g][2 * hp + 1]}, mt[hp]);
                             }
                         }
 #pragma unroll
@@ -473,8 +560,8 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
                 // MODE 3.  phase A (Ww): dPT[j][r][hp] <- dP = Ww^T (dP'd * keepscale) of heads (2hp, 2hp+1) at key r
                 f32x2_t dPT[KT][4][H / 2];
                 {
-                float ww[H][H];
-                load_w<H>(a.Ww, ww);
+                float ww[MM ? 1 : H][MM ? 1 : H];
+                if constexpr (!MM) load_w<H>(a.Ww, ww);
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     if (DROP) {
@@ -487,13 +574,23 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         f32x2_t mt[H / 2];
+                        if constexpr (MM) {
+                            float x[H];
 #pragma unroll
-                        for (int hp = 0; hp < H / 2; ++hp) mt[hp] = splat2(0.f);
+                            for (int g = 0; g < H; ++g) x[g] = acc2[j][g][r];
+                            f32x4_t m4[H / 4];
+                            mix_mfma_key<H>(x, Aw, nullptr, m4);
 #pragma unroll
-                        for (int g = 0; g < H; ++g) {
-                            const f32x2_t db = splat2(acc2[j][g][r]);
+                            for (int hp = 0; hp < H / 2; ++hp) mt[hp] = (f32x2_t){m4[hp >> 1][2 * (hp & 1)], m4[hp >> 1][2 * (hp & 1) + 1]};
+                        } else {
 #pragma unroll
-                            for (int hp = 0; hp < H / 2; ++hp) mt[hp] = fma2(db, (f32x2_t){ww[g][2 * hp], ww[g][2 * hp + 1]}, mt[hp]);
+                            for (int hp = 0; hp < H / 2; ++hp) mt[hp] = splat2(0.f);
+#pragma unroll
+                            for (int g = 0; g < H; ++g) {
+                                const f32x2_t db = splat2(acc2[j][g][r]);
+#pragma unroll
+                                for (int hp = 0; hp < H / 2; ++hp) mt[hp] = fma2(db, (f32x2_t){ww[g][2 * hp], ww[g][2 * hp + 1]}, mt[hp]);
+                            }
                         }
 #pragma unroll
                         for (int hp = 0; hp < H / 2; ++hp) dPT[j][r][hp] = mt[hp];
@@ -543,13 +640,23 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
                     f32x2_t ds[4][H / 2];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        if constexpr (MM) {
+                            float x[H];
 #pragma unroll
-                        for (int hp = 0; hp < H / 2; ++hp) ds[r][hp] = splat2(0.f);
+                            for (int g = 0; g < H; ++g) x[g] = d2[r][g / 2][g & 1];
+                            f32x4_t m4[H / 4];
+                            mix_mfma_key<H>(x, Al, nullptr, m4);               // dS = Wl^T dS' of this key
 #pragma unroll
-                        for (int g = 0; g < H; ++g) {
-                            const f32x2_t db = splat2(d2[r][g / 2][g & 1]);
+                            for (int hp = 0; hp < H / 2; ++hp) ds[r][hp] = (f32x2_t){m4[hp >> 1][2 * (hp & 1)], m4[hp >> 1][2 * (hp & 1) + 1]};
+                        } else {
 #pragma unroll
-                            for (int hp = 0; hp < H / 2; ++hp) ds[r][hp] = fma2(db, (f32x2_t){wl[g][2 * hp], wl[g][2 * hp + 1]}, ds[r][hp]);
+                            for (int hp = 0; hp < H / 2; ++hp) ds[r][hp] = splat2(0.f);
+#pragma unroll
+                            for (int g = 0; g < H; ++g) {
+                                const f32x2_t db = splat2(d2[r][g / 2][g & 1]);
+#pragma unroll
+                                for (int hp = 0; hp < H / 2; ++hp) ds[r][hp] = fma2(db, (f32x2_t){wl[g][2 * hp], wl[g][2 * hp + 1]}, ds[r][hp]);
+                            }
                         }
                     }
                     if (TV(j)) {
