@@ -62,9 +62,11 @@ int spe_gemm_tile(int M, int N, int nbatch);
  * models/transformer.py:264-265,342-344 eps 1e-5).  C % 4 == 0, C <= 1024.
  * bwd: dgamma/dbeta are ACCUMULATED into (pre-zeroed or running) buffers; add (optional, [R][C]; may alias dx) is added to
  * dx - the gradient arriving over the residual path around the normalised branch (x feeds both: cait.py:404-405), which
- * autograd would otherwise sum with one more elementwise launch. */
+ * autograd would otherwise sum with one more elementwise launch.
+ * fwd: y16 (optional, bf16 [R][C]): the same result rounded to bf16 - the operand of the Linear that consumes y, written by
+ * the same pass instead of by a separate spe_cvt_bf16 launch. */
 int spe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                      float* rstd, long R, int C, float eps, spe_stream_t stream);
+                      float* rstd, long R, int C, float eps, void* y16, spe_stream_t stream);
 int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                       const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,
                       const float* add, spe_stream_t stream);
@@ -83,6 +85,13 @@ int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const
 int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const float* bias, float* C2,
                     int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int splitk,
                     spe_stream_t stream);
+/* spe_gemm_bf16tn: C[m][n] = alpha * sum_r A16[r][m] * B16[r][n] - the weight gradient dW = dy^T x of a Linear (autograd of
+ * reference models/cait.py:376,390,409, models/transformer.py:368-425) on ROW-MAJOR bf16 operands A16 [R, lda] (M columns)
+ * and B16 [R, ldb] (N columns): the contraction runs over rows, the MFMA operands are formed by LDS transpose reads
+ * (ds_read_b64_tr_b16), no transposed copies of x or dy exist.  splitk < 0: |splitk| private slabs of M*ldc floats over
+ * the row range (sum them with spe_colsum).  Operands 16-B aligned; lda, ldb, M, N multiples of 8. */
+int spe_gemm_bf16tn(const void* A16, const void* B16, float* C, int M, int N, int R, long lda, long ldb, long ldc,
+                    float alpha, int splitk, spe_stream_t stream);
 /* spe_gemm_bf16nt_ex: the same product with an epilogue that feeds the NEXT GEMMs directly (no fp32 round trip, no
  * separate conversion launch):  v = alpha A16 B16^T + bias ; C2 = v (optional) ; v = act(v), or with aux != NULL
  * v = v * act'(aux) (aux [M][ldc]: act 1 = ReLU with the forward output, act 2 = erf-GELU with the pre-activation) ;
@@ -168,7 +177,7 @@ int spe_attn_pack16(const float* x, long sb, long sn, long sh, int B, int N, int
 int spe_attn_pack_multi(int njobs, const float* const* xs, const long* strides, const float* scales, const int* kinds,
                         void* const* outs, const int* Ns, const int* dhs, int B, int H, spe_stream_t stream);
 int spe_attn_contract(const void* T, const void* X16, float* out, long ob, long on, long oh, int B, int H, int N, int dh,
-                      int trans, float alpha, float* ws, unsigned int* counters, long ws_floats, spe_stream_t stream);
+                      int trans, float alpha, float* ws, unsigned int* counters, long ws_floats, void* out16, spe_stream_t stream);
 
 /* ---- out[c] += sum_r in[r*ld + c] (bias gradients; autograd of nn.Linear bias). */
 int spe_colsum(const float* in, float* out, long R, int C, long ld, spe_stream_t stream);

@@ -36,7 +36,8 @@ template <int DT, bool TRANS>
 __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restrict__ T, const uint2* __restrict__ X,
                                                             float* __restrict__ out, long ob, long on, long oh,
                                                             int H, int N, int nt, int dh, int ngrp, float alpha,
-                                                            int bhn, int nfull, float* ws, unsigned* counters) {
+                                                            int bhn, int nfull, float* ws, unsigned* counters,
+                                                            unsigned short* __restrict__ out16) {
     constexpr int R = CONTRACT_R;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4_t* red = reinterpret_cast<f32x4_t*>(smem_raw);          // [2 waves][R][DT][64]
@@ -188,6 +189,16 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
 #pragma unroll
                         for (int i = 0; i < 4; ++i) if (dc + i < dh) dst[dc + i] = v[i];
                     }
+                    if (out16) {        // bf16 copy with the same element strides: the operand of the Linear that consumes the result
+                        unsigned short* d16 = out16 + b * ob + (long)row * on + h * oh + dc;
+                        bf16x4c_t hv;
+                        hv[0] = (__bf16)v[0]; hv[1] = (__bf16)v[1]; hv[2] = (__bf16)v[2]; hv[3] = (__bf16)v[3];
+                        if (dc + 3 < dh && ((((uintptr_t)d16) & 7) == 0)) *reinterpret_cast<uint2*>(d16) = __builtin_bit_cast(uint2, hv);
+                        else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) if (dc + i < dh) d16[i] = __builtin_bit_cast(s16x4_t, hv)[i];
+                        }
+                    }
                 }
             }
         }
@@ -295,7 +306,7 @@ extern "C" int spe_attn_pack_multi(int njobs, const float* const* xs, const long
 // therefore split into quarters of the contraction range (4x shorter) and combined by the last arriver.
 template <int DT, bool TRANS>
 static int launch_contract(const void* T, const void* X, float* out, long ob, long on, long oh, int B, int H, int N, int nt, int dh,
-                           float alpha, float* ws, unsigned* counters, long ws_floats, hipStream_t st) {
+                           float alpha, float* ws, unsigned* counters, long ws_floats, void* out16, hipStream_t st) {
     const int ngrp = (nt + CONTRACT_R - 1) / CONTRACT_R;
     const long bhn = (long)B * H, full = bhn * ngrp;
     int nlo = 0;
@@ -308,18 +319,18 @@ static int launch_contract(const void* T, const void* X, float* out, long ob, lo
     const int smem = 2 * CONTRACT_R * DT * 64 * 16;
     hipLaunchKernelGGL((attn_contract_kernel<DT, TRANS>), dim3((unsigned)(bhn * nfull + bhn * nlo * 4)), dim3(256), smem, st,
                        reinterpret_cast<const uint2*>(T), reinterpret_cast<const uint2*>(X), out, ob, on, oh, H, N, nt, dh, ngrp, alpha,
-                       (int)bhn, nfull, ws, counters);
+                       (int)bhn, nfull, ws, counters, reinterpret_cast<unsigned short*>(out16));
     SPE_CHECK_LAUNCH();
     return 0;
 }
 
 // C-ABI: see include/spe_hip.h (spe_attn_contract).  Returns -2 for head dims above 64.
 extern "C" int spe_attn_contract(const void* T, const void* X16, float* out, long ob, long on, long oh, int B, int H, int N, int dh,
-                                 int trans, float alpha, float* ws, unsigned int* counters, long ws_floats, hipStream_t st) {
+                                 int trans, float alpha, float* ws, unsigned int* counters, long ws_floats, void* out16, hipStream_t st) {
     const int nt = (N + 15) / 16, DT = (dh + 15) / 16;
     if (B <= 0 || H <= 0 || N <= 0) return 0;
-#define SPE_CONTRACT_CASE(D) case D: return trans ? launch_contract<D, true>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, ws, counters, ws_floats, st) \
-                                                  : launch_contract<D, false>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, ws, counters, ws_floats, st);
+#define SPE_CONTRACT_CASE(D) case D: return trans ? launch_contract<D, true>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, ws, counters, ws_floats, out16, st) \
+                                                  : launch_contract<D, false>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, ws, counters, ws_floats, out16, st);
     switch (DT) {
         SPE_CONTRACT_CASE(1)
         SPE_CONTRACT_CASE(2)

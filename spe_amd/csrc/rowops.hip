@@ -13,7 +13,7 @@
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
-                                                     long R, int C, float eps) {
+                                                     long R, int C, float eps, unsigned short* __restrict__ y16) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
@@ -50,6 +50,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             o.x = (v[i].x - mu) * rs * g.x + b.x; o.y = (v[i].y - mu) * rs * g.y + b.y;
             o.z = (v[i].z - mu) * rs * g.z + b.z; o.w = (v[i].w - mu) * rs * g.w + b.w;
             yr[c] = o;
+            if (y16) {      // the bf16 operand of the Linear that consumes y (same rounding as spe_cvt_bf16), from the same pass
+                typedef __bf16 bf16x4l_t __attribute__((ext_vector_type(4)));
+                bf16x4l_t h;
+                h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
+                *reinterpret_cast<uint2*>(y16 + row * C + 4 * c) = __builtin_bit_cast(uint2, h);
+            }
         }
     }
 }
@@ -205,10 +211,11 @@ extern "C" int spe_layernorm_res_fwd(const float* x, const float* z, const float
 }
 
 extern "C" int spe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                                 float* rstd, long R, int C, float eps, hipStream_t st) {
+                                 float* rstd, long R, int C, float eps, void* y16, hipStream_t st) {
     if (R <= 0) return 0;
     if ((C & 3) || C > 256 * LN_MAXV) return -2;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, C, eps);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, C, eps,
+                       reinterpret_cast<unsigned short*>(y16));
     SPE_CHECK_LAUNCH();
     return 0;
 }

@@ -300,6 +300,12 @@ def gemm16(A16, B16, C, M, N, K, lda, ldb, ldc, bias=None, C2=None, alpha=1.0, a
     return C
 
 
+def gemm16_tn(A16, B16, C, M, N, R, lda, ldb, ldc, alpha=1.0, splitk=1):
+    """C[M,N] = alpha * A16[:R,:M].T @ B16[:R,:N] on row-major bf16 operands (spe_gemm_bf16tn); splitk < 0: slabs."""
+    _call("spe_gemm_bf16tn", _p(A16), _p(B16), _p(C), M, N, R, lda, ldb, ldc, float(alpha), int(splitk), _st())
+    return C
+
+
 def gemm16_ex(A16, B16, M, N, K, lda, ldb, bias=None, C=None, C2=None, out16=None, out16T=None, colsum=None, aux=None,
               alpha=1.0, act=0, res=None, rgamma=None):
     """spe_gemm_bf16nt_ex: v = alpha * A16 @ B16.T + bias; C2 = v; v = act(v) or v * act'(aux); optional fp32 C [M,N], bf16
@@ -314,13 +320,18 @@ def mlp16_ok(R, K, Hd, N):
     return _lin16_ok(R, Hd, K) and _lin16_ok(R, N, Hd)
 
 
-def layerscale_residual_bwd16(dout2, y2, gamma, Rp, db_out=None, dg_out=None, want_rowmajor=True):
+# Weight gradients on ROW-MAJOR bf16 operands (spe_gemm_bf16tn: LDS transpose reads): no producer writes a transposed bf16
+# copy any more - not the activation conversions (x16T), not the backward conversions (dy16T), not the GEMM epilogues.
+DW_TN = os.environ.get("SPE_DW_TN", "1") != "0"
+
+
+def layerscale_residual_bwd16(dout2, y2, gamma, Rp, db_out=None, dg_out=None, want_rowmajor=True, want_T=True):
     """Backward of out = x + gamma * y when y is the output of a Linear on the bf16-copy GEMMs: -> (dy16 [R,C], dy16T
     [C,Rp], db [C], dgamma [C]); dy = gamma * dout exists only as those bf16 operands."""
     R, C = dout2.shape
     dev = dout2.device
     dy16 = torch.empty((R, C), device=dev, dtype=torch.bfloat16) if want_rowmajor else None
-    dy16T = torch.empty((C, Rp), device=dev, dtype=torch.bfloat16)
+    dy16T = torch.empty((C, Rp), device=dev, dtype=torch.bfloat16) if want_T else None
     db = _zeros_or(db_out, C, dev)
     dg = _zeros_or(dg_out, C, dev)
     _call("spe_layerscale_residual_bwd16", _p(dout2), _p(y2), _p(gamma), _p(dy16), _p(dy16T), Rp, _p(db), _p(dg), R, C, _st())
@@ -332,22 +343,27 @@ def linear_res_fwd(x2, W, b, res, gamma, save=True, src=None):
     R, K = x2.shape
     N = W.shape[0]
     dev = x2.device
-    x16, x16T = act16(x2, save, src)
+    x16, x16T = act16(x2, save and not DW_TN, src)
     out = torch.empty((R, N), device=dev, dtype=torch.float32)
     y = torch.empty((R, N), device=dev, dtype=torch.float32) if save else None
     gemm16_ex(x16, weight16(W)[0], R, N, K, K, K, bias=b, C=out, C2=y, res=res, rgamma=gamma)
-    return out, (x16T, y)
+    return out, ((x16 if DW_TN else x16T), y)
 
 
 def linear_res_bwd(dout2, saved, W, gamma, need_dx=True, grad_bufs=(None, None, None)):
     """Backward of linear_res_fwd: (dx, dW, db, dgamma); gamma * dout only exists as the bf16 operands of the two GEMMs."""
-    x16T, y = saved
+    xs, y = saved
     R, N = dout2.shape
     K = W.shape[1]
-    Rp = x16T.shape[1]
     gW, gb, gg = grad_bufs
-    dy16, dy16T, db, dg = layerscale_residual_bwd16(dout2, y, gamma, Rp, db_out=gb, dg_out=gg, want_rowmajor=need_dx)
-    dW = _dw16(dy16T, x16T, N, K, Rp, gW)
+    if _is_rowmajor_save(xs, R):
+        Rp = ((R + 63) // 64) * 64
+        dy16, _, db, dg = layerscale_residual_bwd16(dout2, y, gamma, Rp, db_out=gb, dg_out=gg, want_rowmajor=True, want_T=False)
+        dW = _dw16_tn(dy16, xs, N, K, R, gW)
+    else:
+        Rp = xs.shape[1]
+        dy16, dy16T, db, dg = layerscale_residual_bwd16(dout2, y, gamma, Rp, db_out=gb, dg_out=gg, want_rowmajor=need_dx)
+        dW = _dw16(dy16T, xs, N, K, Rp, gW)
     dx = None
     if need_dx:
         dx = torch.empty((R, K), device=dout2.device, dtype=torch.float32)
@@ -363,13 +379,15 @@ def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True, src=None):
     Hd, N = W1.shape[0], W2.shape[0]
     dev = x2.device
     # save = False (no gradient wanted: inference): none of the tensors that only the backward reads is produced
-    x16, x16T = act16(x2, save, src)
+    x16, x16T = act16(x2, save and not DW_TN, src)
     Rp = ((R + 63) // 64) * 64
     pre = torch.empty((R, Hd), device=dev, dtype=torch.float32) if save else None
     h16 = torch.empty((R, Hd), device=dev, dtype=torch.bfloat16)
-    h16T = torch.empty((Hd, Rp), device=dev, dtype=torch.bfloat16) if save else None
+    h16T = torch.empty((Hd, Rp), device=dev, dtype=torch.bfloat16) if (save and not DW_TN) else None
     gemm16_ex(x16, weight16(W1)[0], R, Hd, K, K, K, bias=b1, C2=pre, out16=h16, out16T=h16T, act=2)
     y = torch.empty((R, N), device=dev, dtype=torch.float32)
+    if DW_TN:
+        x16T, h16T = x16, h16            # what the backward gets: the row-major copies
     if res is None:
         gemm16(h16, weight16(W2)[0], y, R, N, Hd, Hd, Hd, N, bias=b2)
         return y, (x16T, pre, h16T)
@@ -392,6 +410,24 @@ def _dw16(dy16T, x16T, N, K, Rp, dW_out):
     return dW
 
 
+def _is_rowmajor_save(xs, R):
+    """Saved bf16 activations are row-major [R, K] (DW_TN, fixed for the life of the process) or the padded transpose [K, Rp]."""
+    return DW_TN and xs.dtype == torch.bfloat16
+
+
+def _dw16_tn(dy16, x16, N, K, R, dW_out):
+    """dW [N,K] = dy16 [R,N]^T @ x16 [R,K] on row-major operands; split over the rows into slabs summed into dW_out."""
+    dev = dy16.device
+    sk = min(auto_splitk(N, K, R, 1), max(1, R // 64))
+    if sk > 1:
+        ws = torch.empty((sk, N * K), device=dev, dtype=torch.float32)
+        gemm16_tn(dy16, x16, ws, N, K, R, N, K, K, splitk=-sk)
+        return colsum(ws, out=None if dW_out is None else dW_out.view(-1)).view(N, K)
+    dW = dW_out if dW_out is not None else torch.empty((N, K), device=dev, dtype=torch.float32)
+    gemm16_tn(dy16, x16, dW, N, K, R, N, K, K)
+    return dW
+
+
 def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, None), gamma=None, dg_out=None):
     """Backward of mlp_gelu_fwd.  dy2 [R,N] fp32.  -> (dx, dW1, db1, dW2, db2).  The gradient w.r.t. the pre-activation
     exists only as the bf16 copies (row-major for dx, transposed for dW1) written by the dh GEMM's epilogue, which also
@@ -399,22 +435,23 @@ def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, 
     x16T, pre, h16T = saved[:3]
     R, N = dy2.shape
     Hd, K = W1.shape
-    Rp = x16T.shape[1]
+    tn = _is_rowmajor_save(x16T, R)
+    Rp = ((R + 63) // 64) * 64 if tn else x16T.shape[1]
     dev = dy2.device
     gW1, gb1, gW2, gb2 = grad_bufs
     dg = None
     if gamma is not None:        # residual form: dy2 is d(out); the branch gradient gamma * dout only exists in bf16
-        dy16, dy16T, db2, dg = layerscale_residual_bwd16(dy2, saved[3], gamma, Rp, db_out=gb2, dg_out=dg_out)
+        dy16, dy16T, db2, dg = layerscale_residual_bwd16(dy2, saved[3], gamma, Rp, db_out=gb2, dg_out=dg_out, want_T=not tn)
     else:
         db2 = _zeros_or(gb2, N, dev)
-        dy16, dy16T = cvt_bf16(dy2, True, True, ldt=Rp, colsum_out=db2)
-    dW2 = _dw16(dy16T, h16T, N, Hd, Rp, gW2)
+        dy16, dy16T = cvt_bf16(dy2, True, not tn, ldt=Rp, colsum_out=db2)
+    dW2 = _dw16_tn(dy16, h16T, N, Hd, R, gW2) if tn else _dw16(dy16T, h16T, N, Hd, Rp, gW2)
     # dpre = (dy @ W2) * gelu'(pre): bf16 only
     db1 = _zeros_or(gb1, Hd, dev)
-    dp16 = torch.empty((R, Hd), device=dev, dtype=torch.bfloat16) if need_dx else None
-    dp16T = torch.empty((Hd, Rp), device=dev, dtype=torch.bfloat16)
+    dp16 = torch.empty((R, Hd), device=dev, dtype=torch.bfloat16) if (need_dx or tn) else None
+    dp16T = torch.empty((Hd, Rp), device=dev, dtype=torch.bfloat16) if not tn else None
     gemm16_ex(dy16, weight16(W2)[1], R, Hd, N, N, N, out16=dp16, out16T=dp16T, colsum=db1, aux=pre, act=2)
-    dW1 = _dw16(dp16T, x16T, Hd, K, Rp, gW1)
+    dW1 = _dw16_tn(dp16, x16T, Hd, K, R, gW1) if tn else _dw16(dp16T, x16T, Hd, K, Rp, gW1)
     dx = None
     if need_dx:
         dx = torch.empty((R, K), device=dev, dtype=torch.float32)
@@ -448,9 +485,9 @@ def linear_fwd(x2, W, b, act=0, want_pre=False, save_for_dw=True, src=None):
     y = torch.empty((R, N), device=x2.device, dtype=torch.float32)
     pre = torch.empty_like(y) if want_pre else None
     if _lin16_ok(R, N, K) and W.is_contiguous():
-        x16, x16T = act16(x2, save_for_dw, src)
+        x16, x16T = act16(x2, save_for_dw and not DW_TN, src)
         gemm16(x16, weight16(W)[0], y, R, N, K, K, K, N, bias=b, C2=pre, act=act)
-        return y, pre, (x16T if save_for_dw else x2)
+        return y, pre, ((x16 if DW_TN else x16T) if save_for_dw else x2)
     gemm(x2, W, y, R, N, K, K, K, N, False, True, bias=b, C2=pre, act=act)
     return y, pre, x2
 
@@ -465,15 +502,19 @@ def linear_bwd(dy2, xsave, W, need_dx=True, need_dw=True, need_db=True, dW_out=N
     dx = dW = db = None
     x16 = xsave.dtype == torch.bfloat16
     if (x16 or not need_dw) and _lin16_ok(R, N, K) and W.is_contiguous():
-        Rp = xsave.shape[1] if x16 else None
+        tn = x16 and _is_rowmajor_save(xsave, R)
+        Rp = None if (tn or not x16) else xsave.shape[1]
         if need_db:                     # the bias gradient rides on the conversion pass over dy
             db = _zeros_or(db_out, N, dy2.device)
-        dy16, dy16T = cvt_bf16(dy2, need_dx, need_dw and x16, ldt=Rp, colsum_out=db, act_aux=act_aux if act else None, act=act)
+        dy16, dy16T = cvt_bf16(dy2, need_dx or (need_dw and tn), need_dw and x16 and not tn, ldt=Rp, colsum_out=db,
+                               act_aux=act_aux if act else None, act=act)
         need_db = False
         if need_dx:
             dx = torch.empty((R, K), device=dy2.device, dtype=torch.float32)
             gemm16(dy16, weight16(W)[1], dx, R, K, N, N, N, K)
-        if need_dw:
+        if need_dw and tn:
+            dW = _dw16_tn(dy16, xsave, N, K, R, dW_out)
+        elif need_dw:
             sk = min(auto_splitk(N, K, R, 1), Rp // 64)
             if sk > 1:
                 ws = torch.empty((sk, N * K), device=dy2.device, dtype=torch.float32)
@@ -524,14 +565,27 @@ def act_bwd(dy, aux, mode):
 
 
 # ---- LayerNorm ------------------------------------------------------------------------------
-def layernorm_fwd(x2, g, b, eps):
+def layernorm_fwd(x2, g, b, eps, want16=False):
+    """-> (y, mean, rstd[, y16]); want16: also the bf16 copy of y (what act16 would convert) from the same pass."""
     _chk(x2, g, b)
     R, C = x2.shape
     y = torch.empty_like(x2)
     mean = torch.empty((R,), device=x2.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
-    _call("spe_layernorm_fwd", _p(x2), _p(g), _p(b), _p(y), _p(mean), _p(rstd), R, C, float(eps), _st())
-    return y, mean, rstd
+    y16 = torch.empty((R, C), device=x2.device, dtype=torch.bfloat16) if want16 else None
+    _call("spe_layernorm_fwd", _p(x2), _p(g), _p(b), _p(y), _p(mean), _p(rstd), R, C, float(eps), _p(y16), _st())
+    return (y, mean, rstd, y16) if want16 else (y, mean, rstd)
+
+
+def produces16(R, C):
+    """A producer of a [R, C] activation should also emit its bf16 copy: the consumer Linear takes the bf16-copy GEMM path and
+    needs no transposed copy (DW_TN)."""
+    return DW_TN and LINEAR16 and _PRECISION == 0 and R >= LINEAR16_MIN_ROWS and C % 8 == 0
+
+
+def attach16(t, x16):
+    """Remember the bf16 copy ON the activation tensor (what act16 looks up)."""
+    t._spe16 = (t._version, x16, None)
 
 
 def layernorm_bwd(dy2, x2, g, mean, rstd, dg_out=None, db_out=None, add=None):
@@ -844,14 +898,15 @@ def _contract_ws(device):
     return ent
 
 
-def attn_contract(T, X16, out4, trans, alpha=1.0):
+def attn_contract(T, X16, out4, trans, alpha=1.0, out16=None):
     """out4[b, row, h, :] = alpha * sum T[b,h][q,key] x[.., :]  (trans=False: rows = q, sum over keys; True: rows = keys,
-    sum over q).  out4: [B,N,H,dh] fp32 view with unit last stride."""
+    sum over q).  out4: [B,N,H,dh] fp32 view with unit last stride.  out16: optional bf16 tensor addressed with the SAME element
+    strides (the bf16 copy of the result for the Linear that consumes it)."""
     B, N, H, dh = out4.shape
     assert out4.stride(3) == 1
     ws, cnt = _contract_ws(out4.device)
     _call("spe_attn_contract", _p(T), _p(X16), _p(out4), out4.stride(0), out4.stride(1), out4.stride(2), B, H, N, dh,
-          int(trans), float(alpha), _p(ws), _p(cnt), ws.numel(), _st())
+          int(trans), float(alpha), _p(ws), _p(cnt), ws.numel(), _p(out16), _st())
     return out4
 
 

@@ -121,8 +121,13 @@ class _LayerNormSkip(Function):
         x2 = x.reshape(-1, x.shape[-1])
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        y, mean, rstd = K.layernorm_fwd(x2, g, b, eps)
-        yv = y.view(x.shape)
+        if K.produces16(*x2.shape):          # the Linear behind this norm runs on bf16 copies: emit its operand here
+            y, mean, rstd, y16 = K.layernorm_fwd(x2, g, b, eps, want16=True)
+            yv = y.view(x.shape)
+            K.attach16(yv, y16)
+        else:
+            y, mean, rstd = K.layernorm_fwd(x2, g, b, eps)
+            yv = y.view(x.shape)
         ctx.params = (g, b)
         ctx.save_for_backward(x2, g, mean, rstd)
         return yv, x.view_as(x)
@@ -285,7 +290,10 @@ class _TalkingHeadsAttentionFused(Function):
         Pd = K.score_blocks(B, H, N, qkv.device)
         K.talking_fused(1, Qf, Kf, None, None, Wl, bl, Ww, bw, M, IL, None, None, None, Pd, B, H, N, dh, p_drop, seed, off)
         O = torch.empty((B, N, C), device=qkv.device, dtype=torch.float32)
-        K.attn_contract(Pd, V16, O.view(B, N, H, dh), False)
+        O16 = torch.empty((B * N, C), device=qkv.device, dtype=torch.bfloat16) if K.produces16(B * N, C) else None
+        K.attn_contract(Pd, V16, O.view(B, N, H, dh), False, out16=O16)
+        if O16 is not None:
+            K.attach16(O, O16)               # the output projection's operand, written by the contraction's epilogue
         ctx.meta = (B, N, C, H, dh, nt, scale, p_drop, seed, off)
         ctx.wparams = (Wl, bl, Ww, bw)      # leaves: looked up in backward for their gradient buckets
         ctx.save_for_backward(qkv, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw)

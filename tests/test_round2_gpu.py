@@ -447,3 +447,24 @@ def test_res_drop_layer_norm(dev, R, C, p):
         dz, dx = res[True][2], res[True][1]
         dropped = (dz == 0) & (dx != 0)
         assert abs(float(dropped.float().mean()) - p) < 0.02
+
+
+@pytest.mark.parametrize("M,N,R,sk", [(384, 384, 8300, 14), (1536, 384, 8300, 14), (384, 1536, 8300, 1), (1152, 384, 8300, 8), (72, 136, 400, 1),
+                                      (64, 64, 77, 1), (384, 768, 4241, 4), (8, 8, 5, 1)])
+def test_gemm_bf16tn(dev, M, N, R, sk):
+    """spe_gemm_bf16tn (weight gradient on row-major operands through LDS transpose reads) against an fp64 product of the
+    same bf16-rounded values; asymmetric random operands (a transposed or mis-tiled read cannot pass)."""
+    from spe_amd import kernels as K
+    g_ = torch.Generator().manual_seed(M + N + R)
+    A = torch.randn(R, M, generator=g_).to(dev).to(torch.bfloat16)
+    Bm = (torch.randn(R, N, generator=g_) + 0.3).to(dev).to(torch.bfloat16)
+    ref = 0.7 * (A.double().t() @ Bm.double())
+    if sk > 1:
+        ws = torch.full((sk, M * N), float("nan"), device=dev)
+        K.gemm16_tn(A, Bm, ws, M, N, R, M, N, N, alpha=0.7, splitk=-sk)
+        C = ws.sum(0).view(M, N)
+    else:
+        C = torch.full((M, N), float("nan"), device=dev)
+        K.gemm16_tn(A, Bm, C, M, N, R, M, N, N, alpha=0.7)
+    assert torch.isfinite(C).all()
+    assert rel(C, ref) < 2e-6, rel(C, ref)
