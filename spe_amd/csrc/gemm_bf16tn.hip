@@ -189,6 +189,9 @@ extern "C" int spe_gemm_bf16tn(const void* A16, const void* B16, float* C, int M
     if (splitk < 1) splitk = 1;
     p.splitk = splitk;
     p.rt_per_split = (rtiles + splitk - 1) / splitk;
+    // decoder-size problems (a few hundred rows, no split): 64x64 tiles put 4x the workgroups on the chip (384 x 384: 36 instead of 9)
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splitk;
+    if (t128 < 64) return launch_tn<64, 64>(p, stream);
     if (M > 64 && N > 64) return launch_tn<128, 128>(p, stream);
     if (M > 64) return launch_tn<128, 64>(p, stream);
     return launch_tn<64, 64>(p, stream);
