@@ -186,17 +186,20 @@ def _lin16_ok(R, N, K):
     return LINEAR16 and _PRECISION == 0 and R >= LINEAR16_MIN_ROWS and N % 8 == 0 and K % 8 == 0
 
 
-def cvt_bf16(x2, want=True, wantT=False, ldt=None, colsum_out=None, act_aux=None, act=0):
+def cvt_bf16(x2, want=True, wantT=False, ldt=None, colsum_out=None, act_aux=None, act=0, out=None, ldo=None):
     """bf16 (RNE) copies of a contiguous fp32 [R, C]: row-major [R, C] and/or the transpose [C, ldt] (zero padded);
-    colsum_out (zeroed or running fp32 [C]) += column sums of x2 from the same pass."""
+    colsum_out (zeroed or running fp32 [C]) += column sums of x2 from the same pass.  out / ldo: write the row-major copy
+    into a column block of a wider bf16 matrix (row stride ldo) instead of a fresh tensor."""
     _chk(x2)
     R, C = x2.shape
-    out = torch.empty((R, C), device=x2.device, dtype=torch.bfloat16) if want else None
+    if out is None:
+        out = torch.empty((R, C), device=x2.device, dtype=torch.bfloat16) if want else None
+        ldo = C
     outT = None
     if wantT:
         ldt = ldt or ((R + 63) // 64) * 64
         outT = torch.empty((C, ldt), device=x2.device, dtype=torch.bfloat16)
-    _call("spe_cvt_bf16", _p(x2), x2.stride(0), R, C, _p(out), C, _p(outT), ldt or 0, _p(colsum_out), _p(act_aux), int(act), _st())
+    _call("spe_cvt_bf16", _p(x2), x2.stride(0), R, C, _p(out), ldo or C, _p(outT), ldt or 0, _p(colsum_out), _p(act_aux), int(act), _st())
     return out, outT
 
 
@@ -274,6 +277,29 @@ def weight16(W):
         _W16.clear()
     _W16[key] = (weakref.ref(owner), owner._version, _W16_EPOCH, W16, W16T)
     return W16, W16T
+
+
+_WCAT = {}      # tuple of weight ids -> (epoch, versions, Wcat16 [sum N, K], Wcat16T [K, sum N], bcat [sum N])
+
+
+def weightcat16(Ws, bs):
+    """bf16 copies of several [N_i, K] weights stacked along the output axis (and the transposed stack for the input gradient)
+    plus the stacked fp32 biases - the operands of ONE GEMM that evaluates all the Linears sharing an input (ops.multi_linear).
+    Rebuilt from the cached per-weight copies when any weight changed (three concatenations)."""
+    key = tuple(id(W) for W in Ws)
+    vers = tuple(W._version for W in Ws) + tuple(b._version for b in bs)
+    ent = _WCAT.get(key)
+    if ent is not None and ent[0] == _W16_EPOCH and ent[1] == vers:
+        return ent[2], ent[3], ent[4]
+    with torch.no_grad():
+        pairs = [weight16(W) for W in Ws]
+        Wc = torch.cat([p_[0] for p_ in pairs], 0)
+        WcT = torch.cat([p_[1] for p_ in pairs], 1)
+        bc = torch.cat([b.detach() for b in bs])
+    if len(_WCAT) > 64:
+        _WCAT.clear()
+    _WCAT[key] = (_W16_EPOCH, vers, Wc, WcT, bc)
+    return Wc, WcT, bc
 
 
 def gemm_splitk_into(A, B, out, M, N, K, lda, ldb, ldc, transA, transB, batch0, batch1, sA, sB, sC, alpha=1.0):
@@ -415,16 +441,18 @@ def _is_rowmajor_save(xs, R):
     return DW_TN and xs.dtype == torch.bfloat16
 
 
-def _dw16_tn(dy16, x16, N, K, R, dW_out):
-    """dW [N,K] = dy16 [R,N]^T @ x16 [R,K] on row-major operands; split over the rows into slabs summed into dW_out."""
+def _dw16_tn(dy16, x16, N, K, R, dW_out, lda=None):
+    """dW [N,K] = dy16 [R,N]^T @ x16 [R,K] on row-major operands; split over the rows into slabs summed into dW_out.
+    lda: row stride of dy16 when it is a column block of a wider matrix."""
     dev = dy16.device
+    lda = N if lda is None else lda
     sk = min(auto_splitk(N, K, R, 1), max(1, R // 64))
     if sk > 1:
         ws = torch.empty((sk, N * K), device=dev, dtype=torch.float32)
-        gemm16_tn(dy16, x16, ws, N, K, R, N, K, K, splitk=-sk)
+        gemm16_tn(dy16, x16, ws, N, K, R, lda, K, K, splitk=-sk)
         return colsum(ws, out=None if dW_out is None else dW_out.view(-1)).view(N, K)
     dW = dW_out if dW_out is not None else torch.empty((N, K), device=dev, dtype=torch.float32)
-    gemm16_tn(dy16, x16, dW, N, K, R, N, K, K)
+    gemm16_tn(dy16, x16, dW, N, K, R, lda, K, K)
     return dW
 
 

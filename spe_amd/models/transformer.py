@@ -20,6 +20,9 @@ from .attention import MultiheadAttention
 from .layers import MLP, Dropout, LayerNorm, Linear
 
 
+MEMSIDE_BATCH = __import__("os").environ.get("SPE_MEMSIDE_BATCH", "1") != "0"
+
+
 def gen_sineembed_for_position(pos_tensor, d_model=256):
     """[.., 2] normalised (x, y) -> [.., d_model] sine embedding.  The exponent divisor is the
     reference's hard-coded 128 (transformer.py:41), NOT d_model/2.  Tiny [B,Q,d] tensor ops."""
@@ -174,6 +177,26 @@ class TransformerDecoder(nn.Module):
         for layer_id in range(num_layers - 1):
             self.layers[layer_id + 1].ca_qpos_proj = None      # only the first layer adds query_pos (transformer.py:203-204)
 
+    def _memory_side_all(self, memory, pos, mem_cache):
+        """The memory-side keys / values of EVERY layer from two GEMMs: memory x [ca_kcontent | ca_v of all layers] and
+        pos x [ca_kpos of all layers] (they depend on neither the queries nor the previous layer; the reference evaluates the
+        3 * num_layers projections one by one, per decoder pass: transformer.py:389-396).  Same arithmetic per output column."""
+        mem_w = [m for layer in self.layers for m in (layer.ca_kcontent_proj, layer.ca_v_proj)]
+        pos_w = [layer.ca_kpos_proj for layer in self.layers]
+        Wm, bm = [m.weight for m in mem_w], [m.bias for m in mem_w]
+        Wp, bp = [m.weight for m in pos_w], [m.bias for m in pos_w]
+        if not (MEMSIDE_BATCH and memory.is_cuda and ops.multi_linear_ok(memory, Wm, bm) and ops.multi_linear_ok(pos, Wp, bp)):
+            return
+        B, S, d = memory.shape
+        H, dh = self.layers[0].nhead, d // self.layers[0].nhead
+        ym = ops.multi_linear(memory, Wm, bm)                 # 2*L column blocks [B, S, d] of one [B, S, 2*L*d] buffer
+        yp = ops.multi_linear(pos, Wp, bp)                    # L column blocks
+        for l in range(len(self.layers)):
+            kc, v, kp = ym[2 * l], ym[2 * l + 1], yp[l]
+            k = kc + kp if l == 0 else kc
+            k = torch.cat([k.view(B, S, H, dh), kp.view(B, S, H, dh)], dim=3)
+            mem_cache[l] = (k.view(B, S, 2 * d), v)
+
     def forward(self, tgt, memory, memory_key_padding_mask, pos, query_pos, mem_cache=None, n_stages=1):
         """tgt/query_pos [B, R*Q, d] (R stages stacked along the query axis); memory/pos [B,S,d].
         -> (hs [L,B,R*Q,d], reference_points [B,R*Q,2])."""
@@ -184,6 +207,8 @@ class TransformerDecoder(nn.Module):
         # the reference points do not change from layer to layer (transformer.py:187-193 recomputes the embedding in every
         # layer): one evaluation, ~25 small launches of sin / cos / stack / cat and their backward saved per further layer
         sine0 = gen_sineembed_for_position(reference_points[..., :2], self.d_model)
+        if not mem_cache:
+            self._memory_side_all(memory, pos, mem_cache)
         for layer_id, layer in enumerate(self.layers):
             if layer_id not in mem_cache:
                 mem_cache[layer_id] = layer.memory_side(memory, pos, layer_id == 0)

@@ -52,6 +52,75 @@ def linear(x, W, b=None, act=ACT_NONE):
     return _Linear.apply(x, W, b, act)
 
 
+class _MultiLinear(Function):
+    """(x W_0^T + b_0, x W_1^T + b_1, ...) for several nn.Linear of equal shape applied to ONE input - the query-independent
+    memory-side projections of the conditional cross attention of ALL decoder layers (reference models/transformer.py:
+    389-396: ca_kcontent_proj / ca_v_proj of `memory`, ca_kpos_proj of `pos`, evaluated per layer and per decoder pass there) as one
+    [R, K] x [K, n*N] GEMM whose column blocks are the n results (views of one buffer); the input gradient is one GEMM over the
+    stacked weights (instead of n GEMMs and n - 1 full-size adds), the weight gradients are n row-major TN products on column
+    blocks of the stacked bf16 dy, the bias gradients ride on the n conversion passes."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        n = len(wb) // 2
+        Ws, bs = wb[:n], wb[n:]
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        R, Kd = x2.shape
+        N = Ws[0].shape[0]
+        Wc, WcT, bc = K.weightcat16(Ws, bs)
+        x16, _ = K.act16(x2, False, x)
+        y = torch.empty((R, n * N), device=x.device, dtype=torch.float32)
+        K.gemm16(x16, Wc, y, R, n * N, Kd, Kd, Kd, n * N, bias=bc)
+        ctx.params = (Ws, bs)
+        ctx.save_for_backward(x16, WcT)
+        ctx.dims = (n, N, Kd, R)
+        y = y.view(*shp[:-1], n * N)
+        return tuple(y[..., i * N:(i + 1) * N] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x16, WcT = ctx.saved_tensors
+        n, N, Kd, R = ctx.dims
+        Ws, bs = ctx.params
+        dev = x16.device
+        dy16 = torch.empty((R, n * N), device=dev, dtype=torch.bfloat16)
+        dWs, dbs = [], []
+        for i in range(n):
+            blk = dy16[:, i * N:(i + 1) * N]
+            if dys[i] is None:
+                blk.zero_()
+                dWs.append(None); dbs.append(None)
+                continue
+            d2 = dys[i].reshape(R, N)
+            if not d2.is_contiguous():
+                d2 = d2.contiguous()
+            db = K._zeros_or(K.grad_buffer(bs[i]), N, dev)
+            K.cvt_bf16(d2, True, False, colsum_out=db, out=blk, ldo=n * N)
+            dbs.append(db)
+            dWs.append(K._dw16_tn(blk, x16, N, Kd, R, K.grad_buffer(Ws[i]), lda=n * N))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((R, Kd), device=dev, dtype=torch.float32)
+            K.gemm16(dy16, WcT, dx, R, Kd, n * N, n * N, n * N, Kd)
+            dx = dx.view(*dys[0].shape[:-1], Kd) if dys[0] is not None else dx
+        return (dx, *dWs, *dbs)
+
+
+def multi_linear_ok(x, Ws, bs):
+    R = x.numel() // x.shape[-1]
+    N, Kd = Ws[0].shape
+    return (K.DW_TN and K._lin16_ok(R, len(Ws) * N, Kd) and all(W.shape == Ws[0].shape and W.is_contiguous() for W in Ws)
+            and all(b is not None for b in bs) and N % 8 == 0)
+
+
+def multi_linear(x, Ws, bs):
+    """-> tuple of n tensors [.., N] (column blocks of one buffer); element i is linear(x, Ws[i], bs[i])."""
+    return _MultiLinear.apply(x, *Ws, *bs)
+
+
 # ---------------------------------------------------------------------------------------------
 class _LayerNorm(Function):
     @staticmethod
