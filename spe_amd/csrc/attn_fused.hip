@@ -186,7 +186,11 @@ template <int H, int DSTEPS, bool TAIL16, int MODE, bool DROP, int KT>
 #endif
 __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(FusedArgs a) {
     constexpr int NFR = H * DSTEPS;                        // fragments (16 B per lane) per q-tile
-    constexpr int JB = (MODE >= 2) ? ((H >= SPE_FUSED_JB2) ? SPE_FUSED_JB2 : H) : H;  // MFMA jobs per operand-fragment batch
+    // MFMA jobs per operand-fragment batch: whole tile in the forward passes; backward pass 1 has registers for 4 heads at a
+    // time, backward pass 2 - since its two transposed mixes left the vector pipe - for 8 (0.380 -> 0.356 ms at cfg2; pass 1
+    // spills with 8: 0.37 -> 0.43 ms)
+    constexpr int JBW = (MODE == 3) ? 2 * SPE_FUSED_JB2 : SPE_FUSED_JB2;
+    constexpr int JB = (MODE >= 2) ? ((H >= JBW) ? JBW : ((H >= SPE_FUSED_JB2) ? SPE_FUSED_JB2 : H)) : H;
     // request the next macro step's first batch before the VALU phases (its registers stay live through them)
 #ifndef SPE_FUSED_PREF1
 #define SPE_FUSED_PREF1 1

@@ -788,9 +788,10 @@ def box_loss_bwd(srow_i64, lidx_i32, g1, g2, c1, c2, shape):
 
 
 # ---- fused talking-heads attention (bf16 mode) ----------------------------------------------
-# workgroups per fused pass (256 CUs): the statistics and write passes need <= 168 VGPRs (3 waves per SIMD), the
-# backward passes ~250 (2 per SIMD).  Modes 2 and 3 share ws_w rows, so they use the same count.
-FUSED_NWG = {0: int(os.environ.get("SPE_FUSED_NWG0", 768)), 1: int(os.environ.get("SPE_FUSED_NWG1", 768)),
+# workgroups per fused pass (256 CUs): every pass runs at 2 waves per SIMD (239-256 registers), i.e. 512 resident workgroups -
+# more only adds a partial second round (statistics / write pass 0.188 -> 0.180 ms at cfg2 with 512 instead of 768).  Modes 2
+# and 3 share ws_w rows, so they use the same count.
+FUSED_NWG = {0: int(os.environ.get("SPE_FUSED_NWG0", 512)), 1: int(os.environ.get("SPE_FUSED_NWG1", 512)),
              2: int(os.environ.get("SPE_FUSED_NWG2", 512)), 3: int(os.environ.get("SPE_FUSED_NWG3", 512))}
 
 
