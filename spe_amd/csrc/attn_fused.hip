@@ -154,6 +154,26 @@ __device__ __forceinline__ void mix_mfma_key(const float (&x)[H], const s16x4m_t
     }
 }
 
+// Dropout of the mixed probabilities (reference models/cait.py:387, attn_drop): keep flags for the lane's 4 keys of TWO heads
+// from ONE Philox4x32-10 call - the 128 random bits are eight 16-bit lots (keep iff lot >= p * 65536: the rate is exact to
+// 1.5e-5).  The counter is (b, head pair, query, 4-key group): aligned by construction, so the write pass and both backward
+// passes regenerate identical masks with H/2 calls per lane and tile.  (Round 1 drew one call per ELEMENT on an index that
+// is not 4-aligned when N % 4 != 0: 32 calls per lane and tile, 3-5x the cost of everything else in the pass.)
+template <int H>
+__device__ __forceinline__ void fused_keep_scales(uint64_t seed, uint64_t offset, float p, int b, int hp, int q, int key0, int N,
+                                                  float (&s0)[4], float (&s1)[4]) {
+    const uint64_t ctr = (((uint64_t)b * (H / 2) + hp) * (uint64_t)N + (uint64_t)q) * (uint64_t)((N + 3) >> 2) + (uint64_t)(key0 >> 2);
+    uint32_t o[4];
+    spe_philox4((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    const uint32_t thr = (uint32_t)(p * 65536.0f);
+    const float inv = 1.0f / (1.0f - p);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        s0[2 * i] = ((o[i] & 0xffffu) >= thr) ? inv : 0.f;      s0[2 * i + 1] = ((o[i] >> 16) >= thr) ? inv : 0.f;
+        s1[2 * i] = ((o[2 + i] & 0xffffu) >= thr) ? inv : 0.f;  s1[2 * i + 1] = ((o[2 + i] >> 16) >= thr) ? inv : 0.f;
+    }
+}
+
 // Fragment record of one (b, h, 16-row tile): FULL = DSTEPS - TAIL16 steps of 32 head dims (64 lanes x 16 B) followed,
 // when TAIL16, by one step of 16 dims (64 lanes x 8 B: the v_mfma_f32_16x16x16_bf16 operand).  dh = 48 is 32 + 16:
 // 1.5 KB per record instead of the 2 KB of two padded 32-steps - the score kernels are sensitive to exactly this
@@ -455,12 +475,11 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
                     }
                     if (DROP) {
 #pragma unroll
-                        for (int g = 0; g < H; ++g) {
-                            const uint64_t e0 = (uint64_t)((((long)b * H + g) * N + q) * (long)N + KB(j));
-                            lo[g][0] *= spe_drop_scale(a.seed, a.offset, e0, a.p_drop);
-                            lo[g][1] *= spe_drop_scale(a.seed, a.offset, e0 + 1, a.p_drop);
-                            hi[g][0] *= spe_drop_scale(a.seed, a.offset, e0 + 2, a.p_drop);
-                            hi[g][1] *= spe_drop_scale(a.seed, a.offset, e0 + 3, a.p_drop);
+                        for (int hp = 0; hp < H / 2; ++hp) {
+                            float k0[4], k1[4];
+                            fused_keep_scales<H>(a.seed, a.offset, a.p_drop, b, hp, q, KB(j), N, k0, k1);
+                            lo[2 * hp][0] *= k0[0]; lo[2 * hp][1] *= k0[1]; hi[2 * hp][0] *= k0[2]; hi[2 * hp][1] *= k0[3];
+                            lo[2 * hp + 1][0] *= k1[0]; lo[2 * hp + 1][1] *= k1[1]; hi[2 * hp + 1][0] *= k1[2]; hi[2 * hp + 1][1] *= k1[3];
                         }
                     }
                     // lane owns 4 consecutive keys of row q: one 8-B store per head
@@ -525,10 +544,12 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
                     }
                     if (DROP) {
 #pragma unroll
-                        for (int g = 0; g < H; ++g)
+                        for (int hp = 0; hp < H / 2; ++hp) {
+                            float k0[4], k1[4];
+                            fused_keep_scales<H>(a.seed, a.offset, a.p_drop, b, hp, q, KB(j), N, k0, k1);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                acc2[j][g][r] *= spe_drop_scale(a.seed, a.offset, (uint64_t)((((long)b * H + g) * N + q) * (long)N + KB(j) + r), a.p_drop);
+                            for (int r = 0; r < 4; ++r) { acc2[j][2 * hp][r] *= k0[r]; acc2[j][2 * hp + 1][r] *= k1[r]; }
+                        }
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -570,10 +591,12 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
                 for (int j = 0; j < KT; ++j) {
                     if (DROP) {
 #pragma unroll
-                        for (int g = 0; g < H; ++g)
+                        for (int hp = 0; hp < H / 2; ++hp) {
+                            float k0[4], k1[4];
+                            fused_keep_scales<H>(a.seed, a.offset, a.p_drop, b, hp, q, KB(j), N, k0, k1);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                acc2[j][g][r] *= spe_drop_scale(a.seed, a.offset, (uint64_t)((((long)b * H + g) * N + q) * (long)N + KB(j) + r), a.p_drop);
+                            for (int r = 0; r < 4; ++r) { acc2[j][2 * hp][r] *= k0[r]; acc2[j][2 * hp + 1][r] *= k1[r]; }
+                        }
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {

@@ -108,7 +108,11 @@ def test_oracle_matches_reference_at_config_dims(name):
 # these fixtures: outputs <= 5e-3, loss keys <= 7e-3, total loss <= 1.2e-3, median gradient 1-4e-2): a parameter whose
 # gradient is a small difference of large terms (a few decoder matrices) carries bf16 rounding noise of its own size, so
 # the worst gradient is only sanity-bounded and the median carries the assertion.
-TOL = {"bf16x3": (1e-3, 1e-3, 1e-3, 1e-2, 5e-2), "bf16": (1.5e-2, 2e-2, 5e-3, 8e-2, 1.5)}
+# The fixtures hold 64 strided samples per gradient: a tensor whose samples fall on its small entries reads far worse than its
+# norm-relative error over all elements (cfg5 bbox_embed.1.layers.1.weight: 1.2 sampled, 9e-2 over the full tensor against the
+# bf16x3 run, tools/debug/grad_modes.py) - so the bound on the worst tensor is a sanity bound and the 90th percentile is asserted.
+TOL = {"bf16x3": (1e-3, 1e-3, 1e-3, 1e-2, 5e-2), "bf16": (1.5e-2, 2e-2, 5e-3, 8e-2, 3.0)}
+P90 = {"bf16x3": 2e-2, "bf16": 0.25}
 
 
 @pytest.mark.gpu
@@ -145,7 +149,7 @@ def test_product_matches_reference_at_config_dims(dev, name, prec):
         gs = sorted(ge.values())
         rec = {"case": name, "precision": prec, "tokens": int(out[0]["x_patch"].tensors.shape[2] * out[0]["x_patch"].tensors.shape[3]),
                "worst_output": wo, "pred_logits": oe["0.pred_logits"], "pred_boxes": oe["0.pred_boxes"], "x_patch": oe["0.x_patch"],
-               "worst_loss": wl, "total_loss_rel_err": te, "worst_grad": wg, "median_grad": gs[len(gs) // 2], "grads_compared": len(ge)}
+               "worst_loss": wl, "total_loss_rel_err": te, "worst_grad": wg, "median_grad": gs[len(gs) // 2], "p90_grad": gs[(9 * len(gs)) // 10], "grads_compared": len(ge)}
         print(f"[{name} {prec}] " + json.dumps(rec))
         od = os.path.join(os.path.dirname(HERE), "gpurun_out")
         if os.path.isdir(od):
@@ -155,6 +159,7 @@ def test_product_matches_reference_at_config_dims(dev, name, prec):
         assert wo[1] < to, wo
         assert wl[1] < tl and te < tt, (wl, te)
         assert gs[len(gs) // 2] < tgm and wg[1] < tgw and len(ge) > 100, (gs[len(gs) // 2], wg)
+        assert gs[(9 * len(gs)) // 10] < P90[prec], gs[(9 * len(gs)) // 10]
         for p, r, mg in zip(pr, blob["pseudo"], blob["pseudo_margins"]):
             assert torch.equal(p["labels"].cpu(), r["labels"])
             assert rel(p["scores"], r["scores"]) < to

@@ -33,7 +33,8 @@ def t(fn, n=5):
     for _ in range(n): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
-f = lambda mode, out=None: K.talking_fused(mode, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, ws, ws_w, out, B, H, N, dh, 0.0, 0, 0)
+PD = float(os.environ.get("PDROP", "0"))
+f = lambda mode, out=None: K.talking_fused(mode, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, ws, ws_w, out, B, H, N, dh, PD if mode else 0.0, 7, 3)
 print("pack q", t(lambda: K.attn_pack(q, scale * K.LOG2E)))
 for mode, out in ((0, None), (1, PT), (2, None), (3, dST)):
     print("mode", mode, "%.3f ms" % t(lambda: f(mode, out)))
