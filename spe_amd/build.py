@@ -6,6 +6,7 @@ import glob
 import hashlib
 import os
 import subprocess
+import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -59,7 +60,7 @@ def _compile(src, hipcc, verbose):
         return obj
     cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj + ".tmp"]
     if verbose:
-        print(" ".join(cmd), flush=True)
+        print(" ".join(cmd), file=sys.stderr, flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
     os.replace(obj + ".tmp", obj)
     with open(tag, "w") as fh:
@@ -81,7 +82,7 @@ def build(force=False, verbose=False):
     tmp = LIB + ".tmp.%d" % os.getpid()
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
-        print(" ".join(cmd), flush=True)
+        print(" ".join(cmd), file=sys.stderr, flush=True)       # stderr: bench.py's stdout carries exactly one JSON line
     subprocess.run(cmd, check=True, cwd=CSRC)
     os.replace(tmp, LIB)                      # never leave a half-written library behind
     # the collective layer is its own small library: it needs librccl.so.1 (the process' copy - torch's - is reused when
@@ -92,7 +93,7 @@ def build(force=False, verbose=False):
     ccmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", ctmp,
             os.path.join(CSRC, "comm", "comm.hip"), "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath," + tl, "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
-        print(" ".join(ccmd), flush=True)
+        print(" ".join(ccmd), file=sys.stderr, flush=True)
     subprocess.run(ccmd, check=True, cwd=CSRC)
     os.replace(ctmp, COMM_LIB)
     with open(STAMP, "w") as fh:

@@ -19,6 +19,7 @@
 // This path is HBM-streaming (2 B per score element, read once).  A workgroup owns R = 4 consecutive output
 // tiles of one (b, h) (so the X fragments of a step are loaded once for 4 blocks), its 4 waves take the
 // contraction steps round-robin and the partial tiles are summed through LDS.
+#include <cstdlib>
 #include "common.h"
 #include "attn_pack.h"
 
@@ -32,7 +33,29 @@ typedef __bf16 bf16x4c_t __attribute__((ext_vector_type(4)));
 #define CONTRACT_PD 4
 #endif
 
-template <int DT, bool TRANS>
+// LDS-DMA variant of the streaming loop (LDSRING = true): every wave owns a private ring of CL_D step slots in LDS and fills it
+// with global_load_lds_dwordx4 (1 KB per instruction: two 512-B pieces - score blocks or X fragments - lanes 0-31 fetch one,
+// lanes 32-63 the other; no staging registers, no VGPR write-back), counted s_waitcnt vmcnt(N) keeps CL_D - 1 steps in flight,
+// the MFMA operands are read back with conflict-free ds_read_b64.  The guide's LDS-DMA stream reaches ~25 GB/s per CU against
+// the ~19 GB/s register loads reach here.  Measured at cfg2 (isolated, same box): 0.131 / 0.129 / 0.133 / 0.128 ms (PV / dV / dQ / dK)
+// -> 0.125 / 0.114 / 0.122 / 0.115 with 4 slots (2 slots: 0.119 / 0.120 / 0.119 / 0.117; 6 and 8 slots and `nt` loads are slower);
+// in the training step 0.135 -> 0.128 ms per launch (4.1 -> 4.3 TB/s), 60.0 -> 59.3 ms per step.
+#ifndef CL_D
+#define CL_D 4
+#endif
+#ifdef CL_USE_NT
+#define CL_NT " nt"
+#else
+#define CL_NT ""
+#endif
+#define CL_SLOT 4096
+__device__ __forceinline__ void cl_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" CL_NT "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int DT, bool TRANS, bool LDSRING = false>
 __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restrict__ T, const uint2* __restrict__ X,
                                                             float* __restrict__ out, long ob, long on, long oh,
                                                             int H, int N, int nt, int dh, int ngrp, float alpha,
@@ -73,6 +96,61 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
 #pragma unroll
     for (int r = 0; r < R; ++r) tr[r] = min(t0 + r, nt - 1);
 
+    if constexpr (LDSRING) {
+        unsigned char* ring = smem_raw + wave * (CL_D * CL_SLOT);
+        const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)ring);
+        const int first = cbeg + wave;
+        const int ns = (cend > first) ? (cend - first + 3) / 4 : 0;
+        const int half = lane >> 5, l16 = (lane & 31) * 16;
+        auto issue = [&](int st) {
+            const int cc = min(first + 4 * st, nt - 1);                       // clamped: steps past the range fetch valid memory, unused
+            const unsigned dst = ring_lds + (unsigned)((st % CL_D) * CL_SLOT);
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {                                    // score blocks of output tiles 2pp, 2pp+1
+                const int r = 2 * pp + half;
+                const uint2* src = TRANS ? Tb + ((long)cc * nt + tr[r]) * 64 : Tb + ((long)tr[r] * nt + cc) * 64;
+                cl_glds16(reinterpret_cast<const unsigned char*>(src) + l16, dst + pp * 1024);
+            }
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {                                    // X fragments of d tiles 2pp, 2pp+1 (clamped to DT-1)
+                const int d = min(2 * pp + half, DT - 1);
+                const uint2* src = Xb + ((long)cc * DT + d) * 64;
+                cl_glds16(reinterpret_cast<const unsigned char*>(src) + l16, dst + 2048 + pp * 1024);
+            }
+        };
+        static_assert(CONTRACT_R == 4 && DT <= 4, "ring slot layout: 4 score blocks + up to 4 X fragments");
+#pragma unroll
+        for (int st = 0; st < CL_D; ++st) issue(st);
+        for (int st = 0; st < ns; ++st) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((CL_D - 1) * 4) : "memory");     // the 4 pieces of step st have landed
+            const unsigned char* sl = ring + (st % CL_D) * CL_SLOT;
+            uint2 tbs[R], xfs[DT];
+#pragma unroll
+            for (int r = 0; r < R; ++r) tbs[r] = *reinterpret_cast<const uint2*>(sl + r * 512 + lane * 8);
+#pragma unroll
+            for (int d = 0; d < DT; ++d) xfs[d] = *reinterpret_cast<const uint2*>(sl + 2048 + d * 512 + lane * 8);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          // slot read: free for the refill
+            issue(st + CL_D);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                s16x4_t bt;
+                if (TRANS) {
+                    const f32x4_t t = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, tbs[r]), ident,
+                                                                                  (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    bf16x4c_t tv;
+                    tv[0] = (__bf16)t[0]; tv[1] = (__bf16)t[1]; tv[2] = (__bf16)t[2]; tv[3] = (__bf16)t[3];
+                    bt = __builtin_bit_cast(s16x4_t, tv);
+                } else {
+                    bt = __builtin_bit_cast(s16x4_t, tbs[r]);
+                }
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+                    acc[r][d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, xfs[d]), bt, acc[r][d], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                // drain the ring before LDS is reused below
+        __syncthreads();
+    } else {
     // PD contraction steps are requested together (loads are unconditional with clamped indices - a branch around a
     // load costs a full vmcnt(0) drain)
     constexpr int PD = CONTRACT_PD;
@@ -114,6 +192,7 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
         }
     }
 #undef LOAD_STEP
+    }
 
     // ---- sum the 4 waves' partial tiles: (2,3) -> LDS -> (0,1) ; then 1 -> LDS -> 0
     if (wave >= 2) {
@@ -316,6 +395,22 @@ static int launch_contract(const void* T, const void* X, float* out, long ob, lo
         if (over > 0 && l <= 2 && l < ngrp && bhn * l * 4 <= 256 && bhn * l * 4 * (CONTRACT_R * DT * 256) <= ws_floats) nlo = (int)l;
     }
     const int nfull = ngrp - nlo;
+    static const int use_ring = getenv("SPE_CONTRACT_LDS") ? atoi(getenv("SPE_CONTRACT_LDS")) : 1;   // 0: register-load loop (A/B)
+    if (use_ring) {
+        const int smem_r = 4 * CL_D * CL_SLOT;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_contract_kernel<DT, TRANS, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_r);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((attn_contract_kernel<DT, TRANS, true>), dim3((unsigned)(bhn * nfull + bhn * nlo * 4)), dim3(256), smem_r, st,
+                           reinterpret_cast<const uint2*>(T), reinterpret_cast<const uint2*>(X), out, ob, on, oh, H, N, nt, dh, ngrp, alpha,
+                           (int)bhn, nfull, ws, counters, reinterpret_cast<unsigned short*>(out16));
+        SPE_CHECK_LAUNCH();
+        return 0;
+    }
     const int smem = 2 * CONTRACT_R * DT * 64 * 16;
     hipLaunchKernelGGL((attn_contract_kernel<DT, TRANS>), dim3((unsigned)(bhn * nfull + bhn * nlo * 4)), dim3(256), smem, st,
                        reinterpret_cast<const uint2*>(T), reinterpret_cast<const uint2*>(X), out, ob, on, oh, H, N, nt, dh, ngrp, alpha,

@@ -45,8 +45,9 @@ def main():
     fe, nf = per_launch(fetch_dir, "FETCH_SIZE")
     wr, nw = per_launch(write_dir, "WRITE_SIZE")
     res = {"note": note, "units": "bytes per launch; fetch = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE", "kernels": {}}
-    if os.path.exists(out):
-        old = json.load(open(out))
+    prev = out if os.path.exists(out) else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "roofline_inputs.json")
+    if os.path.exists(prev):
+        old = json.load(open(prev))
         for k in ("peaks_measured",):
             if k in old:
                 res[k] = old[k]
