@@ -21,8 +21,8 @@ KERNELS = {
     "talking_fused_mode1": "talking_fused_kernel<8, 2, true, 1,",
     "talking_fused_mode2": "talking_fused_kernel<8, 2, true, 2,",
     "talking_fused_mode3": "talking_fused_kernel<8, 2, true, 3,",
-    "attn_contract": "attn_contract_kernel<3, false>",
-    "attn_contract_T": "attn_contract_kernel<3, true>",
+    "attn_contract": "attn_contract_kernel<3, false",
+    "attn_contract_T": "attn_contract_kernel<3, true",
 }
 
 
