@@ -222,7 +222,10 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
     // room and read them (and dO) from LDS in groups of QG jobs
     constexpr bool QREG = (MODE <= 1);
     constexpr int QG = QREG ? ((JB >= 4) ? 4 : JB) : ((JB >= SPE_FUSED_QG) ? SPE_FUSED_QG : JB);
-    constexpr bool PREF = (MODE == 0) || (MODE == 1 && SPE_FUSED_PREF1) || (MODE == 2 && !DROP);
+    #ifndef SPE_FUSED_PREF2
+#define SPE_FUSED_PREF2 1
+#endif
+    constexpr bool PREF = (MODE == 0) || (MODE == 1 && SPE_FUSED_PREF1) || (MODE == 2 && !DROP && SPE_FUSED_PREF2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4_t* sQ = reinterpret_cast<u32x4_t*>(smem_raw);    // [NFR][64]
     u32x4_t* sdO = sQ + NFR * 64;                          // [NFR][64]   (modes 2, 3)
