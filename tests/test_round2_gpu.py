@@ -468,3 +468,28 @@ def test_gemm_bf16tn(dev, M, N, R, sk):
         K.gemm16_tn(A, Bm, C, M, N, R, M, N, N, alpha=0.7)
     assert torch.isfinite(C).all()
     assert rel(C, ref) < 2e-6, rel(C, ref)
+
+
+def test_nms_known_answers(dev):
+    """Hand-derived cases of greedy per-class NMS as torchvision documents it (`torchvision.ops.nms`: "iteratively removes
+    lower scoring boxes which have an IoU greater than iou_threshold with another (higher scoring) box"; the reference calls it
+    per predicted class at engine_loc.py:154-174): the threshold is strict (IoU == 0.5 survives), suppression is by KEPT boxes
+    only (a box removed earlier suppresses nobody), classes do not interact, survivors come back per class in score order."""
+    from spe_amd import infer
+    boxes = torch.tensor([
+        [0., 0., 10., 10.],      # 0  class 1  s .90  kept
+        [0., 0., 10., 5.],       # 1  class 1  s .80  IoU with 0 = 50/100 = 0.5 exactly -> kept (not > 0.5)
+        [1., 1., 10., 10.],      # 2  class 1  s .70  IoU with 0 = 81/100 -> removed
+        [0., 0., 10., 10.],      # 3  class 2  s .60  same box as 0, other class -> kept
+        [20., 0., 30., 10.],     # 4  class 2  s .95  kept
+        [24., 0., 34., 10.],     # 5  class 2  s .85  IoU with 4 = 60/140 = 0.43 -> kept
+        [28., 0., 38., 10.],     # 6  class 2  s .75  IoU with 5 = 0.43, with 4 = 20/180 -> kept
+        [21., 0., 31., 10.],     # 7  class 2  s .50  IoU with 4 = 90/110 = 0.82 -> removed
+        [22.5, 0., 32.5, 10.],   # 8  class 2  s .40  IoU with 4 = 75/125 = 0.6 -> removed; 7 (removed) would not have mattered
+    ])
+    labels = torch.tensor([1, 1, 1, 2, 2, 2, 2, 2, 2])
+    scores = torch.tensor([.90, .80, .70, .60, .95, .85, .75, .50, .40])
+    out = infer.per_class_nms([{"scores": scores.to(dev), "labels": labels.to(dev), "boxes": boxes.to(dev)}], 0.5)[0]
+    assert out["labels"].tolist() == [1, 1, 2, 2, 2, 2]
+    assert torch.allclose(out["scores"].cpu(), torch.tensor([.90, .80, .95, .85, .75, .60]))
+    assert torch.equal(out["boxes"].cpu(), boxes[[0, 1, 4, 5, 6, 3]])
