@@ -259,20 +259,25 @@ class SetCriterion(nn.Module):
             sizes_t = host_to_device(sizes, torch.float, dev)
             card = (amax.view(L, B, Q) != Kc - 1).sum(2).float()                # [L, B] predicted non-background counts
             card_err = (card - sizes_t[None, :]).abs().mean(1)                  # = F.l1_loss(card[l], sizes) per layer
+        # one unbind per loss vector (its backward is ONE stack; indexing element by element costs a zero fill, a copy and an
+        # accumulation per key in the backward - ~100 tiny launches per criterion call)
+        ce_l = loss_ce.unbind(0) if "labels" in self.losses else None
+        bl_f = bl.reshape(-1).unbind(0) if "boxes" in self.losses else None
+        card_l = card_err.unbind(0) if card_err is not None else None
         for l in range(L):
             sfx = suffix[l]
             if "labels" in self.losses:
-                losses["loss_ce" + sfx] = loss_ce[l]
+                losses["loss_ce" + sfx] = ce_l[l]
                 if l == 0:                                                      # top-1 error on matched rows (logging)
                     m0 = (lidx == 0).float()          # sync-free masked mean (0 when nothing is matched)
                     hit = (amax.view(-1)[srow].long() == labels_o).float()
                     acc = (hit * m0).sum() / m0.sum().clamp(min=1) * 100
                     losses["class_error"] = 100 - acc
             if "boxes" in self.losses:
-                losses["loss_bbox" + sfx] = bl[l, 0]
-                losses["loss_giou" + sfx] = bl[l, 1]
+                losses["loss_bbox" + sfx] = bl_f[2 * l]
+                losses["loss_giou" + sfx] = bl_f[2 * l + 1]
             if card_err is not None:
-                losses["cardinality_error" + sfx] = card_err[l]
+                losses["cardinality_error" + sfx] = card_l[l]
             if l == 0 and "image_label" in self.losses:
                 losses.update(self.loss_img_label(outputs, targets_cp))
         return losses
