@@ -48,7 +48,7 @@ typedef __bf16 bf16x4c_t __attribute__((ext_vector_type(4)));
 #else
 #define CL_NT ""
 #endif
-#define CL_SLOT 4096
+#define CL_SLOT (CONTRACT_R * 512 + 2048)
 __device__ __forceinline__ void cl_glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" CL_NT "\n\ts_mov_b32 m0, %0"
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
             const int cc = min(first + 4 * st, nt - 1);                       // clamped: steps past the range fetch valid memory, unused
             const unsigned dst = ring_lds + (unsigned)((st % CL_D) * CL_SLOT);
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {                                    // score blocks of output tiles 2pp, 2pp+1
+            for (int pp = 0; pp < R / 2; ++pp) {                                // score blocks of output tiles 2pp, 2pp+1
                 const int r = 2 * pp + half;
                 const uint2* src = TRANS ? Tb + ((long)cc * nt + tr[r]) * 64 : Tb + ((long)tr[r] * nt + cc) * 64;
                 cl_glds16(reinterpret_cast<const unsigned char*>(src) + l16, dst + pp * 1024);
@@ -115,20 +115,20 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
             for (int pp = 0; pp < 2; ++pp) {                                    // X fragments of d tiles 2pp, 2pp+1 (clamped to DT-1)
                 const int d = min(2 * pp + half, DT - 1);
                 const uint2* src = Xb + ((long)cc * DT + d) * 64;
-                cl_glds16(reinterpret_cast<const unsigned char*>(src) + l16, dst + 2048 + pp * 1024);
+                cl_glds16(reinterpret_cast<const unsigned char*>(src) + l16, dst + R * 512 + pp * 1024);
             }
         };
-        static_assert(CONTRACT_R == 4 && DT <= 4, "ring slot layout: 4 score blocks + up to 4 X fragments");
+        static_assert(CONTRACT_R % 2 == 0 && DT <= 4, "ring slot layout: R score blocks + up to 4 X fragments");
 #pragma unroll
         for (int st = 0; st < CL_D; ++st) issue(st);
         for (int st = 0; st < ns; ++st) {
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((CL_D - 1) * 4) : "memory");     // the 4 pieces of step st have landed
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((CL_D - 1) * (R / 2 + 2)) : "memory");     // the pieces of step st have landed
             const unsigned char* sl = ring + (st % CL_D) * CL_SLOT;
             uint2 tbs[R], xfs[DT];
 #pragma unroll
             for (int r = 0; r < R; ++r) tbs[r] = *reinterpret_cast<const uint2*>(sl + r * 512 + lane * 8);
 #pragma unroll
-            for (int d = 0; d < DT; ++d) xfs[d] = *reinterpret_cast<const uint2*>(sl + 2048 + d * 512 + lane * 8);
+            for (int d = 0; d < DT; ++d) xfs[d] = *reinterpret_cast<const uint2*>(sl + R * 512 + d * 512 + lane * 8);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          // slot read: free for the refill
             issue(st + CL_D);
 #pragma unroll
@@ -397,7 +397,7 @@ static int launch_contract(const void* T, const void* X, float* out, long ob, lo
     const int nfull = ngrp - nlo;
     static const int use_ring = getenv("SPE_CONTRACT_LDS") ? atoi(getenv("SPE_CONTRACT_LDS")) : 1;   // 0: register-load loop (A/B)
     if (use_ring) {
-        const int smem_r = 4 * CL_D * CL_SLOT;
+        const int smem_r = (4 * CL_D * CL_SLOT > 2 * CONTRACT_R * DT * 64 * 16) ? 4 * CL_D * CL_SLOT : 2 * CONTRACT_R * DT * 64 * 16;
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_contract_kernel<DT, TRANS, true>),

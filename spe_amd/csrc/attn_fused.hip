@@ -80,7 +80,11 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #define PLO(v) __builtin_shufflevector(v, v, 0, 1)
 #define PHI(v) __builtin_shufflevector(v, v, 2, 3)
 #define PCAT(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3)
+#ifdef SPE_DBG_NOEXP
+#define EXP2(x) ((x) * 0.5f)
+#else
 #define EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
 #define SPE_LOG2E 1.4426950408889634f
 #define SPE_LN2 0.6931471805599453f
 __device__ __forceinline__ f32x2_t fma2(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
@@ -92,6 +96,11 @@ template <int H>
 __device__ __forceinline__ void mix_rows(const f32x4_t (&s)[H], const float (&w)[H][H], const float (&c)[H], f32x2_t (&lo)[H], f32x2_t (&hi)[H]) {
 #pragma unroll
     for (int g = 0; g < H; ++g) { lo[g] = splat2(c[g]); hi[g] = lo[g]; }
+#ifdef SPE_DBG_NOMIX
+#pragma unroll
+    for (int g = 0; g < H; ++g) { lo[g] += PLO(s[g]); hi[g] += PHI(s[g]); }
+    return;
+#endif
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         const f32x2_t sl = PLO(s[h]), sh = PHI(s[h]);
@@ -154,6 +163,42 @@ __device__ __forceinline__ void mix_mfma_key(const float (&x)[H], const s16x4m_t
     }
 }
 
+// The softmax-input mix S' = Wl S + bl on the matrix pipe IN FP32: v_mfma_f32_4x4x1_16b_f32 computes, in each of its 16 blocks of
+// 4 lanes, the outer product D[i][j] += A[i] B[j] with D[i][.] in register i of lane 4b + j (probed on gfx950:
+// tools/debug/probe_mfma4x4.hip) - i.e. register i of a lane accumulates (A of lane 4b + i) * (the lane's OWN B).  With
+// A := W[4gh + (lane & 3)][h] (a per-lane constant) and B := the lane's score of head h, one instruction adds head h's
+// contribution to output heads 4gh .. 4gh+3 of the lane's own (query, key) element: H * H/4 instructions per key are the whole
+// H x H mix, bit-for-bit the fmaf chain the packed FMAs computed (an f32 MFMA is a k-ordered fmaf chain) at the same
+// FLOP rate (64 / clk / SIMD) - but on the pipe that is ~10 % busy instead of the one that bounds these kernels.  Measured
+// (cfg2, isolated): removing the packed-FMA mix altogether is worth 0.049 of the statistics pass' 0.176 ms.
+#ifndef SPE_FUSED_MIX4
+#define SPE_FUSED_MIX4 1
+#endif
+template <int H, bool TRANSPOSE>
+__device__ __forceinline__ void mixA4_build(const float* __restrict__ W, int lane, float (&A)[H / 4][H]) {
+#pragma unroll
+    for (int gh = 0; gh < H / 4; ++gh)
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const int go = 4 * gh + (lane & 3);
+            A[gh][h] = TRANSPOSE ? W[h * H + go] : W[go * H + h];
+        }
+}
+// out[r][gh][i] = c[4gh + i] + sum_h W[4gh + i][h] s[h][r]   (r: the lane's 4 keys)
+template <int H>
+__device__ __forceinline__ void mix_keys_f32(const f32x4_t (&s)[H], const float (&A)[H / 4][H], const float (&c)[H], f32x4_t (&out)[4][H / 4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int gh = 0; gh < H / 4; ++gh) out[r][gh] = (f32x4_t){c[4 * gh], c[4 * gh + 1], c[4 * gh + 2], c[4 * gh + 3]};
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int gh = 0; gh < H / 4; ++gh) out[r][gh] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[gh][h], s[h][r], out[r][gh], 0, 0, 0);
+}
+
 // Dropout of the mixed probabilities (reference models/cait.py:387, attn_drop): keep flags for the lane's 4 keys of TWO heads
 // from ONE Philox4x32-10 call - the 128 random bits are eight 16-bit lots (keep iff lot >= p * 65536: the rate is exact to
 // 1.5e-5).  The counter is (b, head pair, query, 4-key group): aligned by construction, so the write pass and both backward
@@ -192,9 +237,32 @@ __device__ __forceinline__ u32x4_t frag_load(const u32x4_t* __restrict__ base, l
 // The tail step's 8-B operands are zero-extended (frag_load) and go through the same 16x16x32 instruction: lane group
 // g then holds k-slots 8g..8g+3 = head dims FULL*32 + 4g..4g+3 in BOTH operands and zeros in slots 8g+4..8g+7, so the
 // products line up - the saving of the tail step is its load bytes, the matrix pipe is idle anyway.
+#ifndef SPE_FUSED_TAIL1K
+#define SPE_FUSED_TAIL1K 1
+#endif
 template <int DSTEPS, bool TAIL16>
 __device__ __forceinline__ f32x4_t frag_mfma(int st, u32x4_t a, u32x4_t b, f32x4_t c) {
+    // the 16-dim tail step as v_mfma_f32_16x16x16_bf16 on the 8-B halves: same products (lane group g holds head dims FULL*32 + 4g..4g+3
+    // in both operands either way) without the two zero registers per fragment that the 32-deep form needs (2 v_mov per fragment
+    // and tile on the pipe that bounds these kernels, 2 live registers per staged fragment)
+    if (SPE_FUSED_TAIL1K && TAIL16 && st == DSTEPS - 1) {
+        typedef unsigned u32x2f_t __attribute__((ext_vector_type(2)));
+        typedef short s16x4f_t __attribute__((ext_vector_type(4)));
+        const u32x2f_t al = {a[0], a[1]}, bl = {b[0], b[1]};
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4f_t, al), __builtin_bit_cast(s16x4f_t, bl), c, 0, 0, 0);
+    }
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// same record, addressed as (uniform byte pointer of the (b, h) row of records) + (32-bit byte offset of the tile's record): the
+// row pointers are computed once per segment, so a fragment costs no 64-bit address arithmetic in the tile loop
+template <int DSTEPS, bool TAIL16>
+__device__ __forceinline__ u32x4_t frag_load_row(const char* __restrict__ row, unsigned recoff, int st, int lane) {
+    constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0);
+    if (TAIL16 && st == FULL) {
+        const uint2 v = *reinterpret_cast<const uint2*>(row + (recoff + (unsigned)(FULL * 1024) + (unsigned)lane * 8u));
+        return (u32x4_t){v.x, v.y, 0u, 0u};
+    }
+    return *reinterpret_cast<const u32x4_t*>(row + (recoff + (unsigned)(st * 1024) + (unsigned)lane * 16u));
 }
 
 template <int H, int DSTEPS, bool TAIL16, int MODE, bool DROP, int KT>
@@ -231,7 +299,14 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
     u32x4_t* sdO = sQ + NFR * 64;                          // [NFR][64]   (modes 2, 3)
     float* sred = reinterpret_cast<float*>(sdO + ((MODE >= 2) ? NFR * 64 : 0));   // [4][H][16][2]
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a SCALAR: everything derived from it (macro step, key tile, fragment record addresses, tail masks) then lives
+    // in SGPRs and the fragment loads take an SGPR base + one per-lane offset.  With threadIdx.x >> 6 the compiler cannot prove
+    // uniformity and rebuilt every 64-bit record address on the vector pipe (16 v_mad_u64_u32 + ~70 moves/adds per tile in the
+    // forward passes, twice that in the backward ones: ~20 % of the issue slots of kernels that are vector-pipe bound)
+#ifndef SPE_FUSED_SWAVE
+#define SPE_FUSED_SWAVE 1
+#endif
+    const int lane = threadIdx.x & 63, wave = SPE_FUSED_SWAVE ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (threadIdx.x >> 6);
     const int nt = a.nt, N = a.N;
     const int nch = fused_nch(nt);
     const int chunk = (blockIdx.x & 7) % nch, wg_j = (blockIdx.x >> 3) * (8 / nch) + (blockIdx.x & 7) / nch;   // index within the chunk
@@ -252,6 +327,9 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
     if constexpr (MM && MODE == 1) mixA_build<H, false>(a.Ww, lane, Aw);
     if constexpr (MM && MODE >= 2) mixA_build<H, true>(a.Ww, lane, Aw);
     if constexpr (MM && MODE == 3) mixA_build<H, true>(a.Wl, lane, Al);
+    constexpr bool M4 = SPE_FUSED_MIX4 && (H % 4 == 0);
+    float Al4[M4 ? H / 4 : 1][M4 ? H : 1];                 // f32 operand of the S' mix (see mix_keys_f32)
+    if constexpr (M4) mixA4_build<H, false>(a.Wl, lane, Al4);
     // weight-gradient accumulators (whole workgroup range)
     // as head pairs: mode 2 gWp[g*(H/2)+hp] = (dWw[g][2hp], dWw[g][2hp+1]) ; mode 3 gWp[gp*H+h] = (dWl[2gp][h], dWl[2gp+1][h])
     f32x2_t gWp[(MODE >= 2) ? H * H / 2 : 1], gb2[(MODE == 3) ? H / 2 : 1];
@@ -312,16 +390,35 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
         // operand-fragment staging registers for one batch of jobs, and the batch loader: job jb of a macro step is
         // (tile jb / NH, head job jb % NH); head jobs >= H read the V fragments
         u32x4_t fr[JB * DSTEPS];
+        constexpr unsigned RECB = (unsigned)((DSTEPS - (TAIL16 ? 1 : 0)) * 1024 + (TAIL16 ? 512 : 0));   // bytes per fragment record
+#ifndef SPE_FUSED_ROWPTR
+#define SPE_FUSED_ROWPTR 1
+#endif
+        const char* krow[SPE_FUSED_ROWPTR ? H : 1];
+        const char* vrow[(SPE_FUSED_ROWPTR && MODE >= 2) ? H : 1];
+        if (SPE_FUSED_ROWPTR) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                krow[SPE_FUSED_ROWPTR ? h : 0] = reinterpret_cast<const char*>(a.Kf) + ((long)b * H + h) * nt * (long)RECB;
+                if (MODE >= 2) vrow[(SPE_FUSED_ROWPTR && MODE >= 2) ? h : 0] = reinterpret_cast<const char*>(a.Vf) + ((long)b * H + h) * nt * (long)RECB;
+            }
+        }
         auto load_batch = [&](int bi, int kt_first_) {
             constexpr int NH_ = (MODE >= 2) ? 2 * H : H;
 #pragma unroll
             for (int jj = 0; jj < JB; ++jj) {
                 const int jb = bi * JB + jj;
                 const int hj = jb % NH_, tj = jb / NH_;
-                const u32x4_t* srcp = (hj < H) ? a.Kf : a.Vf;
                 const int ktl = min(kt_first_ + tj, nt - 1);
+                if (SPE_FUSED_ROWPTR) {
+                    const char* row = (hj < H) ? krow[SPE_FUSED_ROWPTR ? hj % H : 0] : vrow[(SPE_FUSED_ROWPTR && MODE >= 2) ? hj % H : 0];
 #pragma unroll
-                for (int st = 0; st < DSTEPS; ++st) fr[jj * DSTEPS + st] = frag_load<DSTEPS, TAIL16>(srcp, ((long)b * H + (hj % H)) * nt + ktl, st, lane);
+                    for (int st = 0; st < DSTEPS; ++st) fr[jj * DSTEPS + st] = frag_load_row<DSTEPS, TAIL16>(row, (unsigned)ktl * RECB, st, lane);
+                } else {
+                    const u32x4_t* srcp = (hj < H) ? a.Kf : a.Vf;
+#pragma unroll
+                    for (int st = 0; st < DSTEPS; ++st) fr[jj * DSTEPS + st] = frag_load<DSTEPS, TAIL16>(srcp, ((long)b * H + (hj % H)) * nt + ktl, st, lane);
+                }
             }
         };
         for (int km = wave; km * KT < seg; km += 4) {
@@ -336,7 +433,11 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
             constexpr int NB = NJ / JB;
             f32x4_t acc[KT][H];
             f32x4_t acc2[(MODE >= 2) ? KT : 1][(MODE >= 2) ? H : 1];
-            if (!PREF || km == wave) load_batch(0, kt_first);   // first macro step of the segment: nothing prefetched yet
+#ifdef SPE_DBG_NOLOAD
+            if (km == wave) load_batch(0, kt_first);
+#else
+            if (!PREF || km == wave) load_batch(0, kt_first);
+#endif   // first macro step of the segment: nothing prefetched yet
 #pragma unroll
             for (int bi = 0; bi < NB; ++bi) {
                 // jobs of a batch go through the matrix pipe in groups of QG: the group's Q / dO fragments are read
@@ -374,8 +475,10 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef SPE_DBG_NOLOAD
                 if (bi + 1 < NB) load_batch(bi + 1, kt_first);
                 else if (PREF && (km + 4) * KT < seg) load_batch(0, kt0 + (km + 4) * KT);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             // this lane's 4 consecutive keys of tile j: kb(j) + r ; tiles past the segment end belong to another workgroup
@@ -389,7 +492,42 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
             // of a phase stay in SGPRs (both matrices together do not fit the scalar file).  All H x H mixes are
             // packed-fp32 FMAs (v_pk_fma_f32): either pairs over a lane's adjacent keys with a broadcast SGPR weight
             // (mix_rows) or pairs over adjacent heads with an SGPR weight pair and a broadcast (op_sel) operand.
-            if constexpr (MODE == 0) {
+            if constexpr (MODE == 0 && M4) {
+                f32x4_t sp[KT][4][H / 4];
+                float tmax[H];
+#pragma unroll
+                for (int g = 0; g < H; ++g) tmax[g] = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < KT; ++j) {
+                    mix_keys_f32<H>(acc[j], Al4, vbl2, sp[j]);
+                    if (TMASK(j)) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool kv = KVAL(j, r);
+#pragma unroll
+                            for (int g = 0; g < H; ++g) sp[j][r][g >> 2][g & 3] = kv ? sp[j][r][g >> 2][g & 3] : -INFINITY;
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < H; ++g) {
+                        tmax[g] = fmaxf(fmaxf(tmax[g], sp[j][0][g >> 2][g & 3]), sp[j][1][g >> 2][g & 3]);
+                        tmax[g] = fmaxf(fmaxf(tmax[g], sp[j][2][g >> 2][g & 3]), sp[j][3][g >> 2][g & 3]);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < H; ++g) {
+                    // branch-free: the subtrahend is clamped, so a row that has seen no valid key yet (max = -inf) gives
+                    // exp2(-inf - (-1e30)) = 0 everywhere instead of NaN
+                    const float mn = fmaxf(rm[g], tmax[g]), ms = fmaxf(mn, -1e30f);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < KT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sum += EXP2(sp[j][r][g >> 2][g & 3] - ms);
+                    rl[g] = rl[g] * EXP2(rm[g] - ms) + sum;
+                    rm[g] = mn;
+                }
+            } else if constexpr (MODE == 0) {
                 // phase A (Wl): S' in place + macro-step max ; then one rescale + 4*KT exp2 per head
                 float wl[H][H];
                 load_w<H>(a.Wl, wl);
@@ -433,7 +571,24 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
                 }
             } else if constexpr (MODE == 1) {
                 // phase A (Wl): acc <- P = exp2(S' + c0)   (c0 = bl - m + log2(1/l), all in the log2 domain)
-                {
+                if constexpr (M4) {
+#pragma unroll
+                for (int j = 0; j < KT; ++j) {
+                    f32x4_t sp[4][H / 4];
+                    mix_keys_f32<H>(acc[j], Al4, c0, sp);
+#pragma unroll
+                    for (int g = 0; g < H; ++g)
+                        acc[j][g] = (f32x4_t){EXP2(sp[0][g >> 2][g & 3]), EXP2(sp[1][g >> 2][g & 3]), EXP2(sp[2][g >> 2][g & 3]), EXP2(sp[3][g >> 2][g & 3])};
+                    if (TMASK(j)) {
+                        const bool k0 = KVAL(j, 0), k1 = KVAL(j, 1), k2 = KVAL(j, 2), k3 = KVAL(j, 3);
+#pragma unroll
+                        for (int g = 0; g < H; ++g) {
+                            acc[j][g][0] = k0 ? acc[j][g][0] : 0.f; acc[j][g][1] = k1 ? acc[j][g][1] : 0.f;
+                            acc[j][g][2] = k2 ? acc[j][g][2] : 0.f; acc[j][g][3] = k3 ? acc[j][g][3] : 0.f;
+                        }
+                    }
+                }
+                } else {
                 float wl[H][H];
                 load_w<H>(a.Wl, wl);
 #pragma unroll
@@ -510,18 +665,27 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
                 // results can be written to any register, so the transposition is free)
                 f32x2_t PT[KT][4][H / 2];
                 {
-                float wl[H][H];
-                load_w<H>(a.Wl, wl);
+                float wl[M4 ? 1 : H][M4 ? 1 : H];
+                if constexpr (!M4) load_w<H>(a.Wl, wl);
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
-                    f32x2_t lo[H], hi[H];
-                    mix_rows<H>(acc[j], wl, c0, lo, hi);
                     const bool tm = TMASK(j);
                     const bool k0 = !tm || KVAL(j, 0), k1 = !tm || KVAL(j, 1), k2 = !tm || KVAL(j, 2), k3 = !tm || KVAL(j, 3);
+                    if constexpr (M4) {
+                        f32x4_t sp[4][H / 4];
+                        mix_keys_f32<H>(acc[j], Al4, c0, sp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int g = 0; g < H; ++g) PT[j][r][g / 2][g & 1] = EXP2(sp[r][g >> 2][g & 3]);
+                    } else {
+                    f32x2_t lo[H], hi[H];
+                    mix_rows<H>(acc[j], wl, c0, lo, hi);
 #pragma unroll
                     for (int g = 0; g < H; ++g) {
                         PT[j][0][g / 2][g & 1] = EXP2(lo[g][0]); PT[j][1][g / 2][g & 1] = EXP2(lo[g][1]);
                         PT[j][2][g / 2][g & 1] = EXP2(hi[g][0]); PT[j][3][g / 2][g & 1] = EXP2(hi[g][1]);
+                    }
                     }
                     if (tm) {
 #pragma unroll
@@ -576,7 +740,9 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
                             gb[g] += dv;
 #pragma unroll
                             for (int hp = 0; hp < H / 2; ++hp) {
+#ifndef SPE_DBG_NOGW
                                 gWp[g * (H / 2) + hp] = fma2(db, PT[j][r][hp], gWp[g * (H / 2) + hp]);
+#endif
                                 if constexpr (!MM) mt[hp] = fma2(db, (f32x2_t){ww[g][2 * hp], ww[g][2 * hp + 1]}, mt[hp]);
                             }
                         }
@@ -628,13 +794,20 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
                 }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                float wl[H][H];
-                load_w<H>(a.Wl, wl);
+                float wl[(M4 && MM) ? 1 : H][(M4 && MM) ? 1 : H];
+                if constexpr (!(M4 && MM)) load_w<H>(a.Wl, wl);
                 // phase B (Wl both ways): P from raw S, dS' = P (dP - D), dWl += dS' S^T, dS = Wl^T dS'
 #pragma unroll
                 for (int j = 0; j < KT; ++j) {
                     f32x2_t d2[4][H / 2];
-                    {
+                    if constexpr (M4) {
+                        f32x4_t sp[4][H / 4];
+                        mix_keys_f32<H>(acc[j], Al4, c0, sp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int g = 0; g < H; ++g) d2[r][g / 2][g & 1] = EXP2(sp[r][g >> 2][g & 3]);
+                    } else {
                         f32x2_t lo[H], hi[H];
                         mix_rows<H>(acc[j], wl, c0, lo, hi);
 #pragma unroll
@@ -664,7 +837,11 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
                         for (int h = 0; h < H; ++h) {
                             const f32x2_t sb = splat2(acc[j][h][r]);
 #pragma unroll
+#ifndef SPE_DBG_NOGW
                             for (int gp = 0; gp < H / 2; ++gp) gWp[gp * H + h] = fma2(d2[r][gp], sb, gWp[gp * H + h]);
+#else
+                            for (int gp = 0; gp < ((h == 0) ? H / 2 : 0); ++gp) gWp[gp * H + h] = fma2(d2[r][gp], sb, gWp[gp * H + h]);
+#endif
                         }
                     }
                     f32x2_t ds[4][H / 2];
