@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
     constexpr int R = CONTRACT_R;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4_t* red = reinterpret_cast<f32x4_t*>(smem_raw);          // [2 waves][R][DT][64]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // scalar: step indices and block addresses stay in SGPRs
     // Workgroups [0, bhn*nfull): one group of R output tiles over the whole contraction range.  The ngrp - nfull
     // left-over groups per (b, h) come LAST in the grid, each as 4 workgroups over a quarter of the range: they start
     // when the first full workgroups retire and run alone, so their length is the tail of the launch (see the launcher).
