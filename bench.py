@@ -336,9 +336,10 @@ def main():
         mf = (2.0 * N * N * dh_) * Hh * a.batch
         ach = 2 * mf / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
         ach_alg = mf / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
-        # the kernel's real limiter is the fp32 head-mix VALU work (3 mixes + the dWl outer product, 2*H FLOP each
-        # per score and head): reported alongside against the 157.3 TFLOP/s vector peak
-        valu_flop = 4 * (2.0 * Hh * Hh) * N * N * a.batch
+        # vector-pipe work that is left in this pass: the dWl outer product (2*H FLOP per score and head; the three head
+        # mixes run on the matrix pipe since round 2 - S' = Wl S in fp32 on v_mfma_f32_4x4x1, dP and dS in bf16), reported
+        # against the 157.3 TFLOP/s vector peak; exp2 (quarter rate) and the bf16 packing are not counted as FLOP
+        valu_flop = 1 * (2.0 * Hh * Hh) * N * N * a.batch
         valu = valu_flop / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
         # second-largest kernel family, HBM-bound: the streaming contractions over the blocked bf16 score tensors
         # (algorithmic bytes per launch: B*H*N*N*2 B read once; operands/outputs are < 2 % of that)
@@ -370,7 +371,10 @@ def main():
                          "peak_measured": pk.get("mfma_bf16_tflops"), "unit": "TFLOP/s", "frac": ach / 2500.0,
                          "frac_algorithmic": ach_alg / 2500.0,
                          "traffic": kin.get("talking_fused_mode3", {}).get("traffic_bytes"),   # bytes/launch, PMC (profiles/roofline_inputs.json)
-                         "note": "not MFMA-bound: fp32 head mixes (no MFMA form), fragment loads and MFMA phases serialise at 2 waves/SIMD", "valu_achieved": valu, "valu_peak": 157.3,
+                         "note": "not MFMA-bound: per 16x16 tile and wave the matrix pipe is busy ~1150 cycles (QK^T, dO V^T and the three head mixes) and the "
+                                 "vector pipe ~1700 (dWl outer product, exp2, bf16 packing) of ~5900 elapsed - operand-fragment round trips and "
+                                 "MFMA->VALU dependencies are exposed at the 2 waves/SIMD that 256 registers allow (DESIGN.md 4.1)",
+                         "valu_achieved": valu, "valu_peak": 157.3,
                          "valu_frac": valu / 157.3,
                          "hbm_kernel": {"bound": "hbm", "kernel": "attn_contract_kernel<3,*> (PV / dV / dQ / dK over blocked bf16 scores)",
                                         "launches": c_launch, "avg_ms": c_ms, "achieved": c_bw, "peak": 8000.0,

@@ -5,7 +5,7 @@ import torch
 from spe_amd import kernels as K, ops
 dev = torch.device("cuda:0")
 K.set_precision("bf16")
-H, N, dh, B = 8, 1100, 48, 1
+H, N, dh, B = int(os.environ.get("HH", 8)), int(os.environ.get("N", 1100)), 48, 1
 g = torch.Generator().manual_seed(5)
 C = H * dh
 qkv = (1.5 * torch.randn(B, N, 3 * C, generator=g)).to(dev).requires_grad_()
