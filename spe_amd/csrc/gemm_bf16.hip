@@ -69,7 +69,21 @@ __device__ __forceinline__ void g16_stage(unsigned short* lds, const u32x4g_t (&
 // load round trips of the pipelined loop - 10 us for 0.1 GFLOP): all NTS K tiles of the workgroup are requested at once
 // (NTS * (BM + BN) / 32 16-B registers per thread), staged into NTS LDS slots behind ONE wait and barrier, then multiplied
 // back to back.  K tiles past the contraction length load zeros.
-template <int BM, int BN, bool EX, int NTS = 0>
+// RING > 0 ("ring" variant, long contractions): the K tiles travel global -> LDS by global_load_lds_dwordx4 (no staging
+// registers, nothing for hipcc to drain at the loop head) into a ring of RING stages; RING - 1 tiles are in flight per
+// workgroup and a counted s_waitcnt vmcnt admits the oldest.  The pipelined loop below keeps ONE tile in flight beyond the one
+// waiting in registers, so an iteration lasts (memory latency) / 2 ~ 1 us when its MFMAs need 0.1 us (fc2 forward, K = 1536:
+// 24 iterations = 20 of its 29 us).  A DMA instruction deposits lane l's 16 B at (base + 16 l): 8 rows x 128 B per wave
+// instruction, rows unpadded - so the 16-B chunks of a row are XOR-swizzled by the row index through the choice of the GLOBAL
+// chunk each lane fetches (LDS slot (r, c) holds chunk c ^ (r & 7)), which leaves the operand reads 2-way conflicted at worst.
+// Needs K % 64 == 0 (every model dimension is).
+__device__ __forceinline__ void gb_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int BM, int BN, bool EX, int NTS = 0, int RING = 0>
 __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     constexpr int NFM = BM / 32, NFN = BN / 32;        // 16x16 MFMA tiles per wave (wave tile BM/2 x BN/2)
@@ -109,6 +123,57 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
 #pragma unroll
         for (int j = 0; j < NFN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (RING > 0) {
+        constexpr int STG = (BM + BN) * 64;               // bf16 per stage: rows of 64 elements = 128 B, unpadded
+        constexpr int PW = (BM + BN) / 32;                // 1-KB pieces (8 rows) per wave and stage
+        const int ws = __builtin_amdgcn_readfirstlane(w);
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)smem16);
+        auto issue = [&](int t, int slot) {
+            const int tc = min(t, nt - 1);                // past the range: a valid tile, never used (keeps the vmcnt arithmetic static)
+            const long k0 = (long)(kt_begin + tc) * GB_BK;
+#pragma unroll
+            for (int i = 0; i < PW; ++i) {
+                const int piece = ws + 4 * i;             // [0, BM/8): A rows ; [BM/8, (BM+BN)/8): B rows
+                const bool isA = piece < BM / 8;
+                const int r8 = (isA ? piece : piece - BM / 8) * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ (r8 & 7);
+                const unsigned short* src = isA ? p.A + (long)min(m0 + r8, p.M - 1) * p.lda + k0 + c * 8
+                                                : p.B + (long)min(n0 + r8, p.N - 1) * p.ldb + k0 + c * 8;
+                gb_glds16(src, lds0 + (unsigned)((slot * STG + piece * 512) * 2));
+            }
+        };
+#pragma unroll
+        for (int st = 0; st < RING - 1; ++st) issue(st, st);
+        for (int t = 0; t < nt; ++t) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RING - 2) * PW) : "memory");     // this wave's pieces of tile t have landed
+            __syncthreads();                              // everybody's have, and everybody is done reading tile t - 1
+            issue(t + RING - 1, (t + RING - 1) % RING);   // refill the slot of tile t - 1
+            const unsigned short* tA = smem16 + (t % RING) * STG;
+            const unsigned short* tB = tA + BM * 64;
+#pragma unroll
+            for (int ks = 0; ks < GB_BK / 32; ++ks) {
+                const int kc = ks * 4 + (lane >> 4);
+                bf16x8_t a[NFM], b[NFN];
+#pragma unroll
+                for (int i = 0; i < NFM; ++i) {
+                    const int row = wm * WM + i * 16 + fr;
+                    a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(tA + row * 64 + ((kc ^ (row & 7)) * 8)));
+                }
+#pragma unroll
+                for (int j = 0; j < NFN; ++j) {
+                    const int row = wn * WN + j * 16 + fr;
+                    b[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(tB + row * 64 + ((kc ^ (row & 7)) * 8)));
+                }
+#pragma unroll
+                for (int i = 0; i < NFM; ++i)
+#pragma unroll
+                    for (int j = 0; j < NFN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the ring before the epilogue reuses the buffers
+        __syncthreads();
+    }
     if constexpr (NTS > 0) {
         u32x4g_t ra[NTS][BM / 32], rb[NTS][BN / 32];
 #pragma unroll
@@ -149,7 +214,7 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
     for (int i = 0; i < BM / 32; ++i) na[i] = (u32x4g_t){0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i) nb[i] = (u32x4g_t){0u, 0u, 0u, 0u};
-    if (NTS == 0 && nt > 0) {
+    if (NTS == 0 && RING == 0 && nt > 0) {
         g16_load<BM>(p.A, p.lda, m0, p.M, kt_begin * GB_BK, p.K, ca);
         g16_load<BN>(p.B, p.ldb, n0, p.N, kt_begin * GB_BK, p.K, cb);
         g16_stage<BM>(sA(0), ca);
@@ -412,12 +477,14 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
     }
 }
 
-template <int BM, int BN, bool EX = false, int NTS = 0>
+template <int BM, int BN, bool EX = false, int NTS = 0, int RING = 0>
 static int launch_gemm16(const Gemm16Args& p, hipStream_t stream) {
-    constexpr int smem = (NTS > 0 ? NTS : 2) * (BM + BN) * GB_LDR * (int)sizeof(unsigned short);
+    constexpr int smem = RING > 0 ? RING * (BM + BN) * 64 * (int)sizeof(unsigned short)
+                                  : (NTS > 0 ? NTS : 2) * (BM + BN) * GB_LDR * (int)sizeof(unsigned short);
+    static_assert(RING == 0 || RING * 64 >= 2 * GB_LDR, "the staged epilogue tiles must fit the ring");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16nt_kernel<BM, BN, EX, NTS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16nt_kernel<BM, BN, EX, NTS, RING>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -433,7 +500,7 @@ static int launch_gemm16(const Gemm16Args& p, hipStream_t stream) {
     if (q.xcd_bind == 1) tiles = 8 * ((tiles_m + 7) / 8) * tiles_n;
     if (q.xcd_bind == 2) tiles = 8 * ((tiles_n + 7) / 8) * tiles_m;
     dim3 grid(tiles, 1, p.splitk);
-    hipLaunchKernelGGL((gemm_bf16nt_kernel<BM, BN, EX, NTS>), grid, dim3(256), smem, stream, q);
+    hipLaunchKernelGGL((gemm_bf16nt_kernel<BM, BN, EX, NTS, RING>), grid, dim3(256), smem, stream, q);
     SPE_CHECK_LAUNCH();
     return 0;
 }
@@ -472,7 +539,15 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const
     // epilogue (bias / activation / up to three output tensors) is as long as its main loop here, 2000-3000 small
     // workgroups at 4 per CU overlap one's stores with another's loads, and the 1.1-1.5 rounds that 585 / 780 wide tiles
     // make on 512 slots disappear.  The weight-gradient products (few output tiles, split-K) keep the wide tiles.
-    if (splitk == 1 && M >= 2048) return launch_gemm16<64, 64>(p, stream);
+    if (splitk == 1 && M >= 2048) {
+        // long contraction into a narrow output (fc2 forward, fc1 / qkv input gradients, the stacked decoder projections'
+        // input gradient): 128x64 tiles fed by the LDS-DMA ring - half the A-panel re-reads of the 64x64 tiles and 2 tiles
+        // in flight per workgroup (K = 1536: 30.5 -> 25.6 us, K = 1152: 23.3 -> 20.7, K = 4608: 85 -> 64; with more stages
+        // or on the K = 384 products the lost occupancy costs more than the ring brings).  SPE_GEMM16_RING=0 disables it (A/B).
+        static const int ring = getenv("SPE_GEMM16_RING") ? atoi(getenv("SPE_GEMM16_RING")) : 1;
+        if (ring && (K % GB_BK) == 0 && K >= 1024 && N <= 512) return launch_gemm16<128, 64, false, 0, 3>(p, stream);
+        return launch_gemm16<64, 64>(p, stream);
+    }
     // tile: 128x128 when that already fills the chip, else narrower tiles (more workgroups in flight)
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splitk;
     if (t128 >= 384 && N > 64) return launch_gemm16<128, 128>(p, stream);
@@ -515,7 +590,11 @@ extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, float* C, co
         if (forced == 2 && reach128) return launch_gemm16<128, 64, true>(p, stream);
         if (forced == 3 && reach64) return launch_gemm16<64, 64, true>(p, stream);
     }
-    if (M >= 2048 && reach64) return launch_gemm16<64, 64, true>(p, stream);      // see spe_gemm_bf16nt
+    {   // see spe_gemm_bf16nt
+        static const int ring = getenv("SPE_GEMM16_RING") ? atoi(getenv("SPE_GEMM16_RING")) : 1;
+        if (ring && M >= 2048 && reach128 && (K % GB_BK) == 0 && K >= 1024 && N <= 512) return launch_gemm16<128, 64, true, 0, 3>(p, stream);
+    }
+    if (M >= 2048 && reach64) return launch_gemm16<64, 64, true>(p, stream);
     if (reach128 && t128 >= 384 && N > 64) return launch_gemm16<128, 128, true>(p, stream);
     const long t64n = (long)((M + 127) / 128) * ((N + 63) / 64);
     if (reach128 && ((t64n >= 256 && M > 64) || !reach64)) return launch_gemm16<128, 64, true>(p, stream);

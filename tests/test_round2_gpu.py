@@ -470,6 +470,32 @@ def test_gemm_bf16tn(dev, M, N, R, sk):
     assert rel(C, ref) < 2e-6, rel(C, ref)
 
 
+@pytest.mark.parametrize("M,N,Kd", [(2100, 384, 1536), (8300, 200, 1024), (2048, 512, 1152), (2051, 64, 4608)])
+def test_gemm_bf16nt_ring(dev, M, N, Kd):
+    """The LDS-DMA ring variant of spe_gemm_bf16nt / _ex (128x64 tiles, taken for M >= 2048, K >= 1024, N <= 512: fc2 forward,
+    fc1 / qkv input gradients) against an fp64 product of the same bf16 values: plain with bias, and the extended epilogue with the
+    LayerScale residual, the pre-residual copy and the bf16 copy.  Ragged M / N exercise the clamped rows of the DMA."""
+    from spe_amd import kernels as K
+    g_ = torch.Generator().manual_seed(M + N + Kd)
+    A = torch.randn(M, Kd, generator=g_).to(dev).to(torch.bfloat16)
+    Bm = (torch.randn(N, Kd, generator=g_) + 0.2).to(dev).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g_).to(dev)
+    ref = A.double() @ Bm.double().t() + bias.double()
+    C = torch.full((M, N), float("nan"), device=dev)
+    K.gemm16(A, Bm, C, M, N, Kd, Kd, Kd, N, bias=bias)
+    assert torch.isfinite(C).all()
+    assert rel(C, ref) < 2e-6, rel(C, ref)
+    res = torch.randn(M, N, generator=g_).to(dev)
+    gam = torch.randn(N, generator=g_).to(dev)
+    out = torch.full((M, N), float("nan"), device=dev)
+    y = torch.full((M, N), float("nan"), device=dev)
+    o16 = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
+    K.gemm16_ex(A, Bm, M, N, Kd, Kd, Kd, bias=bias, C=out, C2=y, out16=o16, res=res, rgamma=gam)
+    assert rel(y, ref) < 2e-6, rel(y, ref)
+    assert rel(out, res.double() + gam.double() * ref) < 2e-6
+    assert rel(o16.float(), ref) < 4e-3
+
+
 def test_nms_known_answers(dev):
     """Hand-derived cases of greedy per-class NMS as torchvision documents it (`torchvision.ops.nms`: "iteratively removes
     lower scoring boxes which have an IoU greater than iou_threshold with another (higher scoring) box"; the reference calls it
