@@ -470,6 +470,57 @@ def test_gemm_bf16tn(dev, M, N, R, sk):
     assert rel(C, ref) < 2e-6, rel(C, ref)
 
 
+@pytest.mark.parametrize("case", ["one_empty", "all_empty", "more_targets_than_queries", "more_targets_refine"])
+def test_criterion_edge_cases_match_oracle(dev, case):
+    """SetCriterion / SetCriterionRefine on ragged target lists against the oracle (= the reference's formulas with SciPy's
+    assignment): an image without boxes (all its queries are background, `num_boxes` clamps at 1), a batch without any box, and
+    more targets than queries (the assignment is then Q pairs per image - what the 5x one-to-many jitter of training produces
+    for crowded images).  Every loss key and the gradients w.r.t. logits and boxes, all decoder layers."""
+    import copy
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import spe_oracle as O
+    from spe_amd.models import build_model
+    blob = torch.load(os.path.join(GOLD, "e2e_single.pt"), weights_only=False)
+    args = argparse.Namespace(**blob["args"]); args.device = "cuda"
+    _, crit, crit_r, _, _ = build_model(args)
+    refine = case == "more_targets_refine"
+    cr = (crit_r if refine else crit).to(dev).eval()
+    g_ = torch.Generator().manual_seed(11)
+    B, Q, Kc, Kimg, L = 2, 10, 21, 20, 3
+    counts = {"one_empty": [0, 4], "all_empty": [0, 0], "more_targets_than_queries": [14, 3], "more_targets_refine": [13, 11]}[case]
+    def stage():
+        return {"pred_logits": torch.randn(B, Q, Kc, generator=g_), "pred_boxes": torch.rand(B, Q, 4, generator=g_) * 0.5 + 0.2}
+    outs = stage(); outs["aux_outputs"] = [stage() for _ in range(L - 1)]
+    outs["x_logits"] = torch.randn(B, Kimg, generator=g_); outs["x_cls_logits"] = torch.randn(B, Kimg, generator=g_)
+    targets = []
+    for m in counts:
+        t = {"labels": torch.randint(1, Kc - 1, (m,), generator=g_), "boxes": torch.rand(m, 4, generator=g_) * 0.4 + 0.2,
+             "img_label": (torch.rand(Kimg, generator=g_) > 0.7).long(), "orig_size": torch.tensor([64, 64])}
+        if refine:
+            t["scores"] = torch.rand(m, generator=g_) * 0.9 + 0.05
+        targets.append(t)
+    def leaves(o, dev_):
+        c = {k: (v.clone().to(dev_).requires_grad_() if torch.is_tensor(v) else v) for k, v in o.items() if k != "aux_outputs"}
+        c["aux_outputs"] = [{k: v.clone().to(dev_).requires_grad_() for k, v in a.items()} for a in o["aux_outputs"]]
+        return c
+    o_ref, o_dev = leaves(outs, "cpu"), leaves(outs, dev)
+    ref = O.set_criterion(o_ref, copy.deepcopy(targets), refine=refine)
+    got = cr(o_dev, to_dev(targets, dev))
+    assert set(got.keys()) == set(ref.keys()), (sorted(got.keys()), sorted(ref.keys()))
+    for k in ref:
+        assert torch.isfinite(got[k]).all(), k
+        gv, rv = float(got[k].detach()), float(ref[k].detach())
+        assert abs(gv - rv) <= 2e-5 * max(1.0, abs(rv)), (k, gv, rv)
+    wd = cr.weight_dict
+    sum(ref[k] * wd[k] for k in ref if k in wd).backward()
+    sum(got[k] * wd[k] for k in got if k in wd).backward()
+    for a_, b_ in [(o_dev, o_ref)] + list(zip(o_dev["aux_outputs"], o_ref["aux_outputs"])):
+        for k in ("pred_logits", "pred_boxes"):
+            gr = b_[k].grad if b_[k].grad is not None else torch.zeros_like(b_[k])
+            gd = a_[k].grad if a_[k].grad is not None else torch.zeros_like(a_[k])
+            assert (gd.cpu() - gr).abs().max() <= 1e-5 * max(1.0, float(gr.abs().max())), (k, float((gd.cpu() - gr).abs().max()))
+
+
 @pytest.mark.parametrize("M,N,Kd", [(2100, 384, 1536), (8300, 200, 1024), (2048, 512, 1152), (2051, 64, 4608)])
 def test_gemm_bf16nt_ring(dev, M, N, Kd):
     """The LDS-DMA ring variant of spe_gemm_bf16nt / _ex (128x64 tiles, taken for M >= 2048, K >= 1024, N <= 512: fc2 forward,
