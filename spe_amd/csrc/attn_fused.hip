@@ -272,7 +272,13 @@ template <int H, int DSTEPS, bool TAIL16, int MODE, bool DROP, int KT>
 #ifndef SPE_FUSED_JB2
 #define SPE_FUSED_JB2 4
 #endif
-__global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(FusedArgs a) {
+#ifndef SPE_FUSED_MINW01
+#define SPE_FUSED_MINW01 SPE_FUSED_MINW
+#endif
+#ifndef SPE_FUSED_QREG01
+#define SPE_FUSED_QREG01 1
+#endif
+__global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MINW) void talking_fused_kernel(FusedArgs a) {
     constexpr int NFR = H * DSTEPS;                        // fragments (16 B per lane) per q-tile
     // MFMA jobs per operand-fragment batch: whole tile in the forward passes; backward pass 1 has registers for 4 heads at a
     // time, backward pass 2 - since its two transposed mixes left the vector pipe - for 8 (0.380 -> 0.356 ms at cfg2; pass 1
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(256, SPE_FUSED_MINW) void talking_fused_kernel(Fuse
 #endif
     // modes 0, 1 keep the q-tile's Q fragments in registers (64 VGPRs at H = 8, dh <= 64); the backward modes have no
     // room and read them (and dO) from LDS in groups of QG jobs
-    constexpr bool QREG = (MODE <= 1);
+    constexpr bool QREG = (MODE <= 1) && SPE_FUSED_QREG01;
     constexpr int QG = QREG ? ((JB >= 4) ? 4 : JB) : ((JB >= SPE_FUSED_QG) ? SPE_FUSED_QG : JB);
     #ifndef SPE_FUSED_PREF2
 #define SPE_FUSED_PREF2 1
