@@ -547,6 +547,29 @@ def test_gemm_bf16nt_ring(dev, M, N, Kd):
     assert rel(o16.float(), ref) < 4e-3
 
 
+def test_cam_prepare_known_answers(dev):
+    """Hand-derived cases of the CAM -> thresholded image stage (reference cams_deit.resize_cam + get_multi_bboxes,
+    engine.py:356-398) from the documented semantics of the cv2 calls it makes: `cv2.resize(..., INTER_LINEAR)` samples at
+    src = (dst + 0.5) * (src_size / dst_size) - 0.5 with replicated borders; min-max normalisation; `np.uint8(255 * cam)`
+    truncates; `cv2.threshold(img, int(thr * img.max()), 255, THRESH_TOZERO)` keeps values STRICTLY above the threshold.
+      1 x 2 map [0, 1] -> 1 x 4: samples at -0.25, 0.25, 0.75, 1.25 -> [0, .25, .75, 1] -> uint8 [0, 63, 191, 255];
+      thr 0.5 -> level int(127.5) = 127 -> [0, 0, 191, 255]; thr 0.2 -> level 51 -> [0, 63, 191, 255];
+      2 x 2 map [[0, 1], [1, 2]] -> 4 x 4 is the separable product: corner 0, then .25 steps -> after normalisation (max 2)
+      row 0 = [0, .125, .375, .5], and the image is symmetric."""
+    from spe_amd import kernels as K
+    m = torch.tensor([[[0.0, 1.0]]], device=dev)
+    assert K.cam_prepare(m, 1, 4, 0.5).cpu().view(-1).tolist() == [0, 0, 191, 255]
+    assert K.cam_prepare(m, 1, 4, 0.2).cpu().view(-1).tolist() == [0, 63, 191, 255]
+    m2 = torch.tensor([[[0.0, 1.0], [1.0, 2.0]]], device=dev)
+    got = K.cam_prepare(m2, 4, 4, 0.0).cpu().view(4, 4)
+    u = [0.0, 0.25, 0.75, 1.0]
+    exp = torch.tensor([[int(255 * ((u[i] + u[j]) / 2.0)) for j in range(4)] for i in range(4)], dtype=torch.uint8)
+    assert torch.equal(got, exp), (got, exp)
+    assert torch.equal(got, got.t())
+    # a constant offset and scale of the map change nothing (min-max normalisation)
+    assert torch.equal(K.cam_prepare(3.0 * m2 - 7.0, 4, 4, 0.0).cpu().view(4, 4), exp)
+
+
 def test_nms_known_answers(dev):
     """Hand-derived cases of greedy per-class NMS as torchvision documents it (`torchvision.ops.nms`: "iteratively removes
     lower scoring boxes which have an IoU greater than iou_threshold with another (higher scoring) box"; the reference calls it
