@@ -481,7 +481,7 @@ template <int BM, int BN, bool EX = false, int NTS = 0, int RING = 0>
 static int launch_gemm16(const Gemm16Args& p, hipStream_t stream) {
     constexpr int smem = RING > 0 ? RING * (BM + BN) * 64 * (int)sizeof(unsigned short)
                                   : (NTS > 0 ? NTS : 2) * (BM + BN) * GB_LDR * (int)sizeof(unsigned short);
-    static_assert(RING == 0 || RING * 64 >= 2 * GB_LDR, "the staged epilogue tiles must fit the ring");
+    static_assert(RING == 0 || !EX || RING * 64 >= 2 * GB_LDR, "the staged epilogue tiles must fit the ring");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16nt_kernel<BM, BN, EX, NTS, RING>),
@@ -545,6 +545,12 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const
         // in flight per workgroup (K = 1536: 30.5 -> 25.6 us, K = 1152: 23.3 -> 20.7, K = 4608: 85 -> 64; with more stages
         // or on the K = 384 products the lost occupancy costs more than the ring brings).  SPE_GEMM16_RING=0 disables it (A/B).
         static const int ring = getenv("SPE_GEMM16_RING") ? atoi(getenv("SPE_GEMM16_RING")) : 1;
+        if (ring > 1 && (K % GB_BK) == 0) {          // developer knob: force a ring configuration for every activation-sized product
+            if (ring == 1282) return launch_gemm16<128, 128, false, 0, 2>(p, stream);
+            if (ring == 1283) return launch_gemm16<128, 128, false, 0, 3>(p, stream);
+            if (ring == 642) return launch_gemm16<128, 64, false, 0, 2>(p, stream);
+            if (ring == 643) return launch_gemm16<128, 64, false, 0, 3>(p, stream);
+        }
         if (ring && (K % GB_BK) == 0 && K >= 1024 && N <= 512) return launch_gemm16<128, 64, false, 0, 3>(p, stream);
         return launch_gemm16<64, 64>(p, stream);
     }
