@@ -91,6 +91,12 @@ def test_matcher(ops, tag):
     idx = O.hungarian(g["outputs"], g["targets"])
     for (i, j), (ri, rj) in zip(idx, g["indices"]):
         assert torch.equal(i, ri) and torch.equal(j, rj)
+    # the cost matrices the reference handed to SciPy (captured at its linear_sum_assignment call), incl. M > Q and M = 0
+    for b, (t, c) in enumerate(zip(g["targets"], g["cost"])):
+        mine = O.matcher_cost(g["outputs"]["pred_logits"][b], g["outputs"]["pred_boxes"][b], t["labels"], t["boxes"])
+        assert mine.shape == c.shape
+        if c.numel():
+            close(mine, c)
 
 
 @pytest.mark.parametrize("gam", [0.5, 2.0])

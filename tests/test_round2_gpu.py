@@ -547,6 +547,47 @@ def test_gemm_bf16nt_ring(dev, M, N, Kd):
     assert rel(o16.float(), ref) < 4e-3
 
 
+@pytest.mark.parametrize("tag", ["small", "many"])
+def test_matcher_cost_matches_reference_golden(dev, tag):
+    """spe_matcher_cost against the cost matrices the REFERENCE handed to SciPy (tests/golden/ops.pt, captured at the
+    reference's linear_sum_assignment call by tools/gen_golden.py): 2 images, M > Q and an image without targets; and the
+    device Hungarian on them gives the reference's pairs."""
+    from spe_amd import kernels as K
+    g_ = torch.load(os.path.join(GOLD, "ops.pt"), weights_only=False)[f"matcher_{tag}"]
+    logits, boxes = g_["outputs"]["pred_logits"].to(dev)[None], g_["outputs"]["pred_boxes"].to(dev)[None]      # L = 1
+    B, Q = logits.shape[1], logits.shape[2]
+    sizes = [int(len(t["labels"])) for t in g_["targets"]]
+    toff = [0]
+    for s_ in sizes:
+        toff.append(toff[-1] + s_)
+    tgt_ids = torch.cat([t["labels"] for t in g_["targets"]]).int().to(dev)
+    tgt_boxes = torch.cat([t["boxes"] for t in g_["targets"]]).float().to(dev)
+    toff_t = torch.tensor(toff, dtype=torch.int32, device=dev)
+    cost, err = K.matcher_cost(logits, boxes, tgt_ids, tgt_boxes, toff_t, toff[-1], 2.0, 5.0, 2.0)
+    assert int(err.item()) == 0
+    for b in range(B):
+        if sizes[b] == 0:
+            continue
+        got = cost[0, Q * toff[b]:Q * toff[b + 1]].view(Q, sizes[b]).cpu()
+        ref = g_["cost"][b].float()
+        assert (got - ref).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max())), (b, float((got - ref).abs().max()))
+    from spe_amd.models.matcher import HungarianMatcher
+    m = HungarianMatcher(2, 5, 2, 5)
+    tg = to_dev(g_["targets"], dev)
+    per = m.match_many(logits, boxes, tg)[0]                  # host SciPy on the device cost (the path taken when M > Q)
+    for b in range(B):
+        assert torch.equal(per[b][0], g_["indices"][b][0]) and torch.equal(per[b][1], g_["indices"][b][1]), b
+    flat = m.match_flat(logits, boxes, tg)                    # device Hungarian (None when an image has more targets than queries)
+    assert (flat is None) == (max(sizes) > Q)
+    if flat is not None:
+        srow, gidx = flat[0].cpu(), flat[1].cpu()
+        for b in range(B):
+            ri, rj = g_["indices"][b]
+            sel = (srow >= b * Q) & (srow < (b + 1) * Q)
+            pairs = sorted(zip((srow[sel] - b * Q).tolist(), (gidx[sel] - toff[b]).tolist()))
+            assert pairs == sorted(zip(ri.tolist(), rj.tolist())), (b, pairs)
+
+
 def test_cam_prepare_known_answers(dev):
     """Hand-derived cases of the CAM -> thresholded image stage (reference cams_deit.resize_cam + get_multi_bboxes,
     engine.py:356-398) from the documented semantics of the cv2 calls it makes: `cv2.resize(..., INTER_LINEAR)` samples at

@@ -234,8 +234,17 @@ def ops_golden(seed=7):
         outs = {"pred_logits": rn(2, Q, 21) * 2, "pred_boxes": torch.cat([torch.rand(2, Q, 2, generator=g) * 0.6 + 0.2,
                                                                         torch.rand(2, Q, 2, generator=g) * 0.3 + 0.05], -1)}
         tg = make_targets(g, 20, sizes)
-        idx = m(outs, tg)
-        G[f"matcher_{tag}"] = {"outputs": outs, "targets": tg, "indices": idx}
+        # the cost matrices the reference hands to SciPy (matcher.py:82-86), captured at the call (no RNG is consumed)
+        costs, lsa = [], rm.linear_sum_assignment
+        def record(c):
+            costs.append(torch.as_tensor(c).clone())
+            return lsa(c)
+        rm.linear_sum_assignment = record
+        try:
+            idx = m(outs, tg)
+        finally:
+            rm.linear_sum_assignment = lsa
+        G[f"matcher_{tag}"] = {"outputs": outs, "targets": tg, "indices": idx, "cost": costs}
     # weighted focal, gamma 0.5 and 2 (conditional_detr.py:468-494)
     crit = rd.SetCriterion(21, m, {}, 0.25, ["labels"], 2.0, 0.1)
     x = rn(2, 6, 21) * 3
