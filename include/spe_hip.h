@@ -150,7 +150,9 @@ int spe_talking_softmax_bwd(const float* dPd, const float* P, const float* S, co
  * Supported: H in {4,8}, head dim <= 64.  Returns -2 otherwise (use the materialised path). */
 int spe_attn_pack(const float* x, long sb, long sn, long sh, int B, int N, int H, int dh, float scale,
                   void* out, spe_stream_t stream);
-int spe_talking_fused_plan(int B, int N, int nwg, int* steps_per_wg, int* nwg_used);
+/* the launcher's work split for pass `mode` (workgroups walk (q-tile group, key tile) steps; the forward passes group two
+ * q-tiles per workgroup): steps per workgroup - the value spe_attn_merge needs for the same mode - and workgroups used */
+int spe_talking_fused_plan(int B, int N, int nwg, int mode, int* steps_per_wg, int* nwg_used);
 int spe_talking_fused(int mode, const void* Qf, const void* Kf, const void* Vf, const void* dOf,
                       const float* Wl, const float* bl, const float* Ww, const float* bw,
                       const float* M, const float* IL, const float* D, float* ws_stats, float* ws_w, void* outT,

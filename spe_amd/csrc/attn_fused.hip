@@ -64,6 +64,17 @@ __device__ __forceinline__ void load_w(const float* p, float (&w)[H][H]) {
 }
 
 #define FUSED_MAXSLOT 8
+// q-tiles per workgroup: with 2, waves (0,1) work on q-tile 2p and waves (2,3) on q-tile 2p+1 and BOTH pairs walk the same key
+// tiles in step, so every K / V fragment is requested twice within a few hundred cycles by one CU and the second request is
+// served by (or merged into the pending miss of) the vector L1 - the L1 -> L2 request stream, which bounds the backward passes
+// (DESIGN.md 4.1), halves.  Measured with duplicated tile walks before the change: ~10 % per tile in passes 0, 2 and 3.
+// Measured (cfg2, isolated): statistics pass 0.135 -> 0.126 ms, write pass 0.157 -> 0.152; the backward passes, which would
+// have to keep the Q and dO fragments of both q-tiles in LDS, lose (0.305 -> 0.341, 0.354 -> 0.362 ms) and keep one q-tile.
+#ifndef SPE_FUSED_QP
+#define SPE_FUSED_QP 2
+#endif
+__host__ __device__ __forceinline__ int fused_qp(int mode) { return (mode <= 1) ? SPE_FUSED_QP : 1; }
+__host__ __device__ __forceinline__ int fused_npair(int nt, int mode) { return (nt + fused_qp(mode) - 1) / fused_qp(mode); }
 
 // Key chunks bound to XCDs.  A workgroup with blockIdx b runs on XCD b % 8 (8 private 4 MB L2s).  The K and V
 // fragments of an image are 4-8 MB; when every workgroup sweeps all keys each L2 thrashes on them (rocprof: 1.9 GB of
@@ -301,9 +312,10 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
 #endif
     constexpr bool PREF = (MODE == 0) || (MODE == 1 && SPE_FUSED_PREF1) || (MODE == 2 && !DROP && SPE_FUSED_PREF2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u32x4_t* sQ = reinterpret_cast<u32x4_t*>(smem_raw);    // [NFR][64]
-    u32x4_t* sdO = sQ + NFR * 64;                          // [NFR][64]   (modes 2, 3)
-    float* sred = reinterpret_cast<float*>(sdO + ((MODE >= 2) ? NFR * 64 : 0));   // [4][H][16][2]
+    constexpr int QP = (MODE <= 1) ? SPE_FUSED_QP : 1, WPQ = 4 / QP;        // q-tiles per workgroup, waves per q-tile
+    u32x4_t* sQ = reinterpret_cast<u32x4_t*>(smem_raw);    // [QP][NFR][64]
+    u32x4_t* sdO = sQ + QP * NFR * 64;                     // [QP][NFR][64]   (modes 2, 3)
+    float* sred = reinterpret_cast<float*>(sdO + ((MODE >= 2) ? QP * NFR * 64 : 0));   // [4][H][16][2]
 
     // the wave index as a SCALAR: everything derived from it (macro step, key tile, fragment record addresses, tail masks) then lives
     // in SGPRs and the fragment loads take an SGPR base + one per-lane offset.  With threadIdx.x >> 6 the compiler cannot prove
@@ -317,7 +329,8 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
     const int nch = fused_nch(nt);
     const int chunk = (blockIdx.x & 7) % nch, wg_j = (blockIdx.x >> 3) * (8 / nch) + (blockIdx.x & 7) / nch;   // index within the chunk
     const int kbeg = fused_kbeg(chunk, nt, nch), klen = fused_kbeg(chunk + 1, nt, nch) - kbeg;
-    const long total_c = (long)a.B * nt * klen;
+    const int npair = fused_npair(nt, MODE);
+    const long total_c = (long)a.B * npair * klen;
     const long s_begin = (long)wg_j * a.steps_per_wg;
     long s_end = s_begin + a.steps_per_wg; if (s_end > total_c) s_end = total_c;
 
@@ -354,22 +367,28 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
 
     long s = s_begin;
     while (s < s_end) {
-        const int bq = (int)(s / klen), kt0 = kbeg + (int)(s % klen);
+        const int bqp = (int)(s / klen), kt0 = kbeg + (int)(s % klen);
         int seg = kbeg + klen - kt0; if (seg > s_end - s) seg = (int)(s_end - s);
-        const int b = bq / nt, qt = bq % nt;
+        const int b = bqp / npair, qp = bqp % npair;
+        const int qt_own = qp * QP + wave / WPQ;              // this wave's q-tile; past the last tile (odd tile count): the wave idles
+        const bool qt_valid = qt_own < nt;
+        const int qt = qt_valid ? qt_own : nt - 1;
+        const int bq = b * nt + qt;
         const int q = qt * 16 + (lane & 15);
-        const bool qv = q < N;
-        // ---- stage this q-tile's Q (and dO) fragments in LDS
+        const bool qv = qt_valid && q < N;
+        // ---- stage the q-tiles' Q (and dO) fragments in LDS
         u32x4_t qreg[QREG ? NFR : 1];
+        const u32x4_t* sQw = sQ + (wave / WPQ) * NFR * 64;
+        const u32x4_t* sdOw = sdO + (wave / WPQ) * NFR * 64;
         if (QREG) {
             __syncthreads();                                   // sred of the previous segment has been consumed
 #pragma unroll
             for (int f = 0; f < NFR; ++f) qreg[QREG ? f : 0] = frag_load<DSTEPS, TAIL16>(a.Qf, ((long)b * H + f / DSTEPS) * nt + qt, f % DSTEPS, lane);
         } else {
             __syncthreads();
-            for (int i = threadIdx.x; i < NFR * 64; i += 256) {
-                const int fr = i >> 6, ln = i & 63, h = fr / DSTEPS, st = fr % DSTEPS;
-                const long rec = ((long)b * H + h) * nt + qt;
+            for (int i = threadIdx.x; i < QP * NFR * 64; i += 256) {
+                const int u = i / (NFR * 64), fr = (i >> 6) % NFR, ln = i & 63, h = fr / DSTEPS, st = fr % DSTEPS;
+                const long rec = ((long)b * H + h) * nt + min(qp * QP + u, nt - 1);
                 sQ[i] = frag_load<DSTEPS, TAIL16>(a.Qf, rec, st, ln);
                 if (MODE >= 2) sdO[i] = frag_load<DSTEPS, TAIL16>(a.dOf, rec, st, ln);
             }
@@ -427,7 +446,9 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                 }
             }
         };
-        for (int km = wave; km * KT < seg; km += 4) {
+#define KM0 (wave % WPQ)
+#define KMS WPQ
+        for (int km = KM0; qt_valid && km * KT < seg; km += KMS) {
             const int kt_first = kt0 + km * KT;
             // ---- raw scores of all heads acc[j][h] = K_tile(h).Q_tile(h)^T (and acc2[j][g] = V_tile(g).dO_tile(g)^T).
             // The (operand, tile, head) jobs are issued in batches of JB: the JB*DSTEPS operand fragments of a batch
@@ -440,9 +461,9 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
             f32x4_t acc[KT][H];
             f32x4_t acc2[(MODE >= 2) ? KT : 1][(MODE >= 2) ? H : 1];
 #ifdef SPE_DBG_NOLOAD
-            if (km == wave) load_batch(0, kt_first);
+            if (km == KM0) load_batch(0, kt_first);
 #else
-            if (!PREF || km == wave) load_batch(0, kt_first);
+            if (!PREF || km == KM0) load_batch(0, kt_first);
 #endif   // first macro step of the segment: nothing prefetched yet
 #pragma unroll
             for (int bi = 0; bi < NB; ++bi) {
@@ -458,7 +479,7 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
 #pragma unroll
                         for (int jj = 0; jj < QG; ++jj) {
                             const int hj = (bi * JB + g0 + jj) % NH;
-                            const u32x4_t* lds = (hj < H) ? sQ : sdO;
+                            const u32x4_t* lds = (hj < H) ? sQw : sdOw;
 #pragma unroll
                             for (int st = 0; st < DSTEPS; ++st) qf[jj * DSTEPS + st] = lds[((hj % H) * DSTEPS + st) * 64 + lane];
                         }
@@ -483,7 +504,7 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef SPE_DBG_NOLOAD
                 if (bi + 1 < NB) load_batch(bi + 1, kt_first);
-                else if (PREF && (km + 4) * KT < seg) load_batch(0, kt0 + (km + 4) * KT);
+                else if (PREF && (km + KMS) * KT < seg) load_batch(0, kt0 + (km + KMS) * KT);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -921,20 +942,23 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                 }
             }
             __syncthreads();
-            const int first_j = (int)(((long)bq * klen) / a.steps_per_wg);
+            const int first_j = (int)(((long)bqp * klen) / a.steps_per_wg);
             const int slot = chunk * (FUSED_MAXSLOT / nch) + (wg_j - first_j);
-            for (int i = threadIdx.x; i < H * 16; i += 256) {
-                float* dst = a.ws_stats + ((((long)bq * FUSED_MAXSLOT + slot) * H * 16) + i) * 2;
+            for (int i2 = threadIdx.x; i2 < QP * H * 16; i2 += 256) {
+                const int u = i2 / (H * 16), i = i2 % (H * 16);
+                if (qp * QP + u >= nt) continue;
+                const long bq_u = (long)b * nt + qp * QP + u;
+                float* dst = a.ws_stats + (((bq_u * FUSED_MAXSLOT + slot) * H * 16) + i) * 2;
                 if (MODE == 0) {
                     float mn = -INFINITY;
-                    for (int w = 0; w < 4; ++w) mn = fmaxf(mn, sred[((w * H * 16) + i) * 2]);
+                    for (int w = u * WPQ; w < (u + 1) * WPQ; ++w) mn = fmaxf(mn, sred[((w * H * 16) + i) * 2]);
                     float l = 0.f;
                     if (mn > -INFINITY)
-                        for (int w = 0; w < 4; ++w) l += sred[((w * H * 16) + i) * 2 + 1] * EXP2(sred[((w * H * 16) + i) * 2] - mn);
+                        for (int w = u * WPQ; w < (u + 1) * WPQ; ++w) l += sred[((w * H * 16) + i) * 2 + 1] * EXP2(sred[((w * H * 16) + i) * 2] - mn);
                     dst[0] = mn; dst[1] = l;
                 } else {
                     float d = 0.f;
-                    for (int w = 0; w < 4; ++w) d += sred[((w * H * 16) + i) * 2];
+                    for (int w = u * WPQ; w < (u + 1) * WPQ; ++w) d += sred[((w * H * 16) + i) * 2];
                     dst[0] = d; dst[1] = 0.f;
                 }
             }
@@ -984,7 +1008,8 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
         for (int c = 0; c < nch; ++c) {
             const int klen = fused_kbeg(c + 1, nt, nch) - fused_kbeg(c, nt, nch);
             if (klen <= 0) continue;
-            const int first_j = (int)(((long)bq * klen) / steps_per_wg), last_j = (int)((((long)bq + 1) * klen - 1) / steps_per_wg);
+            const long bqp = (long)b * fused_npair(nt, mode) + qt / fused_qp(mode);   // the workgroups walk (q-group, key tile) steps
+            const int first_j = (int)((bqp * klen) / steps_per_wg), last_j = (int)(((bqp + 1) * klen - 1) / steps_per_wg);
             for (int s = 0; s <= last_j - first_j; ++s) {
                 const float* e = base + (c * spc + s) * stride;
                 if (mode != 0) d += e[0];
@@ -1059,12 +1084,12 @@ extern "C" int spe_talking_wgrad_reduce(const float* ws_w, int nwg, int H, float
 
 // steps per workgroup of a chunk: even split over the chunk's workgroups, but the chunk's part of a q-tile may
 // spread over at most FUSED_MAXSLOT / nch workgroups (its slots in the statistics workspace)
-static void make_plan(int B, int nt, int nwg, int* spw_out, int* nwg_out) {
+static void make_plan(int B, int nt, int nwg, int mode, int* spw_out, int* nwg_out) {
     const int nch = fused_nch(nt), spc = FUSED_MAXSLOT / nch;
     int nwg8 = nwg & ~7; if (nwg8 < 8) nwg8 = 8;
     const int wpc = nwg8 / nch;
     const int len_max = (nt + nch - 1) / nch;
-    long spw = ((long)B * nt * len_max + wpc - 1) / wpc;
+    long spw = ((long)B * fused_npair(nt, mode) * len_max + wpc - 1) / wpc;
     const long min_spw = (len_max + (spc - 1) - 1) / (spc - 1);       // ceil(len / (spc-1)): <= spc slots
     if (spw < min_spw) spw = min_spw;
     *spw_out = (int)spw; *nwg_out = nwg8;
@@ -1073,7 +1098,7 @@ static void make_plan(int B, int nt, int nwg, int* spw_out, int* nwg_out) {
 template <int H, int DSTEPS, bool TAIL16, int MODE, bool DROP, int KT>
 static int launch_fused(const FusedArgs& a, int nwg, hipStream_t st) {
     constexpr int NFR = H * DSTEPS;
-    constexpr int smem = NFR * 64 * 16 * ((MODE >= 2) ? 2 : 1) + 4 * (H * 16 * 2 > (H * H + H) ? H * 16 * 2 : (H * H + H)) * 4;
+    constexpr int smem = ((MODE <= 1) ? SPE_FUSED_QP : 1) * NFR * 64 * 16 * ((MODE >= 2) ? 2 : 1) + 4 * (H * 16 * 2 > (H * H + H) ? H * 16 * 2 : (H * H + H)) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&talking_fused_kernel<H, DSTEPS, TAIL16, MODE, DROP, KT>),
@@ -1120,7 +1145,7 @@ extern "C" int spe_talking_fused(int mode, const void* Qf, const void* Kf, const
     a.B = B; a.N = N; a.nt = (N + 15) / 16;
     a.total_steps = (long)B * a.nt * a.nt;
     if (a.total_steps <= 0) return 0;
-    make_plan(B, a.nt, nwg, &a.steps_per_wg, &nwg);
+    make_plan(B, a.nt, nwg, mode, &a.steps_per_wg, &nwg);
     a.p_drop = p_drop; a.seed = seed; a.offset = offset;
     const bool drop = p_drop > 0.f;
     // head dim -> d-steps: full 32-wide steps, plus a 16-wide tail step when the remainder is 1..16
@@ -1139,9 +1164,9 @@ extern "C" int spe_talking_fused(int mode, const void* Qf, const void* Kf, const
 }
 
 // steps_per_wg the launcher will use for (B, N, nwg): callers size the workspaces with it.
-extern "C" int spe_talking_fused_plan(int B, int N, int nwg, int* steps_per_wg, int* nwg_used) {
+extern "C" int spe_talking_fused_plan(int B, int N, int nwg, int mode, int* steps_per_wg, int* nwg_used) {
     const int nt = (N + 15) / 16;
     if ((long)B * nt * nt <= 0) { *steps_per_wg = 0; *nwg_used = 0; return 0; }
-    make_plan(B, nt, nwg, steps_per_wg, nwg_used);
+    make_plan(B, nt, nwg, mode, steps_per_wg, nwg_used);
     return 0;
 }

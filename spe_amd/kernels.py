@@ -815,7 +815,7 @@ def attn_pack(x4, scale=1.0):
 def fused_plan(B, N, mode):
     """(steps per workgroup, workgroups) the launcher uses for pass `mode` (sizes ws_w, parametrises attn_merge)."""
     spw, nwg = ctypes.c_int(0), ctypes.c_int(0)
-    lib.call("spe_talking_fused_plan", B, N, FUSED_NWG[mode], ctypes.byref(spw), ctypes.byref(nwg))
+    lib.call("spe_talking_fused_plan", B, N, FUSED_NWG[mode], int(mode), ctypes.byref(spw), ctypes.byref(nwg))
     return spw.value, nwg.value
 
 
