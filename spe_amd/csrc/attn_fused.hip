@@ -386,6 +386,9 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
             for (int f = 0; f < NFR; ++f) qreg[QREG ? f : 0] = frag_load<DSTEPS, TAIL16>(a.Qf, ((long)b * H + f / DSTEPS) * nt + qt, f % DSTEPS, lane);
         } else {
             __syncthreads();
+#ifdef SPE_DBG_NOSTAGE      // timing experiment: Q / dO staged for the workgroup's first segment only
+            if (s == s_begin)
+#endif
             for (int i = threadIdx.x; i < QP * NFR * 64; i += 256) {
                 const int u = i / (NFR * 64), fr = (i >> 6) % NFR, ln = i & 63, h = fr / DSTEPS, st = fr % DSTEPS;
                 const long rec = ((long)b * H + h) * nt + min(qp * QP + u, nt - 1);
