@@ -414,6 +414,51 @@ def test_dp_path_rccl_world1_product_model(dev):
         assert abs(x - y) <= 2e-2 * abs(x), (la, lc)
 
 
+def test_torch_ddp_wrapper_world1(dev):
+    """The reference's own distributed path, unchanged: `DistributedDataParallel(model, find_unused_parameters=True)`
+    (main.py:171-173) around the product model in a one-rank RCCL group, both criteria, torch AdamW - same loss and the same
+    parameter gradients as the unwrapped model ("works as is")."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from spe_amd import kernels as K
+    from spe_amd.util.misc import NestedTensor
+    blob = torch.load(os.path.join(GOLD, "e2e_single.pt"), weights_only=False)
+    tr = blob["train"]
+
+    def run(wrap):
+        model, crit, crit_r, pp, rpp = build(blob, dev)
+        model.train(); crit.train(); crit_r.train()
+        net = DDP(model, device_ids=[dev.index], find_unused_parameters=True) if wrap else model
+        samples = NestedTensor(blob["tensors"].to(dev), blob["mask"].to(dev))
+        out = net(samples)
+        l0 = crit(out[0], to_dev(blob["targets"], dev), targets_cp=to_dev(tr["targets_cp0"], dev))
+        l1 = crit_r(out[1], to_dev(tr["pseudo"], dev), targets_cp=to_dev(tr["targets_cp1"], dev))
+        wd = tr["weight_dict"]
+        total = sum(l0[k] * wd[k] for k in l0 if k in wd) + sum(l1[k] * wd[k] for k in l1 if k in wd)
+        total.backward()
+        return float(total.detach()), {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+
+    K.set_precision("bf16x3")
+    created = False
+    try:
+        la, ga = run(False)
+        if not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+            created = True
+        lb, gb = run(True)
+    finally:
+        K.set_precision("bf16")
+        if created:
+            dist.destroy_process_group()
+    assert abs(la - float(tr["total"])) <= 2e-4 * abs(float(tr["total"]))
+    assert abs(la - lb) <= 1e-6 * abs(la), (la, lb)
+    for n in ga:
+        assert (ga[n] is None) == (gb[n] is None), n
+        if ga[n] is not None:
+            assert rel(gb[n], ga[n]) < 1e-5, (n, rel(gb[n], ga[n]))
+
+
 @pytest.mark.parametrize("R,C,p", [(400, 384, 0.1), (8300, 384, 0.0), (77, 64, 0.3)])
 def test_res_drop_layer_norm(dev, R, C, p):
     """norm(x + dropout(z)) in one kernel each way (reference models/transformer.py:384-386 etc.) against dropout + add +
