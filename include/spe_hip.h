@@ -26,6 +26,8 @@ extern "C" {
 
 typedef struct ihipStream_t* spe_stream_t; /* == hipStream_t */
 
+/* 2 since round 2 (changed signatures: spe_hungarian, spe_adamw_flat, spe_layernorm_fwd, spe_attn_contract,
+ * spe_talking_fused_plan; new entry points) */
 int spe_abi_version(void);
 
 /* ---- contraction ----------------------------------------------------------------------
