@@ -414,6 +414,90 @@ def test_dp_path_rccl_world1_product_model(dev):
         assert abs(x - y) <= 2e-2 * abs(x), (la, lc)
 
 
+def _dp2_worker(rank, world, port, out):
+    """One of two processes on the SAME GPU (gloo moves the device buckets through the host; RCCL refuses two ranks on one
+    device): product model, per-rank data, GradAllReducer + FlatAdamW."""
+    import argparse as _ap
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from spe_amd import kernels as K
+        from spe_amd.dp import GradAllReducer
+        from spe_amd.optim import FlatAdamW
+        from spe_amd.util.misc import NestedTensor
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        K.set_precision("bf16x3")
+        blob = torch.load(os.path.join(GOLD, "e2e_single.pt"), weights_only=False)
+        tr = blob["train"]
+        torch.manual_seed(1000 + rank)                      # the reference seeds with seed + rank before build_model
+        model, crit, crit_r, pp, rpp = build(blob, dev)
+        if rank == 1:                                       # make the replicas differ before the reducer broadcasts rank 0's
+            with torch.no_grad():
+                for p_ in model.parameters():
+                    p_.add_(0.01)
+        model.train(); crit.train(); crit_r.train()
+        named = [(n, p_) for n, p_ in model.named_parameters() if p_.requires_grad]
+        red = GradAllReducer([p_ for _, p_ in named], bucket_bytes=1 << 16, flatten_params=True)
+        assert red.collective
+        opt = FlatAdamW([{"params": [p_ for _, p_ in named], "lr": 1e-3}], red, weight_decay=1e-2, max_grad_norm=0.1)
+        g_ = torch.Generator().manual_seed(50 + rank)       # different images and one target less on rank 1
+        img = blob["tensors"] + (0.3 * torch.randn(blob["tensors"].shape, generator=g_) if rank else 0.0)
+        samples = NestedTensor(img.to(dev), blob["mask"].to(dev))
+        tg, cp0, ps, cp1 = (to_dev(x, dev) for x in (blob["targets"], tr["targets_cp0"], tr["pseudo"], tr["targets_cp1"]))
+        wd = tr["weight_dict"]
+        if rank == 1:                                       # one target less on rank 1: the ranks' num_boxes differ
+            for lst in (cp0, cp1):
+                n0 = lst[0]["labels"].shape[0]
+                for k in ("boxes", "labels", "scores"):
+                    if k in lst[0] and lst[0][k].shape[0] == n0:
+                        lst[0][k] = lst[0][k][:-1]
+
+        def loss_of():
+            o = model(samples)
+            l0 = crit(o[0], tg, targets_cp=cp0)
+            l1 = crit_r(o[1], ps, targets_cp=cp1)
+            return sum(l0[k] * wd[k] for k in l0 if k in wd) + sum(l1[k] * wd[k] for k in l1 if k in wd)
+
+        for it in range(2):
+            # local gradient of this rank (no bucket hooks: torch.autograd.grad), averaged over the ranks by hand
+            ps_ = [p_ for _, p_ in named]
+            gl = torch.autograd.grad(loss_of(), ps_, allow_unused=True)
+            flat = torch.cat([(g if g is not None else torch.zeros_like(p_)).flatten() for g, p_ in zip(gl, ps_)])
+            dist.all_reduce(flat)
+            flat /= world
+            opt.zero_grad()
+            loss_of().backward()
+            red.finish()
+            got = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).flatten() for p_ in ps_]) * red.grad_scale()
+            err = float((got - flat).norm() / flat.norm())
+            assert err < 1e-5, ("bucket gradients != mean of the ranks' gradients", rank, it, err)
+            opt.step()
+            mine = torch.cat([p_.detach().flatten() for p_ in ps_])
+            both = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+            assert torch.equal(both[0], both[1]), ("replicas diverged", it)
+        red.remove()
+        out[rank] = True
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_dp_world2_product_model_two_processes_one_gpu(dev):
+    """world_size 2 with the PRODUCT model on the GPU: two processes share the device and exchange through gloo.  Checks what a
+    one-rank group cannot: rank 0's weights reach rank 1 at construction, the reduced buckets (x the 1/world the fused AdamW
+    folds in) equal the mean of the two ranks' local gradients - with `num_boxes` all-reduced between different target
+    counts inside both criteria (conditional_detr.py:436-440) - and the replicas stay bit-identical through optimiser steps."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp2_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out.get(0) and out.get(1)
+
+
 def test_torch_ddp_wrapper_world1(dev):
     """The reference's own distributed path, unchanged: `DistributedDataParallel(model, find_unused_parameters=True)`
     (main.py:171-173) around the product model in a one-rank RCCL group, both criteria, torch AdamW - same loss and the same
