@@ -230,11 +230,18 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # developer knobs for exercising the N > 1 code path on a one-GPU box: all ranks on one device, exchange through gloo
+    # (RCCL refuses two ranks on one device).  Never set by the driver.
+    backend = os.environ.get("SPE_BENCH_BACKEND", "nccl")
+    local = int(os.environ.get("SPE_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # the HIP library is built in-tree by __graft_entry__.build(); if this checkout has none (or a stale one), local
     # rank 0 builds it once and the other ranks wait for the file - there is no CPU fallback to run instead
