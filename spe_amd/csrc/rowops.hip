@@ -2,6 +2,7 @@
 // column sums (bias / gamma gradients), LayerScale-residual, GELU/ReLU backward, dropout.
 // All tensors fp32, row-major, contiguous unless a stride is passed.  HBM-bound kernels:
 // every lane moves 16 B per access where the row length allows it.
+#include <cstdlib>
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------
@@ -198,6 +199,80 @@ __global__ __launch_bounds__(256) void ln_res_fwd_kernel(const float* __restrict
     }
 }
 
+// Half-wave-per-row variant for C = 128 * NV (NV <= 4: 128, 256, 384, 512 - every model width here): a wave normalises TWO rows,
+// 32 lanes each, so no lane idles (C = 384 is 96 float4: 64 + 32 in the wave-per-row mapping) and a lane keeps NV 16-B loads in
+// flight instead of 1.5 on average; the reductions are 5 DPP steps inside the half.  Same arithmetic order per row element
+// as ln_fwd_kernel up to the reduction tree.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_hw_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y,
+                                                        float* __restrict__ mean, float* __restrict__ rstd,
+                                                        long R, float eps, unsigned short* __restrict__ y16) {
+    constexpr int C4 = 32 * NV, C = 4 * C4;
+    const int lane = threadIdx.x & 63, hl = lane & 31;
+    const long stride = (long)gridDim.x * 8;
+    long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+    float4 gq[NV], bq[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { gq[i] = g4[hl + 32 * i]; bq[i] = b4[hl + 32 * i]; }
+    float4 v[NV];
+    {
+        const float4* xr = reinterpret_cast<const float4*>(x + (row0 < R ? row0 : R - 1) * C);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = xr[hl + 32 * i];
+    }
+    // rows of this half-wave: row0, row0 + stride, ...; the loop count is wave-uniform (the other half may run one row less)
+    const long first = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    for (long base = first; base < R; base += stride, row0 += stride) {
+        const bool rv = row0 < R;
+        const long row = rv ? row0 : R - 1;
+        float4 nv[NV];
+        {   // next rows requested before this row's reductions
+            const long nr = row0 + stride;
+            const float4* xn = reinterpret_cast<const float4*>(x + (nr < R ? nr : R - 1) * C);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) nv[i] = xn[hl + 32 * i];
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mu = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float a = v[i].x - mu, b = v[i].y - mu, d = v[i].z - mu, e = v[i].w - mu;
+            q += a * a + b * b + d * d + e * e;
+        }
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rs = rsqrtf(q / (float)C + eps);
+        if (rv) {
+            if (hl == 0) { mean[row] = mu; rstd[row] = rs; }
+            float4* yr = reinterpret_cast<float4*>(y + row * C);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = hl + 32 * i;
+                float4 o;
+                o.x = (v[i].x - mu) * rs * gq[i].x + bq[i].x; o.y = (v[i].y - mu) * rs * gq[i].y + bq[i].y;
+                o.z = (v[i].z - mu) * rs * gq[i].z + bq[i].z; o.w = (v[i].w - mu) * rs * gq[i].w + bq[i].w;
+                yr[c] = o;
+                if (y16) {
+                    typedef __bf16 bf16x4h_t __attribute__((ext_vector_type(4)));
+                    bf16x4h_t h;
+                    h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
+                    *reinterpret_cast<uint2*>(y16 + row * C + 4 * c) = __builtin_bit_cast(uint2, h);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = nv[i];
+    }
+}
+
 // C-ABI: see include/spe_hip.h (spe_layernorm_res_fwd).
 extern "C" int spe_layernorm_res_fwd(const float* x, const float* z, const float* gamma, const float* beta, float* sum, float* y,
                                      float* mean, float* rstd, long R, int C, float eps, float p, uint64_t seed, uint64_t offset,
@@ -214,6 +289,21 @@ extern "C" int spe_layernorm_fwd(const float* x, const float* gamma, const float
                                  float* rstd, long R, int C, float eps, void* y16, hipStream_t st) {
     if (R <= 0) return 0;
     if ((C & 3) || C > 256 * LN_MAXV) return -2;
+    static const int hw = getenv("SPE_LN_HALFWAVE") ? atoi(getenv("SPE_LN_HALFWAVE")) : 1;       // 0: wave-per-row kernel (A/B)
+    if (hw && (C % 128) == 0 && C <= 512) {
+        static const int ln_wg = getenv("SPE_LN_WG") ? atoi(getenv("SPE_LN_WG")) : 512;
+        long nwg_ = (R + 7) / 8; if (nwg_ > ln_wg) nwg_ = ln_wg;
+        const dim3 grid((unsigned)nwg_);
+        unsigned short* h16 = reinterpret_cast<unsigned short*>(y16);
+        switch (C / 128) {
+            case 1: hipLaunchKernelGGL(ln_fwd_hw_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16); break;
+            case 2: hipLaunchKernelGGL(ln_fwd_hw_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16); break;
+            case 3: hipLaunchKernelGGL(ln_fwd_hw_kernel<3>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16); break;
+            default: hipLaunchKernelGGL(ln_fwd_hw_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16); break;
+        }
+        SPE_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, C, eps,
                        reinterpret_cast<unsigned short*>(y16));
     SPE_CHECK_LAUNCH();
