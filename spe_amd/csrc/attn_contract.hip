@@ -24,6 +24,7 @@
 #include "attn_pack.h"
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4p_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4c_t __attribute__((ext_vector_type(4)));
 
 #ifndef CONTRACT_R
@@ -352,6 +353,84 @@ __device__ __forceinline__ void attn_pack_job(const PackJob& jb, int B, int H) {
         }
     }
 }
+// One WAVE per (b, h, 16-row tile) record: the per-unit version above spends its time on index arithmetic (three integer
+// divisions per 8-B unit) and, for the 16-wide layout, on 4-B loads from four different rows per lane.  Here the record's
+// coordinates are wave-uniform, every lane loads 16 B of ONE row (row = lane & 15, 8 consecutive head dims per 32-wide step:
+// 128 contiguous bytes per row and step) and
+//   kinds 0 / 2: converts and stores its own 16-B / 8-B fragment pieces directly (the fragment layout IS that load pattern);
+//   kind 1     : passes the 16 x dh tile through a per-wave LDS tile and gathers the 4 rows x 1 column of its unit.
+// Requires 16-B aligned rows (base, strides and dh multiples of 4 floats) and dh <= 64; otherwise the per-unit kernel runs.
+#define PACKR_LD 68                                      // floats per LDS row: 64 + 4 (16-B aligned float4 stores)
+__global__ __launch_bounds__(256) void attn_pack_rec_kernel(PackJobs a) {
+    __shared__ __attribute__((aligned(16))) float tile_s[4][16 * PACKR_LD];
+    const PackJob jb = a.j[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = jb.N, dh = jb.dh, nt = (N + 15) / 16, H = a.H;
+    const long nrec = (long)a.B * H * nt;
+    const int r = lane & 15, g = lane >> 4;
+    typedef __bf16 bf16x4r_t __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x8r_t __attribute__((ext_vector_type(8)));
+    for (long rec = (long)blockIdx.x * 4 + wave; rec < nrec; rec += (long)gridDim.x * 4) {
+        const long bh = rec / nt; const int tile = (int)(rec - bh * nt);
+        const int b = (int)(bh / H), h = (int)(bh - (long)b * H);
+        const int row = tile * 16 + r;
+        const bool rv = row < N;
+        const float* src = jb.x + b * jb.sb + (long)min(row, N - 1) * jb.sn + h * jb.sh;
+        if (jb.kind == 0 || jb.kind == 2) {
+            const int notail = jb.kind == 2;
+            const int rem = dh % 32, full = notail ? (dh + 31) / 32 : dh / 32 + (rem > 16 ? 1 : 0), tail = (!notail && rem > 0 && rem <= 16) ? 1 : 0;
+            uint2* orec = reinterpret_cast<uint2*>(jb.out) + rec * (full * 128 + tail * 64);
+            for (int st = 0; st < full; ++st) {
+                const int d0 = st * 32 + g * 8;
+                float f[8];
+#pragma unroll
+                for (int q4 = 0; q4 < 2; ++q4) {
+                    const int d = d0 + 4 * q4;
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (d < dh) t = *reinterpret_cast<const float4*>(src + d);       // dh % 4 == 0: a float4 is inside or outside
+                    f[4 * q4] = t.x; f[4 * q4 + 1] = t.y; f[4 * q4 + 2] = t.z; f[4 * q4 + 3] = t.w;
+                }
+                bf16x8r_t o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)(rv ? f[e] * jb.scale : 0.f);
+                *reinterpret_cast<u32x4p_t*>(orec + st * 128 + lane * 2) = __builtin_bit_cast(u32x4p_t, o);
+            }
+            if (tail) {
+                const int d = full * 32 + g * 4;
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (d < dh) t = *reinterpret_cast<const float4*>(src + d);
+                bf16x4r_t o;
+                o[0] = (__bf16)(rv ? t.x * jb.scale : 0.f); o[1] = (__bf16)(rv ? t.y * jb.scale : 0.f);
+                o[2] = (__bf16)(rv ? t.z * jb.scale : 0.f); o[3] = (__bf16)(rv ? t.w * jb.scale : 0.f);
+                orec[full * 128 + lane] = __builtin_bit_cast(uint2, o);
+            }
+        } else {
+            const int DT = (dh + 15) / 16;
+            float* tl = tile_s[wave];
+            // 16 rows x up to 64 dims: lane (r, g) brings dims g*16 .. g*16+15 of row r
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int d = g * 16 + 4 * q4;
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (d < dh && rv) t = *reinterpret_cast<const float4*>(src + d);
+                *reinterpret_cast<float4*>(tl + r * PACKR_LD + d) = t;
+            }
+            // wave-private tile: the LDS writes of this wave are visible to it after the wait the compiler places before the reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint2* orec = reinterpret_cast<uint2*>(jb.out) + rec * (DT * 64);
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = dt * 16 + r;                      // this lane's column; its rows: 4 g .. 4 g + 3
+                bf16x4r_t o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (__bf16)(tl[(4 * g + j) * PACKR_LD + d] * jb.scale);
+                orec[dt * 64 + lane] = __builtin_bit_cast(uint2, o);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_pack_multi_kernel(PackJobs a, int narrow) {
     const PackJob jb = a.j[blockIdx.y];
     if (narrow) attn_pack_job<unsigned>(jb, a.B, a.H); else attn_pack_job<long>(jb, a.B, a.H);
@@ -372,6 +451,23 @@ extern "C" int spe_attn_pack_multi(int njobs, const float* const* xs, const long
         if (t > total) total = t;
     }
     a.B = B; a.H = H;
+    {   // wave-per-record kernel when every job has 16-B aligned rows and dh <= 64
+        static const int recpath = getenv("SPE_PACK_REC") ? atoi(getenv("SPE_PACK_REC")) : 1;      // 0: per-unit kernel (A/B)
+        bool ok = recpath != 0;
+        long nrec = 0;
+        for (int i = 0; i < njobs && ok; ++i) {
+            ok = (reinterpret_cast<uintptr_t>(xs[i]) & 15) == 0 && (a.j[i].sb & 3) == 0 && (a.j[i].sn & 3) == 0 && (a.j[i].sh & 3) == 0 &&
+                 (dhs[i] & 3) == 0 && dhs[i] <= 64;
+            const long n = (long)B * H * ((Ns[i] + 15) / 16);
+            if (n > nrec) nrec = n;
+        }
+        if (ok) {
+            long nbr = (nrec + 3) / 4; if (nbr > 4096) nbr = 4096;
+            hipLaunchKernelGGL(attn_pack_rec_kernel, dim3((unsigned)nbr, njobs), dim3(256), 0, st, a);
+            SPE_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     long nb = (total + 255) / 256; if (nb > 2048) nb = 2048;
     const int narrow = total + 2048L * 256 < (1L << 31);          // unit indices (and one grid stride beyond) fit 32 bits
     hipLaunchKernelGGL(attn_pack_multi_kernel, dim3((unsigned)nb, njobs), dim3(256), 0, st, a, narrow);

@@ -249,18 +249,45 @@ __device__ __forceinline__ u32x4_t frag_load(const u32x4_t* __restrict__ base, l
 // g then holds k-slots 8g..8g+3 = head dims FULL*32 + 4g..4g+3 in BOTH operands and zeros in slots 8g+4..8g+7, so the
 // products line up - the saving of the tail step is its load bytes, the matrix pipe is idle anyway.
 #ifndef SPE_FUSED_TAIL1K
-#define SPE_FUSED_TAIL1K 1
+#define SPE_FUSED_TAIL1K 0
 #endif
 template <int DSTEPS, bool TAIL16>
 __device__ __forceinline__ f32x4_t frag_mfma(int st, u32x4_t a, u32x4_t b, f32x4_t c) {
-    // the 16-dim tail step as v_mfma_f32_16x16x16_bf16 on the 8-B halves: same products (lane group g holds head dims FULL*32 + 4g..4g+3
-    // in both operands either way) without the two zero registers per fragment that the 32-deep form needs (2 v_mov per fragment
-    // and tile on the pipe that bounds these kernels, 2 live registers per staged fragment)
-    if (SPE_FUSED_TAIL1K && TAIL16 && st == DSTEPS - 1) {
+    // SPE_FUSED_TAIL1K = 1 (OFF by default): the 16-dim tail step as v_mfma_f32_16x16x16_bf16 on the 8-B halves, accumulating onto
+    // the 16x16x32 result.  Same products, 2 v_mov and 2 live registers less per staged fragment - and NOT SAFE on gfx950 as hipcc
+    // (ROCm 7.2) schedules it: a 16x16x16 MFMA whose SrcC is the destination of the 16x16x32 MFMA issued right before it
+    // (`v_mfma_f32_16x16x32_bf16 v[14:17], ..; s_waitcnt; v_mfma_f32_16x16x16_bf16 v[18:21], .., v[14:17]`) gives run-to-run
+    // different results (tools/debug/race_mode2.py: 51-386 of 300-400 launches at H = 4, dropout on; 0 with 16 wait states in
+    // front of the tail instruction, 0 with the zero-extended 32-deep form).  Accumulate chains therefore stay within ONE MFMA
+    // shape everywhere in this library; the measured cost of the zero-extended form is < 1 % per pass.
+    if (SPE_FUSED_TAIL1K == 1 && TAIL16 && st == DSTEPS - 1) {
         typedef unsigned u32x2f_t __attribute__((ext_vector_type(2)));
         typedef short s16x4f_t __attribute__((ext_vector_type(4)));
         const u32x2f_t al = {a[0], a[1]}, bl = {b[0], b[1]};
-        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4f_t, al), __builtin_bit_cast(s16x4f_t, bl), c, 0, 0, 0);
+#ifdef SPE_DBG_TAILNOP
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        f32x4_t d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4f_t, al), __builtin_bit_cast(s16x4f_t, bl), c, 0, 0, 0);
+#ifndef SPE_DBG_NOKEEP
+        // keep the operands alive past the instruction: hipcc otherwise allocates the destination over a dying source operand
+        // (`v_mfma_f32_16x16x16_bf16 v[76:79], v[86:87], v[78:79], v[14:17]`), and on gfx950 that form gives run-to-run different
+        // results (found with tools/debug/race_mode2.py: 386 of 400 launches differ at H = 4, N = 1100, dropout on)
+        asm volatile("" :: "v"(al), "v"(bl), "v"(d));
+#endif
+        return d;
+    }
+    if (SPE_FUSED_TAIL1K == 2 && TAIL16) {
+        // every step on ONE shape: a 32-deep step as two 16-deep MFMAs on the low / high halves of the same operand registers
+        // (lane group g holds dims 8g..8g+7 of the step in both operands, so the halves pair up), the tail as one
+        typedef unsigned u32x2g_t __attribute__((ext_vector_type(2)));
+        typedef short s16x4g_t __attribute__((ext_vector_type(4)));
+        const u32x2g_t al = {a[0], a[1]}, bl = {b[0], b[1]};
+        c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4g_t, al), __builtin_bit_cast(s16x4g_t, bl), c, 0, 0, 0);
+        if (st == DSTEPS - 1) return c;
+        const u32x2g_t ah = {a[2], a[3]}, bh = {b[2], b[3]};
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4g_t, ah), __builtin_bit_cast(s16x4g_t, bh), c, 0, 0, 0);
     }
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }

@@ -322,6 +322,41 @@ def test_fused_attention_with_dropout(dev, H, N, dh, B, p):
     assert all(v < 2e-2 for v in errs.values()), errs
 
 
+@pytest.mark.parametrize("H,N,B,p", [(4, 200, 1, 0.05), (4, 1100, 1, 0.05), (8, 331, 2, 0.05), (8, 1100, 1, 0.0)])
+def test_fused_attention_run_to_run_determinism(dev, H, N, B, p):
+    """Forward + backward of the fused talking-heads attention repeated with other kernels in between and the allocator's free
+    blocks poisoned: every output and gradient must be BITWISE identical from run to run (no atomics on this path).  Guards
+    against reads of memory no kernel wrote and against MFMA dependency hazards: a 16x16x16 MFMA accumulating onto the result of
+    the 16x16x32 MFMA issued right before it gave run-to-run different weight gradients on gfx950 (tools/debug/race_mode2.py)."""
+    from spe_amd import kernels as K, ops
+    dh = 48
+    g_ = torch.Generator().manual_seed(5)
+    C = H * dh
+    qkv0 = (1.5 * torch.randn(B, N, 3 * C, generator=g_)).to(dev)
+    Wl0 = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g_)).to(dev); Ww0 = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g_)).to(dev)
+    bl0 = (0.1 * torch.randn(H, generator=g_)).to(dev); bw0 = (0.1 * torch.randn(H, generator=g_)).to(dev)
+    go = torch.randn(B, N, C, generator=g_).to(dev)
+    xs = torch.randn(2048, 1024, device=dev)
+
+    def run():
+        K.manual_seed(77)
+        t = [x.clone().requires_grad_() for x in (qkv0, Wl0, bl0, Ww0, bw0)]
+        out = ops.talking_heads_attention(t[0], t[1], t[2], t[3], t[4], H, dh ** -0.5, p, fused=True)
+        return [out.detach()] + [x.detach() for x in torch.autograd.grad(out, t, go)]
+
+    K.set_precision("bf16")
+    ref = run()
+    for trial in range(10):
+        junk = [torch.full((1 << 24,), float("nan") if trial % 2 else 1e30, device=dev) for _ in range(4)]
+        small = [torch.full((n,), 1e30, device=dev) for n in (1 << 10, 1 << 14, 1 << 18, 1 << 22) for _ in range(4)]
+        del junk, small
+        if trial % 3:
+            (xs @ xs.t()[:, :512]).sum()
+        r = run()
+        for nm, a, b_ in zip(("out", "dqkv", "dWl", "dbl", "dWw", "dbw"), r, ref):
+            assert torch.isfinite(a).all() and torch.equal(a, b_), (trial, nm, float((a - b_).abs().max()))
+
+
 # ------------------------------------------------------------------------------------------ DP path under RCCL, one rank
 def _free_port():
     s = socket.socket()
