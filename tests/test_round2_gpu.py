@@ -357,6 +357,48 @@ def test_fused_attention_run_to_run_determinism(dev, H, N, B, p):
             assert torch.isfinite(a).all() and torch.equal(a, b_), (trial, nm, float((a - b_).abs().max()))
 
 
+def test_atomic_free_kernels_run_to_run_determinism(dev):
+    """Contractions, bf16 GEMMs (register pipeline, LDS-DMA ring, TN with split slabs) and the flash MHA forward + backward have
+    no atomics: repeated launches with foreign kernels in between must agree bitwise (tools/debug/race_others.py, shortened)."""
+    from spe_amd import kernels as K, ops
+    K.set_precision("bf16")
+    g_ = torch.Generator().manual_seed(3)
+    xs = torch.randn(2048, 1024, device=dev)
+
+    def check(name, fn, n=25):
+        ref = [r.clone() for r in fn()]
+        for t in range(n):
+            if t % 3 == 1:
+                (xs @ xs.t()[:, :512]).sum()
+            elif t % 3 == 2:
+                torch.softmax(xs * (1 + t), dim=1)
+            for a, b_ in zip(fn(), ref):
+                assert torch.equal(a, b_), (name, t)
+
+    B, H, N, dh = 2, 8, 1100, 48
+    PT = K.score_blocks(B, H, N, dev); PT.view(torch.int16).random_(0, 16000)
+    V16 = K.attn_pack16(torch.randn(B, N, H, dh, generator=g_).to(dev))
+    O = torch.empty(B, N, H * dh, device=dev)
+    check("contract", lambda: [K.attn_contract(PT, V16, O.view(B, N, H, dh), False).clone()])
+    check("contract^T", lambda: [K.attn_contract(PT, V16, O.view(B, N, H, dh), True).clone()])
+    for (M, Nn, Kd) in ((8300, 1536, 384), (8300, 384, 1536), (400, 384, 384)):
+        A = torch.randn(M, Kd, generator=g_).to(dev).to(torch.bfloat16); Bm = torch.randn(Nn, Kd, generator=g_).to(dev).to(torch.bfloat16)
+        C = torch.empty(M, Nn, device=dev)
+        check(f"gemm16 {M}x{Nn}x{Kd}", lambda A=A, Bm=Bm, C=C, M=M, Nn=Nn, Kd=Kd: (K.gemm16(A, Bm, C, M, Nn, Kd, Kd, Kd, Nn), [C.clone()])[1])
+    A = torch.randn(8300, 1536, generator=g_).to(dev).to(torch.bfloat16); Bm = torch.randn(8300, 384, generator=g_).to(dev).to(torch.bfloat16)
+    ws = torch.empty(14, 1536 * 384, device=dev)
+    check("gemm16_tn", lambda: (K.gemm16_tn(A, Bm, ws, 1536, 384, 8300, 1536, 384, 384, splitk=-14), [ws.clone()])[1])
+    q0 = torch.randn(2, 200, 8, 96, generator=g_).to(dev); k0 = torch.randn(2, 4150, 8, 96, generator=g_).to(dev); v0 = torch.randn(2, 4150, 8, 48, generator=g_).to(dev)
+    go = torch.randn(2, 200, 8 * 48, generator=g_).to(dev)
+
+    def mha():
+        K.manual_seed(5)
+        t = [x.clone().requires_grad_() for x in (q0, k0, v0)]
+        o, _ = ops.attention(t[0], t[1], t[2], None, 96 ** -0.5, 0.1)
+        return [o.detach()] + [x.detach() for x in torch.autograd.grad(o, t, go.view_as(o))]
+    check("flash MHA", mha, 12)
+
+
 # ------------------------------------------------------------------------------------------ DP path under RCCL, one rank
 def _free_port():
     s = socket.socket()
