@@ -209,7 +209,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--enc-layers", type=int, default=0, help="0 = north_star headline (backbone+decoder); 3 = script value")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16s", "bf16x3"])
     ap.add_argument("--backbone", default="TSCAM_cait_S24")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)

@@ -27,7 +27,9 @@ extern "C" {
 typedef struct ihipStream_t* spe_stream_t; /* == hipStream_t */
 
 /* 2 since round 2 (changed signatures: spe_hungarian, spe_adamw_flat, spe_layernorm_fwd, spe_attn_contract,
- * spe_talking_fused_plan; new entry points) */
+ * spe_talking_fused_plan; new entry points); 3 since round 3 (fp16 forward formats of the fused attention: spe_attn_contract
+ * takes `fmt`, spe_attn_pack_multi kinds carry an element-format bit, spe_talking_fused expects fp16 Q / K fragments and writes
+ * fp16 P'd blocks; split-operand GEMM entry points) */
 int spe_abi_version(void);
 
 /* ---- contraction ----------------------------------------------------------------------
@@ -66,9 +68,10 @@ int spe_gemm_tile(int M, int N, int nbatch);
  * dx - the gradient arriving over the residual path around the normalised branch (x feeds both: cait.py:404-405), which
  * autograd would otherwise sum with one more elementwise launch.
  * fwd: y16 (optional, bf16 [R][C]): the same result rounded to bf16 - the operand of the Linear that consumes y, written by
- * the same pass instead of by a separate spe_cvt_bf16 launch. */
+ * the same pass instead of by a separate spe_cvt_bf16 launch; y16lo (optional, needs y16): bf16(y - bf16(y)), the low part of
+ * the SPLIT operand of precision mode bf16s (see spe_gemm_bf16nt). */
 int spe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                      float* rstd, long R, int C, float eps, void* y16, spe_stream_t stream);
+                      float* rstd, long R, int C, float eps, void* y16, void* y16lo, spe_stream_t stream);
 int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                       const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,
                       const float* add, spe_stream_t stream);
@@ -83,9 +86,14 @@ int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const
  * and/or outT[C][ldt] = transpose, columns R..ldt-1 zero filled; colsum[c] += sum_r x[r][c] (fp32; the bias gradient
  * of the Linear, from the same read).  Any of the three outputs may be NULL.  aux != NULL: x is first multiplied by the
  * activation derivative at aux (act 1: ReLU with aux = forward output, 2: erf-GELU with aux = pre-activation; same
- * layout and leading dimension as x) - the backward of a fused Linear+activation without an fp32 intermediate. */
-int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const float* bias, float* C2,
-                    int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int splitk,
+ * layout and leading dimension as x) - the backward of a fused Linear+activation without an fp32 intermediate.
+ * SPLIT operands (precision mode "bf16s", the forward products): A16lo / B16lo (both or neither; same leading dimensions as
+ * A16 / B16) hold bf16(x - bf16(x)) of the fp32 operands, written next to the high parts by every producer (out_lo of
+ * spe_cvt_bf16 / spe_cvt_bf16_multi, y16lo of spe_layernorm_fwd, out16lo of spe_attn_contract and spe_gemm_bf16nt_ex); the
+ * product is then A_hi B_hi + A_lo B_hi + A_hi B_lo - ~16 significant operand bits instead of 8 at 3x the MFMA work of kernels
+ * that are load / store bound (no split-K with split operands). */
+int spe_gemm_bf16nt(const void* A16, const void* B16, const void* A16lo, const void* B16lo, float* C, const float* bias,
+                    float* C2, int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int splitk,
                     spe_stream_t stream);
 /* spe_gemm_bf16tn: C[m][n] = alpha * sum_r A16[r][m] * B16[r][n] - the weight gradient dW = dy^T x of a Linear (autograd of
  * reference models/cait.py:376,390,409, models/transformer.py:368-425) on ROW-MAJOR bf16 operands A16 [R, lda] (M columns)
@@ -102,16 +110,16 @@ int spe_gemm_bf16tn(const void* A16, const void* B16, float* C, int M, int N, in
  * the LayerScale residual of the block is applied by the epilogue, C = res[m][n] + rgamma[n] * v (res [M][ldc]), while C2
  * keeps v for the gamma gradient.  Used by the fused MLP of the backbone block (reference models/cait.py:405-416 = timm
  * Mlp fc1 -> GELU -> fc2 inside x + gamma_2 * mlp(norm2(x)), and its autograd). */
-int spe_gemm_bf16nt_ex(const void* A16, const void* B16, float* C, const float* bias, float* C2,
-                       void* out16, long ld16, void* out16T, long ld16t, float* colsum, const float* aux,
+int spe_gemm_bf16nt_ex(const void* A16, const void* B16, const void* A16lo, const void* B16lo, float* C, const float* bias,
+                       float* C2, void* out16, void* out16lo, long ld16, void* out16T, long ld16t, float* colsum, const float* aux,
                        const float* res, const float* rgamma, int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, spe_stream_t stream);
-int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, long ldo, void* outT, long ldt, float* colsum,
+int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, void* out_lo, long ldo, void* outT, long ldt, float* colsum,
                  const float* aux, int act, spe_stream_t stream);
 /* spe_cvt_bf16_multi: the row-major and transposed bf16 copies of njobs contiguous fp32 matrices in ONE launch (every
- * Linear weight after an optimizer step).  jobs_dev: device array of njobs records of 48 bytes
- *   { const float* x; void* out; void* outT; long ldt; int R, C, tile0, tiles_c; }     out [R][C], outT [C][ldt], ldt >= R;
+ * Linear weight after an optimizer step).  jobs_dev: device array of njobs records of 56 bytes
+ *   { const float* x; void* out; void* outT; long ldt; int R, C, tile0, tiles_c; void* out_lo; }     out, out_lo [R][C], outT [C][ldt], ldt >= R;
  * tiles_c = ceil(C/64), tile0 = running sum of tiles_c * ceil(max(R, ldt)/64) over the preceding jobs; total_tiles = that
- * sum over all jobs.  out or outT may be NULL per job. */
+ * sum over all jobs.  out, out_lo or outT may be NULL per job. */
 int spe_cvt_bf16_multi(const void* jobs_dev, int njobs, int total_tiles, spe_stream_t stream);
 
 /* ---- masked softmax over scores[B,H,Nq,ld] (Nk valid columns per row).
@@ -141,7 +149,7 @@ int spe_talking_softmax_bwd(const float* dPd, const float* P, const float* S, co
  *   1..16 - one 16-wide tail step of [lane][4] = scale * x[.., FULL*32 + (lane>>4)*4 + i]   (dh = 48: 1.5 KB/record)
  * from x[b][n][h][d] (element strides sb, sn, sh).  spe_talking_fused(mode):
  *   0: partial softmax statistics of S' = proj_l(scale q k^T) per (b,g,q)        -> ws_stats
- *   1: P'd = bf16(attn_drop(proj_w(softmax(S'))))                                  -> outT (blocks)
+ *   1: P'd = fp16(2^8 * attn_drop(proj_w(softmax(S'))))                            -> outT (blocks, scaled by 256)
  *   2: backward pass 1: dP' = (dO V^T)*keepscale, dWw/dbw partials -> ws_w, D = sum_k dP.P partials -> ws_stats
  *   3: backward pass 2: dS' = P(dP - D), dWl/dbl partials -> ws_w, dS = bf16(proj_l^T dS') -> outT (blocks)
  * spe_attn_merge reduces ws_stats to M/IL (mode 0: row max, 1/row sum) or D (mode 2).
@@ -149,6 +157,8 @@ int spe_talking_softmax_bwd(const float* dPd, const float* P, const float* S, co
  * (column-sum them with spe_colsum, or spe_talking_wgrad_reduce: the four sums written to four gradient buffers); outT: bf16 16x16 blocks [B,H,nt,nt][64][4], lane l of block (qt,kt) =
  * query qt*16+(l&15), keys kt*16+4*(l>>4)+i.  The Q fragments must be packed with scale*log2(e) (the kernels
  * work in the log2 domain; M is the log2-domain row max).
+ * Element formats: Qf and Kf are FP16 fragments (spe_attn_pack_multi kinds 0 + 16), Vf and dOf BF16 (kind 0); the forward
+ * quantities are O(1) and take the 3 extra mantissa bits, gradients keep bf16's range.  outT of mode 1 is fp16, of mode 3 bf16.
  * Supported: H in {4,8}, head dim <= 64.  Returns -2 otherwise (use the materialised path). */
 int spe_attn_pack(const float* x, long sb, long sn, long sh, int B, int N, int H, int dh, float scale,
                   void* out, spe_stream_t stream);
@@ -165,11 +175,13 @@ int spe_attn_merge(const float* ws, float* out0, float* out1, int B, int H, int 
 int spe_talking_wgrad_reduce(const float* ws_w, int nwg, int H, float* dWl, float* dbl, float* dWw, float* dbw,
                              spe_stream_t stream);
 
-/* ---- streaming contractions of a blocked bf16 score tensor T (written by spe_talking_fused modes 1/3):
+/* ---- streaming contractions of a blocked 16-bit score tensor T (written by spe_talking_fused modes 1/3):
  *   trans = 0: out[b, q, h, :]   = alpha * sum_key T[b,h][q,key] x[b, key, h, :]   (`attn @ v`, cait.py:388; dQ)
  *   trans = 1: out[b, key, h, :] = alpha * sum_q   T[b,h][q,key] x[b, q, h, :]     (dV, dK of the same autograd)
  * X16 = spe_attn_pack16(x): bf16 [B,H,nt,ceil(dh/16)][64][4] = x[b, tile*16+4*(lane>>4)+i, h, dtile*16+(lane&15)]
  * (x element strides sb, sn, sh; 0 outside).  out element strides ob (batch), on (row), oh (head), unit d stride.
+ * fmt: 0 = bf16 T x bf16 X16 (dQ, dK); 1 = fp16 T x fp16 X16, trans = 0 only (O = P'd V: pass alpha = 2^-8 for mode 1's scale);
+ * 2 = fp16 T x bf16 X16, trans = 1 only (dV = P'd^T dO).
  * Head dim <= 64, returns -2 otherwise.  ws / counters (optional, both or neither): ws_floats floats of scratch and zero-
  * initialised 32-bit counters (at least B*H*2; left zero again by every launch) that let the launcher cut the groups of
  * output tiles beyond the last full round of resident workgroups into quarters of the contraction range, combined by the
@@ -177,11 +189,14 @@ int spe_talking_wgrad_reduce(const float* ws_w, int nwg, int H, float* dWl, floa
 int spe_attn_pack16(const float* x, long sb, long sn, long sh, int B, int N, int H, int dh, void* out, spe_stream_t stream);
 /* njobs <= 6 packs of [B,Ns[i],H,dhs[i]] views in one launch: job i reads xs[i] (element strides strides[3i..3i+2] =
  * batch, row, head), multiplies by scales[i] and writes the spe_attn_pack (kinds[i] = 0), spe_attn_pack16 (1) or
- * full-32-steps-only (2: ceil(dh/32) steps of [lane][8], no tail step; spe_mha_*) layout to outs[i].  The pointer/stride tables are HOST arrays (copied into the kernel arguments). */
+ * full-32-steps-only (2: ceil(dh/32) steps of [lane][8], no tail step; spe_mha_*) layout to outs[i]; kinds[i] + 16: the same
+ * layout with IEEE fp16 elements (saturating at +-65504) instead of bf16.  The pointer/stride tables are HOST arrays (copied
+ * into the kernel arguments). */
 int spe_attn_pack_multi(int njobs, const float* const* xs, const long* strides, const float* scales, const int* kinds,
                         void* const* outs, const int* Ns, const int* dhs, int B, int H, spe_stream_t stream);
 int spe_attn_contract(const void* T, const void* X16, float* out, long ob, long on, long oh, int B, int H, int N, int dh,
-                      int trans, float alpha, float* ws, unsigned int* counters, long ws_floats, void* out16, spe_stream_t stream);
+                      int trans, int fmt, float alpha, float* ws, unsigned int* counters, long ws_floats, void* out16,
+                      void* out16lo, spe_stream_t stream);
 
 /* ---- out[c] += sum_r in[r*ld + c] (bias gradients; autograd of nn.Linear bias). */
 int spe_colsum(const float* in, float* out, long R, int C, long ld, spe_stream_t stream);

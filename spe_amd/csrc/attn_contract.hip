@@ -56,13 +56,37 @@ __device__ __forceinline__ void cl_glds16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int DT, bool TRANS, bool LDSRING = false>
+// Element formats (FMT): 0 = bf16 score blocks x bf16 fragments (dQ, dK: gradients);  1 = fp16 blocks x fp16 fragments (O = P'd V
+// of the forward pass: probabilities and values are O(1), 3 more mantissa bits at the same bytes and MFMA rate);  2 = fp16 blocks
+// x bf16 fragments (dV = P'd^T dO: the lane-transposing product against the identity runs in fp16 - exact - and its result is
+// rounded to bf16 like the bf16 blocks' was, to meet the bf16 gradient dO).
+typedef _Float16 f16x4c_t __attribute__((ext_vector_type(4)));
+template <bool F16>
+__device__ __forceinline__ f32x4_t cl_mfma(s16x4_t a, s16x4_t b, f32x4_t c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4c_t, a), __builtin_bit_cast(f16x4c_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ s16x4_t cl_round(f32x4_t t) {
+    if constexpr (F16) {
+        f16x4c_t tv;
+        tv[0] = (_Float16)t[0]; tv[1] = (_Float16)t[1]; tv[2] = (_Float16)t[2]; tv[3] = (_Float16)t[3];
+        return __builtin_bit_cast(s16x4_t, tv);
+    } else {
+        bf16x4c_t tv;
+        tv[0] = (__bf16)t[0]; tv[1] = (__bf16)t[1]; tv[2] = (__bf16)t[2]; tv[3] = (__bf16)t[3];
+        return __builtin_bit_cast(s16x4_t, tv);
+    }
+}
+
+template <int DT, bool TRANS, bool LDSRING = false, int FMT = 0>
 __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restrict__ T, const uint2* __restrict__ X,
                                                             float* __restrict__ out, long ob, long on, long oh,
                                                             int H, int N, int nt, int dh, int ngrp, float alpha,
                                                             int bhn, int nfull, float* ws, unsigned* counters,
-                                                            unsigned short* __restrict__ out16) {
+                                                            unsigned short* __restrict__ out16, unsigned short* __restrict__ out16lo) {
     constexpr int R = CONTRACT_R;
+    constexpr bool TF16 = FMT >= 1, XF16 = FMT == 1;            // element format of the score blocks / of the fragments
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f32x4_t* red = reinterpret_cast<f32x4_t*>(smem_raw);          // [2 waves][R][DT][64]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // scalar: step indices and block addresses stay in SGPRs
@@ -90,7 +114,7 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
         for (int d = 0; d < DT; ++d) acc[r][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     s16x4_t ident;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ident[i] = ((lane & 15) == 4 * (lane >> 4) + i) ? (short)0x3F80 : (short)0;
+    for (int i = 0; i < 4; ++i) ident[i] = ((lane & 15) == 4 * (lane >> 4) + i) ? (short)(TF16 ? 0x3C00 : 0x3F80) : (short)0;
 
     // tile indices of the R output tiles, clamped (a clamped duplicate is computed and never stored)
     int tr[R];
@@ -136,17 +160,14 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
             for (int r = 0; r < R; ++r) {
                 s16x4_t bt;
                 if (TRANS) {
-                    const f32x4_t t = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, tbs[r]), ident,
-                                                                                  (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    bf16x4c_t tv;
-                    tv[0] = (__bf16)t[0]; tv[1] = (__bf16)t[1]; tv[2] = (__bf16)t[2]; tv[3] = (__bf16)t[3];
-                    bt = __builtin_bit_cast(s16x4_t, tv);
+                    const f32x4_t t = cl_mfma<TF16>(__builtin_bit_cast(s16x4_t, tbs[r]), ident, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+                    bt = cl_round<XF16>(t);
                 } else {
                     bt = __builtin_bit_cast(s16x4_t, tbs[r]);
                 }
 #pragma unroll
                 for (int d = 0; d < DT; ++d)
-                    acc[r][d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, xfs[d]), bt, acc[r][d], 0, 0, 0);
+                    acc[r][d] = cl_mfma<XF16>(__builtin_bit_cast(s16x4_t, xfs[d]), bt, acc[r][d]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                // drain the ring before LDS is reused below
@@ -177,17 +198,14 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
                 for (int r = 0; r < R; ++r) {
                     s16x4_t bt;
                     if (TRANS) {
-                        const f32x4_t t = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, tb[s][r]), ident,
-                                                                                      (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                        bf16x4c_t tv;
-                        tv[0] = (__bf16)t[0]; tv[1] = (__bf16)t[1]; tv[2] = (__bf16)t[2]; tv[3] = (__bf16)t[3];
-                        bt = __builtin_bit_cast(s16x4_t, tv);
+                        const f32x4_t t = cl_mfma<TF16>(__builtin_bit_cast(s16x4_t, tb[s][r]), ident, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+                        bt = cl_round<XF16>(t);
                     } else {
                         bt = __builtin_bit_cast(s16x4_t, tb[s][r]);
                     }
 #pragma unroll
                     for (int d = 0; d < DT; ++d)
-                        acc[r][d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, xf[s][d]), bt, acc[r][d], 0, 0, 0);
+                        acc[r][d] = cl_mfma<XF16>(__builtin_bit_cast(s16x4_t, xf[s][d]), bt, acc[r][d]);
                 }
             }
         }
@@ -278,6 +296,17 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
 #pragma unroll
                             for (int i = 0; i < 4; ++i) if (dc + i < dh) d16[i] = __builtin_bit_cast(s16x4_t, hv)[i];
                         }
+                        if (out16lo) {  // low part of the split operand (precision mode bf16s), same addressing
+                            unsigned short* l16 = out16lo + b * ob + (long)row * on + h * oh + dc;
+                            bf16x4c_t lv;
+                            lv[0] = (__bf16)(v[0] - (float)hv[0]); lv[1] = (__bf16)(v[1] - (float)hv[1]);
+                            lv[2] = (__bf16)(v[2] - (float)hv[2]); lv[3] = (__bf16)(v[3] - (float)hv[3]);
+                            if (dc + 3 < dh && ((((uintptr_t)l16) & 7) == 0)) *reinterpret_cast<uint2*>(l16) = __builtin_bit_cast(uint2, lv);
+                            else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) if (dc + i < dh) l16[i] = __builtin_bit_cast(s16x4_t, lv)[i];
+                            }
+                        }
                     }
                 }
             }
@@ -320,17 +349,19 @@ extern "C" int spe_attn_pack16(const float* x, long sb, long sn, long sh, int B,
 // Several packs of one attention call in ONE launch (forward: q, k -> 32-wide fragments, v -> 16-wide; backward: v, dO
 // -> 32-wide, dO, k, q -> 16-wide): the packs are ~10 us each and launch-latency bound.  blockIdx.y = job.
 #define PACK_MAXJOBS 6
-struct PackJob { const float* x; long sb, sn, sh; float scale; int kind; void* out; int N, dh; };   // kind 0: spe_attn_pack layout, 1: spe_attn_pack16, 2: spe_attn_pack layout without the tail step
+// kind & 15 = layout: 0 spe_attn_pack, 1 spe_attn_pack16, 2 spe_attn_pack without the tail step; kind & 16: fp16 elements (else bf16)
+struct PackJob { const float* x; long sb, sn, sh; float scale; int kind; void* out; int N, dh; };
 struct PackJobs { PackJob j[PACK_MAXJOBS]; int B, H; };
 template <typename IT>
 __device__ __forceinline__ void attn_pack_job(const PackJob& jb, int B, int H) {
     const int N = jb.N, dh = jb.dh, nt = (N + 15) / 16;
     const IT stride = (IT)gridDim.x * 256;
-    if (jb.kind == 0 || jb.kind == 2) {
-        const int notail = jb.kind == 2;
+    const int lay = jb.kind & 15, f16 = (jb.kind >> 4) & 1;
+    if (lay == 0 || lay == 2) {
+        const int notail = lay == 2;
         const IT total = (IT)attn_pack_units(B, N, H, dh, notail);
         for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < total; i += stride)
-            attn_pack_unit_t<IT>(jb.x, jb.sb, jb.sn, jb.sh, N, H, dh, nt, jb.scale, i, reinterpret_cast<uint2*>(jb.out), notail);
+            attn_pack_unit_t<IT>(jb.x, jb.sb, jb.sn, jb.sh, N, H, dh, nt, jb.scale, i, reinterpret_cast<uint2*>(jb.out), notail, f16);
     } else {
         const int DT = (dh + 15) / 16;
         const IT total = (IT)((long)B * H * nt * DT * 64);
@@ -342,14 +373,14 @@ __device__ __forceinline__ void attn_pack_job(const PackJob& jb, int B, int H) {
             const int b = (int)(t2 / (IT)H), h = (int)(t2 - (IT)b * (IT)H);
             const int d = dt * 16 + (ln & 15), r0 = tile * 16 + 4 * (ln >> 4);
             const float* src = jb.x + b * jb.sb + h * jb.sh + min(d, dh - 1);
-            bf16x4c_t o;
+            float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = r0 + j;
                 const float f = src[(long)min(row, N - 1) * jb.sn];
-                o[j] = (__bf16)((row < N && d < dh) ? f * jb.scale : 0.f);
+                o[j] = (row < N && d < dh) ? f * jb.scale : 0.f;
             }
-            out[i] = __builtin_bit_cast(uint2, o);
+            out[i] = spe_cvt4_16(o[0], o[1], o[2], o[3], f16);
         }
     }
 }
@@ -368,16 +399,15 @@ __global__ __launch_bounds__(256) void attn_pack_rec_kernel(PackJobs a) {
     const int N = jb.N, dh = jb.dh, nt = (N + 15) / 16, H = a.H;
     const long nrec = (long)a.B * H * nt;
     const int r = lane & 15, g = lane >> 4;
-    typedef __bf16 bf16x4r_t __attribute__((ext_vector_type(4)));
-    typedef __bf16 bf16x8r_t __attribute__((ext_vector_type(8)));
+    const int lay = jb.kind & 15, f16 = (jb.kind >> 4) & 1;
     for (long rec = (long)blockIdx.x * 4 + wave; rec < nrec; rec += (long)gridDim.x * 4) {
         const long bh = rec / nt; const int tile = (int)(rec - bh * nt);
         const int b = (int)(bh / H), h = (int)(bh - (long)b * H);
         const int row = tile * 16 + r;
         const bool rv = row < N;
         const float* src = jb.x + b * jb.sb + (long)min(row, N - 1) * jb.sn + h * jb.sh;
-        if (jb.kind == 0 || jb.kind == 2) {
-            const int notail = jb.kind == 2;
+        if (lay == 0 || lay == 2) {
+            const int notail = lay == 2;
             const int rem = dh % 32, full = notail ? (dh + 31) / 32 : dh / 32 + (rem > 16 ? 1 : 0), tail = (!notail && rem > 0 && rem <= 16) ? 1 : 0;
             uint2* orec = reinterpret_cast<uint2*>(jb.out) + rec * (full * 128 + tail * 64);
             for (int st = 0; st < full; ++st) {
@@ -390,19 +420,17 @@ __global__ __launch_bounds__(256) void attn_pack_rec_kernel(PackJobs a) {
                     if (d < dh) t = *reinterpret_cast<const float4*>(src + d);       // dh % 4 == 0: a float4 is inside or outside
                     f[4 * q4] = t.x; f[4 * q4 + 1] = t.y; f[4 * q4 + 2] = t.z; f[4 * q4 + 3] = t.w;
                 }
-                bf16x8r_t o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (__bf16)(rv ? f[e] * jb.scale : 0.f);
-                *reinterpret_cast<u32x4p_t*>(orec + st * 128 + lane * 2) = __builtin_bit_cast(u32x4p_t, o);
+                for (int e = 0; e < 8; ++e) f[e] = rv ? f[e] * jb.scale : 0.f;
+                const uint2 lo = spe_cvt4_16(f[0], f[1], f[2], f[3], f16), hi = spe_cvt4_16(f[4], f[5], f[6], f[7], f16);
+                *reinterpret_cast<u32x4p_t*>(orec + st * 128 + lane * 2) = (u32x4p_t){lo.x, lo.y, hi.x, hi.y};
             }
             if (tail) {
                 const int d = full * 32 + g * 4;
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (d < dh) t = *reinterpret_cast<const float4*>(src + d);
-                bf16x4r_t o;
-                o[0] = (__bf16)(rv ? t.x * jb.scale : 0.f); o[1] = (__bf16)(rv ? t.y * jb.scale : 0.f);
-                o[2] = (__bf16)(rv ? t.z * jb.scale : 0.f); o[3] = (__bf16)(rv ? t.w * jb.scale : 0.f);
-                orec[full * 128 + lane] = __builtin_bit_cast(uint2, o);
+                orec[full * 128 + lane] = spe_cvt4_16(rv ? t.x * jb.scale : 0.f, rv ? t.y * jb.scale : 0.f, rv ? t.z * jb.scale : 0.f,
+                                                      rv ? t.w * jb.scale : 0.f, f16);
             }
         } else {
             const int DT = (dh + 15) / 16;
@@ -421,10 +449,8 @@ __global__ __launch_bounds__(256) void attn_pack_rec_kernel(PackJobs a) {
             uint2* orec = reinterpret_cast<uint2*>(jb.out) + rec * (DT * 64);
             for (int dt = 0; dt < DT; ++dt) {
                 const int d = dt * 16 + r;                      // this lane's column; its rows: 4 g .. 4 g + 3
-                bf16x4r_t o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (__bf16)(tl[(4 * g + j) * PACKR_LD + d] * jb.scale);
-                orec[dt * 64 + lane] = __builtin_bit_cast(uint2, o);
+                orec[dt * 64 + lane] = spe_cvt4_16(tl[(4 * g) * PACKR_LD + d] * jb.scale, tl[(4 * g + 1) * PACKR_LD + d] * jb.scale,
+                                                   tl[(4 * g + 2) * PACKR_LD + d] * jb.scale, tl[(4 * g + 3) * PACKR_LD + d] * jb.scale, f16);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
@@ -479,9 +505,9 @@ extern "C" int spe_attn_pack_multi(int njobs, const float* const* xs, const long
 // workgroups beyond the resident slots run alone after the rest, latency-bound: 1040 workgroups on 1024 slots cost
 // 0.136 ms against 0.117 ms for the first 1024 (cfg2).  With a workspace the groups beyond the last full round are
 // therefore split into quarters of the contraction range (4x shorter) and combined by the last arriver.
-template <int DT, bool TRANS>
+template <int DT, bool TRANS, int FMT>
 static int launch_contract(const void* T, const void* X, float* out, long ob, long on, long oh, int B, int H, int N, int nt, int dh,
-                           float alpha, float* ws, unsigned* counters, long ws_floats, void* out16, hipStream_t st) {
+                           float alpha, float* ws, unsigned* counters, long ws_floats, void* out16, void* out16lo, hipStream_t st) {
     const int ngrp = (nt + CONTRACT_R - 1) / CONTRACT_R;
     const long bhn = (long)B * H, full = bhn * ngrp;
     int nlo = 0;
@@ -496,32 +522,37 @@ static int launch_contract(const void* T, const void* X, float* out, long ob, lo
         const int smem_r = (4 * CL_D * CL_SLOT > 2 * CONTRACT_R * DT * 64 * 16) ? 4 * CL_D * CL_SLOT : 2 * CONTRACT_R * DT * 64 * 16;
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_contract_kernel<DT, TRANS, true>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_contract_kernel<DT, TRANS, true, FMT>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem_r);
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
-        hipLaunchKernelGGL((attn_contract_kernel<DT, TRANS, true>), dim3((unsigned)(bhn * nfull + bhn * nlo * 4)), dim3(256), smem_r, st,
+        hipLaunchKernelGGL((attn_contract_kernel<DT, TRANS, true, FMT>), dim3((unsigned)(bhn * nfull + bhn * nlo * 4)), dim3(256), smem_r, st,
                            reinterpret_cast<const uint2*>(T), reinterpret_cast<const uint2*>(X), out, ob, on, oh, H, N, nt, dh, ngrp, alpha,
-                           (int)bhn, nfull, ws, counters, reinterpret_cast<unsigned short*>(out16));
+                           (int)bhn, nfull, ws, counters, reinterpret_cast<unsigned short*>(out16), reinterpret_cast<unsigned short*>(out16lo));
         SPE_CHECK_LAUNCH();
         return 0;
     }
     const int smem = 2 * CONTRACT_R * DT * 64 * 16;
-    hipLaunchKernelGGL((attn_contract_kernel<DT, TRANS>), dim3((unsigned)(bhn * nfull + bhn * nlo * 4)), dim3(256), smem, st,
+    hipLaunchKernelGGL((attn_contract_kernel<DT, TRANS, false, FMT>), dim3((unsigned)(bhn * nfull + bhn * nlo * 4)), dim3(256), smem, st,
                        reinterpret_cast<const uint2*>(T), reinterpret_cast<const uint2*>(X), out, ob, on, oh, H, N, nt, dh, ngrp, alpha,
-                       (int)bhn, nfull, ws, counters, reinterpret_cast<unsigned short*>(out16));
+                       (int)bhn, nfull, ws, counters, reinterpret_cast<unsigned short*>(out16), reinterpret_cast<unsigned short*>(out16lo));
     SPE_CHECK_LAUNCH();
     return 0;
 }
 
-// C-ABI: see include/spe_hip.h (spe_attn_contract).  Returns -2 for head dims above 64.
+// C-ABI: see include/spe_hip.h (spe_attn_contract).  Returns -2 for head dims above 64 or an unsupported (trans, fmt) pair.
 extern "C" int spe_attn_contract(const void* T, const void* X16, float* out, long ob, long on, long oh, int B, int H, int N, int dh,
-                                 int trans, float alpha, float* ws, unsigned int* counters, long ws_floats, void* out16, hipStream_t st) {
+                                 int trans, int fmt, float alpha, float* ws, unsigned int* counters, long ws_floats, void* out16,
+                                 void* out16lo, hipStream_t st) {
     const int nt = (N + 15) / 16, DT = (dh + 15) / 16;
     if (B <= 0 || H <= 0 || N <= 0) return 0;
-#define SPE_CONTRACT_CASE(D) case D: return trans ? launch_contract<D, true>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, ws, counters, ws_floats, out16, st) \
-                                                  : launch_contract<D, false>(T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, ws, counters, ws_floats, out16, st);
+    if (fmt < 0 || fmt > 2 || (fmt == 1 && trans) || (fmt == 2 && !trans) || (out16lo && !out16)) return -2;
+#define SPE_CONTRACT_ARGS T, X16, out, ob, on, oh, B, H, N, nt, dh, alpha, ws, counters, ws_floats, out16, out16lo, st
+#define SPE_CONTRACT_CASE(D) case D:                                                          \
+        if (fmt == 1) return launch_contract<D, false, 1>(SPE_CONTRACT_ARGS);                 \
+        if (fmt == 2) return launch_contract<D, true, 2>(SPE_CONTRACT_ARGS);                  \
+        return trans ? launch_contract<D, true, 0>(SPE_CONTRACT_ARGS) : launch_contract<D, false, 0>(SPE_CONTRACT_ARGS);
     switch (DT) {
         SPE_CONTRACT_CASE(1)
         SPE_CONTRACT_CASE(2)
@@ -529,5 +560,6 @@ extern "C" int spe_attn_contract(const void* T, const void* X16, float* out, lon
         SPE_CONTRACT_CASE(4)
     }
 #undef SPE_CONTRACT_CASE
+#undef SPE_CONTRACT_ARGS
     return -2;
 }

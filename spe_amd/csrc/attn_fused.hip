@@ -13,8 +13,15 @@
 // backward ones with their H*H weight-gradient accumulators - fits 256 registers without spilling and
 // two workgroups share a CU (a 32x32 tile needs 256 accumulator registers and spills; measured 4x slower).
 //
-// Operands come from "row-fragment" packed bf16 arrays produced by spe_attn_pack (one 16-B load per
+// Operands come from "row-fragment" packed 16-bit arrays produced by spe_attn_pack_multi (one 16-B load per
 // lane per MFMA operand, 1 KB contiguous per wave): X_f[b][h][tile16][dstep][lane][8].
+//
+// Element formats.  The FORWARD quantities are O(1) and go through fp16: the Q (scaled) and K fragments, the probabilities that
+// enter the second head mix, and the stored P'd (scaled by SPE_PD_SCALE = 2^8 so that probabilities of 1e-4 .. 1e-7 stay normal
+// numbers; the PV contraction multiplies by 2^-8) - 11 significant bits instead of bf16's 8 at the same bytes and MFMA rate,
+// which takes the attention's share of the forward error from ~2e-4 to ~3e-5 of the outputs (tools/error_budget.py).  The
+// backward passes recompute S from the same fp16 fragments (so P matches the forward statistics exactly) and keep bf16 for
+// everything that carries a gradient (V.dO^T operands, dP, dS): gradient magnitudes are not bounded.
 //
 // Modes (one template, same skeleton):
 //   0  forward statistics : partial (max, sum) of softmax_k(S'_g) per (b, g, q)
@@ -96,6 +103,7 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #else
 #define EXP2(x) __builtin_amdgcn_exp2f(x)
 #endif
+#define SPE_PD_SCALE 256.0f
 #define SPE_LOG2E 1.4426950408889634f
 #define SPE_LN2 0.6931471805599453f
 __device__ __forceinline__ f32x2_t fma2(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
@@ -137,39 +145,52 @@ __device__ __forceinline__ void mix_rows(const f32x4_t (&s)[H], const float (&w)
 #define SPE_FUSED_MFMAMIX 1
 #endif
 typedef short s16x4m_t __attribute__((ext_vector_type(4)));
-template <int H, bool TRANSPOSE>
+typedef _Float16 f16x4m_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8m_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ _Float16 f2h_sat(float f) { return (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f); }
+// 4 floats -> one 8-B MFMA operand (F16: saturating fp16, else bf16), both round to nearest even
+template <bool F16>
+__device__ __forceinline__ s16x4m_t pack4(float a, float b, float c, float d) {
+    if constexpr (F16) {
+        f16x4m_t v; v[0] = f2h_sat(a); v[1] = f2h_sat(b); v[2] = f2h_sat(c); v[3] = f2h_sat(d);
+        return __builtin_bit_cast(s16x4m_t, v);
+    } else {
+        bf16x4_t v; v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
+        return __builtin_bit_cast(s16x4m_t, v);
+    }
+}
+template <int H, bool TRANSPOSE, bool F16 = false>
 __device__ __forceinline__ void mixA_build(const float* __restrict__ W, int lane, s16x4m_t (&A)[H / 4][H / 4]) {
     const bool nz = ((lane & 15) >> 2) == (lane >> 4);
 #pragma unroll
     for (int gh = 0; gh < H / 4; ++gh)
 #pragma unroll
         for (int hh = 0; hh < H / 4; ++hh) {
-            bf16x4_t v;
+            float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int go = 4 * gh + (lane & 3), hi = 4 * hh + i;
                 const float w = TRANSPOSE ? W[hi * H + go] : W[go * H + hi];
-                v[i] = (__bf16)(nz ? w : 0.f);
+                v[i] = nz ? w : 0.f;
             }
-            A[gh][hh] = __builtin_bit_cast(s16x4m_t, v);
+            A[gh][hh] = pack4<F16>(v[0], v[1], v[2], v[3]);
         }
 }
 // out[gh][r] = init[4gh + r] + sum_h A(4gh + r, h) x[h]  for ONE key of the lane (x[h]: the H heads' values at that key)
-template <int H>
+// F16: x and A in fp16 (the forward mix P' = Ww P + bw; x arrives scaled by SPE_PD_SCALE, so does init), else bf16
+template <int H, bool F16 = false>
 __device__ __forceinline__ void mix_mfma_key(const float (&x)[H], const s16x4m_t (&A)[H / 4][H / 4], const float* init, f32x4_t (&out)[H / 4]) {
     s16x4m_t bv[H / 4];
 #pragma unroll
-    for (int hh = 0; hh < H / 4; ++hh) {
-        bf16x4_t v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (__bf16)x[4 * hh + i];
-        bv[hh] = __builtin_bit_cast(s16x4m_t, v);
-    }
+    for (int hh = 0; hh < H / 4; ++hh) bv[hh] = pack4<F16>(x[4 * hh], x[4 * hh + 1], x[4 * hh + 2], x[4 * hh + 3]);
 #pragma unroll
     for (int gh = 0; gh < H / 4; ++gh) {
         f32x4_t d = init ? (f32x4_t){init[4 * gh], init[4 * gh + 1], init[4 * gh + 2], init[4 * gh + 3]} : (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int hh = 0; hh < H / 4; ++hh) d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A[gh][hh], bv[hh], d, 0, 0, 0);
+        for (int hh = 0; hh < H / 4; ++hh) {
+            if constexpr (F16) d = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4m_t, A[gh][hh]), __builtin_bit_cast(f16x4m_t, bv[hh]), d, 0, 0, 0);
+            else d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A[gh][hh], bv[hh], d, 0, 0, 0);
+        }
         out[gh] = d;
     }
 }
@@ -251,8 +272,10 @@ __device__ __forceinline__ u32x4_t frag_load(const u32x4_t* __restrict__ base, l
 #ifndef SPE_FUSED_TAIL1K
 #define SPE_FUSED_TAIL1K 0
 #endif
-template <int DSTEPS, bool TAIL16>
+template <int DSTEPS, bool TAIL16, bool F16 = false>
 __device__ __forceinline__ f32x4_t frag_mfma(int st, u32x4_t a, u32x4_t b, f32x4_t c) {
+    // F16: fp16 operands (the K.Q^T products of every pass); the zero-extended tail step works the same way
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8m_t, a), __builtin_bit_cast(f16x8m_t, b), c, 0, 0, 0);
     // SPE_FUSED_TAIL1K = 1 (OFF by default): the 16-dim tail step as v_mfma_f32_16x16x16_bf16 on the 8-B halves, accumulating onto
     // the 16x16x32 result.  Same products, 2 v_mov and 2 live registers less per staged fragment - and NOT SAFE on gfx950 as hipcc
     // (ROCm 7.2) schedules it: a 16x16x16 MFMA whose SrcC is the destination of the 16x16x32 MFMA issued right before it
@@ -370,7 +393,7 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
     constexpr bool MM = SPE_FUSED_MFMAMIX && (H % 4 == 0);
     s16x4m_t Aw[(MM && MODE >= 1) ? H / 4 : 1][(MM && MODE >= 1) ? H / 4 : 1];       // mode 1: Ww ; modes 2, 3: Ww^T
     s16x4m_t Al[(MM && MODE == 3) ? H / 4 : 1][(MM && MODE == 3) ? H / 4 : 1];       // mode 3: Wl^T
-    if constexpr (MM && MODE == 1) mixA_build<H, false>(a.Ww, lane, Aw);
+    if constexpr (MM && MODE == 1) mixA_build<H, false, true>(a.Ww, lane, Aw);          // forward mix: fp16 operands
     if constexpr (MM && MODE >= 2) mixA_build<H, true>(a.Ww, lane, Aw);
     if constexpr (MM && MODE == 3) mixA_build<H, true>(a.Wl, lane, Al);
     constexpr bool M4 = SPE_FUSED_MIX4 && (H % 4 == 0);
@@ -522,7 +545,8 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                         for (int jj = 0; jj < QG; ++jj) {
                             const int hj = (bi * JB + g0 + jj) % NH;
                             const u32x4_t qv4 = QREG ? qreg[QREG ? (hj % H) * DSTEPS + st : 0] : qf[QREG ? 0 : jj * DSTEPS + st];
-                            c[jj] = frag_mfma<DSTEPS, TAIL16>(st, fr[(g0 + jj) * DSTEPS + st], qv4, c[jj]);
+                            c[jj] = (hj < H) ? frag_mfma<DSTEPS, TAIL16, true>(st, fr[(g0 + jj) * DSTEPS + st], qv4, c[jj])
+                                             : frag_mfma<DSTEPS, TAIL16, false>(st, fr[(g0 + jj) * DSTEPS + st], qv4, c[jj]);
                         }
 #pragma unroll
                     for (int jj = 0; jj < QG; ++jj) {
@@ -672,13 +696,17 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                 for (int j = 0; j < KT; ++j) {
                     f32x2_t lo[H], hi[H];
                     if constexpr (MM) {
+                        // P * 2^8 in fp16 against fp16 Ww, onto bw * 2^8: the result is P' * 2^8, the stored scale
                         f32x4_t pr[4][H / 4];
+                        float vbws[H];
+#pragma unroll
+                        for (int g = 0; g < H; ++g) vbws[g] = vbw[g] * SPE_PD_SCALE;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float x[H];
 #pragma unroll
-                            for (int h = 0; h < H; ++h) x[h] = acc[j][h][r];
-                            mix_mfma_key<H>(x, Aw, vbw, pr[r]);
+                            for (int h = 0; h < H; ++h) x[h] = acc[j][h][r] * SPE_PD_SCALE;
+                            mix_mfma_key<H, true>(x, Aw, vbws, pr[r]);
                         }
 #pragma unroll
                         for (int g = 0; g < H; ++g) {
@@ -687,6 +715,8 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                         }
                     } else {
                         mix_rows<H>(acc[j], ww, vbw, lo, hi);
+#pragma unroll
+                        for (int g = 0; g < H; ++g) { lo[g] *= splat2(SPE_PD_SCALE); hi[g] *= splat2(SPE_PD_SCALE); }
                     }
                     if (DROP) {
 #pragma unroll
@@ -701,8 +731,7 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                     if (TV(j)) {
 #pragma unroll
                         for (int g = 0; g < H; ++g) {
-                            bf16x4_t o;
-                            o[0] = (__bf16)lo[g][0]; o[1] = (__bf16)lo[g][1]; o[2] = (__bf16)hi[g][0]; o[3] = (__bf16)hi[g][1];
+                            const s16x4m_t o = pack4<true>(lo[g][0], lo[g][1], hi[g][0], hi[g][1]);       // fp16(P'd * 2^8)
 #ifndef FUSED_PLAIN_STORE
                             {   // non-temporal: the 554 MB of blocks are read next by another kernel, never again by this one -
                                 // kept out of L2 they neither evict the K / V fragments nor leave dirty lines for the
@@ -712,7 +741,7 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                                                             reinterpret_cast<u32x2nt_t*>(a.outT + (((((long)b * H + g) * nt + qt) * nt + (kt_first + j)) * 64 + lane) * 4));
                             }
 #else
-                            *reinterpret_cast<bf16x4_t*>(a.outT + (((((long)b * H + g) * nt + qt) * nt + (kt_first + j)) * 64 + lane) * 4) = o;
+                            *reinterpret_cast<s16x4m_t*>(a.outT + (((((long)b * H + g) * nt + qt) * nt + (kt_first + j)) * 64 + lane) * 4) = o;
 #endif
                         }
                     }

@@ -12,6 +12,13 @@
 //   dW = dy^T x          A = dy16T [N, Rp]     B = x16T  [K, Rp]       (transposed activations, zero padded to Rp)
 // Replaces the nn.Linear GEMMs of reference models/cait.py:376,390,409 and models/transformer.py:368-425.
 //
+// SPLIT operands (precision mode "bf16s", forward products): A = A_hi + A_lo and B = B_hi + B_lo, each part bf16 (lo = the
+// bf16 rounding of the residual, written next to hi by every producer), and the product is evaluated as
+//   A_hi B_hi + A_lo B_hi + A_hi B_lo          (3 MFMAs per tile step; the lo x lo term is below 2^-17 of the result)
+// i.e. with ~16 significant bits per operand instead of 8: north_star's 1e-3 on logits / losses needs this in the FORWARD
+// GEMMs (a single bf16 rounding of the Linear operands alone costs 2e-3 of pred_logits over 24 blocks, tools/error_budget.py),
+// the matrix pipe has the room (these kernels are load / store bound), and the backward products stay single-term.
+//
 // Block = 256 threads = 4 waves (2x2); block tile BM x BN x 64 (BM, BN in {128, 64}); v_mfma_f32_16x16x32_bf16.
 // Pipeline per workgroup: tile t is multiplied out of LDS buffer t&1 while tile t+1 waits in registers and tile
 // t+2 is being fetched (16-B loads of 8 elements, no conversion work).
@@ -25,6 +32,8 @@ typedef unsigned int u32x4g_t __attribute__((ext_vector_type(4)));
 
 struct Gemm16Args {
     const unsigned short* A; const unsigned short* B; float* C; float* C2; const float* bias;
+    const unsigned short* Alo; const unsigned short* Blo;     // SPLIT kernels: the low parts (same leading dimensions)
+    unsigned short* out16lo;                                   // EX epilogue of SPLIT kernels: bf16(v - bf16(v)) next to out16
     int M, N, K;               // K: logical contraction length (multiple of 8; operands zero padded beyond it if needed)
     long lda, ldb, ldc;
     float alpha;
@@ -83,14 +92,18 @@ __device__ __forceinline__ void gb_glds16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int BM, int BN, bool EX, int NTS = 0, int RING = 0>
+template <int BM, int BN, bool EX, int NTS = 0, int RING = 0, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    static_assert(!SPLIT || (NTS == 0 && RING == 0), "split operands run on the register-pipelined loop");
     constexpr int NFM = BM / 32, NFN = BN / 32;        // 16x16 MFMA tiles per wave (wave tile BM/2 x BN/2)
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TA_ = BM * GB_LDR, TB_ = BN * GB_LDR;
-    auto sA = [&](int buf) { return smem16 + buf * (TA_ + TB_); };
-    auto sB = [&](int buf) { return smem16 + buf * (TA_ + TB_) + TA_; };
+    constexpr int BUF_ = (TA_ + TB_) * (SPLIT ? 2 : 1);  // one pipeline stage: [A hi][B hi]([A lo][B lo])
+    auto sA = [&](int buf) { return smem16 + buf * BUF_; };
+    auto sB = [&](int buf) { return smem16 + buf * BUF_ + TA_; };
+    auto sAl = [&](int buf) { return smem16 + buf * BUF_ + TA_ + TB_; };
+    auto sBl = [&](int buf) { return smem16 + buf * BUF_ + 2 * TA_ + TB_; };
 
     // workgroup b runs on XCD b % 8: the panels of the operand with more rows are bound to XCDs (all tiles reading
     // one such panel run on the same XCD), so that operand is fetched into one L2 only; the other one is re-fetched
@@ -210,18 +223,33 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
     }
     u32x4g_t ca[BM / 32], cb[BN / 32];     // tile t+1 (landed or landing)
     u32x4g_t na[BM / 32], nb[BN / 32];     // tile t+2 (being fetched)
+    constexpr int SA_ = SPLIT ? BM / 32 : 1, SB_ = SPLIT ? BN / 32 : 1;
+    u32x4g_t cal[SA_], cbl[SB_], nal[SA_], nbl[SB_];       // the low parts of the same tiles (SPLIT)
 #pragma unroll
     for (int i = 0; i < BM / 32; ++i) na[i] = (u32x4g_t){0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i) nb[i] = (u32x4g_t){0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < SA_; ++i) nal[i] = (u32x4g_t){0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < SB_; ++i) nbl[i] = (u32x4g_t){0u, 0u, 0u, 0u};
     if (NTS == 0 && RING == 0 && nt > 0) {
         g16_load<BM>(p.A, p.lda, m0, p.M, kt_begin * GB_BK, p.K, ca);
         g16_load<BN>(p.B, p.ldb, n0, p.N, kt_begin * GB_BK, p.K, cb);
+        if constexpr (SPLIT) {
+            g16_load<BM>(p.Alo, p.lda, m0, p.M, kt_begin * GB_BK, p.K, cal);
+            g16_load<BN>(p.Blo, p.ldb, n0, p.N, kt_begin * GB_BK, p.K, cbl);
+        }
         g16_stage<BM>(sA(0), ca);
         g16_stage<BN>(sB(0), cb);
+        if constexpr (SPLIT) { g16_stage<BM>(sAl(0), cal); g16_stage<BN>(sBl(0), cbl); }
         if (nt > 1) {
             g16_load<BM>(p.A, p.lda, m0, p.M, (kt_begin + 1) * GB_BK, p.K, ca);
             g16_load<BN>(p.B, p.ldb, n0, p.N, (kt_begin + 1) * GB_BK, p.K, cb);
+            if constexpr (SPLIT) {
+                g16_load<BM>(p.Alo, p.lda, m0, p.M, (kt_begin + 1) * GB_BK, p.K, cal);
+                g16_load<BN>(p.Blo, p.ldb, n0, p.N, (kt_begin + 1) * GB_BK, p.K, cbl);
+            }
         }
         __syncthreads();
         for (int t = 0; t < nt; ++t) {
@@ -229,30 +257,50 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
             if (t + 2 < nt) {
                 g16_load<BM>(p.A, p.lda, m0, p.M, (kt_begin + t + 2) * GB_BK, p.K, na);
                 g16_load<BN>(p.B, p.ldb, n0, p.N, (kt_begin + t + 2) * GB_BK, p.K, nb);
+                if constexpr (SPLIT) {
+                    g16_load<BM>(p.Alo, p.lda, m0, p.M, (kt_begin + t + 2) * GB_BK, p.K, nal);
+                    g16_load<BN>(p.Blo, p.ldb, n0, p.N, (kt_begin + t + 2) * GB_BK, p.K, nbl);
+                }
             }
 #pragma unroll
             for (int ks = 0; ks < GB_BK / 32; ++ks) {
-                bf16x8_t a[NFM], b[NFN];
+                bf16x8_t a[NFM], b[NFN], al[SPLIT ? NFM : 1], bl[SPLIT ? NFN : 1];
 #pragma unroll
-                for (int i = 0; i < NFM; ++i)
+                for (int i = 0; i < NFM; ++i) {
                     a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sA(buf) + (wm * WM + i * 16 + fr) * GB_LDR + ks * 32 + fk));
+                    if constexpr (SPLIT) al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sAl(buf) + (wm * WM + i * 16 + fr) * GB_LDR + ks * 32 + fk));
+                }
 #pragma unroll
-                for (int j = 0; j < NFN; ++j)
+                for (int j = 0; j < NFN; ++j) {
                     b[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sB(buf) + (wn * WN + j * 16 + fr) * GB_LDR + ks * 32 + fk));
+                    if constexpr (SPLIT) bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u16x8_t*>(sBl(buf) + (wn * WN + j * 16 + fr) * GB_LDR + ks * 32 + fk));
+                }
 #pragma unroll
                 for (int i = 0; i < NFM; ++i)
 #pragma unroll
-                    for (int j = 0; j < NFN; ++j)
+                    for (int j = 0; j < NFN; ++j) {
+                        if constexpr (SPLIT) {        // the two cross terms first, then hi x hi (each accumulator: one MFMA shape)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], a[i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], al[i], acc[i][j], 0, 0, 0);
+                        }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                    }
             }
             if (t + 1 < nt) {
                 g16_stage<BM>(sA(buf ^ 1), ca);
                 g16_stage<BN>(sB(buf ^ 1), cb);
+                if constexpr (SPLIT) { g16_stage<BM>(sAl(buf ^ 1), cal); g16_stage<BN>(sBl(buf ^ 1), cbl); }
             }
 #pragma unroll
             for (int i = 0; i < BM / 32; ++i) ca[i] = na[i];
 #pragma unroll
             for (int i = 0; i < BN / 32; ++i) cb[i] = nb[i];
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int i = 0; i < SA_; ++i) cal[i] = nal[i];
+#pragma unroll
+                for (int i = 0; i < SB_; ++i) cbl[i] = nbl[i];
+            }
             __syncthreads();
         }
     }
@@ -265,7 +313,9 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
         constexpr int LR = BN + 8, LT = BM + 8;            // bf16 per LDS row of the two staged tiles
         unsigned short* sR = smem16;                         // [BM][LR]  row-major tile
         unsigned short* sT = smem16 + BM * LR;               // [BN][LT]  transposed tile
+        unsigned short* sRl = sT + BN * LT;                  // [BM][LR]  low part of the row-major tile (SPLIT kernels)
         static_assert((BM * LR + BN * LT) <= 2 * (BM + BN) * GB_LDR, "staged tiles must fit the operand buffers");
+        static_assert(!SPLIT || (2 * BM * LR + BN * LT) <= 4 * (BM + BN) * GB_LDR, "staged tiles must fit the operand buffers");
         __syncthreads();
         typedef short s16x4i_t __attribute__((ext_vector_type(4)));
         s16x4i_t ident;
@@ -276,7 +326,7 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
                          (!p.res || (reinterpret_cast<uintptr_t>(p.res) & 15) == 0);
         // interior tiles request the whole aux tile up front (the operand staging registers are free now): 16 loads in
         // flight per lane instead of one exposed round trip per 16x16 block
-        const bool stage = p.out16 || p.out16T || p.colsum;      // bf16 copies / column sums wanted at all
+        const bool stage = p.out16 || p.out16T || p.colsum || (SPLIT && p.out16lo);      // bf16 copies / column sums wanted at all
         const bool interior = vst && (m0 + BM <= p.M) && (n0 + BN <= p.N);
         float4 hq[NFN][NFM];
         const float* pre_src = p.aux ? p.aux : p.res;              // aux and res are mutually exclusive
@@ -370,6 +420,14 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
                 hb[0] = (__bf16)v[0]; hb[1] = (__bf16)v[1]; hb[2] = (__bf16)v[2]; hb[3] = (__bf16)v[3];
                 const uint2 u = __builtin_bit_cast(uint2, hb);
                 *reinterpret_cast<uint2*>(sR + ml * LR + nl) = u;
+                if constexpr (SPLIT) {
+                    if (p.out16lo) {
+                        bf16x4v_t lb;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) lb[r] = (__bf16)(v[r] - (float)hb[r]);
+                        *reinterpret_cast<uint2*>(sRl + ml * LR + nl) = __builtin_bit_cast(uint2, lb);
+                    }
+                }
                 // transposed copy: one MFMA against the identity moves the lane ownership from (row m, 4 columns) to
                 // (column n, 4 rows) - exact in bf16 - so the transposed tile is staged with 8-B writes as well
                 {
@@ -395,17 +453,20 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
             }
         }
         __syncthreads();
-        if (p.out16) {       // [BM][BN] row-major: 16 B = 8 columns per thread and pass
+        for (int part = 0; part < (SPLIT ? 2 : 1); ++part) {       // [BM][BN] row-major: 16 B = 8 columns per thread and pass
+            unsigned short* o16 = part ? p.out16lo : p.out16;
+            const unsigned short* sS = part ? sRl : sR;
+            if (!o16) continue;
             constexpr int CH = BN / 8;
             for (int idx = threadIdx.x; idx < BM * CH; idx += 256) {
                 const int ml = idx / CH, ch = idx % CH, m = m0 + ml, n = n0 + ch * 8;
                 if (m >= p.M || n >= p.N) continue;
-                const u32x4g_t q = *reinterpret_cast<const u32x4g_t*>(sR + ml * LR + ch * 8);
-                unsigned short* dst = p.out16 + (long)m * p.ld16 + n;
+                const u32x4g_t q = *reinterpret_cast<const u32x4g_t*>(sS + ml * LR + ch * 8);
+                unsigned short* dst = o16 + (long)m * p.ld16 + n;
                 if (n + 7 < p.N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) spe_store16_stream(dst, q);
                 else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) if (n + e < p.N) dst[e] = sR[ml * LR + ch * 8 + e];
+                    for (int e = 0; e < 8; ++e) if (n + e < p.N) dst[e] = sS[ml * LR + ch * 8 + e];
                 }
             }
         }
@@ -477,14 +538,14 @@ __global__ __launch_bounds__(256) void gemm_bf16nt_kernel(Gemm16Args p) {
     }
 }
 
-template <int BM, int BN, bool EX = false, int NTS = 0, int RING = 0>
+template <int BM, int BN, bool EX = false, int NTS = 0, int RING = 0, bool SPLIT = false>
 static int launch_gemm16(const Gemm16Args& p, hipStream_t stream) {
     constexpr int smem = RING > 0 ? RING * (BM + BN) * 64 * (int)sizeof(unsigned short)
-                                  : (NTS > 0 ? NTS : 2) * (BM + BN) * GB_LDR * (int)sizeof(unsigned short);
+                                  : (NTS > 0 ? NTS : 2) * (SPLIT ? 2 : 1) * (BM + BN) * GB_LDR * (int)sizeof(unsigned short);
     static_assert(RING == 0 || !EX || RING * 64 >= 2 * GB_LDR, "the staged epilogue tiles must fit the ring");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16nt_kernel<BM, BN, EX, NTS, RING>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16nt_kernel<BM, BN, EX, NTS, RING, SPLIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -500,22 +561,24 @@ static int launch_gemm16(const Gemm16Args& p, hipStream_t stream) {
     if (q.xcd_bind == 1) tiles = 8 * ((tiles_m + 7) / 8) * tiles_n;
     if (q.xcd_bind == 2) tiles = 8 * ((tiles_n + 7) / 8) * tiles_m;
     dim3 grid(tiles, 1, p.splitk);
-    hipLaunchKernelGGL((gemm_bf16nt_kernel<BM, BN, EX, NTS, RING>), grid, dim3(256), smem, stream, q);
+    hipLaunchKernelGGL((gemm_bf16nt_kernel<BM, BN, EX, NTS, RING, SPLIT>), grid, dim3(256), smem, stream, q);
     SPE_CHECK_LAUNCH();
     return 0;
 }
 
 // C-ABI: see include/spe_hip.h (spe_gemm_bf16nt).  -2: unsupported alignment, -3: bias/act with split-K,
 // -5: more splits than K tiles.
-extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const float* bias, float* C2,
-                               int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int splitk,
+extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, const void* A16lo, const void* B16lo, float* C, const float* bias,
+                               float* C2, int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int splitk,
                                hipStream_t stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0) return -4;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    if (!al16(A16) || !al16(B16) || (lda & 7) || (ldb & 7) || (K & 7)) return -2;
+    if (!al16(A16) || !al16(B16) || !al16(A16lo) || !al16(B16lo) || (lda & 7) || (ldb & 7) || (K & 7)) return -2;
+    if ((A16lo != nullptr) != (B16lo != nullptr)) return -2;
     Gemm16Args p;
     p.A = reinterpret_cast<const unsigned short*>(A16); p.B = reinterpret_cast<const unsigned short*>(B16);
+    p.Alo = reinterpret_cast<const unsigned short*>(A16lo); p.Blo = reinterpret_cast<const unsigned short*>(B16lo); p.out16lo = nullptr;
     p.C = C; p.C2 = C2; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.act = act; p.slab = 0;
     p.out16 = nullptr; p.out16T = nullptr; p.colsum = nullptr; p.aux = nullptr; p.ld16 = 0; p.ld16t = 0; p.res = nullptr; p.rgamma = nullptr;
@@ -528,6 +591,10 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const
     p.kt_per_split = (ktiles + splitk - 1) / splitk;
     p.splitk = splitk;
     if (splitk > 1 && (act != 0 || C2 != nullptr || bias != nullptr)) return -3;
+    if (p.Alo) {            // split operands: 64x64 tiles at two workgroups per CU (73 KB of LDS each); 128x64 when that fills the chip less
+        if (splitk != 1) return -3;
+        return launch_gemm16<64, 64, false, 0, 0, true>(p, stream);
+    }
     {   // developer knob (tools/bench_gemm.py): SPE_GEMM16_TILE = 1 / 2 / 3 forces 128x128 / 128x64 / 64x64
         static const int forced = getenv("SPE_GEMM16_TILE") ? atoi(getenv("SPE_GEMM16_TILE")) : 0;
         if (forced == 1) return launch_gemm16<128, 128>(p, stream);
@@ -566,14 +633,15 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, float* C, const
 }
 
 // C-ABI: see include/spe_hip.h (spe_gemm_bf16nt_ex).  -2: unsupported alignment / leading dimensions.
-extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, float* C, const float* bias, float* C2,
-                                  void* out16, long ld16, void* out16T, long ld16t, float* colsum, const float* aux,
-                                  const float* res, const float* rgamma,
+extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, const void* A16lo, const void* B16lo, float* C, const float* bias,
+                                  float* C2, void* out16, void* out16lo, long ld16, void* out16T, long ld16t, float* colsum,
+                                  const float* aux, const float* res, const float* rgamma,
                                   int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, hipStream_t stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0) return -4;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    if (!al16(A16) || !al16(B16) || (lda & 7) || (ldb & 7) || (K & 7)) return -2;
+    if (!al16(A16) || !al16(B16) || !al16(A16lo) || !al16(B16lo) || (lda & 7) || (ldb & 7) || (K & 7)) return -2;
+    if ((A16lo != nullptr) != (B16lo != nullptr) || (out16lo && !A16lo)) return -2;
     if (out16T && ld16t < M) return -2;
     if (aux && act != 1 && act != 2) return -2;
     if ((res != nullptr) != (rgamma != nullptr) || (res && (!C || act != 0 || aux))) return -2;
@@ -581,6 +649,8 @@ extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, float* C, co
     p.A = reinterpret_cast<const unsigned short*>(A16); p.B = reinterpret_cast<const unsigned short*>(B16);
     p.C = C; p.C2 = C2; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.act = act; p.slab = 0; p.splitk = 1;
+    p.Alo = reinterpret_cast<const unsigned short*>(A16lo); p.Blo = reinterpret_cast<const unsigned short*>(B16lo);
+    p.out16lo = reinterpret_cast<unsigned short*>(out16lo);
     p.kt_per_split = (K + GB_BK - 1) / GB_BK;
     p.out16 = reinterpret_cast<unsigned short*>(out16); p.ld16 = ld16;
     p.out16T = reinterpret_cast<unsigned short*>(out16T); p.ld16t = ld16t;
@@ -590,6 +660,7 @@ extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, float* C, co
     const bool reach128 = !out16T || ld16t <= (long)((M + 127) / 128) * 128;
     const bool reach64 = !out16T || ld16t <= (long)((M + 63) / 64) * 64;
     if (!reach128 && !reach64) return -2;
+    if (p.Alo) return reach64 ? launch_gemm16<64, 64, true, 0, 0, true>(p, stream) : -2;
     {   // developer knob: SPE_GEMM16_TILE also applies here
         static const int forced = getenv("SPE_GEMM16_TILE") ? atoi(getenv("SPE_GEMM16_TILE")) : 0;
         if (forced == 1 && reach128) return launch_gemm16<128, 128, true>(p, stream);
@@ -614,7 +685,7 @@ extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, float* C, co
 // x := x * act'(aux) (act 1: ReLU, aux = forward output; act 2: exact-erf GELU, aux = pre-activation; the
 // arithmetic of act_bwd_kernel in rowops.hip) - the fp32 gradient w.r.t. the pre-activation never reaches HBM.
 __device__ __forceinline__ void cvt_bf16_tile(const float* __restrict__ x, long ldx, int R, int C,
-                                              unsigned short* __restrict__ out, long ldo,
+                                              unsigned short* __restrict__ out, unsigned short* __restrict__ out_lo, long ldo,
                                               unsigned short* __restrict__ outT, long ldt, float* __restrict__ colsum,
                                               const float* __restrict__ aux, int act, const int r0, const int c0) {
     __shared__ unsigned short tile[64][66];
@@ -660,6 +731,17 @@ __device__ __forceinline__ void cvt_bf16_tile(const float* __restrict__ x, long 
                 for (int j = 0; j < 4; ++j) if (c + j < C) out[(long)r * ldo + c + j] = e[j];
             }
         }
+        if (out_lo && r < R) {          // low part of the split operand: bf16(x - bf16(x)), same layout as `out`
+            bf16x4v_t l;
+            l[0] = (__bf16)(v[0] - (float)h[0]); l[1] = (__bf16)(v[1] - (float)h[1]); l[2] = (__bf16)(v[2] - (float)h[2]); l[3] = (__bf16)(v[3] - (float)h[3]);
+            const uint2 ul = __builtin_bit_cast(uint2, l);
+            if (c + 3 < C && ((ldo & 3) == 0)) *reinterpret_cast<uint2*>(out_lo + (long)r * ldo + c) = ul;
+            else {
+                const unsigned short e[4] = {(unsigned short)(ul.x & 0xffff), (unsigned short)(ul.x >> 16), (unsigned short)(ul.y & 0xffff), (unsigned short)(ul.y >> 16)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (c + j < C) out_lo[(long)r * ldo + c + j] = e[j];
+            }
+        }
         if (outT) {
             tile[ty + 16 * i][tx * 4 + 0] = (unsigned short)(u.x & 0xffff); tile[ty + 16 * i][tx * 4 + 1] = (unsigned short)(u.x >> 16);
             tile[ty + 16 * i][tx * 4 + 2] = (unsigned short)(u.y & 0xffff); tile[ty + 16 * i][tx * 4 + 3] = (unsigned short)(u.y >> 16);
@@ -698,17 +780,17 @@ __device__ __forceinline__ void cvt_bf16_tile(const float* __restrict__ x, long 
 }
 
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ x, long ldx, int R, int C,
-                                                       unsigned short* __restrict__ out, long ldo,
+                                                       unsigned short* __restrict__ out, unsigned short* __restrict__ out_lo, long ldo,
                                                        unsigned short* __restrict__ outT, long ldt, float* __restrict__ colsum,
                                                        const float* __restrict__ aux, int act) {
-    cvt_bf16_tile(x, ldx, R, C, out, ldo, outT, ldt, colsum, aux, act, blockIdx.y * 64, blockIdx.x * 64);
+    cvt_bf16_tile(x, ldx, R, C, out, out_lo, ldo, outT, ldt, colsum, aux, act, blockIdx.y * 64, blockIdx.x * 64);
 }
 
 // Many contiguous matrices in one launch (the bf16 copies of every Linear weight after an optimizer step: ~190
 // launch-bound conversions of 0.1-0.6 M elements otherwise).  jobs (device memory, built once by the host side):
 // tile0 = first 64x64 tile of the job in the launch, ascending; a workgroup finds its job by bisection.
-struct CvtJob { const float* x; unsigned short* out; unsigned short* outT; long ldt; int R, C, tile0, tiles_c; };
-static_assert(sizeof(CvtJob) == 48, "spe_cvt_job_t layout");
+struct CvtJob { const float* x; unsigned short* out; unsigned short* outT; long ldt; int R, C, tile0, tiles_c; unsigned short* out_lo; };
+static_assert(sizeof(CvtJob) == 56, "spe_cvt_job_t layout");
 __global__ __launch_bounds__(256) void cvt_bf16_multi_kernel(const CvtJob* __restrict__ jobs, int njobs) {
     const int t = blockIdx.x;
     int lo = 0, hi = njobs - 1;
@@ -718,7 +800,7 @@ __global__ __launch_bounds__(256) void cvt_bf16_multi_kernel(const CvtJob* __res
     }
     const CvtJob j = jobs[lo];
     const int lt = t - j.tile0;
-    cvt_bf16_tile(j.x, j.C, j.R, j.C, j.out, j.C, j.outT, j.ldt, nullptr, nullptr, 0, (lt / j.tiles_c) * 64, (lt % j.tiles_c) * 64);
+    cvt_bf16_tile(j.x, j.C, j.R, j.C, j.out, j.out_lo, j.C, j.outT, j.ldt, nullptr, nullptr, 0, (lt / j.tiles_c) * 64, (lt % j.tiles_c) * 64);
 }
 
 // C-ABI: see include/spe_hip.h (spe_cvt_bf16_multi).
@@ -731,15 +813,16 @@ extern "C" int spe_cvt_bf16_multi(const void* jobs_dev, int njobs, int total_til
 }
 
 // C-ABI: see include/spe_hip.h (spe_cvt_bf16).
-extern "C" int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, long ldo, void* outT, long ldt, float* colsum,
+extern "C" int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, void* out_lo, long ldo, void* outT, long ldt, float* colsum,
                             const float* aux, int act, hipStream_t stream) {
     if (R <= 0 || C <= 0) return 0;
-    if (!out && !outT && !colsum) return 0;
+    if (!out && !out_lo && !outT && !colsum) return 0;
     if (outT && ldt < R) return -2;
     // the grid covers the padded row range of the transpose so that its zero columns are written too
     const long rows = outT ? ((ldt > R) ? ldt : R) : R;
     dim3 grid((C + 63) / 64, (unsigned)((rows + 63) / 64));
-    hipLaunchKernelGGL(cvt_bf16_kernel, grid, dim3(256), 0, stream, x, ldx, R, C, reinterpret_cast<unsigned short*>(out), ldo,
+    hipLaunchKernelGGL(cvt_bf16_kernel, grid, dim3(256), 0, stream, x, ldx, R, C, reinterpret_cast<unsigned short*>(out),
+                       reinterpret_cast<unsigned short*>(out_lo), ldo,
                        reinterpret_cast<unsigned short*>(outT), ldt, colsum, aux, act);
     SPE_CHECK_LAUNCH();
     return 0;

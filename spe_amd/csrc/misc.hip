@@ -117,7 +117,7 @@ extern "C" int spe_bicubic(const float* src, float* dst, int gh, int gw, int h, 
     return 0;
 }
 
-extern "C" int spe_abi_version(void) { return 2; }    // 2: round 2 (signatures of spe_hungarian, spe_adamw_flat, spe_layernorm_fwd, spe_attn_contract, spe_talking_fused_plan changed; new entry points)
+extern "C" int spe_abi_version(void) { return 3; }    // 2: round 2 (signatures of spe_hungarian, spe_adamw_flat, spe_layernorm_fwd, spe_attn_contract, spe_talking_fused_plan changed; new entry points)
 
 
 // ------------------------------------------------------------------------------------------

@@ -14,7 +14,8 @@
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
-                                                     long R, int C, float eps, unsigned short* __restrict__ y16) {
+                                                     long R, int C, float eps, unsigned short* __restrict__ y16,
+                                                     unsigned short* __restrict__ y16lo) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
@@ -56,6 +57,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 bf16x4l_t h;
                 h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
                 *reinterpret_cast<uint2*>(y16 + row * C + 4 * c) = __builtin_bit_cast(uint2, h);
+                if (y16lo) {    // low part of the split operand (precision mode bf16s): bf16(y - bf16(y))
+                    bf16x4l_t l;
+                    l[0] = (__bf16)(o.x - (float)h[0]); l[1] = (__bf16)(o.y - (float)h[1]); l[2] = (__bf16)(o.z - (float)h[2]); l[3] = (__bf16)(o.w - (float)h[3]);
+                    *reinterpret_cast<uint2*>(y16lo + row * C + 4 * c) = __builtin_bit_cast(uint2, l);
+                }
             }
         }
     }
@@ -211,7 +217,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_hw_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         float* __restrict__ mean, float* __restrict__ rstd,
-                                                        long R, float eps, unsigned short* __restrict__ y16) {
+                                                        long R, float eps, unsigned short* __restrict__ y16,
+                                                        unsigned short* __restrict__ y16lo) {
     constexpr int C4 = 32 * NV, C = 4 * C4;
     const int lane = threadIdx.x & 63, hl = lane & 31;
     const long stride = (long)gridDim.x * 8;
@@ -269,6 +276,11 @@ __global__ __launch_bounds__(256) void ln_fwd_hw_kernel(const float* __restrict_
                     bf16x4h_t h;
                     h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
                     *reinterpret_cast<uint2*>(y16 + row * C + 4 * c) = __builtin_bit_cast(uint2, h);
+                    if (y16lo) {
+                        bf16x4h_t l;
+                        l[0] = (__bf16)(o.x - (float)h[0]); l[1] = (__bf16)(o.y - (float)h[1]); l[2] = (__bf16)(o.z - (float)h[2]); l[3] = (__bf16)(o.w - (float)h[3]);
+                        *reinterpret_cast<uint2*>(y16lo + row * C + 4 * c) = __builtin_bit_cast(uint2, l);
+                    }
                 }
             }
         }
@@ -290,26 +302,27 @@ extern "C" int spe_layernorm_res_fwd(const float* x, const float* z, const float
 }
 
 extern "C" int spe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                                 float* rstd, long R, int C, float eps, void* y16, hipStream_t st) {
+                                 float* rstd, long R, int C, float eps, void* y16, void* y16lo, hipStream_t st) {
     if (R <= 0) return 0;
-    if ((C & 3) || C > 256 * LN_MAXV) return -2;
+    if ((C & 3) || C > 256 * LN_MAXV || (y16lo && !y16)) return -2;
     static const int hw = getenv("SPE_LN_HALFWAVE") ? atoi(getenv("SPE_LN_HALFWAVE")) : 1;       // 0: wave-per-row kernel (A/B)
     if (hw && (C % 128) == 0 && C <= 512) {
         static const int ln_wg = getenv("SPE_LN_WG") ? atoi(getenv("SPE_LN_WG")) : 512;
         long nwg_ = (R + 7) / 8; if (nwg_ > ln_wg) nwg_ = ln_wg;
         const dim3 grid((unsigned)nwg_);
         unsigned short* h16 = reinterpret_cast<unsigned short*>(y16);
+        unsigned short* l16 = reinterpret_cast<unsigned short*>(y16lo);
         switch (C / 128) {
-            case 1: hipLaunchKernelGGL(ln_fwd_hw_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16); break;
-            case 2: hipLaunchKernelGGL(ln_fwd_hw_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16); break;
-            case 3: hipLaunchKernelGGL(ln_fwd_hw_kernel<3>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16); break;
-            default: hipLaunchKernelGGL(ln_fwd_hw_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16); break;
+            case 1: hipLaunchKernelGGL(ln_fwd_hw_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16, l16); break;
+            case 2: hipLaunchKernelGGL(ln_fwd_hw_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16, l16); break;
+            case 3: hipLaunchKernelGGL(ln_fwd_hw_kernel<3>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16, l16); break;
+            default: hipLaunchKernelGGL(ln_fwd_hw_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16, l16); break;
         }
         SPE_CHECK_LAUNCH();
         return 0;
     }
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, C, eps,
-                       reinterpret_cast<unsigned short*>(y16));
+                       reinterpret_cast<unsigned short*>(y16), reinterpret_cast<unsigned short*>(y16lo));
     SPE_CHECK_LAUNCH();
     return 0;
 }

@@ -10,8 +10,39 @@ import torch
 
 from . import lib
 
-# 0 = bf16 MFMA operands / fp32 accumulate (benchmark mode); 1 = 3-term bf16 split (~fp32, parity mode)
+# Precision modes (operand format of the MFMA products; accumulation, residual stream, LayerNorm / softmax statistics and the
+# losses are fp32 in every mode):
+#   0 "bf16"   single bf16 operands everywhere
+#   1 "bf16x3" 3-term bf16 split (hi*hi + lo*hi + hi*lo, ~fp32) everywhere, fp32 materialised attention (csrc/talking.hip)
+#   2 "bf16s"  FORWARD products on split operands (what north_star's 1e-3 on logits / losses needs), BACKWARD products on
+#              single bf16 operands (gradients carry bf16 rounding like any mixed-precision trainer) - the benchmark mode
 _PRECISION = 0
+_IN_BWD = False      # set by @backward_scope around every autograd backward of spe_amd.ops
+
+
+def backward_scope(fn):
+    """Decorator of the `backward` staticmethods: products issued inside run at the mode's BACKWARD operand precision."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(ctx, *grads):
+        global _IN_BWD
+        prev, _IN_BWD = _IN_BWD, True
+        try:
+            return fn(ctx, *grads)
+        finally:
+            _IN_BWD = prev
+    return wrapped
+
+
+def split_now():
+    """True when the product about to be issued takes split (hi + lo) bf16 operands."""
+    return _PRECISION == 1 or (_PRECISION == 2 and not _IN_BWD)
+
+
+def split_fwd():
+    """bf16s forward: the bf16-copy GEMMs run on (hi, lo) operand pairs and every producer of such an operand also writes lo."""
+    return _PRECISION == 2 and not _IN_BWD
 # Philox stream for dropout: (seed, running offset).  Each dropout site draws a fresh offset.
 # seed None = not set by the caller: derived on first use from torch's seed (the reference's main.py:161-164 seeds torch
 # with args.seed + rank and nothing else, so its dropout masks differ per rank and per run; ours then do too).
@@ -20,11 +51,11 @@ _RNG = {"seed": None, "offset": 0}
 
 def set_precision(mode):
     global _PRECISION
-    _PRECISION = {"bf16": 0, "bf16x3": 1, 0: 0, 1: 1}[mode]
+    _PRECISION = {"bf16": 0, "bf16x3": 1, "bf16s": 2, 0: 0, 1: 1, 2: 2}[mode]
 
 
 def get_precision():
-    return "bf16x3" if _PRECISION else "bf16"
+    return ("bf16", "bf16x3", "bf16s")[_PRECISION]
 
 
 def manual_seed(seed):
@@ -58,7 +89,7 @@ def timing_results():
 
 # entry point -> positions of (M, N, K) in its argument list: GEMM launches can be timed per problem shape, e.g.
 # enable_timing(["spe_gemm_bf16nt:8300,384,384"])
-_GEMM_DIMS = {"spe_gemm_bf16nt": (5, 6, 7), "spe_gemm_bf16nt_ex": (13, 14, 15)}
+_GEMM_DIMS = {"spe_gemm_bf16nt": (7, 8, 9), "spe_gemm_bf16nt_ex": (16, 17, 18)}
 
 
 def _call(name, *args):
@@ -159,7 +190,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
     """Raw strided (batched) GEMM on already-allocated tensors; returns C."""
     _call("spe_gemm_f32", _p(A), _p(B), _p(C), _p(bias), _p(C2), M, N, K, lda, ldb, ldc,
              int(transA), int(transB), batch0, batch1, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
-             float(alpha), int(act), int(splitk), _PRECISION, _st())
+             float(alpha), int(act), int(splitk), int(split_now()), _st())
     return C
 
 
@@ -183,13 +214,14 @@ def weights_changed():
 
 
 def _lin16_ok(R, N, K):
-    return LINEAR16 and _PRECISION == 0 and R >= LINEAR16_MIN_ROWS and N % 8 == 0 and K % 8 == 0
+    return LINEAR16 and _PRECISION != 1 and R >= LINEAR16_MIN_ROWS and N % 8 == 0 and K % 8 == 0
 
 
-def cvt_bf16(x2, want=True, wantT=False, ldt=None, colsum_out=None, act_aux=None, act=0, out=None, ldo=None):
+def cvt_bf16(x2, want=True, wantT=False, ldt=None, colsum_out=None, act_aux=None, act=0, out=None, ldo=None, out_lo=None):
     """bf16 (RNE) copies of a contiguous fp32 [R, C]: row-major [R, C] and/or the transpose [C, ldt] (zero padded);
     colsum_out (zeroed or running fp32 [C]) += column sums of x2 from the same pass.  out / ldo: write the row-major copy
-    into a column block of a wider bf16 matrix (row stride ldo) instead of a fresh tensor."""
+    into a column block of a wider bf16 matrix (row stride ldo) instead of a fresh tensor.  out_lo (same layout as out):
+    receives bf16(x - bf16(x)), the low part of a split operand."""
     _chk(x2)
     R, C = x2.shape
     if out is None:
@@ -199,7 +231,8 @@ def cvt_bf16(x2, want=True, wantT=False, ldt=None, colsum_out=None, act_aux=None
     if wantT:
         ldt = ldt or ((R + 63) // 64) * 64
         outT = torch.empty((C, ldt), device=x2.device, dtype=torch.bfloat16)
-    _call("spe_cvt_bf16", _p(x2), x2.stride(0), R, C, _p(out), ldo or C, _p(outT), ldt or 0, _p(colsum_out), _p(act_aux), int(act), _st())
+    _call("spe_cvt_bf16", _p(x2), x2.stride(0), R, C, _p(out), _p(out_lo), ldo or C, _p(outT), ldt or 0, _p(colsum_out), _p(act_aux),
+          int(act), _st())
     return out, outT
 
 
@@ -223,21 +256,21 @@ def _refresh_weights16():
     _W16_REFRESHED = _W16_EPOCH
     if not live:
         return
-    sig = tuple(_W16)
+    sig = tuple((k, e[5] is not None) for k, _, e in live)
     if _W16_TABLE is None or _W16_TABLE[0] != sig:
         rec = np.zeros(len(live), dtype=np.dtype([("x", "<u8"), ("out", "<u8"), ("outT", "<u8"), ("ldt", "<i8"), ("R", "<i4"),
-                                                   ("C", "<i4"), ("tile0", "<i4"), ("tiles_c", "<i4")]))
+                                                   ("C", "<i4"), ("tile0", "<i4"), ("tiles_c", "<i4"), ("out_lo", "<u8")]))
         t0 = 0
         for i, ((ptr, R, C), _, e) in enumerate(live):
             tc = (C + 63) // 64
-            rec[i] = (ptr, e[3].data_ptr(), e[4].data_ptr(), e[4].shape[1], R, C, t0, tc)
+            rec[i] = (ptr, e[3].data_ptr(), e[4].data_ptr(), e[4].shape[1], R, C, t0, tc, e[5].data_ptr() if e[5] is not None else 0)
             t0 += tc * ((max(R, e[4].shape[1]) + 63) // 64)
         table = host_table(rec.view(np.uint8), live[0][2][3].device)
         _W16_TABLE = (sig, table, len(live), t0)
     _, table, n, tiles = _W16_TABLE
     _call("spe_cvt_bf16_multi", _p(table), n, tiles, _st())
     for key, owner, e in live:
-        _W16[key] = (e[0], owner._version, _W16_EPOCH, e[3], e[4])
+        _W16[key] = (e[0], owner._version, _W16_EPOCH, e[3], e[4], e[5])
 
 
 def _owns(owner, ptr):
@@ -255,10 +288,11 @@ def host_table(bytes_np, device):
     return dev
 
 
-def weight16(W):
+def weight16(W, lo=False):
     """(W16 [N,K], W16T [K,N]) of a contiguous 2-D weight (or 2-D view of one: the patch-embedding filter), cached until
-    the optimizer (or a state-dict load) changes it.  Cache key: (address, shape); an entry lives as long as the tensor
-    that owns the storage.  The first lookup after weights_changed() refreshes every cached copy in one launch."""
+    the optimizer (or a state-dict load) changes it; lo=True: (W16, W16T, W16lo [N,K]) with W16lo = bf16(W - W16), the low
+    part of the split forward operand (precision mode bf16s).  Cache key: (address, shape); an entry lives as long as the
+    tensor that owns the storage.  The first lookup after weights_changed() refreshes every cached copy in one launch."""
     import weakref
     key = (W.data_ptr(), W.shape[0], W.shape[1])
     ent = _W16.get(key)
@@ -268,38 +302,46 @@ def weight16(W):
             if _W16_BATCH and ent[2] != _W16_EPOCH and _W16_REFRESHED != _W16_EPOCH:
                 _refresh_weights16()
                 ent = _W16.get(key, ent)
-            if ent[1] == owner._version and ent[2] == _W16_EPOCH:
-                return ent[3], ent[4]
+            if ent[1] == owner._version and ent[2] == _W16_EPOCH and (ent[5] is not None or not lo):
+                return (ent[3], ent[4], ent[5]) if lo else (ent[3], ent[4])
     owner = W._base if W._base is not None else W
+    want_lo = lo or _PRECISION == 2
     with torch.no_grad():
-        W16, W16T = cvt_bf16(W.detach(), True, True, ldt=W.shape[0])
+        W16lo = torch.empty(W.shape, device=W.device, dtype=torch.bfloat16) if want_lo else None
+        W16, W16T = cvt_bf16(W.detach(), True, True, ldt=W.shape[0], out_lo=W16lo)
     if len(_W16) > 4096:
         _W16.clear()
-    _W16[key] = (weakref.ref(owner), owner._version, _W16_EPOCH, W16, W16T)
-    return W16, W16T
+    _W16[key] = (weakref.ref(owner), owner._version, _W16_EPOCH, W16, W16T, W16lo)
+    return (W16, W16T, W16lo) if lo else (W16, W16T)
 
 
-_WCAT = {}      # tuple of weight ids -> (epoch, versions, Wcat16 [sum N, K], Wcat16T [K, sum N], bcat [sum N])
+_WCAT = {}      # ((address, shape) per weight) -> (owner weakrefs, epoch, versions, Wcat16, Wcat16T, bcat, Wcat16lo)
 
 
-def weightcat16(Ws, bs):
+def weightcat16(Ws, bs, lo=False):
     """bf16 copies of several [N_i, K] weights stacked along the output axis (and the transposed stack for the input gradient)
-    plus the stacked fp32 biases - the operands of ONE GEMM that evaluates all the Linears sharing an input (ops.multi_linear).
-    Rebuilt from the cached per-weight copies when any weight changed (three concatenations)."""
-    key = tuple(id(W) for W in Ws)
+    plus the stacked fp32 biases - the operands of ONE GEMM that evaluates all the Linears sharing an input (ops.multi_linear);
+    lo=True: also the stacked low parts (split forward operand).  Rebuilt from the cached per-weight copies when any weight
+    changed (three concatenations).  Keyed like weight16 on (address, shape) with weak references to the owning tensors: an
+    `id()` can be reused by a later model in the same process."""
+    import weakref
+    key = tuple((W.data_ptr(), tuple(W.shape)) for W in Ws)
     vers = tuple(W._version for W in Ws) + tuple(b._version for b in bs)
     ent = _WCAT.get(key)
-    if ent is not None and ent[0] == _W16_EPOCH and ent[1] == vers:
-        return ent[2], ent[3], ent[4]
+    if ent is not None and ent[1] == _W16_EPOCH and ent[2] == vers and (ent[6] is not None or not lo):
+        owners = [r() for r in ent[0]]
+        if all(o is not None and _owns(o, W.data_ptr()) for o, W in zip(owners, Ws)) and ent[3].shape == (sum(W.shape[0] for W in Ws), Ws[0].shape[1]):
+            return (ent[3], ent[4], ent[5], ent[6]) if lo else (ent[3], ent[4], ent[5])
     with torch.no_grad():
-        pairs = [weight16(W) for W in Ws]
-        Wc = torch.cat([p_[0] for p_ in pairs], 0)
-        WcT = torch.cat([p_[1] for p_ in pairs], 1)
+        trip = [weight16(W, lo=lo) for W in Ws]
+        Wc = torch.cat([t_[0] for t_ in trip], 0)
+        WcT = torch.cat([t_[1] for t_ in trip], 1)
+        Wclo = torch.cat([t_[2] for t_ in trip], 0) if lo else None
         bc = torch.cat([b.detach() for b in bs])
     if len(_WCAT) > 64:
         _WCAT.clear()
-    _WCAT[key] = (_W16_EPOCH, vers, Wc, WcT, bc)
-    return Wc, WcT, bc
+    _WCAT[key] = ([weakref.ref(W._base if W._base is not None else W) for W in Ws], _W16_EPOCH, vers, Wc, WcT, bc, Wclo)
+    return (Wc, WcT, bc, Wclo) if lo else (Wc, WcT, bc)
 
 
 def gemm_splitk_into(A, B, out, M, N, K, lda, ldb, ldc, transA, transB, batch0, batch1, sA, sB, sC, alpha=1.0):
@@ -319,9 +361,10 @@ def gemm_splitk_into(A, B, out, M, N, K, lda, ldb, ldc, transA, transB, batch0, 
     return out
 
 
-def gemm16(A16, B16, C, M, N, K, lda, ldb, ldc, bias=None, C2=None, alpha=1.0, act=0, splitk=1):
-    """C = act(alpha * A16 @ B16.T + bias) on bf16 operands (both k-contiguous); splitk < 0: slabs."""
-    _call("spe_gemm_bf16nt", _p(A16), _p(B16), _p(C), _p(bias), _p(C2), M, N, K, lda, ldb, ldc, float(alpha), int(act),
+def gemm16(A16, B16, C, M, N, K, lda, ldb, ldc, bias=None, C2=None, alpha=1.0, act=0, splitk=1, Alo=None, Blo=None):
+    """C = act(alpha * A16 @ B16.T + bias) on bf16 operands (both k-contiguous); splitk < 0: slabs.  Alo / Blo (both or
+    neither): the low parts of split operands - the product becomes A B + Alo B + A Blo."""
+    _call("spe_gemm_bf16nt", _p(A16), _p(B16), _p(Alo), _p(Blo), _p(C), _p(bias), _p(C2), M, N, K, lda, ldb, ldc, float(alpha), int(act),
           int(splitk), _st())
     return C
 
@@ -333,10 +376,11 @@ def gemm16_tn(A16, B16, C, M, N, R, lda, ldb, ldc, alpha=1.0, splitk=1):
 
 
 def gemm16_ex(A16, B16, M, N, K, lda, ldb, bias=None, C=None, C2=None, out16=None, out16T=None, colsum=None, aux=None,
-              alpha=1.0, act=0, res=None, rgamma=None):
+              alpha=1.0, act=0, res=None, rgamma=None, Alo=None, Blo=None, out16lo=None):
     """spe_gemm_bf16nt_ex: v = alpha * A16 @ B16.T + bias; C2 = v; v = act(v) or v * act'(aux); optional fp32 C [M,N], bf16
-    out16 [M,N], bf16 transposed out16T [N, ldt] (zero padded), colsum [N] += column sums.  All fp32 tensors have ld = N."""
-    _call("spe_gemm_bf16nt_ex", _p(A16), _p(B16), _p(C), _p(bias), _p(C2), _p(out16), N, _p(out16T),
+    out16 [M,N], bf16 transposed out16T [N, ldt] (zero padded), colsum [N] += column sums.  All fp32 tensors have ld = N.
+    Alo / Blo: low parts of split operands; out16lo [M,N]: bf16(v - out16), the low part of the result for the next split GEMM."""
+    _call("spe_gemm_bf16nt_ex", _p(A16), _p(B16), _p(Alo), _p(Blo), _p(C), _p(bias), _p(C2), _p(out16), _p(out16lo), N, _p(out16T),
           out16T.shape[1] if out16T is not None else 0, _p(colsum), _p(aux), _p(res), _p(rgamma), M, N, K, lda, ldb, N,
           float(alpha), int(act), _st())
 
@@ -369,10 +413,12 @@ def linear_res_fwd(x2, W, b, res, gamma, save=True, src=None):
     R, K = x2.shape
     N = W.shape[0]
     dev = x2.device
-    x16, x16T = act16(x2, save and not DW_TN, src)
+    sp = split_fwd()
+    x16, x16T, x16lo = act16(x2, save and not DW_TN, src, want_lo=sp)
     out = torch.empty((R, N), device=dev, dtype=torch.float32)
     y = torch.empty((R, N), device=dev, dtype=torch.float32) if save else None
-    gemm16_ex(x16, weight16(W)[0], R, N, K, K, K, bias=b, C=out, C2=y, res=res, rgamma=gamma)
+    Wt = weight16(W, lo=sp)
+    gemm16_ex(x16, Wt[0], R, N, K, K, K, bias=b, C=out, C2=y, res=res, rgamma=gamma, Alo=x16lo, Blo=Wt[2] if sp else None)
     return out, ((x16 if DW_TN else x16T), y)
 
 
@@ -405,21 +451,25 @@ def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True, src=None):
     Hd, N = W1.shape[0], W2.shape[0]
     dev = x2.device
     # save = False (no gradient wanted: inference): none of the tensors that only the backward reads is produced
-    x16, x16T = act16(x2, save and not DW_TN, src)
+    sp = split_fwd()                         # bf16s forward: both products on (hi, lo) operand pairs, fc1 emits gelu(pre) as a pair
+    x16, x16T, x16lo = act16(x2, save and not DW_TN, src, want_lo=sp)
     Rp = ((R + 63) // 64) * 64
     pre = torch.empty((R, Hd), device=dev, dtype=torch.float32) if save else None
     h16 = torch.empty((R, Hd), device=dev, dtype=torch.bfloat16)
+    h16lo = torch.empty((R, Hd), device=dev, dtype=torch.bfloat16) if sp else None
     h16T = torch.empty((Hd, Rp), device=dev, dtype=torch.bfloat16) if (save and not DW_TN) else None
-    gemm16_ex(x16, weight16(W1)[0], R, Hd, K, K, K, bias=b1, C2=pre, out16=h16, out16T=h16T, act=2)
+    W1t, W2t = weight16(W1, lo=sp), weight16(W2, lo=sp)
+    W1lo, W2lo = (W1t[2], W2t[2]) if sp else (None, None)
+    gemm16_ex(x16, W1t[0], R, Hd, K, K, K, bias=b1, C2=pre, out16=h16, out16T=h16T, act=2, Alo=x16lo, Blo=W1lo, out16lo=h16lo)
     y = torch.empty((R, N), device=dev, dtype=torch.float32)
     if DW_TN:
         x16T, h16T = x16, h16            # what the backward gets: the row-major copies
     if res is None:
-        gemm16(h16, weight16(W2)[0], y, R, N, Hd, Hd, Hd, N, bias=b2)
+        gemm16(h16, W2t[0], y, R, N, Hd, Hd, Hd, N, bias=b2, Alo=h16lo, Blo=W2lo)
         return y, (x16T, pre, h16T)
     # LayerScale residual in the fc2 epilogue: out = res + gamma * y ; y is kept for the gamma gradient
     out = torch.empty((R, N), device=dev, dtype=torch.float32)
-    gemm16_ex(h16, weight16(W2)[0], R, N, Hd, Hd, Hd, bias=b2, C=out, C2=y if save else None, res=res, rgamma=gamma)
+    gemm16_ex(h16, W2t[0], R, N, Hd, Hd, Hd, bias=b2, C=out, C2=y if save else None, res=res, rgamma=gamma, Alo=h16lo, Blo=W2lo)
     return out, (x16T, pre, h16T, y)
 
 
@@ -489,19 +539,22 @@ def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, 
     return dx, dW1, db1, dW2, db2
 
 
-def act16(x2, wantT, src=None):
-    """bf16 copies (row-major, and transposed when wantT) of an activation [R,K].  `src`: the tensor object the caller
-    holds (x2 is a reshape of it) - the copies are remembered ON that object (attribute, checked against its version
-    counter), so an activation that feeds several Linears (the decoder's memory, positional embedding, tgt, query_pos;
-    q / k / v of the class attention) is converted once; they die with the tensor."""
+def act16(x2, wantT, src=None, want_lo=False):
+    """bf16 copies (row-major, transposed when wantT, and the low part of the split operand when want_lo) of an activation
+    [R,K] -> (x16, x16T, x16lo).  `src`: the tensor object the caller holds (x2 is a reshape of it) - the copies are
+    remembered ON that object (attribute, checked against its version counter), so an activation that feeds several Linears
+    (the decoder's memory, positional embedding, tgt, query_pos; q / k / v of the class attention) is converted once; they die
+    with the tensor."""
     if src is not None:
         ent = getattr(src, "_spe16", None)
-        if ent is not None and ent[0] == src._version and ent[1].shape == x2.shape and (ent[2] is not None or not wantT):
-            return ent[1], ent[2]
-    x16, x16T = cvt_bf16(x2, True, wantT)
+        if (ent is not None and ent[0] == src._version and ent[1].shape == x2.shape and (ent[2] is not None or not wantT)
+                and (ent[3] is not None or not want_lo)):
+            return ent[1], ent[2], ent[3]
+    x16lo = torch.empty(x2.shape, device=x2.device, dtype=torch.bfloat16) if want_lo else None
+    x16, x16T = cvt_bf16(x2, True, wantT, out_lo=x16lo)
     if src is not None:
-        src._spe16 = (src._version, x16, x16T)
-    return x16, x16T
+        src._spe16 = (src._version, x16, x16T, x16lo)
+    return x16, x16T, x16lo
 
 
 def linear_fwd(x2, W, b, act=0, want_pre=False, save_for_dw=True, src=None):
@@ -513,8 +566,10 @@ def linear_fwd(x2, W, b, act=0, want_pre=False, save_for_dw=True, src=None):
     y = torch.empty((R, N), device=x2.device, dtype=torch.float32)
     pre = torch.empty_like(y) if want_pre else None
     if _lin16_ok(R, N, K) and W.is_contiguous():
-        x16, x16T = act16(x2, save_for_dw and not DW_TN, src)
-        gemm16(x16, weight16(W)[0], y, R, N, K, K, K, N, bias=b, C2=pre, act=act)
+        sp = split_fwd()
+        x16, x16T, x16lo = act16(x2, save_for_dw and not DW_TN, src, want_lo=sp)
+        Wt = weight16(W, lo=sp)
+        gemm16(x16, Wt[0], y, R, N, K, K, K, N, bias=b, C2=pre, act=act, Alo=x16lo, Blo=Wt[2] if sp else None)
         return y, pre, ((x16 if DW_TN else x16T) if save_for_dw else x2)
     gemm(x2, W, y, R, N, K, K, K, N, False, True, bias=b, C2=pre, act=act)
     return y, pre, x2
@@ -594,26 +649,28 @@ def act_bwd(dy, aux, mode):
 
 # ---- LayerNorm ------------------------------------------------------------------------------
 def layernorm_fwd(x2, g, b, eps, want16=False):
-    """-> (y, mean, rstd[, y16]); want16: also the bf16 copy of y (what act16 would convert) from the same pass."""
+    """-> (y, mean, rstd[, y16, y16lo]); want16: also the bf16 copy of y (what act16 would convert) from the same pass, and
+    in the bf16s forward the low part of the split operand (else y16lo is None)."""
     _chk(x2, g, b)
     R, C = x2.shape
     y = torch.empty_like(x2)
     mean = torch.empty((R,), device=x2.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     y16 = torch.empty((R, C), device=x2.device, dtype=torch.bfloat16) if want16 else None
-    _call("spe_layernorm_fwd", _p(x2), _p(g), _p(b), _p(y), _p(mean), _p(rstd), R, C, float(eps), _p(y16), _st())
-    return (y, mean, rstd, y16) if want16 else (y, mean, rstd)
+    y16lo = torch.empty((R, C), device=x2.device, dtype=torch.bfloat16) if (want16 and split_fwd()) else None
+    _call("spe_layernorm_fwd", _p(x2), _p(g), _p(b), _p(y), _p(mean), _p(rstd), R, C, float(eps), _p(y16), _p(y16lo), _st())
+    return (y, mean, rstd, y16, y16lo) if want16 else (y, mean, rstd)
 
 
 def produces16(R, C):
     """A producer of a [R, C] activation should also emit its bf16 copy: the consumer Linear takes the bf16-copy GEMM path and
     needs no transposed copy (DW_TN)."""
-    return DW_TN and LINEAR16 and _PRECISION == 0 and R >= LINEAR16_MIN_ROWS and C % 8 == 0
+    return DW_TN and LINEAR16 and _PRECISION != 1 and R >= LINEAR16_MIN_ROWS and C % 8 == 0
 
 
-def attach16(t, x16):
-    """Remember the bf16 copy ON the activation tensor (what act16 looks up)."""
-    t._spe16 = (t._version, x16, None)
+def attach16(t, x16, x16lo=None):
+    """Remember the bf16 copy (and the low part of the split operand) ON the activation tensor (what act16 looks up)."""
+    t._spe16 = (t._version, x16, None, x16lo)
 
 
 def layernorm_bwd(dy2, x2, g, mean, rstd, dg_out=None, db_out=None, add=None):
@@ -824,10 +881,14 @@ def talking_fused(mode, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, ws_stats, ws_
           _p(ws_stats), _p(ws_w), _p(outT), B, H, N, dh, FUSED_NWG[mode], float(p_drop), seed, offset, _st())
 
 
-def score_blocks(B, H, N, device):
-    """Uninitialised blocked bf16 score tensor [B,H,nt,nt,64,4] (16x16 blocks; see csrc/attn_contract.hip)."""
+PD_SCALE = 256.0       # spe_talking_fused mode 1 stores fp16(P'd * 2^8) (csrc/attn_fused.hip: SPE_PD_SCALE)
+
+
+def score_blocks(B, H, N, device, dtype=torch.bfloat16):
+    """Uninitialised blocked score tensor [B,H,nt,nt,64,4] (16x16 blocks; see csrc/attn_contract.hip): fp16 for the forward
+    P'd (written scaled by PD_SCALE), bf16 for the backward dS."""
     nt = (N + 15) // 16
-    return torch.empty((B, H, nt, nt, 64, 4), device=device, dtype=torch.bfloat16)
+    return torch.empty((B, H, nt, nt, 64, 4), device=device, dtype=dtype)
 
 
 def attn_pack16(x4):
@@ -848,10 +909,13 @@ def frag_record_elems(dh):
     return full * 512 + (256 if 0 < rem <= 16 else 0)
 
 
+F16 = 1000             # attn_pack_multi: kind + F16 = the same layout with fp16 elements (forward operands: q, k, v)
+
+
 def attn_pack_multi(jobs):
     """jobs: list of (x4 [B,N,H,dh] fp32 view with unit last stride, scale, kind): kind 32 -> attn_pack layout (32-wide
-    steps + 16-wide tail), 16 -> attn_pack16 layout, 322 -> 32-wide steps only (mha_flash).  N and dh may differ between
-    jobs (same B and H).  One launch; -> list of packed bf16 tensors."""
+    steps + 16-wide tail), 16 -> attn_pack16 layout, 322 -> 32-wide steps only (mha_flash); kind + F16: fp16 elements instead
+    of bf16.  N and dh may differ between jobs (same B and H).  One launch; -> list of packed bf16 / fp16 tensors."""
     B, _, H, _ = jobs[0][0].shape
     n = len(jobs)
     outs = []
@@ -859,17 +923,17 @@ def attn_pack_multi(jobs):
         Bn, N, Hn, dh = x4.shape
         assert Bn == B and Hn == H and x4.stride(3) == 1 and x4.dtype == torch.float32
         nt = (N + 15) // 16
-        if kind == 32:
+        if kind % F16 == 32:
             shape = (B, H, nt, frag_record_elems(dh))
-        elif kind == 322:
+        elif kind % F16 == 322:
             shape = (B, H, nt, (dh + 31) // 32, 64, 8)
         else:
             shape = (B, H, nt, (dh + 15) // 16, 64, 4)
-        outs.append(torch.empty(shape, device=x4.device, dtype=torch.bfloat16))
+        outs.append(torch.empty(shape, device=x4.device, dtype=torch.float16 if kind >= F16 else torch.bfloat16))
     xs = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs])
     strides = (ctypes.c_long * (3 * n))(*[s for j in jobs for s in (j[0].stride(0), j[0].stride(1), j[0].stride(2))])
     scales = (ctypes.c_float * n)(*[float(j[1]) for j in jobs])
-    kinds = (ctypes.c_int * n)(*[{32: 0, 16: 1, 322: 2}[j[2]] for j in jobs])
+    kinds = (ctypes.c_int * n)(*[{32: 0, 16: 1, 322: 2}[j[2] % F16] + (16 if j[2] >= F16 else 0) for j in jobs])
     optr = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
     Ns = (ctypes.c_int * n)(*[j[0].shape[1] for j in jobs])
     dhs = (ctypes.c_int * n)(*[j[0].shape[3] for j in jobs])
@@ -927,15 +991,18 @@ def _contract_ws(device):
     return ent
 
 
-def attn_contract(T, X16, out4, trans, alpha=1.0, out16=None):
+def attn_contract(T, X16, out4, trans, alpha=1.0, out16=None, out16lo=None):
     """out4[b, row, h, :] = alpha * sum T[b,h][q,key] x[.., :]  (trans=False: rows = q, sum over keys; True: rows = keys,
     sum over q).  out4: [B,N,H,dh] fp32 view with unit last stride.  out16: optional bf16 tensor addressed with the SAME element
-    strides (the bf16 copy of the result for the Linear that consumes it)."""
+    strides (the bf16 copy of the result for the Linear that consumes it).  Element formats from the dtypes: bf16 T x bf16 X16;
+    fp16 T x fp16 X16 (trans=False: the forward P'd V); fp16 T x bf16 X16 (trans=True: dV)."""
     B, N, H, dh = out4.shape
     assert out4.stride(3) == 1
+    tf, xf = T.dtype == torch.float16, X16.dtype == torch.float16
+    fmt = {(False, False): 0, (True, True): 1, (True, False): 2}[(tf, xf)]
     ws, cnt = _contract_ws(out4.device)
     _call("spe_attn_contract", _p(T), _p(X16), _p(out4), out4.stride(0), out4.stride(1), out4.stride(2), B, H, N, dh,
-          int(trans), float(alpha), _p(ws), _p(cnt), ws.numel(), _p(out16), _st())
+          int(trans), fmt, float(alpha), _p(ws), _p(cnt), ws.numel(), _p(out16), _p(out16lo), _st())
     return out4
 
 

@@ -33,6 +33,7 @@ class _Linear(Function):
         return y.view(*shp[:-1], W.shape[0])
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dy):
         x2, W, aux = ctx.saved_tensors
         dy2 = dy.reshape(-1, W.shape[0])
@@ -70,10 +71,12 @@ class _MultiLinear(Function):
             x2 = x2.contiguous()
         R, Kd = x2.shape
         N = Ws[0].shape[0]
-        Wc, WcT, bc = K.weightcat16(Ws, bs)
-        x16, _ = K.act16(x2, False, x)
+        sp = K.split_fwd()                    # bf16s forward: (hi, lo) operand pairs
+        cat = K.weightcat16(Ws, bs, lo=sp)
+        Wc, WcT, bc = cat[:3]
+        x16, _, x16lo = K.act16(x2, False, x, want_lo=sp)
         y = torch.empty((R, n * N), device=x.device, dtype=torch.float32)
-        K.gemm16(x16, Wc, y, R, n * N, Kd, Kd, Kd, n * N, bias=bc)
+        K.gemm16(x16, Wc, y, R, n * N, Kd, Kd, Kd, n * N, bias=bc, Alo=x16lo, Blo=cat[3] if sp else None)
         ctx.params = (Ws, bs)
         ctx.save_for_backward(x16, WcT)
         ctx.dims = (n, N, Kd, R)
@@ -81,6 +84,7 @@ class _MultiLinear(Function):
         return tuple(y[..., i * N:(i + 1) * N] for i in range(n))
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, *dys):
         x16, WcT = ctx.saved_tensors
         n, N, Kd, R = ctx.dims
@@ -134,6 +138,7 @@ class _LayerNorm(Function):
         return y.view(x.shape)
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dy):
         x2, g, mean, rstd = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
@@ -166,6 +171,7 @@ class _ResDropLayerNorm(Function):
         return y.view(x.shape)
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dy):
         sm, g, mean, rstd = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
@@ -191,9 +197,9 @@ class _LayerNormSkip(Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         if K.produces16(*x2.shape):          # the Linear behind this norm runs on bf16 copies: emit its operand here
-            y, mean, rstd, y16 = K.layernorm_fwd(x2, g, b, eps, want16=True)
+            y, mean, rstd, y16, y16lo = K.layernorm_fwd(x2, g, b, eps, want16=True)
             yv = y.view(x.shape)
-            K.attach16(yv, y16)
+            K.attach16(yv, y16, y16lo)
         else:
             y, mean, rstd = K.layernorm_fwd(x2, g, b, eps)
             yv = y.view(x.shape)
@@ -202,6 +208,7 @@ class _LayerNormSkip(Function):
         return yv, x.view_as(x)
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dy, dskip):
         x2, g, mean, rstd = ctx.saved_tensors
         gp, bp = ctx.params
@@ -241,6 +248,7 @@ class _LayerScaleResidual(Function):
         return out.view(x.shape)
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dout):
         y2, gamma, ss = ctx.saved_tensors
         d2 = dout.reshape(-1, dout.shape[-1]).contiguous()
@@ -269,6 +277,7 @@ class _Dropout(Function):
         return K.dropout(x.contiguous(), p, seed, off)
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dy):
         return K.dropout(dy.contiguous(), ctx.p, ctx.seed, ctx.off), None
 
@@ -307,6 +316,7 @@ class _TalkingHeadsAttention(Function):
         return O
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dO):
         qkv, P, Pd, Wl, Ww = ctx.saved_tensors
         B, N, C, H, dh, ld, scale, p_drop, seed, off = ctx.meta
@@ -335,9 +345,9 @@ class _TalkingHeadsAttention(Function):
 
 class _TalkingHeadsAttentionFused(Function):
     """Same operator on the fused score kernels (csrc/attn_fused.hip): no fp32 N x N tensor in HBM.
-    forward : pack q*scale*log2e,k -> statistics pass -> write pass (P'd, blocked bf16) -> O = P'd V (streaming contraction)
+    forward : pack q*scale*log2e, k, v (fp16) -> statistics pass -> write pass (P'd * 2^8, blocked fp16) -> O = P'd V (streaming contraction)
     backward: dV = P'd^T dO ; pass 1 (D, dWw, dbw) ; pass 2 (dS blocked bf16, dWl, dbl) ; dQ, dK contractions.
-    Saved for backward: qkv, the packed q/k fragments, P'd (bf16) and the row statistics."""
+    Saved for backward: qkv, the packed q/k fragments (fp16), P'd (fp16) and the row statistics."""
 
     @staticmethod
     def forward(ctx, qkv, Wl, bl, Ww, bw, H, scale, p_drop):
@@ -350,25 +360,28 @@ class _TalkingHeadsAttentionFused(Function):
         nt = (N + 15) // 16
         spw0, _ = K.fused_plan(B, N, 0)
         # the fused kernels work in the log2 domain: scale * log2(e) is folded into the Q fragments
-        Qf, Kf, V16 = K.attn_pack_multi([(q, scale * K.LOG2E, 32), (k, 1.0, 32), (v, 1.0, 16)])
+        # forward operands in fp16 (O(1) values: 3 more mantissa bits than bf16 at the same size and MFMA rate)
+        Qf, Kf, V16 = K.attn_pack_multi([(q, scale * K.LOG2E, 32 + K.F16), (k, 1.0, 32 + K.F16), (v, 1.0, 16 + K.F16)])
         Wl, bl, Ww, bw = Wl.contiguous(), bl.contiguous(), Ww.contiguous(), bw.contiguous()
         ws_stats = torch.empty((B * nt * 8 * H * 32,), device=qkv.device, dtype=torch.float32)
         seed, off = K.next_rng() if p_drop > 0 else (0, 0)
         K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws_stats, None, None, B, H, N, dh, 0.0, 0, 0)
         M, IL = K.attn_merge(ws_stats, B, H, N, spw0, 0)
-        Pd = K.score_blocks(B, H, N, qkv.device)
+        Pd = K.score_blocks(B, H, N, qkv.device, torch.float16)          # fp16(P'd * PD_SCALE)
         K.talking_fused(1, Qf, Kf, None, None, Wl, bl, Ww, bw, M, IL, None, None, None, Pd, B, H, N, dh, p_drop, seed, off)
         O = torch.empty((B, N, C), device=qkv.device, dtype=torch.float32)
         O16 = torch.empty((B * N, C), device=qkv.device, dtype=torch.bfloat16) if K.produces16(B * N, C) else None
-        K.attn_contract(Pd, V16, O.view(B, N, H, dh), False, out16=O16)
+        O16lo = torch.empty((B * N, C), device=qkv.device, dtype=torch.bfloat16) if (O16 is not None and K.split_fwd()) else None
+        K.attn_contract(Pd, V16, O.view(B, N, H, dh), False, alpha=1.0 / K.PD_SCALE, out16=O16, out16lo=O16lo)
         if O16 is not None:
-            K.attach16(O, O16)               # the output projection's operand, written by the contraction's epilogue
+            K.attach16(O, O16, O16lo)        # the output projection's operand, written by the contraction's epilogue
         ctx.meta = (B, N, C, H, dh, nt, scale, p_drop, seed, off)
         ctx.wparams = (Wl, bl, Ww, bw)      # leaves: looked up in backward for their gradient buckets
         ctx.save_for_backward(qkv, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw)
         return O
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dO):
         qkv, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw = ctx.saved_tensors
         B, N, C, H, dh, nt, scale, p_drop, seed, off = ctx.meta
@@ -390,7 +403,7 @@ class _TalkingHeadsAttentionFused(Function):
         K.talking_fused(3, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, None, ws_w, dS, B, H, N, dh, p_drop, seed, off)
         # dV[key,d] = sum_q P'd[q,key] dO[q,d] - issued here, between backward pass 2 and the contractions that re-read
         # its 554 MB of dS: a streaming read right after a pass that wrote that much runs ~20 % slower (measured)
-        K.attn_contract(Pd, dO16, dv, True)
+        K.attn_contract(Pd, dO16, dv, True, alpha=1.0 / K.PD_SCALE)
         dWl, dbl, dWw, dbw = K.talking_wgrad_reduce(ws_w, H, ctx.wparams)
         # dQ[q,d] = scale * sum_key dS[q,key] K[key,d] ; dK[key,d] = scale * sum_q dS[q,key] Q[q,d]
         K.attn_contract(dS, K16, dq, False, alpha=scale)
@@ -417,6 +430,7 @@ class _MlpGelu(Function):
         return y.view(*shp[:-1], W2.shape[0])
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dy):
         x16T, pre, h16T, W1, W2 = ctx.saved_tensors
         dy2 = dy.reshape(-1, W2.shape[0])
@@ -453,6 +467,7 @@ class _LinearRes(Function):
         return out.view(xres.shape)
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dout):
         x16T, y, W, gamma = ctx.saved_tensors
         d2 = dout.reshape(-1, W.shape[0])
@@ -496,6 +511,7 @@ class _MlpGeluRes(Function):
         return out.view(xres.shape)
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dout):
         x16T, pre, h16T, y, W1, W2, gamma = ctx.saved_tensors
         d2 = dout.reshape(-1, W2.shape[0])
@@ -531,11 +547,11 @@ def mlp_gelu(x, W1, b1, W2, b2):
 
 
 def talking_heads_attention(qkv, Wl, bl, Ww, bw, num_heads, scale, p_drop=0.0, fused=None):
-    """fused=None: use the fused kernels in bf16 mode when the head geometry is supported; the 3-term
-    (bf16x3) parity mode keeps the fp32 materialised path."""
+    """fused=None: use the fused kernels in the bf16 / bf16s modes when the head geometry is supported (their forward runs
+    on fp16 operands in both modes, csrc/attn_fused.hip); the 3-term (bf16x3) parity mode keeps the fp32 materialised path."""
     dh = qkv.shape[-1] // (3 * num_heads)
     if fused is None:
-        fused = K.get_precision() == "bf16" and K.fused_supported(num_heads, dh)
+        fused = K.get_precision() != "bf16x3" and K.fused_supported(num_heads, dh)
     fn = _TalkingHeadsAttentionFused if fused else _TalkingHeadsAttention
     return fn.apply(qkv, Wl, bl, Ww, bw, num_heads, scale, p_drop)
 
@@ -579,6 +595,7 @@ class _Attention(Function):
         return O, None
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dO, _dmap):
         q, k, v, P, Pd = ctx.saved_tensors
         B, Lq, Lk, H, dk, dv, ld, scale, p_drop, seed, off = ctx.meta
@@ -626,6 +643,7 @@ class _AttentionFlash(Function):
         return O
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dO):
         Qf, Kf, Q16, K16, Vf, O, lse, mask_u8, keep = ctx.saved_tensors
         B, Lq, Lk, H, dk, dv, nch, scale, p_drop = ctx.meta
@@ -648,7 +666,7 @@ def attention(q, k, v, key_padding_mask=None, scale=1.0, p_drop=0.0, need_map=Fa
         m = key_padding_mask.to(torch.uint8).contiguous()
     # flash kernels when no map is wanted and the key axis is long (decoder self-attention over 100 queries is cheaper
     # through the three small materialising launches)
-    if (FLASH_MHA and not need_map and K.get_precision() == "bf16" and q.is_cuda and q.shape[3] <= 96 and v.shape[3] <= 64
+    if (FLASH_MHA and not need_map and K.get_precision() != "bf16x3" and q.is_cuda and q.shape[3] <= 96 and v.shape[3] <= 64
             and k.shape[1] >= FLASH_MIN_KEYS and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1):
         return _AttentionFlash.apply(q, k, v, m, float(scale), float(p_drop)), None
     return _Attention.apply(q, k, v, m, float(scale), float(p_drop), need_map)
@@ -669,6 +687,7 @@ class _PatchEmbed(Function):
         return y.view(B, (Hi // P) * (Wi // P), W.shape[0])
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dy):
         xsave, W2 = ctx.saved_tensors
         dy2 = dy.reshape(-1, W2.shape[0]).contiguous()
@@ -689,6 +708,7 @@ class _AddRows(Function):
         return K.add_rows(x.contiguous(), table.contiguous())
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dy):
         dy = dy.contiguous()
         dt = None
@@ -711,6 +731,7 @@ class _Add(Function):
         return K.add_rows(a, b)
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dy):
         return dy, dy
 
@@ -729,6 +750,7 @@ class _BicubicGrid(Function):
         return K.bicubic(pe[0].contiguous(), gh, gw, h, w).unsqueeze(0)
 
     @staticmethod
+    @K.backward_scope
     def backward(ctx, dy):
         gh, gw, h, w = ctx.g
         return K.bicubic(dy[0].contiguous(), gh, gw, h, w, backward=True).unsqueeze(0), None, None, None, None

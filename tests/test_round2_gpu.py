@@ -295,14 +295,14 @@ def test_fused_attention_with_dropout(dev, H, N, dh, B, p):
     # --- recover the mask: the write pass with and without dropout on the same statistics
     with torch.no_grad():
         v5 = qkv.detach().view(B, N, 3, H, dh)
-        Qf, Kf, _ = K.attn_pack_multi([(v5[:, :, 0], scale * K.LOG2E, 32), (v5[:, :, 1], 1.0, 32), (v5[:, :, 2], 1.0, 16)])
+        Qf, Kf, _ = K.attn_pack_multi([(v5[:, :, 0], scale * K.LOG2E, 32 + K.F16), (v5[:, :, 1], 1.0, 32 + K.F16), (v5[:, :, 2], 1.0, 16)])
         nt = (N + 15) // 16
         spw0, _ = K.fused_plan(B, N, 0)
         ws = torch.empty((B * nt * 8 * H * 32,), device=dev)
         args = [t.detach().contiguous() for t in (Wl, bl, Ww, bw)]
         K.talking_fused(0, Qf, Kf, None, None, *args, None, None, None, ws, None, None, B, H, N, dh, 0.0, 0, 0)
         M, IL = K.attn_merge(ws, B, H, N, spw0, 0)
-        Pd, P0 = K.score_blocks(B, H, N, dev), K.score_blocks(B, H, N, dev)
+        Pd, P0 = K.score_blocks(B, H, N, dev, torch.float16), K.score_blocks(B, H, N, dev, torch.float16)      # fp16(P'd * 2^8)
         K.talking_fused(1, Qf, Kf, None, None, *args, M, IL, None, None, None, Pd, B, H, N, dh, p, seed, off)
         K.talking_fused(1, Qf, Kf, None, None, *args, M, IL, None, None, None, P0, B, H, N, dh, 0.0, 0, 0)
         dPd, dP0 = _dense_from_blocks(Pd, N).float(), _dense_from_blocks(P0, N).float()

@@ -36,7 +36,7 @@ def register_reference_backbones():
     import models.cait as rc
     from timm.models.registry import register_model
     from torch import nn
-    for name, c in cc.CASES.items():
+    for name, c in cc.ALL_CASES.items():
         if hasattr(rc, c["backbone"]):
             continue                                     # the reference's own factory (TSCAM_cait_XXS24)
 
@@ -47,6 +47,17 @@ def register_reference_backbones():
             return m, _c["width"]
         fac.__name__ = c["backbone"]
         register_model(fac)
+
+
+def checkpoint_blocks(model):
+    """Full-depth cases: run every backbone block of the REFERENCE under torch.utils.checkpoint and drop the per-block
+    `attention_map` clone (models/cait.py:392; only blocks_token_only[0]'s map is read, :658) - harness-side memory
+    management, the arithmetic and its order are the reference's."""
+    from torch.utils.checkpoint import checkpoint
+    body = model.backbone[0].body
+    for blk in body.blocks:
+        blk.forward = (lambda x, _f=blk.forward: checkpoint(_f, x, use_reentrant=False))
+        blk.attn.register_forward_hook(lambda m, i, o: setattr(m, "attention_map", None))
 
 
 def keep(t):
@@ -75,7 +86,8 @@ def run_case(name):
     from models import build_model as ref_build
     import util.misc as um
     from oracle import spe_oracle as O
-    c = cc.CASES[name]
+    c = cc.ALL_CASES[name]
+    full = name in cc.FULL_CASES
     args, (pmodel, *_), tensors, mask, targets = cc.build_case(name)
     sd = {k: v.detach().clone() for k, v in pmodel.state_dict().items()}
     del pmodel
@@ -83,6 +95,8 @@ def run_case(name):
         model, crit, crit_r, pp, rpp = ref_build(copy.deepcopy(args))
     model.load_state_dict(sd, strict=True)                   # identical keys and shapes: the boundary contract
     model.train(); crit.eval(); crit_r.eval()                # every drop rate is 0; eval criteria = no jitter
+    if full:
+        checkpoint_blocks(model)
     t0 = time.time()
     out = model(um.NestedTensor(tensors, mask))
     l0 = crit(out[0], targets)
@@ -118,6 +132,11 @@ def run_case(name):
             "sd_checksum": float(sum(v.double().abs().sum() for v in sd.values() if v.is_floating_point()))}
     path = os.path.join(OUT, f"cfg_{name}.pt")
     torch.save(blob, path)
+    if full:                                                 # the oracle's eager autograd does not fit here at full depth
+        rep = {"reference_seconds": round(t_ref, 2), "pseudo_label_top2_margin": margin, "fixture_bytes": os.path.getsize(path),
+               "total_loss_reference": float(total.detach()), "blocks_checkpointed": True}
+        print(name, json.dumps(rep))
+        return rep
 
     # ---- oracle against the reference on the same case (the in-container parity report)
     t0 = time.time()
@@ -154,7 +173,7 @@ def run_case(name):
 
 def main():
     register_reference_backbones()
-    names = sys.argv[1:] or list(cc.CASES)
+    names = sys.argv[1:] or list(cc.CASES)                   # the full-depth cases (cc.FULL_CASES) are named explicitly
     rpath = os.path.join(OUT, "cfg_report.json")
     report = json.load(open(rpath)) if os.path.exists(rpath) else {}
     for n in names:
