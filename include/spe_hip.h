@@ -282,6 +282,7 @@ int spe_box_loss_bwd(const long* srow, const int* lidx, const float* g_l1, const
  * encoder, models/transformer.py:275-277): softmax(scale q k^T + key_padding_mask), dropout, . v, forward and backward
  * without the [B,H,Lq,Lk] score tensor.  Operands are fragments from spe_attn_pack_multi: kind 2 (32-wide steps) of
  * q*scale*log2(e), k, v, dO -> Qf, Kf, Vf, dOf ; kind 1 (16-wide) of v, k, q*scale*log2(e), dO -> V16, K16, Q16, dO16.
+ * Element formats: Qf, Kf and V16 FP16 (kinds + 16: the forward operands), Vf, dOf, K16, Q16, dO16 BF16.
  * q/k head dim <= 96, v head dim <= 64; mask [B,Lk] uint8 (1 = padded) or NULL; Philox dropout on element index
  * ((b*H+h)*Lq + q)*ld4 + key, ld4 = Lk rounded up to 4 (the stream spe_softmax_fwd draws from); the forward records the
  * keep flags in keepbits (B*H*ntq*ntk*4 64-bit words, needed when p_drop > 0) and the backward reads them.

@@ -5,7 +5,12 @@
 // writing the [B,H,Lq,Lk] score tensor (the materialising path moves 4 such fp32 tensors per layer: 53 MB each for
 // the decoder's 200 x 4150 cross-attention, 1.1 GB each for an encoder layer at N = 4150).
 //
-// Same building blocks as the talking-heads kernels: bf16 MFMA operand fragments packed by spe_attn_pack_multi, the
+// Element formats as in attn_fused.hip: the FORWARD operands - q * scale * log2(e), k (Qf, Kf), v (V16) and the probabilities of
+// the P.V product - are O(1) and go through fp16 (3 more mantissa bits than bf16, same size and MFMA rate: the bf16 version of
+// this kernel alone cost 1.1e-3 of pred_logits at cfg2, tools/error_budget.py); the backward recomputes S from the same fp16
+// fragments and keeps bf16 wherever a gradient is an operand (Vf.dOf, P^T dO16, dS K16, dS^T Q16).
+//
+// Same building blocks as the talking-heads kernels: 16-bit MFMA operand fragments packed by spe_attn_pack_multi, the
 // swapped orientation S^T = K_tile . Q_tile^T so that a lane owns one query and 4 keys, and the 16x16 C tile reused
 // directly as the B operand of v_mfma_f32_16x16x16_bf16 for the second contraction (P.V, dS.K, P^T.dO, dS^T.Q).
 // A wave owns one 16-row tile of the non-streamed axis; the 4 waves of a workgroup share the streamed tile's fragments
@@ -44,8 +49,19 @@ struct MhaArgs {
 __device__ __forceinline__ u32x4m_t mha_frag(const u32x4m_t* base, long rec, int ds, int st, int lane) {
     return base[(rec * ds + st) * 64 + lane];
 }
+typedef _Float16 f16x8f_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4f_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4_t mha_mfma32(u32x4m_t a, u32x4m_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// fp16 operands: the K.Q^T products of all three kernels
+__device__ __forceinline__ f32x4_t mha_mfma32h(u32x4m_t a, u32x4m_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8f_t, a), __builtin_bit_cast(f16x8f_t, b), c, 0, 0, 0);
+}
+// fp16 operands: P.V of the forward (probabilities relative to the running maximum are in [0, 1])
+__device__ __forceinline__ f32x4_t mha_mfma16h(uint2 a, float p0, float p1, float p2, float p3, f32x4_t c) {
+    f16x4f_t v; v[0] = (_Float16)p0; v[1] = (_Float16)p1; v[2] = (_Float16)p2; v[3] = (_Float16)p3;
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4f_t, a), v, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4_t mha_mfma16(uint2 a, s16x4m_t b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4m_t, a), b, c, 0, 0, 0);
@@ -116,7 +132,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(MhaArgs a) {
         f32x4_t s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < MHA_DSK; ++st)
-            if (st < dsk) s = mha_mfma32(sK[buf][st * 64 + lane], qf[st], s);
+            if (st < dsk) s = mha_mfma32h(sK[buf][st * 64 + lane], qf[st], s);
         const int kb = kt * 16 + 4 * (lane >> 4);
         float sv[4], tmax = -INFINITY;
 #pragma unroll
@@ -147,12 +163,11 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(MhaArgs a) {
         }
         l = l * alpha + (p[0] + p[1] + p[2] + p[3]);
         m = mn;
-        const s16x4m_t pb = mha_bf16x4(pd[0], pd[1], pd[2], pd[3]);
 #pragma unroll
         for (int d = 0; d < MHA_DVT; ++d)
             if (d < dvt) {
                 o[d] *= alpha;
-                o[d] = mha_mfma16(sV[buf][d * 64 + lane], pb, o[d]);
+                o[d] = mha_mfma16h(sV[buf][d * 64 + lane], pd[0], pd[1], pd[2], pd[3], o[d]);
             }
         if (kt + 1 < kt1) commit(buf ^ 1, sr);
         __syncthreads();
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(MhaArgs a) {
         f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < MHA_DSK; ++st)
-            if (st < dsk) s = mha_mfma32(sK[buf][st * 64 + lane], qf[st], s);
+            if (st < dsk) s = mha_mfma32h(sK[buf][st * 64 + lane], qf[st], s);
 #pragma unroll
         for (int st = 0; st < MHA_DSV; ++st)
             if (st < dsv) dp = mha_mfma32(sV[buf][st * 64 + lane], dof[st], dp);
@@ -355,7 +370,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(MhaArgs a) {
         f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < MHA_DSK; ++st)
-            if (st < dsk) s = mha_mfma32(sQ[buf][st * 64 + lane], kf[st], s);          // C[q, key]
+            if (st < dsk) s = mha_mfma32h(sQ[buf][st * 64 + lane], kf[st], s);         // C[q, key]
 #pragma unroll
         for (int st = 0; st < MHA_DSV; ++st)
             if (st < dsv) dp = mha_mfma32(sdO[buf][st * 64 + lane], vf[st], dp);

@@ -67,10 +67,22 @@ def load():
 
 
 _fn = {}
+COUNTS = None            # entry point -> launches since count_launches(True); None = not counting
+
+
+def count_launches(on=True):
+    """Start (fresh counters) / stop counting the launches per entry point; -> the counters collected so far.  bench.py records
+    them for one step so that a throughput number and a parity claim can be tied to the same kernel set."""
+    global COUNTS
+    prev = COUNTS
+    COUNTS = {} if on else None
+    return prev
 
 
 def call(name, *args):
     """Invoke an entry point; raise on a non-zero status."""
+    if COUNTS is not None:
+        COUNTS[name] = COUNTS.get(name, 0) + 1
     f = _fn.get(name)
     if f is None:
         f = _fn[name] = getattr(load(), name)

@@ -629,7 +629,9 @@ class _AttentionFlash(Function):
         Lk, dv = k.shape[1], v.shape[3]
         sc = scale * K.LOG2E
         need_bwd = any(ctx.needs_input_grad[:3])
-        jobs = [(q, sc, 322), (k, 1.0, 322), (v, 1.0, 16)]
+        # forward operands (q, k for the scores - also recomputed by the backward - and v for P.V) in fp16; the 16-wide q / k and the
+        # 32-wide v fragments meet gradients in the backward and stay bf16
+        jobs = [(q, sc, 322 + K.F16), (k, 1.0, 322 + K.F16), (v, 1.0, 16 + K.F16)]
         if need_bwd:
             jobs += [(q, sc, 16), (k, 1.0, 16), (v, 1.0, 322)]
         packs = K.attn_pack_multi(jobs)

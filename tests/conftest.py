@@ -20,3 +20,11 @@ def dev():
     from spe_amd import lib
     lib.load()  # fail loudly if the HIP library is missing
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _default_precision():
+    """Every test starts from (and leaves behind) the library's default precision mode, bf16s - whatever mode it switched to."""
+    yield
+    if "spe_amd.kernels" in sys.modules:
+        sys.modules["spe_amd.kernels"].set_precision("bf16s")

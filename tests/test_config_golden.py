@@ -3,13 +3,18 @@ tools/gen_config_golden.py from the imported reference; case table and seeded we
 
   CPU  (-m "not gpu"): the oracle against the reference at cfg1 (real TSCAM_cait_XXS24, 24 blocks) and at cfg2 token
                        counts - the oracle is pinned at real dimensions, not only on the tiny e2e fixtures.
-  GPU  (-m gpu)      : the product against the same reference results, in both precision modes:
-        bf16x3 - 3-term split, the mode that meets north_star's 1e-3 on logits / losses (asserted here at 1e-3);
-        bf16   - single-pass bf16 MFMA operands, THE BENCHMARK MODE (bench.py's headline): this is the test that pins
-                 the benchmarked kernel set (fused talking-heads attention at N = 4150 / 6200, bf16-copy GEMMs, fused MLP
-                 and projection nodes, flash MHA) to the reference at real token counts.  Its tolerances are what bf16
-                 operand rounding (2^-9 per operand) allows through the stack with gamma = O(1); the measured errors are
-                 printed and written to gpurun_out/parity_*.json (copied to profiles/ and quoted in DESIGN.md).
+  GPU  (-m gpu)      : the product against the same reference results, in every precision mode:
+        bf16s  - THE BENCHMARK MODE (bench.py's default): forward products on split bf16 operands (Linear GEMMs) / fp16
+                 operands (fused talking-heads attention, flash MHA), backward products on single bf16 operands.  Asserted at
+                 north_star's 1e-3 on EVERY output and EVERY loss key (measured <= 2.2e-4), at the depth-2 cases and at the
+                 FULL-DEPTH cases cfg2_full (24 blocks, batch 2, N = 4150) and cfg5_full (36 blocks, N = 6200) - this is the
+                 test that pins the benchmarked kernel set (fused attention, split bf16-copy GEMMs with fused epilogues,
+                 flash MHA) to the reference at the real depth, batch and token counts.
+        bf16x3 - 3-term split everywhere, fp32 materialised attention: 1e-3 asserted (measured <= 8e-5).
+        bf16   - single bf16 operands everywhere (round 2's headline): bounded at ~2x its measured errors, NOT within
+                 north_star's 1e-3 (kept as the "what the split buys" comparison).
+  The measured errors are printed and written to gpurun_out/parity_*.json (tools/parity_summary.py -> profiles/parity_r03.json,
+  quoted by bench.py and DESIGN.md).
 """
 import json
 import os
@@ -63,8 +68,9 @@ def compare_losses(l0, l1, blob, skip_logging):
     return errs
 
 
-def compare_grads(named_grads, blob):
-    """-> (worst (name, err), compared count, errors); analytically-zero gradients are checked for smallness only."""
+def compare_grads(named_grads, blob, norm_errs=None):
+    """-> errors per parameter (max of the norm's and the 64 samples' relative error); analytically-zero gradients are checked
+    for smallness only.  norm_errs (dict, optional): filled with the relative error of the FULL tensor's norm alone."""
     errs = {}
     gmax = max(r[0] for r in blob["grads"].values() if r is not None)
     for k, g in named_grads:
@@ -76,6 +82,8 @@ def compare_grads(named_grads, blob):
         if ref[0] < 1e-6 * gmax:            # softmax shift invariance etc.: exact gradient ~0, only rounding noise remains
             continue
         errs[k] = cc.sample_err(g.detach().cpu(), ref)
+        if norm_errs is not None:
+            norm_errs[k] = abs(float(g.detach().double().norm()) - ref[0]) / ref[0]
     return errs
 
 
@@ -103,21 +111,21 @@ def test_oracle_matches_reference_at_config_dims(name):
 
 
 # -------------------------------------------------------------------------------------------------- GPU: product
-# norm-relative tolerances: (outputs, each loss key, total loss, median parameter-gradient error, worst parameter-gradient error).
-# bf16x3 = north_star's 1e-3 on logits / losses (measured: <= 8e-5 / <= 3e-5).  bf16 (the benchmark mode; measured on
-# these fixtures: outputs <= 5e-3, loss keys <= 7e-3, total loss <= 1.2e-3, median gradient 1-4e-2): a parameter whose
-# gradient is a small difference of large terms (a few decoder matrices) carries bf16 rounding noise of its own size, so
-# the worst gradient is only sanity-bounded and the median carries the assertion.
-# The fixtures hold 64 strided samples per gradient: a tensor whose samples fall on its small entries reads far worse than its
-# norm-relative error over all elements (cfg5 bbox_embed.1.layers.1.weight: 1.2 sampled, 9e-2 over the full tensor against the
-# bf16x3 run, tools/debug/grad_modes.py) - so the bound on the worst tensor is a sanity bound and the 90th percentile is asserted.
-TOL = {"bf16x3": (1e-3, 1e-3, 1e-3, 1e-2, 5e-2), "bf16": (1.5e-2, 2e-2, 5e-3, 8e-2, 3.0)}
-P90 = {"bf16x3": 2e-2, "bf16": 0.25}
+# norm-relative tolerances: (every output, every loss key, total loss, median / 90th-percentile parameter-gradient error over
+# the 64 stored samples per tensor, worst error of a full-tensor gradient NORM).
+#   bf16s / bf16x3: north_star's 1e-3 on outputs and losses (measured: <= 2.2e-4 / <= 8e-5).  bf16s gradients carry the
+#   backward's single-bf16 operand rounding: measured median 3.5-5.5e-3, p90 <= 1.4e-2 (asserted at ~2.5x that).
+#   bf16: ~2x its measured errors (outputs 6e-3, loss keys 7e-3, total 1.3e-3, median 3.7e-2, p90 5.2e-2).
+# The 64 strided samples of a tensor whose entries are mostly tiny read worse than its norm-relative error over all elements
+# (a few decoder matrices whose gradient is a small difference of large terms: up to 0.17 sampled in bf16s), so the WORST
+# tensor is bounded on the error of its full norm and the sampled errors carry the median / p90 assertions.
+TOL = {"bf16s": (1e-3, 1e-3, 1e-3, 1.5e-2, 4e-2, 5e-2), "bf16x3": (1e-3, 1e-3, 1e-3, 1e-2, 2e-2, 1e-2),
+       "bf16": (1.2e-2, 1.5e-2, 3e-3, 8e-2, 1.2e-1, 6e-1)}
+GPU_CASES = [(n, p) for n in cc.ALL_CASES for p in ("bf16s", "bf16x3", "bf16") if not (n in cc.FULL_CASES and p == "bf16x3" and n != "cfg2_full")]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("name", list(cc.CASES))
+@pytest.mark.parametrize("name,prec", GPU_CASES)
 def test_product_matches_reference_at_config_dims(dev, name, prec):
     from spe_amd import kernels as K
     from spe_amd.util.misc import NestedTensor
@@ -143,11 +151,13 @@ def test_product_matches_reference_at_config_dims(dev, name, prec):
         torch.cuda.synchronize()
         oe = compare_outputs(out, blob)
         le = compare_losses(l0, l1, blob, skip_logging=(prec == "bf16"))
-        ge = compare_grads([(k, p.grad) for k, p in model.named_parameters()], blob)
+        ne = {}
+        ge = compare_grads([(k, p.grad) for k, p in model.named_parameters()], blob, ne)
         te = abs(float(total.detach()) - float(blob["total"])) / abs(float(blob["total"]))
         wo, wl, wg = (max(d.items(), key=lambda kv: kv[1]) for d in (oe, le, ge))
         gs = sorted(ge.values())
-        rec = {"case": name, "precision": prec, "tokens": int(out[0]["x_patch"].tensors.shape[2] * out[0]["x_patch"].tensors.shape[3]),
+        wn = max(ne.items(), key=lambda kv: kv[1])
+        rec = {"case": name, "precision": prec, "worst_grad_norm_err": wn, "tokens": int(out[0]["x_patch"].tensors.shape[2] * out[0]["x_patch"].tensors.shape[3]),
                "worst_output": wo, "pred_logits": oe["0.pred_logits"], "pred_boxes": oe["0.pred_boxes"], "x_patch": oe["0.x_patch"],
                "worst_loss": wl, "total_loss_rel_err": te, "worst_grad": wg, "median_grad": gs[len(gs) // 2], "p90_grad": gs[(9 * len(gs)) // 10], "grads_compared": len(ge)}
         print(f"[{name} {prec}] " + json.dumps(rec))
@@ -155,11 +165,12 @@ def test_product_matches_reference_at_config_dims(dev, name, prec):
         if os.path.isdir(od):
             with open(os.path.join(od, f"parity_{name}_{prec}.json"), "w") as fh:
                 json.dump(rec, fh)
-        to, tl, tt, tgm, tgw = TOL[prec]
+        to, tl, tt, tgm, tg90, tgn = TOL[prec]
         assert wo[1] < to, wo
         assert wl[1] < tl and te < tt, (wl, te)
-        assert gs[len(gs) // 2] < tgm and wg[1] < tgw and len(ge) > 100, (gs[len(gs) // 2], wg)
-        assert gs[(9 * len(gs)) // 10] < P90[prec], gs[(9 * len(gs)) // 10]
+        assert gs[len(gs) // 2] < tgm and len(ge) > 100, gs[len(gs) // 2]
+        assert gs[(9 * len(gs)) // 10] < tg90, gs[(9 * len(gs)) // 10]
+        assert wn[1] < tgn, wn
         for p, r, mg in zip(pr, blob["pseudo"], blob["pseudo_margins"]):
             assert torch.equal(p["labels"].cpu(), r["labels"])
             assert rel(p["scores"], r["scores"]) < to
@@ -167,4 +178,4 @@ def test_product_matches_reference_at_config_dims(dev, name, prec):
             if clear.any():
                 assert rel(p["boxes"].cpu()[clear], r["boxes"][clear]) < to
     finally:
-        K.set_precision("bf16")
+        K.set_precision("bf16s")

@@ -704,7 +704,7 @@ def test_layer_norm_skip_sums_both_gradients(dev):
 
 
 def test_linear_bf16_path_matches_fp32_operand_path(dev):
-    """ops.linear on the bf16-copy GEMMs == the fp32-operand kernel in bf16 mode (same roundings), fwd and bwd."""
+    """ops.linear on the bf16-copy GEMMs == the fp32-operand kernel (same roundings), fwd and bwd, in the bf16 and bf16s modes."""
     from spe_amd import kernels as K
     from spe_amd import ops
     g = torch.Generator().manual_seed(11)
@@ -713,17 +713,24 @@ def test_linear_bf16_path_matches_fp32_operand_path(dev):
     W = (torch.randn(N, Kd, generator=g) * 0.05).to(dev).requires_grad_()
     b = torch.randn(N, generator=g).to(dev).requires_grad_()
     go = torch.randn(2, R // 2, N, generator=g).to(dev)
-    res = {}
     old = K.LINEAR16
-    try:
-        for mode in (True, False):
-            K.LINEAR16 = mode
-            y = ops.linear(x, W, b, ops.ACT_GELU)
-            res[mode] = (y,) + torch.autograd.grad(y, (x, W, b), go)
-    finally:
-        K.LINEAR16 = old
-    for a, c in zip(res[True], res[False]):
-        assert rel(a, c) < 1e-5
+    # bf16: identical roundings on both paths.  bf16s: the forward runs on (hi, lo) pairs on both paths - the bf16-copy kernel reads
+    # the lo part its producer wrote, the fp32-operand kernel splits while staging - and agrees to fp32 round-off of a K = 384 sum
+    for prec, tol in (("bf16", 1e-5), ("bf16s", 5e-5)):
+        K.set_precision(prec)
+        res = {}
+        try:
+            for mode in (True, False):
+                K.LINEAR16 = mode
+                y = ops.linear(x, W, b, ops.ACT_GELU)
+                res[mode] = (y,) + torch.autograd.grad(y, (x, W, b), go)
+        finally:
+            K.LINEAR16 = old
+        for a, c in zip(res[True], res[False]):
+            assert rel(a, c) < tol, (prec, rel(a, c))
+    # and the split forward is fp32-grade: against fp64
+    yd = torch.nn.functional.gelu(x.detach().double() @ W.detach().double().t() + b.detach().double())
+    assert rel(res[True][0], yd) < 2e-5, rel(res[True][0], yd)
 
 
 @pytest.mark.parametrize("L,Q,sizes", [(1, 100, [7, 7]), (7, 100, [1, 20, 0, 64]), (2, 300, [93, 5]), (3, 16, [16, 15]), (1, 1000, [100])])
@@ -915,7 +922,18 @@ def test_weight_cache_follows_flat_optimizer(dev):
     x = torch.randn(300, 32, generator=g).to(dev)                    # >= LINEAR16_MIN_ROWS: bf16-copy path
     red = GradAllReducer([W, b], flatten_params=True)
     opt = FlatAdamW([W, b], red, lr=0.05, weight_decay=0.0)
+    K.set_precision("bf16")                                         # the reference below rounds the operands to bf16 once
     ref = lambda: x.to(torch.bfloat16).double() @ W.detach().to(torch.bfloat16).double().t() + b.detach().double()
+    # bf16s: the cached LOW parts of the split weight must follow the optimiser too (reference: the exact product)
+    K.set_precision("bf16s")
+    for it in range(2):
+        red.reset()
+        y = ops.linear(x, W, b)
+        assert rel(y, x.double() @ W.detach().double().t() + b.detach().double()) < 2e-5, it
+        y.square().sum().backward()
+        red.finish()
+        opt.step()
+    K.set_precision("bf16")
     for it in range(3):
         red.reset()
         y = ops.linear(x, W, b)

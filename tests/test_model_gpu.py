@@ -35,14 +35,15 @@ def build(blob, dev):
     return model.to(dev), crit.to(dev), crit_r.to(dev), pp, rpp
 
 
-OUT_TOL = {"bf16x3": 2e-4, "bf16": 3e-2}
-LOSS_TOL = {"bf16x3": 2e-4, "bf16": 2e-2}
+# bf16s = the benchmark mode (forward on split / fp16 operands): north_star's 1e-3
+OUT_TOL = {"bf16x3": 2e-4, "bf16s": 1e-3, "bf16": 3e-2}
+LOSS_TOL = {"bf16x3": 2e-4, "bf16s": 1e-3, "bf16": 2e-2}
 # bf16 mode: scores/probabilities and their gradients are materialised in bf16 and every contraction rounds its
 # operands to bf16; on the tiny fixture models the worst parameter (a small decoder gradient) sits at 0.11-0.14
-GRAD_TOL = {"bf16x3": 2e-3, "bf16": 2e-1}
+GRAD_TOL = {"bf16x3": 2e-3, "bf16s": 1e-1, "bf16": 2e-1}
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16s", "bf16"])
 @pytest.mark.parametrize("name", ["e2e_single", "e2e_two_branch"])
 def test_forward_and_losses_match_reference(dev, name, prec):
     from spe_amd import kernels as K
@@ -95,7 +96,7 @@ def test_forward_and_losses_match_reference(dev, name, prec):
         K.set_precision("bf16")
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16s", "bf16"])
 @pytest.mark.parametrize("name", ["e2e_single", "e2e_two_branch"])
 def test_train_step_grads_match_reference(dev, name, prec):
     """Train-mode criteria on the reference's captured one-to-many targets -> total loss -> backward
@@ -182,7 +183,7 @@ def test_product_matches_oracle_on_fresh_inputs(dev):
         K.set_precision("bf16")
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16s", "bf16"])
 def test_training_trajectory_flat_stack_equals_torch_stack(dev, prec):
     """Five optimisation steps of the tiny fixture model, twice: (a) plain autograd gradients + clip_grad_norm_ +
     torch.optim.AdamW; (b) GradAllReducer (gradients written into the buckets, flat parameters) + FlatAdamW.  Same

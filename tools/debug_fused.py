@@ -18,7 +18,8 @@ nt = (N + 15) // 16
 spw0, _ = K.fused_plan(B, N, 0)
 spw, nwg = K.fused_plan(B, N, 2)
 print("nt", nt, "spw", spw, "nwg", nwg)
-Qf, Kf, Vf, dOf = K.attn_pack(q, scale * K.LOG2E), K.attn_pack(k), K.attn_pack(v), K.attn_pack(dO.view(B, N, H, dh))
+Qf, Kf = K.attn_pack_multi([(q, scale * K.LOG2E, 32 + K.F16), (k, 1.0, 32 + K.F16)])
+Vf, dOf = K.attn_pack(v), K.attn_pack(dO.view(B, N, H, dh))
 ws = torch.zeros(B * nt * 8 * H * 32, device=dev)
 K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws, None, None, B, H, N, dh, 0.0, 0, 0)
 M, IL = K.attn_merge(ws, B, H, N, spw0, 0)

@@ -17,7 +17,8 @@ q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
 nt = (N + 15) // 16
 spw0, _ = K.fused_plan(B, N, 0)
 spw, nwg = K.fused_plan(B, N, 2)
-Qf, Kf, Vf, dOf = K.attn_pack(q, scale * K.LOG2E), K.attn_pack(k), K.attn_pack(v), K.attn_pack(dO.view(B, N, H, dh))
+Qf, Kf = K.attn_pack_multi([(q, scale * K.LOG2E, 32 + K.F16), (k, 1.0, 32 + K.F16)])
+Vf, dOf = K.attn_pack(v), K.attn_pack(dO.view(B, N, H, dh))
 ws = torch.zeros(B * nt * 8 * H * 32, device=dev)
 ws_w = torch.zeros(nwg, 2 * (H * H + H), device=dev)
 PT = K.score_blocks(B, H, N, dev)

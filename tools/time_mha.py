@@ -30,9 +30,9 @@ for name, (B, Lq, Lk, H, dk, dv) in {"encoder": (2, 4150, 4150, 8, 48, 48), "cro
         print(f"{name:8s} flash={flash}: fwd {tf:.3f} ms  bwd {tb:.3f} ms")
     ops.FLASH_MHA = True
     sc = dk ** -0.5 * K.LOG2E
-    Qf, Kf, V16, Q16, K16, Vf = K.attn_pack_multi([(q, sc, 322), (k, 1.0, 322), (v, 1.0, 16), (q, sc, 16), (k, 1.0, 16), (v, 1.0, 322)])
+    Qf, Kf, V16, Q16, K16, Vf = K.attn_pack_multi([(q, sc, 322 + K.F16), (k, 1.0, 322 + K.F16), (v, 1.0, 16 + K.F16), (q, sc, 16), (k, 1.0, 16), (v, 1.0, 322)])
     nch = K.mha_plan(B, H, Lq, Lk)
-    print("   nch", nch, "pack6 %.3f ms" % t(lambda: K.attn_pack_multi([(q, sc, 322), (k, 1.0, 322), (v, 1.0, 16), (q, sc, 16), (k, 1.0, 16), (v, 1.0, 322)])))
+    print("   nch", nch, "pack6 %.3f ms" % t(lambda: K.attn_pack_multi([(q, sc, 322 + K.F16), (k, 1.0, 322 + K.F16), (v, 1.0, 16 + K.F16), (q, sc, 16), (k, 1.0, 16), (v, 1.0, 322)])))
     print("   fwd+merge %.3f ms" % t(lambda: K.mha_fwd(Qf, Kf, V16, None, B, H, Lq, Lk, dk, dv, nch, 0.1, 1, 2)))
     O, lse, keep = K.mha_fwd(Qf, Kf, V16, None, B, H, Lq, Lk, dk, dv, nch, 0.1, 1, 2)
     dO4 = go.view(B, Lq, H, dv)

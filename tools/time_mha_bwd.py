@@ -21,7 +21,7 @@ for Lq in (16, 64, 200, 400, 800):
     q = torch.randn(B, Lq, H, dk, generator=g).to(dev); k = torch.randn(B, Lk, H, dk, generator=g).to(dev)
     v = torch.randn(B, Lk, H, dv, generator=g).to(dev); go = torch.randn(B, Lq, H, dv, generator=g).to(dev)
     sc = dk ** -0.5 * K.LOG2E
-    Qf, Kf, V16, Q16, K16, Vf = K.attn_pack_multi([(q, sc, 322), (k, 1.0, 322), (v, 1.0, 16), (q, sc, 16), (k, 1.0, 16), (v, 1.0, 322)])
+    Qf, Kf, V16, Q16, K16, Vf = K.attn_pack_multi([(q, sc, 322 + K.F16), (k, 1.0, 322 + K.F16), (v, 1.0, 16 + K.F16), (q, sc, 16), (k, 1.0, 16), (v, 1.0, 322)])
     nch = K.mha_plan(B, H, Lq, Lk)
     O, lse, keep = K.mha_fwd(Qf, Kf, V16, None, B, H, Lq, Lk, dk, dv, nch, 0.0, 1, 2)
     D = (go * O.view(B, Lq, H, dv)).sum(-1).permute(0, 2, 1).contiguous()
