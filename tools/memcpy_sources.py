@@ -13,7 +13,7 @@ from spe_amd.models import build_model
 from spe_amd.util.misc import NestedTensor
 
 dev = torch.device("cuda", 0)
-lib.load(); K.set_precision("bf16"); K.manual_seed(1234)
+lib.load(); K.manual_seed(1234)
 args = bench.model_args()
 torch.manual_seed(0)
 model, crit, crit_r, pp, rpp = build_model(args)
