@@ -241,6 +241,9 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # explicit CU budget of the collective: at most 32 RCCL channels (one persistent workgroup each); GradAllReducer
+        # reserves as many workgroup slots in the single-round attention grids (kernels.set_cu_reserve)
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -384,6 +387,8 @@ def main():
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": loss_val,
                        "drop_rates": {"decoder": 0.1, "drop_path": a.drop_path, "attn_drop": a.attn_drop, "backbone_drop": a.backbone_drop}},
             "per_rank_ms_per_step": [t_ / a.steps * 1e3 for t_ in per_rank],
+            "dp": {"cu_reserve": reducer.cu_reserve, "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
+                   "fused_attention_workgroups": K.FUSED_NWG[3]},
             "allreduce_exposed_ms_per_step": reducer.exposed_ms_mean(),
             "roofline": {"bound": "mfma", "kernel": "talking_fused_kernel<8,2,3> (attention backward pass 2)", "launches": launches,
                          # algorithmic work only (dP' = dO V^T); the recomputed S = Q K^T is reported as `executed`

@@ -198,8 +198,10 @@ int spe_attn_contract(const void* T, const void* X16, float* out, long ob, long 
                       int trans, int fmt, float alpha, float* ws, unsigned int* counters, long ws_floats, void* out16,
                       void* out16lo, spe_stream_t stream);
 
-/* ---- out[c] += sum_r in[r*ld + c] (bias gradients; autograd of nn.Linear bias). */
-int spe_colsum(const float* in, float* out, long R, int C, long ld, spe_stream_t stream);
+/* ---- out[c] (+)= sum_r in[r*ld + c] (bias gradients; autograd of nn.Linear bias; sums of split-K slabs).
+ * accumulate = 1: added to what out holds (a zeroed buffer or a running sum); 0: out is overwritten (a weight gradient written
+ * into its all-reduce bucket view needs no zeroing of the bucket beforehand). */
+int spe_colsum(const float* in, float* out, long R, int C, long ld, int accumulate, spe_stream_t stream);
 
 /* ---- LayerScale residual out = x + s_b*gamma*y (reference models/cait.py:413-416; s_b = the
  * per-sample DropPath keep scale or null).  bwd: dy = s_b*gamma*dout, dgamma += sum s_b*dout*y. */
@@ -338,6 +340,12 @@ int spe_adamw_flat(float* p, float* g, float* m, float* v, long n, const long* s
                    const float* seg_wd, int nseg, float beta1, float beta2, float eps, float bias_c1, float bias_c2,
                    const float* partials, int npartials, float max_norm, int write_grad, float grad_scale,
                    spe_stream_t stream);
+
+/* ---- diagnostic (never launched by the product): keep nwg workgroups resident for `micros` microseconds, streaming copies
+ * through buf (buf_floats floats, 16-B aligned; NULL: idle spinning) - the one-GPU proxy for the CU / HBM share of an RCCL ring
+ * running beside the backward (reference main.py:172: DistributedDataParallel overlaps its all-reduce with the backward);
+ * tools/dp_proxy.py measures the slowdown of the step under it. */
+int spe_occupy(int nwg, long micros, float* buf, long buf_floats, spe_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -52,7 +52,7 @@ class RcclComm:
     """The process' communicator.  rank / world default to RANK / WORLD_SIZE; the unique id travels through `store`
     (a torch.distributed.Store; default: TCPStore on MASTER_ADDR:MASTER_PORT, rank 0 hosts it)."""
 
-    def __init__(self, rank=None, world=None, store=None, device=None):
+    def __init__(self, rank=None, world=None, store=None, device=None, port=None, timeout_s=300):
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
         if device is not None:
@@ -60,9 +60,16 @@ class RcclComm:
         buf = ctypes.create_string_buffer(ID_BYTES)
         if self.world > 1:
             if store is None:
-                from torch.distributed import TCPStore
-                store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29533")) + 1,
-                                 self.world, self.rank == 0)
+                import datetime
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized():
+                    # the process group's own store, under a key prefix: no second port to collide with another job's
+                    store = dist.PrefixStore("spe_comm", dist.distributed_c10d._get_default_store())
+                else:
+                    # SPE_COMM_PORT / `port`: an explicit rendezvous port; default MASTER_PORT + 1 (documented in INTEGRATION.md)
+                    port = int(port or os.environ.get("SPE_COMM_PORT") or int(os.environ.get("MASTER_PORT", "29533")) + 1)
+                    store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, self.world, self.rank == 0,
+                                          timeout=datetime.timedelta(seconds=timeout_s))
             if self.rank == 0:
                 _call("spe_comm_unique_id", buf)
                 store.set("spe_comm_id", buf.raw)
@@ -91,9 +98,17 @@ class RcclComm:
         return t
 
     def broadcast(self, t, root=0):
+        """In place, on the communicator's side stream like the all-reduces (one stream per communicator: the collectives of a
+        communicator are then ordered by the stream, not by RCCL's internals); the current stream waits for the result."""
         assert t.is_cuda and t.is_contiguous() and t.dtype in _DT
-        st = torch.cuda.current_stream()
-        _call("spe_comm_broadcast", ctypes.c_void_p(t.data_ptr()), t.numel(), _DT[t.dtype], root, ctypes.c_void_p(st.cuda_stream))
+        ready = torch.cuda.Event()
+        ready.record()
+        self.stream.wait_event(ready)
+        _call("spe_comm_broadcast", ctypes.c_void_p(t.data_ptr()), t.numel(), _DT[t.dtype], root, ctypes.c_void_p(self.stream.cuda_stream))
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        t.record_stream(self.stream)
+        torch.cuda.current_stream().wait_event(done)
         return t
 
     def destroy(self):

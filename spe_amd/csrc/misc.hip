@@ -117,6 +117,36 @@ extern "C" int spe_bicubic(const float* src, float* dst, int gh, int gw, int h, 
     return 0;
 }
 
+// ---- diagnostic: occupy `nwg` workgroup slots for `micros` microseconds, optionally streaming copies through buf (two halves:
+// the workgroups read one and write the other, over and over) - a stand-in for the CU and HBM share an RCCL ring takes
+// (channels x one persistent workgroup each) on a box with one GPU.  Used by tools/dp_proxy.py and its test to measure how much
+// the hand-balanced attention / GEMM grids lose when a collective runs beside them (reference main.py:172: DDP overlaps its
+// all-reduce with the backward); never launched by the product.
+__global__ __launch_bounds__(256) void occupy_kernel(long ticks, float4* __restrict__ buf, long n4_half) {
+    const long t0 = wall_clock64();                     // constant 100 MHz counter
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    while (wall_clock64() - t0 < ticks) {
+        if (buf) {
+#pragma unroll 4
+            for (int k = 0; k < 16; ++k) {
+                if (i >= n4_half) i -= n4_half;
+                buf[n4_half + i] = buf[i];
+                i += (long)gridDim.x * 256;
+            }
+        } else {
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+}
+extern "C" int spe_occupy(int nwg, long micros, float* buf, long buf_floats, hipStream_t st) {
+    if (nwg <= 0 || micros <= 0) return 0;
+    const long n4_half = buf ? buf_floats / 8 : 0;
+    if (buf && ((reinterpret_cast<uintptr_t>(buf) & 15) || n4_half < (long)nwg * 256)) return -2;
+    hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)nwg), dim3(256), 0, st, micros * 100, reinterpret_cast<float4*>(buf), n4_half);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int spe_abi_version(void) { return 3; }    // 2: round 2 (signatures of spe_hungarian, spe_adamw_flat, spe_layernorm_fwd, spe_attn_contract, spe_talking_fused_plan changed; new entry points)
 
 

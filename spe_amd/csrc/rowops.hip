@@ -447,10 +447,11 @@ extern "C" int spe_softmax_bwd(const float* dPd, const float* P, float* dS, int 
 // tall narrow matrices (bias gradients: R ~ 1e4, C <= 2048).
 //   wide: one thread per 4 columns, float4 loads down the R rows, plain read-modify-write of out (no atomics)
 //   tall: block = 16 column quads (64 columns) x 16 row lanes, float4 loads, LDS reduce, one atomic per column
-__global__ __launch_bounds__(256) void colsum_wide_kernel(const float* __restrict__ in, float* __restrict__ out, int R, long C, long ld) {
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const float* __restrict__ in, float* __restrict__ out, int R, long C, long ld,
+                                                          int accumulate) {
     const long c = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (c >= C) return;
-    float4 acc = *reinterpret_cast<const float4*>(out + c);
+    float4 acc = accumulate ? *reinterpret_cast<const float4*>(out + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
     for (int r = 0; r < R; ++r) {
         const float4 v = *reinterpret_cast<const float4*>(in + r * ld + c);
@@ -492,11 +493,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
     __syncthreads();
     if (rl == 0 && c < C) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
-extern "C" int spe_colsum(const float* in, float* out, long R, int C, long ld, hipStream_t st) {
-    if (R <= 0 || C <= 0) return 0;
+extern "C" int spe_colsum(const float* in, float* out, long R, int C, long ld, int accumulate, hipStream_t st) {
+    if (C <= 0) return 0;
+    if (R <= 0) { if (!accumulate) { hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, st); if (e != hipSuccess) return (int)e; } return 0; }
     const bool al4 = (C % 4 == 0) && (ld % 4 == 0) && ((((uintptr_t)in) | ((uintptr_t)out)) % 16 == 0);
-    if (al4 && R <= 64 && C >= 4096) {
-        hipLaunchKernelGGL(colsum_wide_kernel, dim3((unsigned)((C / 4 + 255) / 256)), dim3(256), 0, st, in, out, (int)R, (long)C, ld);
+    const bool wide = al4 && R <= 64 && C >= 4096;
+    if (!accumulate && !wide) {        // the tall kernels add their partial sums atomically: they need a zeroed destination
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (wide) {
+        hipLaunchKernelGGL(colsum_wide_kernel, dim3((unsigned)((C / 4 + 255) / 256)), dim3(256), 0, st, in, out, (int)R, (long)C, ld, accumulate);
     } else if (al4) {
         const int gx = (C / 4 + 15) / 16;
         long ry = (R + 63) / 64;                       // >= 4 rows per thread

@@ -12,6 +12,8 @@ Parameters that never receive a gradient (e.g. the unused `backbone.0.body.head.
 reference needs find_unused_parameters=True) cannot hang anything: buckets that did not fill during
 backward are reduced by `finish()`.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -28,7 +30,7 @@ class _EventWork:
 
 class GradAllReducer:
     def __init__(self, params, bucket_bytes=64 << 20, average=True, group=None, flatten_params=False, broadcast=True,
-                 always_reduce=False, wire_dtype=None, buffers=(), comm=None):
+                 always_reduce=False, wire_dtype=None, buffers=(), comm=None, cu_reserve=None):
         """flatten_params: also move the parameters themselves into flat per-bucket buffers with the gradient layout
         (param.data becomes a view) - what spe_amd.optim.FlatAdamW steps in one launch per bucket.  Construct the
         reducer AFTER the model is on its device: `module.to(...)` / `.cuda()` re-allocates parameters and would
@@ -40,7 +42,12 @@ class GradAllReducer:
         wire_dtype: torch.bfloat16 sends the buckets in bf16 (half the xGMI bytes, one conversion pass each way); the
         default None keeps DDP's fp32 gradients.
         comm: a spe_amd.comm.RcclComm - the collectives then go through the C ABI of libspe_comm.so (include/spe_comm.h)
-        on its side stream instead of torch.distributed (same RCCL underneath)."""
+        on its side stream instead of torch.distributed (same RCCL underneath).
+        cu_reserve: workgroup slots left free for the RCCL ring that runs beside the backward (kernels.set_cu_reserve: the
+        single-round attention grids shrink from 512 to 512 - cu_reserve workgroups).  Default for world > 1: the channel cap
+        NCCL_MAX_NCHANNELS (bench.py sets 32 before the process group is created), else 32; 0 in a one-rank job.  Measured with
+        tools/dp_proxy.py (a one-GPU proxy, not RCCL): foreign workgroups beside the step cost +9 % with the solo grids and
+        +3 % with 32 slots reserved (profiles/r03_dp_proxy.json)."""
         self.params = [p for p in params if p.requires_grad]
         self.flatten_params = flatten_params
         self.group = group
@@ -48,8 +55,16 @@ class GradAllReducer:
         self.initialised = comm is not None or (dist.is_available() and dist.is_initialized())
         self.world = comm.world if comm is not None else (dist.get_world_size(group) if self.initialised else 1)
         self.collective = self.world > 1 or (always_reduce and self.initialised)
+        if cu_reserve is None:
+            cu_reserve = int(os.environ.get("NCCL_MAX_NCHANNELS", "32")) if self.world > 1 else 0
+        self.cu_reserve = cu_reserve
+        if self.params and self.params[0].is_cuda:
+            from . import kernels as _K
+            _K.set_cu_reserve(cu_reserve)
         self.average = average
-        self.average_in_optimizer = False      # FlatAdamW folds the 1/world into its update launch (no div_ per bucket)
+        # set by FlatAdamW (and only by it): the 1/world is folded into its update launch (no div_ per bucket); p.grad / the
+        # buckets then hold the world SUM after finish() - see grad_scale() / averaged_grad()
+        self.average_in_optimizer = False
         self.wire_dtype = wire_dtype
         self.measure = False                   # bench: record events around the waits of finish() (exposed all-reduce time)
         self.exposed_ms = []
@@ -85,6 +100,7 @@ class GradAllReducer:
         self.learn_unused = True
         self._fired = set()
         self._static_unused = None
+        self._zero_views = None
         self.reset()
 
     def _make_bucket(self, plist):
@@ -107,17 +123,34 @@ class GradAllReducer:
             offsets.append((p, off))
             off += al(p.numel())
             self._bucket_of[p] = len(self.buckets)
+        # wire_dtype: the send / receive buffer of the bucket in the wire format, allocated once (not per step)
+        wire = torch.empty(n, device=dev, dtype=self.wire_dtype) if self.wire_dtype is not None else None
         self.buckets.append({"flat": flat, "flat_p": flat_p, "offsets": offsets, "params": list(plist), "pending": 0,
-                             "work": None})
+                             "work": None, "wire": wire})
+
+    # Gradients of parameters with more than ZERO_MAX elements are always OVERWRITTEN by their producer (GEMM stores, split-K slab
+    # sums with accumulate = 0, or the copy in _on_grad); only the small ones (biases, LayerNorm / LayerScale vectors, head mixers:
+    # their kernels add partial sums atomically into a zeroed view) and the statically unused ones need zeros.
+    ZERO_MAX = 16384
 
     def reset(self):
-        """Call before every backward (after the optimizer consumed the gradients): zero the buckets and detach
-        the .grad views.  With .grad = None autograd adopts the first incoming gradient tensor instead of adding
-        it: kernels that wrote into the bucket view (kernels.grad_buffer) cost nothing extra, any other gradient is
-        moved into the bucket by `_on_grad`; a parameter that gets no gradient keeps its zeros in the bucket."""
+        """Call before every backward (after the optimizer consumed the gradients): re-arm the buckets and detach the .grad
+        views.  With .grad = None autograd adopts the first incoming gradient tensor instead of adding it: kernels that wrote
+        into the bucket view (kernels.grad_buffer) cost nothing extra, any other gradient is moved into the bucket by
+        `_on_grad`; a parameter that gets no gradient ends the step with zeros in the bucket.
+        First step: the whole buckets are zeroed (330 MB at cfg2).  From the second step on only the views that need it are:
+        small accumulate-into gradients and statically unused parameters (< 1 % of the bytes, one multi-tensor launch); a large
+        parameter that unexpectedly received no gradient is zeroed in finish()."""
         skip = self._static_unused or ()
+        if self._static_unused is None:
+            for b in self.buckets:
+                b["flat"].zero_()
+        else:
+            if self._zero_views is None:
+                self._zero_views = [self._views[p] for p in self.params if p.numel() <= self.ZERO_MAX or p in skip]
+            if self._zero_views:
+                torch._foreach_zero_(self._zero_views)
         for b in self.buckets:
-            b["flat"].zero_()
             b["pending"] = sum(1 for p in b["params"] if p not in skip)
             b["work"] = None
             for p in b["params"]:
@@ -133,7 +166,8 @@ class GradAllReducer:
         if self.collective:
             buf = b["flat"]
             if self.wire_dtype is not None:
-                buf = b["wire"] = b["flat"].to(self.wire_dtype)
+                buf = b["wire"]
+                buf.copy_(b["flat"])
             if self.comm is not None:
                 b["work"] = _EventWork(self.comm.all_reduce_async(buf))
             else:
@@ -149,6 +183,7 @@ class GradAllReducer:
                 raise RuntimeError("GradAllReducer: a parameter that got no gradient in the first step received one "
                                    "after its bucket was reduced; construct the reducer with learn_unused = False")
             self._static_unused = self._static_unused - {p}      # used after all: count it from the next step on
+            self._zero_views = None
             b["pending"] += 1
         if p.grad.data_ptr() != view.data_ptr():
             # the gradient was produced outside the bucket (torch op, or a parameter used twice whose contributions
@@ -168,6 +203,14 @@ class GradAllReducer:
 
     def finish(self):
         """Reduce buckets that never filled (unused parameters), wait for every collective, average."""
+        if self._static_unused is not None:
+            # a LARGE parameter that fired in the first step but not in this one still holds the previous step's gradient (its
+            # view is not zeroed by reset()): zero it before its bucket goes out.  Such a bucket cannot have been launched yet -
+            # it was still waiting for this parameter.
+            for b in self.buckets[self._next:]:
+                for p in b["params"]:
+                    if p not in self._fired and p not in self._static_unused and p.numel() > self.ZERO_MAX:
+                        self._views[p].zero_()
         while self._next < len(self.buckets):
             self._launch(self.buckets[self._next])
             self._next += 1
@@ -181,7 +224,7 @@ class GradAllReducer:
             if b["work"] not in (None, "local"):
                 b["work"].wait()
                 if self.wire_dtype is not None:
-                    b["flat"].copy_(b.pop("wire"))
+                    b["flat"].copy_(b["wire"])
             for p in b["params"]:
                 if p.grad is None:                            # unused this step: zeros, like DDP's unused-parameter path
                     p.grad = self._views[p]
@@ -190,6 +233,11 @@ class GradAllReducer:
             self._wait_events.append(ev)
         if self.average and self.world > 1 and not self.average_in_optimizer:
             torch._foreach_div_([b["flat"] for b in self.buckets], float(self.world))
+
+    def averaged_grad(self, p):
+        """The gradient of `p` as DDP would leave it in p.grad (the mean over ranks), whatever the averaging mode: with a
+        FlatAdamW attached the buckets hold the world SUM after finish() and the 1/world is applied inside its update launch."""
+        return self._views[p] * self.grad_scale()
 
     def grad_scale(self):
         """Factor the optimizer still has to apply to the bucket contents (1/world when the averaging is folded in)."""

@@ -357,7 +357,7 @@ def gemm_splitk_into(A, B, out, M, N, K, lda, ldb, ldc, transA, transB, batch0, 
     gemm(A, B, ws, M, N, K, lda, ldb, ldc, transA, transB, batch0=batch0, batch1=batch1, sA=sA, sB=sB, sC=sC, alpha=alpha, splitk=-sk)
     out.zero_()
     n = out.numel()
-    _call("spe_colsum", _p(ws), _p(out), sk, n, extent, _st())
+    _call("spe_colsum", _p(ws), _p(out), sk, n, extent, 1, _st())
     return out
 
 
@@ -480,7 +480,7 @@ def _dw16(dy16T, x16T, N, K, Rp, dW_out):
     if sk > 1:
         ws = torch.empty((sk, N * K), device=dev, dtype=torch.float32)
         gemm16(dy16T, x16T, ws, N, K, Rp, Rp, Rp, K, splitk=-sk)
-        return colsum(ws, out=None if dW_out is None else dW_out.view(-1)).view(N, K)
+        return colsum(ws, out=None if dW_out is None else dW_out.view(-1), accumulate=dW_out is None).view(N, K)
     dW = dW_out if dW_out is not None else torch.empty((N, K), device=dev, dtype=torch.float32)
     gemm16(dy16T, x16T, dW, N, K, Rp, Rp, Rp, K)
     return dW
@@ -500,7 +500,7 @@ def _dw16_tn(dy16, x16, N, K, R, dW_out, lda=None):
     if sk > 1:
         ws = torch.empty((sk, N * K), device=dev, dtype=torch.float32)
         gemm16_tn(dy16, x16, ws, N, K, R, lda, K, K, splitk=-sk)
-        return colsum(ws, out=None if dW_out is None else dW_out.view(-1)).view(N, K)
+        return colsum(ws, out=None if dW_out is None else dW_out.view(-1), accumulate=dW_out is None).view(N, K)
     dW = dW_out if dW_out is not None else torch.empty((N, K), device=dev, dtype=torch.float32)
     gemm16_tn(dy16, x16, dW, N, K, R, lda, K, K)
     return dW
@@ -602,7 +602,7 @@ def linear_bwd(dy2, xsave, W, need_dx=True, need_dw=True, need_db=True, dW_out=N
             if sk > 1:
                 ws = torch.empty((sk, N * K), device=dy2.device, dtype=torch.float32)
                 gemm16(dy16T, xsave, ws, N, K, Rp, Rp, Rp, K, splitk=-sk)
-                dW = colsum(ws, out=None if dW_out is None else dW_out.view(-1)).view(N, K)
+                dW = colsum(ws, out=None if dW_out is None else dW_out.view(-1), accumulate=dW_out is None).view(N, K)
             else:
                 dW = dW_out if dW_out is not None else torch.empty((N, K), device=dy2.device, dtype=torch.float32)
                 gemm16(dy16T, xsave, dW, N, K, Rp, Rp, Rp, K)
@@ -620,23 +620,24 @@ def linear_bwd(dy2, xsave, W, need_dx=True, need_dw=True, need_db=True, dW_out=N
             if sk > 1:       # slab split-K: no atomics; the slabs are summed by one column-sum launch
                 ws = torch.empty((sk, N * K), device=dy2.device, dtype=torch.float32)
                 gemm(dy2, x2, ws, N, K, R, N, K, K, True, False, splitk=-sk)
-                dW = colsum(ws, out=None if dW_out is None else dW_out.view(-1)).view(N, K)
+                dW = colsum(ws, out=None if dW_out is None else dW_out.view(-1), accumulate=dW_out is None).view(N, K)
             else:
                 dW = dW_out if dW_out is not None else torch.empty((N, K), device=dy2.device, dtype=torch.float32)
                 gemm(dy2, x2, dW, N, K, R, N, K, K, True, False)
     if need_db:
         db = _zeros_or(db_out, N, dy2.device)
-        _call("spe_colsum", _p(dy2), _p(db), R, N, N, _st())
+        _call("spe_colsum", _p(dy2), _p(db), R, N, N, 1, _st())
     return dx, dW, db
 
 
-def colsum(x2, out=None):
-    """out (zeroed, or holding a running sum) += column sums of x2."""
+def colsum(x2, out=None, accumulate=True):
+    """out (zeroed, or holding a running sum) += column sums of x2; accumulate=False: out is overwritten (uninitialised memory is
+    fine - what the weight-gradient slab sums into the all-reduce bucket views use, so the buckets need no zeroing)."""
     _chk(x2)
     R, C = x2.shape
     if out is None:
         out = zeros_small(C, x2.device)
-    _call("spe_colsum", _p(x2), _p(out), R, C, x2.stride(0), _st())
+    _call("spe_colsum", _p(x2), _p(out), R, C, x2.stride(0), int(bool(accumulate)), _st())
     return out
 
 
@@ -850,6 +851,18 @@ def box_loss_bwd(srow_i64, lidx_i32, g1, g2, c1, c2, shape):
 # and 3 share ws_w rows, so they use the same count.
 FUSED_NWG = {0: int(os.environ.get("SPE_FUSED_NWG0", 512)), 1: int(os.environ.get("SPE_FUSED_NWG1", 512)),
              2: int(os.environ.get("SPE_FUSED_NWG2", 512)), 3: int(os.environ.get("SPE_FUSED_NWG3", 512))}
+_FUSED_NWG_SOLO = dict(FUSED_NWG)
+
+
+def set_cu_reserve(n):
+    """Leave room for `n` foreign persistent workgroups (the channels of an RCCL ring running beside the backward: one workgroup
+    each, on any CU).  The fused attention passes run ONE round of 2 workgroups per CU at 239-256 registers per lane; a CU that
+    hosts a foreign wave has registers for only one of them, so the chip's capacity for these kernels is 512 - n workgroups and
+    a 512-workgroup launch would need a second, nearly empty round (measured with tools/dp_proxy.py: +8 % per step for ANY
+    number of foreign workgroups from 8 to 64).  With the grids cut to 512 - n the launches stay single-round.
+    spe_amd.dp.GradAllReducer calls this with its channel budget when world > 1; 0 restores the solo grids."""
+    for m in FUSED_NWG:
+        FUSED_NWG[m] = max(8, (_FUSED_NWG_SOLO[m] - int(n)) & ~7) if n > 0 else _FUSED_NWG_SOLO[m]
 
 
 def fused_supported(H, dh):

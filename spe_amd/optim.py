@@ -25,7 +25,13 @@ class FlatAdamW(torch.optim.Optimizer):
             raise ValueError("FlatAdamW needs GradAllReducer(..., flatten_params=True)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.reducer = reducer
-        reducer.average_in_optimizer = True     # gradient averaging (1/world) rides on the update launch
+        # Gradient averaging (1/world) rides on the update launch.  This changes what the reducer's buckets (and p.grad) hold
+        # after finish(): the world SUM, not DDP's mean - any other consumer must multiply by reducer.grad_scale() (or read
+        # reducer.averaged_grad(p)).  A reducer can therefore serve ONE FlatAdamW and nothing that expects means.
+        if getattr(reducer, "_folded_into", None) not in (None, id(self)):
+            raise ValueError("FlatAdamW: this GradAllReducer already folds its averaging into another optimizer")
+        reducer.average_in_optimizer = True
+        reducer._folded_into = id(self)
         self.max_grad_norm = max_grad_norm
         self.write_clipped_grads = write_clipped_grads
         gid = {}
