@@ -344,7 +344,15 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
     // MFMA jobs per operand-fragment batch: whole tile in the forward passes; backward pass 1 has registers for 4 heads at a
     // time, backward pass 2 - since its two transposed mixes left the vector pipe - for 8 (0.380 -> 0.356 ms at cfg2; pass 1
     // spills with 8: 0.37 -> 0.43 ms)
-    constexpr int JBW = (MODE == 3) ? 2 * SPE_FUSED_JB2 : SPE_FUSED_JB2;
+#ifndef SPE_FUSED_GWMFMA
+#define SPE_FUSED_GWMFMA 1
+#endif
+#ifndef SPE_FUSED_JB2G
+#define SPE_FUSED_JB2G 2
+#endif
+    constexpr bool GWM = SPE_FUSED_GWMFMA && (H % 4 == 0) && (MODE == 2);     // weight-gradient outer products on the matrix pipe (below)
+    // backward pass 1 with the outer products on the matrix pipe has ~36 registers to spare: 8 heads per fragment batch there too
+    constexpr int JBW = (MODE == 3) ? 2 * SPE_FUSED_JB2 : (GWM ? SPE_FUSED_JB2G * SPE_FUSED_JB2 : SPE_FUSED_JB2);
     constexpr int JB = (MODE >= 2) ? ((H >= JBW) ? JBW : ((H >= SPE_FUSED_JB2) ? SPE_FUSED_JB2 : H)) : H;
     // request the next macro step's first batch before the VALU phases (its registers stay live through them)
 #ifndef SPE_FUSED_PREF1
@@ -399,11 +407,34 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
     constexpr bool M4 = SPE_FUSED_MIX4 && (H % 4 == 0);
     float Al4[M4 ? H / 4 : 1][M4 ? H : 1];                 // f32 operand of the S' mix (see mix_keys_f32)
     if constexpr (M4) mixA4_build<H, false>(a.Wl, lane, Al4);
+    // Weight-gradient outer products on the MATRIX pipe (GWM): dW[g][h] = sum over (query, key) positions of x_g * y_h (mode 2:
+    // x = dP', y = P -> dWw, dbw) is a contraction over POSITIONS, i.e. D[m = g][n = h] += A[g][pos] B[pos][h] with 16 positions per
+    // v_mfma_f32_16x16x16_bf16.  A lane owns ONE query and 4 keys for all heads, the operands want one HEAD per lane (m = lane & 15)
+    // and 4 keys of query t for the t-th instruction: a (query x head) transpose inside each 16-lane group, done through a
+    // wave-private LDS tile [key group][head][query] of 8-B packets (written with 8 ds_write_b64 per operand, read back as 128
+    // contiguous bytes per lane).  Rows m >= H read a block of zeros, row m = H of the B operand a block of ones: column H of D is
+    // the bias gradient.  16 MFMAs per tile replace H*H/2 * 4 = 128 v_pk_fma_f32 and the H*H/2 accumulator registers (4 x 4 here)
+    // - the vector pipe, not the matrix pipe, bounds these passes; packed fp32 FMAs next to MFMAs are an
+    // anti-lever on this chip (MI355X_MICROARCH.md, price of a filler beside MFMAs).
+    constexpr int GW_RED = 4 * (H * 16 * 2 > (H * H + H) ? H * 16 * 2 : (H * H + H));        // floats of sred
+    unsigned char* gconst = reinterpret_cast<unsigned char*>(sred + GW_RED);                  // [zeros 128 B][ones 128 B]
+    unsigned char* sgw = gconst + 256 + wave * (1024 * H);                                    // this wave's [X | Y] tiles, 512*H bytes each
+    f32x4_t gwacc[GWM ? 4 : 1];
+    const unsigned char* gw_xrd = nullptr; const unsigned char* gw_yrd = nullptr; unsigned char* gw_wr = nullptr;
+    if constexpr (GWM) {
+        if (threadIdx.x < 32) reinterpret_cast<uint2*>(gconst)[threadIdx.x] = (threadIdx.x < 16) ? make_uint2(0u, 0u) : make_uint2(0x3F803F80u, 0x3F803F80u);
+        const int gm = lane & 15, gk = lane >> 4;
+        gw_wr = sgw + ((gk * H) * 16 + gm) * 8;                                 // + h * 128: packet of head h, query gm, key group gk
+        gw_xrd = (gm < H) ? sgw + ((gk * H + gm) * 16) * 8 : gconst;            // 16 packets (queries 0..15) of head gm
+        gw_yrd = (gm < H) ? sgw + 512 * H + ((gk * H + gm) * 16) * 8 : ((gm == H) ? gconst + 128 : gconst);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gwacc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
     // weight-gradient accumulators (whole workgroup range)
     // as head pairs: mode 2 gWp[g*(H/2)+hp] = (dWw[g][2hp], dWw[g][2hp+1]) ; mode 3 gWp[gp*H+h] = (dWl[2gp][h], dWl[2gp+1][h])
-    f32x2_t gWp[(MODE >= 2) ? H * H / 2 : 1], gb2[(MODE == 3) ? H / 2 : 1];
-    float gb[(MODE == 2) ? H : 1];
-    if (MODE >= 2) {
+    f32x2_t gWp[(MODE >= 2 && !GWM) ? H * H / 2 : 1], gb2[(MODE == 3) ? H / 2 : 1];
+    float gb[(MODE == 2 && !GWM) ? H : 1];
+    if (MODE >= 2 && !GWM) {
 #pragma unroll
         for (int i = 0; i < H * H / 2; ++i) gWp[i] = splat2(0.f);
         if (MODE == 2) {
@@ -804,6 +835,28 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                             for (int r = 0; r < 4; ++r) { acc2[j][2 * hp][r] *= k0[r]; acc2[j][2 * hp + 1][r] *= k1[r]; }
                         }
                     }
+                    if constexpr (GWM) {
+                        // dWw += dP' P^T, dbw += dP' over this tile's 256 positions: transpose through the wave's LDS tile, 16 MFMAs
+#pragma unroll
+                        for (int g = 0; g < H; ++g) {
+                            *reinterpret_cast<s16x4m_t*>(gw_wr + g * 128) = pack4<false>(acc2[j][g][0], acc2[j][g][1], acc2[j][g][2], acc2[j][g][3]);
+                            *reinterpret_cast<s16x4m_t*>(gw_wr + 512 * H + g * 128) =
+                                pack4<false>(PT[j][0][g / 2][g & 1], PT[j][1][g / 2][g & 1], PT[j][2][g / 2][g & 1], PT[j][3][g / 2][g & 1]);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // wave-private tile: the other lanes' packets are read next
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const u32x4_t xa = *reinterpret_cast<const u32x4_t*>(gw_xrd + c * 16);
+                            const u32x4_t yb = *reinterpret_cast<const u32x4_t*>(gw_yrd + c * 16);
+                            typedef unsigned u32x2w_t __attribute__((ext_vector_type(2)));
+                            gwacc[(2 * c) & 3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4m_t, (u32x2w_t){xa[0], xa[1]}),
+                                                                                             __builtin_bit_cast(s16x4m_t, (u32x2w_t){yb[0], yb[1]}), gwacc[(2 * c) & 3], 0, 0, 0);
+                            gwacc[(2 * c + 1) & 3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4m_t, (u32x2w_t){xa[2], xa[3]}),
+                                                                                                 __builtin_bit_cast(s16x4m_t, (u32x2w_t){yb[2], yb[3]}), gwacc[(2 * c + 1) & 3], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the tile is rewritten by the next key tile
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         f32x2_t mt[H / 2];
@@ -819,18 +872,20 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
 #pragma unroll
                             for (int hp = 0; hp < H / 2; ++hp) mt[hp] = splat2(0.f);
                         }
+                        if constexpr (!GWM || !MM) {
 #pragma unroll
                         for (int g = 0; g < H; ++g) {
                             const float dv = acc2[j][g][r];
                             const f32x2_t db = splat2(dv);
-                            gb[g] += dv;
+                            if constexpr (!GWM) gb[(MODE == 2 && !GWM) ? g : 0] += dv;
 #pragma unroll
                             for (int hp = 0; hp < H / 2; ++hp) {
 #ifndef SPE_DBG_NOGW
-                                gWp[g * (H / 2) + hp] = fma2(db, PT[j][r][hp], gWp[g * (H / 2) + hp]);
+                                if constexpr (!GWM) gWp[(MODE >= 2 && !GWM) ? g * (H / 2) + hp : 0] = fma2(db, PT[j][r][hp], gWp[(MODE >= 2 && !GWM) ? g * (H / 2) + hp : 0]);
 #endif
                                 if constexpr (!MM) mt[hp] = fma2(db, (f32x2_t){ww[g][2 * hp], ww[g][2 * hp + 1]}, mt[hp]);
                             }
+                        }
                         }
 #pragma unroll
                         for (int hp = 0; hp < H / 2; ++hp) rD2[hp] = fma2(mt[hp], PT[j][r][hp], rD2[hp]);
@@ -1030,16 +1085,28 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
         constexpr int NW = 2 * (H * H + H);
         __syncthreads();
         float* part = sred;                                 // [4][H*H+H]
+        if constexpr (GWM) {
+            // D[m = g][n]: lane holds rows 4*(lane>>4) + r of column lane & 15; columns < H = dW[g][h], column H = the bias gradient
+            const f32x4_t dsum = (gwacc[0] + gwacc[1]) + (gwacc[2] + gwacc[3]);
+            const int nn = lane & 15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int g = 4 * (lane >> 4) + r;
+                if (g < H && nn < H) part[wave * (H * H + H) + g * H + nn] = dsum[r];
+                if (g < H && nn == H) part[wave * (H * H + H) + H * H + g] = dsum[r];
+            }
+        } else {
 #pragma unroll
         for (int g = 0; g < H; ++g) {
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 // mode 3 accumulated dS' . (log2(e) S)^T
-                const float v = (MODE == 2) ? spe_wave_sum(gWp[g * (H / 2) + h / 2][h & 1]) : SPE_LN2 * spe_wave_sum(gWp[(g / 2) * H + h][g & 1]);
+                const float v = (MODE == 2) ? spe_wave_sum(gWp[GWM ? 0 : g * (H / 2) + h / 2][h & 1]) : SPE_LN2 * spe_wave_sum(gWp[GWM ? 0 : (g / 2) * H + h][g & 1]);
                 if (lane == 0) part[wave * (H * H + H) + g * H + h] = v;
             }
-            const float v = spe_wave_sum((MODE == 2) ? gb[(MODE == 2) ? g : 0] : gb2[(MODE == 3) ? g / 2 : 0][g & 1]);
+            const float v = spe_wave_sum((MODE == 2) ? gb[(MODE == 2 && !GWM) ? g : 0] : gb2[(MODE == 3) ? g / 2 : 0][g & 1]);
             if (lane == 0) part[wave * (H * H + H) + H * H + g] = v;
+        }
         }
         __syncthreads();
         // layout of a ws_w row: [dWl | dbl | dWw | dbw]; mode 2 fills the second half, mode 3 the first
@@ -1157,7 +1224,8 @@ static void make_plan(int B, int nt, int nwg, int mode, int* spw_out, int* nwg_o
 template <int H, int DSTEPS, bool TAIL16, int MODE, bool DROP, int KT>
 static int launch_fused(const FusedArgs& a, int nwg, hipStream_t st) {
     constexpr int NFR = H * DSTEPS;
-    constexpr int smem = ((MODE <= 1) ? SPE_FUSED_QP : 1) * NFR * 64 * 16 * ((MODE >= 2) ? 2 : 1) + 4 * (H * 16 * 2 > (H * H + H) ? H * 16 * 2 : (H * H + H)) * 4;
+    constexpr int smem = ((MODE <= 1) ? SPE_FUSED_QP : 1) * NFR * 64 * 16 * ((MODE >= 2) ? 2 : 1) + 4 * (H * 16 * 2 > (H * H + H) ? H * 16 * 2 : (H * H + H)) * 4
+                         + ((MODE == 2 && SPE_FUSED_GWMFMA && H % 4 == 0) ? 256 + 4 * 1024 * H : 0);      // GWM: constants + the 4 waves' transpose tiles
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&talking_fused_kernel<H, DSTEPS, TAIL16, MODE, DROP, KT>),

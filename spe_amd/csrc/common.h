@@ -6,6 +6,23 @@
 
 #define SPE_WAVE 64
 
+// Timing-experiment switches (SPE_DBG_*, SPE_ABL_*, plain-store variants) exist only in -DSPE_ABLATE builds (tools/ab.py); the
+// product library (spe_amd/build.py) never defines SPE_ABLATE, so none of them can change what a parity or benchmark run executes.
+#ifndef SPE_ABLATE
+#undef SPE_DBG_NOEXP
+#undef SPE_DBG_NOMIX
+#undef SPE_DBG_TAILNOP
+#undef SPE_DBG_NOKEEP
+#undef SPE_DBG_NOSTAGE
+#undef SPE_DBG_NOLOAD
+#undef SPE_DBG_NOGW
+#undef SPE_DBG_LN_NOATOMIC
+#undef SPE_ABL_NOSTORE
+#undef SPE_ABL_NOLOOP
+#undef SPE_PLAIN_STORES
+#undef FUSED_PLAIN_STORE
+#endif
+
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));

@@ -60,6 +60,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(Gemm16Args p) {
         if (tm >= tiles_m || tn >= tiles_n) return;
     }
     const int m0 = tm * BM, n0 = tn * BN;
+    // Phase stagger: the two workgroups of a CU start together and would run their main loops (operand loads + MFMA) and then their
+    // epilogues (tens of MB of stores) in lockstep - neither overlaps the other's.  The workgroups that fill the second slot
+    // of the CUs (grid indices 256-511 of the first round) start `stagger` x ~4 us late, so one's epilogue meets the other's loop;
+    // later rounds inherit the offset.
+    if (p.stagger > 0 && (blockIdx.x >> 8) == 1) {
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 #if defined(SPE_ABLATE) && defined(SPE_ABL_NOLOOP)
     const int nt = 1;                              // timing experiment: one stage of the main loop
 #else
@@ -170,6 +177,8 @@ static int launch_nt2(const Gemm16Args& p, hipStream_t stream) {
     }
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     Gemm16Args q = p;
+    static const int stagger = getenv("SPE_NT2_STAGGER") ? atoi(getenv("SPE_NT2_STAGGER")) : 0;
+    q.stagger = stagger;
     q.xcd_bind = 0;
     if (p.M >= p.N && tiles_m >= 16) q.xcd_bind = 1;
     else if (p.N > p.M && tiles_n >= 16) q.xcd_bind = 2;

@@ -2,7 +2,8 @@
 
   python tools/ab.py name1 "-DFOO=1" name2 "-DFOO=2 -DBAR=0" ...
 
-writes build_ab/<name>.so (git-ignored, travels with gpurun); run a tool against one with
+writes build_ab/<name>.so (git-ignored, travels with gpurun), built with -DSPE_ABLATE - the only builds in which the timing-experiment
+switches (SPE_DBG_*, SPE_ABL_*) of csrc/ exist (csrc/common.h); run a tool against one with
   SPE_HIP_LIB=build_ab/<name>.so python tools/time_fused.py
 """
 import os
@@ -17,7 +18,7 @@ from spe_amd.build import CSRC, sources  # noqa: E402
 
 def one(name, flags):
     out = os.path.join(ROOT, "build_ab", name + ".so")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", out] + flags.split() + sources()
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DSPE_ABLATE", "-o", out] + flags.split() + sources()
     subprocess.run(cmd, check=True, cwd=CSRC)
     return out
 

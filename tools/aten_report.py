@@ -24,7 +24,6 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     lib.load()
-    K.set_precision("bf16")
     K.manual_seed(1234)
     args = bench.model_args()
     torch.manual_seed(0)
