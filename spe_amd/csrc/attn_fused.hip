@@ -350,7 +350,11 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
 #ifndef SPE_FUSED_JB2G
 #define SPE_FUSED_JB2G 2
 #endif
-    constexpr bool GWM = SPE_FUSED_GWMFMA && (H % 4 == 0) && (MODE == 2);     // weight-gradient outer products on the matrix pipe (below)
+#ifndef SPE_FUSED_GWMFMA3
+#define SPE_FUSED_GWMFMA3 1
+#endif
+    // weight-gradient outer products on the matrix pipe (below): backward pass 1 (dWw, dbw) and backward pass 2 (dWl, dbl)
+    constexpr bool GWM = SPE_FUSED_GWMFMA && (H % 4 == 0) && (MODE == 2 || (MODE == 3 && SPE_FUSED_GWMFMA3));
     // backward pass 1 with the outer products on the matrix pipe has ~36 registers to spare: 8 heads per fragment batch there too
     constexpr int JBW = (MODE == 3) ? 2 * SPE_FUSED_JB2 : (GWM ? SPE_FUSED_JB2G * SPE_FUSED_JB2 : SPE_FUSED_JB2);
     constexpr int JB = (MODE >= 2) ? ((H >= JBW) ? JBW : ((H >= SPE_FUSED_JB2) ? SPE_FUSED_JB2 : H)) : H;
@@ -434,6 +438,10 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
     // as head pairs: mode 2 gWp[g*(H/2)+hp] = (dWw[g][2hp], dWw[g][2hp+1]) ; mode 3 gWp[gp*H+h] = (dWl[2gp][h], dWl[2gp+1][h])
     f32x2_t gWp[(MODE >= 2 && !GWM) ? H * H / 2 : 1], gb2[(MODE == 3) ? H / 2 : 1];
     float gb[(MODE == 2 && !GWM) ? H : 1];
+    if (MODE == 3 && GWM) {
+#pragma unroll
+        for (int g = 0; g < H / 2; ++g) gb2[(MODE == 3) ? g : 0] = splat2(0.f);
+    }
     if (MODE >= 2 && !GWM) {
 #pragma unroll
         for (int i = 0; i < H * H / 2; ++i) gWp[i] = splat2(0.f);
@@ -970,20 +978,48 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                             for (int gp = 0; gp < H / 2; ++gp) if (!kv) d2[r][gp] = splat2(0.f);
                         }
                     }
+                    if constexpr (GWM) {
+                        // dWl += dS' S^T over this tile's 256 positions on the matrix pipe (see backward pass 1).  dbl stays an fp32 sum
+                        // on the vector pipe: its exact value is 0 (softmax is shift invariant), and the bf16 rounding of dS' in the
+                        // MFMA operand would leave 2^-9-grade noise where the fp32 sum leaves 1e-7
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int gp = 0; gp < H / 2; ++gp) gb2[(MODE == 3) ? gp : 0] += d2[r][gp];
+#pragma unroll
+                        for (int g = 0; g < H; ++g) {
+                            *reinterpret_cast<s16x4m_t*>(gw_wr + g * 128) = pack4<false>(d2[0][g / 2][g & 1], d2[1][g / 2][g & 1], d2[2][g / 2][g & 1], d2[3][g / 2][g & 1]);
+                            *reinterpret_cast<s16x4m_t*>(gw_wr + 512 * H + g * 128) = pack4<false>(acc[j][g][0], acc[j][g][1], acc[j][g][2], acc[j][g][3]);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const u32x4_t xa = *reinterpret_cast<const u32x4_t*>(gw_xrd + c * 16);
+                            const u32x4_t yb = *reinterpret_cast<const u32x4_t*>(gw_yrd + c * 16);
+                            typedef unsigned u32x2w_t __attribute__((ext_vector_type(2)));
+                            gwacc[(2 * c) & 3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4m_t, (u32x2w_t){xa[0], xa[1]}),
+                                                                                             __builtin_bit_cast(s16x4m_t, (u32x2w_t){yb[0], yb[1]}), gwacc[(2 * c) & 3], 0, 0, 0);
+                            gwacc[(2 * c + 1) & 3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4m_t, (u32x2w_t){xa[2], xa[3]}),
+                                                                                                 __builtin_bit_cast(s16x4m_t, (u32x2w_t){yb[2], yb[3]}), gwacc[(2 * c + 1) & 3], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                        for (int gp = 0; gp < H / 2; ++gp) gb2[gp] += d2[r][gp];
+                        for (int gp = 0; gp < H / 2; ++gp) gb2[(MODE == 3) ? gp : 0] += d2[r][gp];
 #pragma unroll
                         for (int h = 0; h < H; ++h) {
                             const f32x2_t sb = splat2(acc[j][h][r]);
 #pragma unroll
 #ifndef SPE_DBG_NOGW
-                            for (int gp = 0; gp < H / 2; ++gp) gWp[gp * H + h] = fma2(d2[r][gp], sb, gWp[gp * H + h]);
+                            for (int gp = 0; gp < H / 2; ++gp) gWp[(MODE >= 2 && !GWM) ? gp * H + h : 0] = fma2(d2[r][gp], sb, gWp[(MODE >= 2 && !GWM) ? gp * H + h : 0]);
 #else
-                            for (int gp = 0; gp < ((h == 0) ? H / 2 : 0); ++gp) gWp[gp * H + h] = fma2(d2[r][gp], sb, gWp[gp * H + h]);
+                            for (int gp = 0; gp < ((h == 0) ? H / 2 : 0); ++gp) gWp[(MODE >= 2 && !GWM) ? gp * H + h : 0] = fma2(d2[r][gp], sb, gWp[(MODE >= 2 && !GWM) ? gp * H + h : 0]);
 #endif
                         }
+                    }
                     }
                     f32x2_t ds[4][H / 2];
 #pragma unroll
@@ -1092,8 +1128,16 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int g = 4 * (lane >> 4) + r;
-                if (g < H && nn < H) part[wave * (H * H + H) + g * H + nn] = dsum[r];
-                if (g < H && nn == H) part[wave * (H * H + H) + H * H + g] = dsum[r];
+                // mode 3 accumulated dS' . (log2(e) S)^T: the weight gradient carries ln 2, the bias gradient does not
+                if (g < H && nn < H) part[wave * (H * H + H) + g * H + nn] = (MODE == 3) ? SPE_LN2 * dsum[r] : dsum[r];
+                if (MODE == 2 && g < H && nn == H) part[wave * (H * H + H) + H * H + g] = dsum[r];
+            }
+            if constexpr (MODE == 3) {
+#pragma unroll
+                for (int g = 0; g < H; ++g) {
+                    const float v = spe_wave_sum(gb2[(MODE == 3) ? g / 2 : 0][g & 1]);
+                    if (lane == 0) part[wave * (H * H + H) + H * H + g] = v;
+                }
             }
         } else {
 #pragma unroll
@@ -1225,7 +1269,7 @@ template <int H, int DSTEPS, bool TAIL16, int MODE, bool DROP, int KT>
 static int launch_fused(const FusedArgs& a, int nwg, hipStream_t st) {
     constexpr int NFR = H * DSTEPS;
     constexpr int smem = ((MODE <= 1) ? SPE_FUSED_QP : 1) * NFR * 64 * 16 * ((MODE >= 2) ? 2 : 1) + 4 * (H * 16 * 2 > (H * H + H) ? H * 16 * 2 : (H * H + H)) * 4
-                         + ((MODE == 2 && SPE_FUSED_GWMFMA && H % 4 == 0) ? 256 + 4 * 1024 * H : 0);      // GWM: constants + the 4 waves' transpose tiles
+                         + (((MODE == 2 || (MODE == 3 && SPE_FUSED_GWMFMA3)) && SPE_FUSED_GWMFMA && H % 4 == 0) ? 256 + 4 * 1024 * H : 0);      // GWM: constants + the 4 waves' transpose tiles
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&talking_fused_kernel<H, DSTEPS, TAIL16, MODE, DROP, KT>),
