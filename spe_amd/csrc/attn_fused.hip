@@ -356,7 +356,13 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
     // weight-gradient outer products on the matrix pipe (below): backward pass 1 (dWw, dbw) and backward pass 2 (dWl, dbl)
     constexpr bool GWM = SPE_FUSED_GWMFMA && (H % 4 == 0) && (MODE == 2 || (MODE == 3 && SPE_FUSED_GWMFMA3));
     // backward pass 1 with the outer products on the matrix pipe has ~36 registers to spare: 8 heads per fragment batch there too
-    constexpr int JBW = (MODE == 3) ? 2 * SPE_FUSED_JB2 : (GWM ? SPE_FUSED_JB2G * SPE_FUSED_JB2 : SPE_FUSED_JB2);
+#ifndef SPE_FUSED_JB3
+#define SPE_FUSED_JB3 8
+#endif
+#ifndef SPE_FUSED_PREF3
+#define SPE_FUSED_PREF3 0
+#endif
+    constexpr int JBW = (MODE == 3) ? SPE_FUSED_JB3 : (GWM ? SPE_FUSED_JB2G * SPE_FUSED_JB2 : SPE_FUSED_JB2);
     constexpr int JB = (MODE >= 2) ? ((H >= JBW) ? JBW : ((H >= SPE_FUSED_JB2) ? SPE_FUSED_JB2 : H)) : H;
     // request the next macro step's first batch before the VALU phases (its registers stay live through them)
 #ifndef SPE_FUSED_PREF1
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
     #ifndef SPE_FUSED_PREF2
 #define SPE_FUSED_PREF2 1
 #endif
-    constexpr bool PREF = (MODE == 0) || (MODE == 1 && SPE_FUSED_PREF1) || (MODE == 2 && !DROP && SPE_FUSED_PREF2);
+    constexpr bool PREF = (MODE == 0) || (MODE == 1 && SPE_FUSED_PREF1) || (MODE == 2 && !DROP && SPE_FUSED_PREF2) || (MODE == 3 && !DROP && SPE_FUSED_PREF3);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int QP = (MODE <= 1) ? SPE_FUSED_QP : 1, WPQ = 4 / QP;        // q-tiles per workgroup, waves per q-tile
     u32x4_t* sQ = reinterpret_cast<u32x4_t*>(smem_raw);    // [QP][NFR][64]

@@ -1060,3 +1060,49 @@ def test_attention_flash(dev, Lq, Lk, H, dk, dv):
         ops.FLASH_MIN_KEYS = old_min
     for a_, b_ in zip(res[True], res[False]):
         assert rel(a_, b_) < 2 * TOL["bf16"]
+
+
+def _split16(x):
+    hi = x.to(torch.bfloat16)
+    return hi, (x - hi.float()).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,Kd", [(2048, 384, 384), (8300, 1152, 384), (4150, 1536, 384), (8211, 1144, 448), (2300, 392, 320), (6200, 64, 128)])
+@pytest.mark.parametrize("split", [False, True])
+def test_gemm_nt2_plain(dev, M, N, Kd, split):
+    """csrc/gemm_nt2.hip (128-row LDS-DMA kernels, >= 2048 rows, K % 64 == 0) through spe_gemm_bf16nt: single-term and split
+    operands, ragged M / N, bias + ReLU + pre-activation copy, against fp64 on the operands the kernel sees."""
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(M + N + Kd)
+    x = torch.randn(M, Kd, generator=g).to(dev); W = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).to(dev); b = torch.randn(N, generator=g).to(dev)
+    xh, xl = _split16(x); Wh, Wl = _split16(W)
+    ref = (x.double() @ W.double().t() if split else xh.double() @ Wh.double().t()) + b.double()
+    C = torch.full((M, N), float("nan"), device=dev); C2 = torch.full((M, N), float("nan"), device=dev)
+    K.gemm16(xh, Wh, C, M, N, Kd, Kd, Kd, N, bias=b, C2=C2, act=1, **(dict(Alo=xl, Blo=Wl) if split else {}))
+    tol = 2e-5 if split else 1e-6
+    assert rel(C2, ref) < tol and rel(C, ref.clamp(min=0)) < tol, (rel(C2, ref), rel(C, ref.clamp(min=0)))
+
+
+@pytest.mark.parametrize("M,N,Kd", [(8300, 1536, 384), (2100, 384, 1536), (4150, 384, 384)])
+def test_gemm_nt2_fused_epilogues(dev, M, N, Kd):
+    """The fused epilogues on the gemm_nt2 kernels: fc1 forward (pre-activation + GELU as a (hi, lo) bf16 pair, split operands),
+    projection + LayerScale residual (split operands), dh backward (gelu'(aux), bf16 result + column sums, single-term)."""
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(M * 3 + N)
+    x = torch.randn(M, Kd, generator=g).to(dev); W = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).to(dev); b = torch.randn(N, generator=g).to(dev)
+    xh, xl = _split16(x); Wh, Wl = _split16(W)
+    ref = x.double() @ W.double().t() + b.double()
+    pre = torch.empty(M, N, device=dev); h = torch.empty(M, N, device=dev, dtype=torch.bfloat16); hl = torch.empty_like(h)
+    K.gemm16_ex(xh, Wh, M, N, Kd, Kd, Kd, bias=b, C2=pre, out16=h, out16lo=hl, act=2, Alo=xl, Blo=Wl)
+    assert rel(pre, ref) < 2e-5 and rel(h.float() + hl.float(), torch.nn.functional.gelu(ref)) < 3e-5
+    assert torch.equal(h, torch.nn.functional.gelu(pre).to(torch.bfloat16)) or rel(h.float(), torch.nn.functional.gelu(ref)) < 3e-3
+    res = torch.randn(M, N, generator=g).to(dev); gam = torch.rand(N, generator=g).to(dev)
+    out = torch.empty(M, N, device=dev); y = torch.empty(M, N, device=dev)
+    K.gemm16_ex(xh, Wh, M, N, Kd, Kd, Kd, bias=b, C=out, C2=y, res=res, rgamma=gam, Alo=xl, Blo=Wl)
+    assert rel(y, ref) < 2e-5 and rel(out, res.double() + gam.double() * ref) < 2e-5
+    aux = torch.randn(M, N, generator=g).to(dev); o16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16); cs = torch.zeros(N, device=dev)
+    K.gemm16_ex(xh, Wh, M, N, Kd, Kd, Kd, out16=o16, colsum=cs, aux=aux, act=2)
+    a64 = aux.double()
+    d = 0.5 * (1 + torch.erf(a64 / 2 ** 0.5)) + a64 * torch.exp(-0.5 * a64 * a64) / (2 * 3.141592653589793) ** 0.5
+    v = (xh.double() @ Wh.double().t()) * d
+    assert rel(o16.float(), v) < 4e-3 and rel(cs, v.sum(0)) < 1e-4
