@@ -95,6 +95,19 @@ int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const
 int spe_gemm_bf16nt(const void* A16, const void* B16, const void* A16lo, const void* B16lo, float* C, const float* bias,
                     float* C2, int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int splitk,
                     spe_stream_t stream);
+/* nn.Linear on a few hundred rows (the decoder / encoder / head side: reference models/transformer.py:21-33, 206-250, 355-427,
+ * models/conditional_detr.py:68-116) as ONE launch each way - these products are bound by dependent launches, not by throughput.
+ * spe_linear_small_fwd: y[R][ldc] = act(x W^T + bias) from the fp32 activations x [R][ldx] and the cached bf16 weight W16 [N][K]
+ *   (W16lo != NULL: split operands, x is split into (hi, lo) while it is staged - precision mode bf16s); pre (optional): the
+ *   pre-activation; x16_out (optional): bf16(x) [R][K], all the backward needs of x.  act: 0 none, 1 ReLU, 2 exact-erf GELU.
+ * spe_linear_small_bwd: dx [R][K] = dy' W, dW [N][K] = dy'^T x, db [N] = colsum(dy') in one grid, dy' = dy (fp32 [R][N]) times
+ *   the derivative of the fused activation at aux (act 1: forward output, act 2: pre-activation; aux NULL: none); x16 [R][K] and
+ *   WT16 [K][N] bf16; any of dx / dW / db may be NULL.  dW and db are OVERWRITTEN (no zeroing needed), db is summed in a fixed
+ *   order (no atomics).  K, N multiples of 8, operands 16-B aligned; -2 otherwise. */
+int spe_linear_small_fwd(const float* x, long ldx, const void* W16, const void* W16lo, const float* bias, float* y, float* pre,
+                         void* x16_out, int R, int N, int K, long ldc, int act, spe_stream_t stream);
+int spe_linear_small_bwd(const float* dy, const float* aux, int act, const void* x16, const void* WT16, float* dx, float* dW,
+                         float* db, int R, int N, int K, spe_stream_t stream);
 /* spe_gemm_bf16tn: C[m][n] = alpha * sum_r A16[r][m] * B16[r][n] - the weight gradient dW = dy^T x of a Linear (autograd of
  * reference models/cait.py:376,390,409, models/transformer.py:368-425) on ROW-MAJOR bf16 operands A16 [R, lda] (M columns)
  * and B16 [R, ldb] (N columns): the contraction runs over rows, the MFMA operands are formed by LDS transpose reads

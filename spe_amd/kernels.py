@@ -213,6 +213,16 @@ def weights_changed():
 
 
 
+LINEAR_SMALL = os.environ.get("SPE_LINEAR_SMALL", "1") != "0"
+LINEAR_SMALL_MAX_ROWS = 2048
+
+
+def _lin_small_ok(R, N, K):
+    """The one-launch Linear of csrc/linear_small.hip: row-major bf16 saves (DW_TN), 128 <= rows < 2048."""
+    return (LINEAR_SMALL and DW_TN and LINEAR16 and _PRECISION != 1 and LINEAR16_MIN_ROWS <= R < LINEAR_SMALL_MAX_ROWS
+            and N % 8 == 0 and K % 8 == 0)
+
+
 def _lin16_ok(R, N, K):
     return LINEAR16 and _PRECISION != 1 and R >= LINEAR16_MIN_ROWS and N % 8 == 0 and K % 8 == 0
 
@@ -565,6 +575,21 @@ def linear_fwd(x2, W, b, act=0, want_pre=False, save_for_dw=True, src=None):
     N = W.shape[0]
     y = torch.empty((R, N), device=x2.device, dtype=torch.float32)
     pre = torch.empty_like(y) if want_pre else None
+    if _lin_small_ok(R, N, K) and W.is_contiguous():
+        # a few hundred rows (decoder / heads): one launch straight from the fp32 activations (csrc/linear_small.hip); it also
+        # leaves bf16(x) behind for the backward unless the activation already carries one
+        sp = split_fwd()
+        Wt = weight16(W, lo=sp)
+        ent = getattr(src, "_spe16", None) if src is not None else None
+        x16 = ent[1] if (ent is not None and ent[0] == src._version and ent[1].shape == x2.shape) else None
+        x16_out = None
+        if x16 is None and save_for_dw:
+            x16 = x16_out = torch.empty((R, K), device=x2.device, dtype=torch.bfloat16)
+            if src is not None:
+                src._spe16 = (src._version, x16, None, None)
+        _call("spe_linear_small_fwd", _p(x2), x2.stride(0), _p(Wt[0]), _p(Wt[2] if sp else None), _p(b), _p(y), _p(pre), _p(x16_out),
+              R, N, K, N, int(act), _st())
+        return y, pre, (x16 if save_for_dw else x2)
     if _lin16_ok(R, N, K) and W.is_contiguous():
         sp = split_fwd()
         x16, x16T, x16lo = act16(x2, save_for_dw and not DW_TN, src, want_lo=sp)
@@ -584,6 +609,18 @@ def linear_bwd(dy2, xsave, W, need_dx=True, need_dw=True, need_db=True, dW_out=N
     K = W.shape[1]
     dx = dW = db = None
     x16 = xsave.dtype == torch.bfloat16
+    if (x16 or not need_dw) and _lin_small_ok(R, N, K) and W.is_contiguous() and (not x16 or _is_rowmajor_save(xsave, R)):
+        # one launch: dx, dW and db (csrc/linear_small.hip); dW / db are overwritten, so the bucket views need no zeroing
+        dev = dy2.device
+        if need_dx:
+            dx = torch.empty((R, K), device=dev, dtype=torch.float32)
+        if need_dw:
+            dW = dW_out if dW_out is not None else torch.empty((N, K), device=dev, dtype=torch.float32)
+        if need_db:
+            db = db_out.view(-1) if db_out is not None else torch.empty((N,), device=dev, dtype=torch.float32)
+        _call("spe_linear_small_bwd", _p(dy2), _p(act_aux if act else None), int(act), _p(xsave if need_dw else None),
+              _p(weight16(W)[1] if need_dx else None), _p(dx), _p(dW), _p(db), R, N, K, _st())
+        return dx, dW, db
     if (x16 or not need_dw) and _lin16_ok(R, N, K) and W.is_contiguous():
         tn = x16 and _is_rowmajor_save(xsave, R)
         Rp = None if (tn or not x16) else xsave.shape[1]
