@@ -18,6 +18,7 @@
  */
 #ifndef SPE_HIP_H
 #define SPE_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -29,8 +30,20 @@ typedef struct ihipStream_t* spe_stream_t; /* == hipStream_t */
 /* 2 since round 2 (changed signatures: spe_hungarian, spe_adamw_flat, spe_layernorm_fwd, spe_attn_contract,
  * spe_talking_fused_plan; new entry points); 3 since round 3 (fp16 forward formats of the fused attention: spe_attn_contract
  * takes `fmt`, spe_attn_pack_multi kinds carry an element-format bit, spe_talking_fused expects fp16 Q / K fragments and writes
- * fp16 P'd blocks; split-operand GEMM entry points) */
+ * fp16 P'd blocks; split-operand GEMM entry points); 4: deterministic reductions - spe_set_reduce_workspace is new and required
+ * before any entry point that sums across workgroups, spe_box_loss takes L, spe_linear_small_fwd / _bwd are new */
 int spe_abi_version(void);
+
+/* ---- reduction workspace --------------------------------------------------------------------
+ * Every sum across workgroups on the gradient path (bias / LayerNorm gamma, beta / LayerScale gamma column sums of
+ * spe_layernorm_bwd, spe_layernorm_res_bwd, spe_colsum, spe_cvt_bf16, spe_gemm_bf16nt_ex, spe_layerscale_residual_bwd(16), the
+ * loss sums of spe_focal_loss; reference: the reductions autograd performs for models/cait.py:376-416, models/transformer.py:
+ * 279-287 and models/conditional_detr.py:253-275) is taken in a FIXED order - per-workgroup partials in slabs, integer tickets, the
+ * last arriver adds (csrc/det_reduce.h) - so gradients are bitwise reproducible run to run; no fp32 atomics.  The slabs and tickets
+ * live in caller-owned device memory registered here once per process (256-B aligned, >= 2 MiB; 16 MiB covers every shape of
+ * the model path); entry points that need it return -4 when none is registered or it is too small.  All launches that use it
+ * must be ordered on one stream at a time.  ws = NULL unregisters. */
+int spe_set_reduce_workspace(void* ws, size_t bytes, spe_stream_t stream);
 
 /* ---- contraction ----------------------------------------------------------------------
  * C[z] = act(alpha * opA(A[z]) @ opB(B[z]) + bias) for z = (z0, z1) in batch0 x batch1, each
@@ -286,10 +299,10 @@ int spe_focal_loss(const float* logits, const int* tclass, const float* roww, fl
 
 /* ---- matched-pair box losses (reference models/conditional_detr.py:300-319, 537-560):
  * pair i = (row srow[i] of pred_boxes[*,4], tbox[i], weight w[i] or null, layer lidx[i]).
- * sums[l][0] += w*L1, sums[l][1] += w*(1-GIoU) (pre-zeroed); g_l1/g_giou = d/d(pred cxcywh).
+ * sums[l][0] += w*L1, sums[l][1] += w*(1-GIoU) for l < L (pairs added in index order); g_l1/g_giou = d/d(pred cxcywh).
  * bwd scatter-adds c1[l]*g_l1 + c2[l]*g_giou into dpred rows. */
 int spe_box_loss(const float* pred_boxes, const long* srow, const float* tbox, const float* w, const int* lidx,
-                 float* sums, float* g_l1, float* g_giou, long n, spe_stream_t stream);
+                 float* sums, float* g_l1, float* g_giou, long n, int L, spe_stream_t stream);
 int spe_box_loss_bwd(const long* srow, const int* lidx, const float* g_l1, const float* g_giou, const float* c1,
                      const float* c2, float* dpred, long n, spe_stream_t stream);
 

@@ -4,6 +4,7 @@
 // WM = BM/2, WN = BN/2, 4 waves as 2 x 2: a lane owns 4 consecutive columns of one row per 16x16 tile (16-B fp32 stores).
 #pragma once
 #include "common.h"
+#include "det_reduce.h"
 
 #define GB_BK 64
 #define GB_LDR 72      // bf16 per LDS row of the register-pipelined kernels: 64 + 8 pad (144-B rows: 16-B aligned, conflict-light ds_read_b128)
@@ -25,7 +26,8 @@ struct Gemm16Args {
     // derivative of a fused activation applied from its saved argument
     unsigned short* out16; long ld16;      // [M][ld16]  bf16(v)
     unsigned short* out16T; long ld16t;    // [N][ld16t] bf16(v) transposed, columns M..ld16t-1 zero
-    float* colsum;                         // [N] += sum_m v
+    float* colsum;                         // [N] += sum_m v (row tiles added in a fixed order: det_reduce.h)
+    DetWs ws;                              // reduction workspace of the column sums
     const float* aux;                      // [M][ldc]: v *= act'(aux) (act 1: aux = forward output, 2: pre-activation)
     const float* res; const float* rgamma; // LayerScale residual: C = res[m][n] + rgamma[n] * v  (C2 still gets v)
 };
@@ -35,8 +37,8 @@ __device__ __forceinline__ float gelu_erf16(float x) { return 0.5f * x * (1.0f +
 
 // ---- extended epilogue.  v = alpha*acc + bias ; C2 = v ; v = act(v) or v * act'(aux) ; C = v (optional);
 // the bf16 copies go through LDS (smem16: the operand buffers, free by now; the caller has synchronised the workgroup) so that both
-// the row-major and the transposed copy leave as 16-B stores of full rows; column sums: 16-lane DPP reduction + one atomic per
-// column and wave row.  SPLIT kernels can also emit out16lo = bf16(v - bf16(v)).  LDS needed (bf16 elements):
+// the row-major and the transposed copy leave as 16-B stores of full rows; column sums: 16-lane reduction per wave row, then a
+// fixed-order sum over the row tiles (det_reduce.h).  SPLIT kernels can also emit out16lo = bf16(v - bf16(v)).  LDS needed (bf16 elements):
 // BM*(BN+8) + BN*(BM+8) (+ BM*(BN+8) with SPLIT); TRANSPOSED = false drops the out16T tile (BN*(BM+8)) and its support.
 template <int BM, int BN, bool SPLIT, bool TRANSPOSED = true>
 __device__ __forceinline__ void gemm16_epilogue_ex(const Gemm16Args& p, f32x4_t (&acc)[BM / 32][BN / 32], unsigned short* smem16,
@@ -49,6 +51,7 @@ __device__ __forceinline__ void gemm16_epilogue_ex(const Gemm16Args& p, f32x4_t 
     unsigned short* sR = smem16;                         // [BM][LR]  row-major tile
     unsigned short* sT = smem16 + BM * LR;               // [BN][LT]  transposed tile
     unsigned short* sRl = sT + (TRANSPOSED ? BN * LT : 0);   // [BM][LR]  low part of the row-major tile (SPLIT kernels)
+    __shared__ float cs_red[2][BN];                        // column sums of the two wave rows
     __syncthreads();
     typedef short s16x4i_t __attribute__((ext_vector_type(4)));
     s16x4i_t ident;
@@ -182,7 +185,7 @@ __device__ __forceinline__ void gemm16_epilogue_ex(const Gemm16Args& p, f32x4_t 
             c += __shfl_xor(c, 4, 64);
             c += __shfl_xor(c, 8, 64);
             const int col = 2 * (fr & 1) + ((fr >> 1) & 1);          // the column this lane ended up with
-            if (fr < 4 && n + col < p.N) atomicAdd(p.colsum + n + col, c);
+            if (fr < 4) cs_red[wm][nl + col] = c;
         }
     }
     __syncthreads();
@@ -217,6 +220,10 @@ __device__ __forceinline__ void gemm16_epilogue_ex(const Gemm16Args& p, f32x4_t 
             }
         }
     }
+    if (p.colsum)       // the two wave rows, then the row tiles of this column tile in index order: colsum += total
+        det_reduce(p.ws, n0 / BN, m0 / BM, (p.M + BM - 1) / BM, BN, threadIdx.x, 256,
+                   [&](int c) { return cs_red[0][c] + cs_red[1][c]; },
+                   [&](int c, float t) { if (n0 + c < p.N) p.colsum[n0 + c] += t; });
 }
 
 // ---- plain epilogue: C = act(alpha*acc + bias) (+ C2 = pre-activation), or the private slab of a K split

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "gemm16_epilogue.h"
+#include "det_reduce.h"
 
 // thread t fetches 16-B chunk (t & 7) of rows (t >> 3) + 32*i ; rows are clamped (never stored), chunks past K zeroed
 template <int R>
@@ -336,6 +337,7 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, const void* A16
     p.Alo = reinterpret_cast<const unsigned short*>(A16lo); p.Blo = reinterpret_cast<const unsigned short*>(B16lo); p.out16lo = nullptr;
     p.C = C; p.C2 = C2; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.act = act; p.slab = 0;
+    p.ws = DetWs{nullptr, nullptr, 0, 0};
     p.out16 = nullptr; p.out16T = nullptr; p.colsum = nullptr; p.aux = nullptr; p.ld16 = 0; p.ld16t = 0; p.res = nullptr; p.rgamma = nullptr;
     const int ktiles = (K + GB_BK - 1) / GB_BK;
     if (splitk < 0) {           // slab mode: C holds |splitk| slabs of M*ldc floats
@@ -412,6 +414,8 @@ extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, const void* 
     p.out16 = reinterpret_cast<unsigned short*>(out16); p.ld16 = ld16;
     p.out16T = reinterpret_cast<unsigned short*>(out16T); p.ld16t = ld16t;
     p.colsum = colsum; p.aux = aux; p.res = res; p.rgamma = rgamma;
+    p.ws = spe_detws();
+    if (colsum) DET_CHECK(p.ws, (N + 63) / 64, (M + 63) / 64, 64);      // bound for the smallest tiles
     // the transposed copy's zero columns M..ld16t-1 are written by the last row tile: it must reach ld16t
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const bool reach128 = !out16T || ld16t <= (long)((M + 127) / 128) * 128;
@@ -438,14 +442,15 @@ extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, const void* 
 
 // ---- fp32 -> bf16 (round to nearest even) copies of a [R, C] matrix: out[R][ldo] (row-major) and/or the
 // transpose outT[C][ldt] whose columns R..ldt-1 are zero filled (the contraction padding of the dW GEMM).
-// colsum (optional): colsum[c] += sum_r x[r][c] in fp32 - the bias gradient of a Linear, taken from the same read of dy.
+// colsum (optional): colsum[c] += sum_r x[r][c] in fp32 - the bias gradient of a Linear, taken from the same read of dy; summed
+// over the row tiles in a fixed order (det_reduce.h).
 // aux (optional, same layout as x): the activation backward of the fused Linear+activation is applied while reading,
 // x := x * act'(aux) (act 1: ReLU, aux = forward output; act 2: exact-erf GELU, aux = pre-activation; the
 // arithmetic of act_bwd_kernel in rowops.hip) - the fp32 gradient w.r.t. the pre-activation never reaches HBM.
 __device__ __forceinline__ void cvt_bf16_tile(const float* __restrict__ x, long ldx, int R, int C,
                                               unsigned short* __restrict__ out, unsigned short* __restrict__ out_lo, long ldo,
                                               unsigned short* __restrict__ outT, long ldt, float* __restrict__ colsum,
-                                              const float* __restrict__ aux, int act, const int r0, const int c0) {
+                                              const float* __restrict__ aux, int act, const int r0, const int c0, const DetWs& ws) {
     __shared__ unsigned short tile[64][66];
     __shared__ float csum[16][64];
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -509,12 +514,15 @@ __device__ __forceinline__ void cvt_bf16_tile(const float* __restrict__ x, long 
 #pragma unroll
         for (int j = 0; j < 4; ++j) csum[ty][tx * 4 + j] = cs[j];
         __syncthreads();
-        if (threadIdx.x < 64) {
-            float t = 0.f;
+        // 16 row lanes in order, then the row tiles of this column tile in order (det_reduce.h): colsum += total
+        det_reduce(ws, c0 / 64, r0 / 64, (R + 63) / 64, 64, threadIdx.x, 256,
+                   [&](int k) {
+                       float t = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) t += csum[i][threadIdx.x];
-            if (c0 + (int)threadIdx.x < C) atomicAdd(colsum + c0 + threadIdx.x, t);
-        }
+                       for (int i = 0; i < 16; ++i) t += csum[i][k];
+                       return t;
+                   },
+                   [&](int k, float t) { if (c0 + k < C) colsum[c0 + k] += t; });
     }
     if (!outT) return;
     __syncthreads();
@@ -540,8 +548,8 @@ __device__ __forceinline__ void cvt_bf16_tile(const float* __restrict__ x, long 
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ x, long ldx, int R, int C,
                                                        unsigned short* __restrict__ out, unsigned short* __restrict__ out_lo, long ldo,
                                                        unsigned short* __restrict__ outT, long ldt, float* __restrict__ colsum,
-                                                       const float* __restrict__ aux, int act) {
-    cvt_bf16_tile(x, ldx, R, C, out, out_lo, ldo, outT, ldt, colsum, aux, act, blockIdx.y * 64, blockIdx.x * 64);
+                                                       const float* __restrict__ aux, int act, DetWs ws) {
+    cvt_bf16_tile(x, ldx, R, C, out, out_lo, ldo, outT, ldt, colsum, aux, act, blockIdx.y * 64, blockIdx.x * 64, ws);
 }
 
 // Many contiguous matrices in one launch (the bf16 copies of every Linear weight after an optimizer step: ~190
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(256) void cvt_bf16_multi_kernel(const CvtJob* __res
     }
     const CvtJob j = jobs[lo];
     const int lt = t - j.tile0;
-    cvt_bf16_tile(j.x, j.C, j.R, j.C, j.out, j.out_lo, j.C, j.outT, j.ldt, nullptr, nullptr, 0, (lt / j.tiles_c) * 64, (lt % j.tiles_c) * 64);
+    cvt_bf16_tile(j.x, j.C, j.R, j.C, j.out, j.out_lo, j.C, j.outT, j.ldt, nullptr, nullptr, 0, (lt / j.tiles_c) * 64, (lt % j.tiles_c) * 64, DetWs{});
 }
 
 // C-ABI: see include/spe_hip.h (spe_cvt_bf16_multi).
@@ -579,9 +587,11 @@ extern "C" int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, v
     // the grid covers the padded row range of the transpose so that its zero columns are written too
     const long rows = outT ? ((ldt > R) ? ldt : R) : R;
     dim3 grid((C + 63) / 64, (unsigned)((rows + 63) / 64));
+    const DetWs ws = spe_detws();
+    if (colsum) DET_CHECK(ws, (C + 63) / 64, (R + 63) / 64, 64);
     hipLaunchKernelGGL(cvt_bf16_kernel, grid, dim3(256), 0, stream, x, ldx, R, C, reinterpret_cast<unsigned short*>(out),
                        reinterpret_cast<unsigned short*>(out_lo), ldo,
-                       reinterpret_cast<unsigned short*>(outT), ldt, colsum, aux, act);
+                       reinterpret_cast<unsigned short*>(outT), ldt, colsum, aux, act, ws);
     SPE_CHECK_LAUNCH();
     return 0;
 }

@@ -3,6 +3,7 @@
 // All decoder layers (and any number of images) go through ONE launch per kernel; only the
 // block-diagonal (same-image) part of the cost matrix is ever computed.
 #include "common.h"
+#include "det_reduce.h"
 
 struct Box { float x0, y0, x1, y1; };
 __device__ __forceinline__ Box to_xyxy(const float* b) {
@@ -170,59 +171,69 @@ extern "C" int spe_hungarian(const float* cost, const int* toff, long* srow, lon
 // argmax[row] = top-1 class (for class_error / cardinality logging).
 __global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ logits, const int* __restrict__ tclass,
                                                     const float* __restrict__ roww, float* __restrict__ grad,
-                                                    float* __restrict__ loss, int* __restrict__ argmax, long rows,
-                                                    long rows_per_l, int Kc, float alpha, float gamma) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int tc = tclass[row];
-    const float w = roww ? roww[row] : 1.f;
-    float acc = 0.f, best = -INFINITY; int bi = 0x7fffffff;
-    for (int c = lane; c < Kc; c += 64) {
-        const float x = logits[row * Kc + c];
-        const float t = (c == tc) ? 1.f : 0.f;
-        const float p = 1.f / (1.f + expf(-x));
-        const float ce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));   // BCE-with-logits, stable form
-        const float pt_raw = p * t + (1.f - p) * (1.f - t);
-        const float pt = fminf(fmaxf(pt_raw, 1e-5f), 1.f - 1e-5f);
-        const bool clamped = (pt_raw < 1e-5f) || (pt_raw > 1.f - 1e-5f);
-        const float om = 1.f - pt;
-        const float mod = powf(om, gamma);
-        const float at = alpha >= 0.f ? alpha * t + (1.f - alpha) * (1.f - t) : 1.f;
-        acc += w * at * ce * mod;
-        const float dpt = clamped ? 0.f : p * (1.f - p) * (2.f * t - 1.f);
-        const float dmod = -gamma * powf(om, gamma - 1.f) * dpt;
-        grad[row * Kc + c] = w * at * ((p - t) * mod + ce * dmod);
-        if (x > best) { best = x; bi = c; }
-    }
-    acc = spe_wave_sum(acc);
-    // argmax with lowest-index tie break
+                                                    float* __restrict__ loss, int* __restrict__ argmax,
+                                                    long rows_per_l, int Kc, float alpha, float gamma, DetWs ws) {
+    // grid (row blocks of a layer, layers): the layer's loss is the fixed-order sum of its row blocks (det_reduce.h)
+    __shared__ float wsum[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long rl = (long)blockIdx.x * 4 + wv;
+    float acc = 0.f;
+    if (rl < rows_per_l) {
+        const long row = (long)blockIdx.y * rows_per_l + rl;
+        const int tc = tclass[row];
+        const float w = roww ? roww[row] : 1.f;
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int c = lane; c < Kc; c += 64) {
+            const float x = logits[row * Kc + c];
+            const float t = (c == tc) ? 1.f : 0.f;
+            const float p = 1.f / (1.f + expf(-x));
+            const float ce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));   // BCE-with-logits, stable form
+            const float pt_raw = p * t + (1.f - p) * (1.f - t);
+            const float pt = fminf(fmaxf(pt_raw, 1e-5f), 1.f - 1e-5f);
+            const bool clamped = (pt_raw < 1e-5f) || (pt_raw > 1.f - 1e-5f);
+            const float om = 1.f - pt;
+            const float mod = powf(om, gamma);
+            const float at = alpha >= 0.f ? alpha * t + (1.f - alpha) * (1.f - t) : 1.f;
+            acc += w * at * ce * mod;
+            const float dpt = clamped ? 0.f : p * (1.f - p) * (2.f * t - 1.f);
+            const float dmod = -gamma * powf(om, gamma - 1.f) * dpt;
+            grad[row * Kc + c] = w * at * ((p - t) * mod + ce * dmod);
+            if (x > best) { best = x; bi = c; }
+        }
+        acc = spe_wave_sum(acc);
+        // argmax with lowest-index tie break
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) argmax[row] = bi;
     }
-    if (lane == 0) { atomicAdd(loss + row / rows_per_l, acc); argmax[row] = bi; }
+    if (lane == 0) wsum[wv] = acc;
+    __syncthreads();
+    det_reduce(ws, blockIdx.y, blockIdx.x, gridDim.x, 1, threadIdx.x, 256,
+               [&](int) { return wsum[0] + wsum[1] + wsum[2] + wsum[3]; },
+               [&](int, float t) { loss[blockIdx.y] += t; });
 }
 extern "C" int spe_focal_loss(const float* logits, const int* tclass, const float* roww, float* grad, float* loss,
                               int* argmax, int L, long rows_per_l, int Kc, float alpha, float gamma, hipStream_t st) {
-    const long rows = (long)L * rows_per_l;
-    if (rows <= 0) return 0;
-    hipLaunchKernelGGL(focal_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, logits, tclass, roww, grad, loss,
-                       argmax, rows, rows_per_l, Kc, alpha, gamma);
+    if (L <= 0 || rows_per_l <= 0) return 0;
+    const long nb = (rows_per_l + 3) / 4;
+    const DetWs ws = spe_detws();
+    DET_CHECK(ws, L, nb, 1);
+    hipLaunchKernelGGL(focal_kernel, dim3((unsigned)nb, (unsigned)L), dim3(256), 0, st, logits, tclass, roww, grad, loss,
+                       argmax, rows_per_l, Kc, alpha, gamma, ws);
     SPE_CHECK_LAUNCH();
     return 0;
 }
 
 // Matched-pair box losses: for pair i (prediction row srow[i] of pred_boxes, target box tbox[i],
 // weight w[i] or 1, layer lidx[i]):  sums[l][0] += w*L1, sums[l][1] += w*(1-GIoU); the gradients
-// w.r.t. the predicted cxcywh box are written to g_l1[i][4], g_giou[i][4].
-__global__ __launch_bounds__(256) void box_loss_kernel(const float* __restrict__ pred_boxes, const long* __restrict__ srow,
-                                                       const float* __restrict__ tbox, const float* __restrict__ w,
-                                                       const int* __restrict__ lidx, float* __restrict__ sums,
-                                                       float* __restrict__ g_l1, float* __restrict__ g_giou, long n) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+// w.r.t. the predicted cxcywh box are written to g_l1[i][4], g_giou[i][4].  One workgroup (a few hundred pairs): the per-pair
+// values pass through LDS in chunks of 1024 and thread (l, k) adds the pairs of layer l in pair order - no atomics.
+__device__ __forceinline__ void box_pair(const float* __restrict__ pred_boxes, const long* __restrict__ srow,
+                                         const float* __restrict__ tbox, const float* __restrict__ w,
+                                         float* __restrict__ g_l1, float* __restrict__ g_giou, long i, float& o_l1, float& o_giou) {
     const float* s = pred_boxes + srow[i] * 4;
     const float* t = tbox + i * 4;
     const float wt = w ? w[i] : 1.f;
@@ -269,20 +280,46 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const float* __restrict__
     g_giou[i * 4 + 1] = -wt * (dg[1] + dg[3]);
     g_giou[i * 4 + 2] = -wt * 0.5f * (dg[2] - dg[0]);
     g_giou[i * 4 + 3] = -wt * 0.5f * (dg[3] - dg[1]);
-    atomicAdd(sums + lidx[i] * 2 + 0, wt * l1);
-    atomicAdd(sums + lidx[i] * 2 + 1, wt * (1.f - giou));
+    o_l1 = wt * l1;
+    o_giou = wt * (1.f - giou);
+}
+__global__ __launch_bounds__(1024) void box_loss_kernel(const float* __restrict__ pred_boxes, const long* __restrict__ srow,
+                                                        const float* __restrict__ tbox, const float* __restrict__ w,
+                                                        const int* __restrict__ lidx, float* __restrict__ sums,
+                                                        float* __restrict__ g_l1, float* __restrict__ g_giou, long n, int L) {
+    __shared__ float val[1024][2];
+    __shared__ int lay[1024];
+    const int t = threadIdx.x;
+    float mine = 0.f;                                   // thread t < 2L: sums[t >> 1][t & 1]
+    for (long c0 = 0; c0 < n; c0 += 1024) {
+        const long i = c0 + t;
+        if (i < n) {
+            float a, b;
+            box_pair(pred_boxes, srow, tbox, w, g_l1, g_giou, i, a, b);
+            val[t][0] = a; val[t][1] = b; lay[t] = lidx[i];
+        }
+        __syncthreads();
+        if (t < 2 * L) {
+            const int l = t >> 1, k = t & 1, cnt = (int)min((long)1024, n - c0);
+            for (int j = 0; j < cnt; ++j) if (lay[j] == l) mine += val[j][k];
+        }
+        __syncthreads();
+    }
+    if (t < 2 * L) sums[t] += mine;
 }
 extern "C" int spe_box_loss(const float* pred_boxes, const long* srow, const float* tbox, const float* w, const int* lidx,
-                            float* sums, float* g_l1, float* g_giou, long n, hipStream_t st) {
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(box_loss_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pred_boxes, srow, tbox, w, lidx,
-                       sums, g_l1, g_giou, n);
+                            float* sums, float* g_l1, float* g_giou, long n, int L, hipStream_t st) {
+    if (n <= 0 || L <= 0) return 0;
+    if (L > 512) return -2;
+    hipLaunchKernelGGL(box_loss_kernel, dim3(1), dim3(1024), 0, st, pred_boxes, srow, tbox, w, lidx, sums, g_l1, g_giou, n, L);
     SPE_CHECK_LAUNCH();
     return 0;
 }
 
 // dpred[srow[i]][:] += c1[lidx[i]] * g_l1[i][:] + c2[lidx[i]] * g_giou[i][:]   (scatter-add of the
-// matched-row gradients; c1/c2 = upstream grad / num_boxes per layer)
+// matched-row gradients; c1/c2 = upstream grad / num_boxes per layer).  A prediction row is matched at most once per
+// criterion call (one-to-one assignment per layer and image), so every address receives a single addend and the result does
+// not depend on the order; the atomic only keeps a hypothetical duplicate row correct.
 __global__ __launch_bounds__(256) void box_loss_bwd_kernel(const long* __restrict__ srow, const int* __restrict__ lidx,
                                                            const float* __restrict__ g_l1, const float* __restrict__ g_giou,
                                                            const float* __restrict__ c1, const float* __restrict__ c2,

@@ -1,5 +1,6 @@
 // Small gather / elementwise kernels around the GEMMs.
 #include "common.h"
+#include "det_reduce.h"
 
 // Patch gather for the 16x16/stride-16 patch-embed convolution (reference models/cait.py:518-528,
 // timm PatchEmbed.proj = Conv2d(3,C,16,16)): img[B,Cin,Hi,Wi] -> cols[B*h*w, Cin*P*P] with the
@@ -62,7 +63,6 @@ __device__ __forceinline__ void cubic_w(float t, float w[4]) {
     w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
     w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
 }
-template <bool BWD>
 __global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ src, float* __restrict__ dst, int gh, int gw, int h,
                                                       int w, int C) {
     const int C4 = C >> 2;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ 
         const int iy = (int)floorf(fy), ix = (int)floorf(fx);
         float wy[4], wx[4];
         cubic_w(fy - iy, wy); cubic_w(fx - ix, wx);
-        if (!BWD) {
+        {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -89,30 +89,59 @@ __global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ 
                 }
             }
             reinterpret_cast<float4*>(dst + (long)o * C)[c4] = acc;
-        } else {      // dst = d(in) (pre-zeroed), src = d(out)
-            const float4 g = reinterpret_cast<const float4*>(src + (long)o * C)[c4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int yy = min(max(iy - 1 + a, 0), gh - 1);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int xx = min(max(ix - 1 + b, 0), gw - 1);
-                    const float wt = wy[a] * wx[b];
-                    if (wt == 0.f) continue;
-                    float* d = dst + ((long)yy * gw + xx) * C + c4 * 4;
-                    atomicAdd(d + 0, wt * g.x); atomicAdd(d + 1, wt * g.y); atomicAdd(d + 2, wt * g.z); atomicAdd(d + 3, wt * g.w);
-                }
-            }
         }
     }
+}
+// Backward as a GATHER (no atomics, fixed order): one thread per (source cell, channel quad) adds up, row by row, the output
+// pixels whose 4 x 4 footprint - with the border clamp of the forward - contains the cell.  Output rows that can reach source row
+// yy lie in a window of ~4 / sy rows around it (the clamp only adds rows next to the border, which the window's limits keep).
+__global__ __launch_bounds__(256) void bicubic_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int gh, int gw, int h,
+                                                          int w, int C) {
+    const int C4 = C >> 2;
+    const long total = (long)gh * gw * C4;
+    const float sy = (float)gh / (float)h, sx = (float)gw / (float)w;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % C4); const int cell = (int)(i / C4);
+    const int yy = cell / gw, xx = cell % gw;
+    auto lo = [](int v, float s, int n) { return max(0, (int)floorf((v - 2 + 0.5f) / s - 0.5f) - 1); };
+    auto hi = [](int v, float s, int n) { return min(n - 1, (int)ceilf((v + 2 + 0.5f) / s - 0.5f) + 1); };
+    const int oy0 = lo(yy, sy, h), oy1 = hi(yy, sy, h), ox0 = lo(xx, sx, w), ox1 = hi(xx, sx, w);
+    // weight of output coordinate o on source coordinate v along one axis: the taps that land on v after clamping
+    auto axis_w = [](int o, float s, int v, int n) {
+        const float f = s * (o + 0.5f) - 0.5f;
+        const int i0 = (int)floorf(f);
+        float wt[4];
+        cubic_w(f - i0, wt);
+        float r = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) if (min(max(i0 - 1 + a, 0), n - 1) == v) r += wt[a];
+        return r;
+    };
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        const float wyv = axis_w(oy, sy, yy, gh);
+        if (wyv == 0.f) continue;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            const float wt = wyv * axis_w(ox, sx, xx, gw);
+            if (wt == 0.f) continue;
+            const float4 g = reinterpret_cast<const float4*>(dout + ((long)oy * w + ox) * C)[c4];
+            acc.x += wt * g.x; acc.y += wt * g.y; acc.z += wt * g.z; acc.w += wt * g.w;
+        }
+    }
+    float4* d = reinterpret_cast<float4*>(din + (long)cell * C) + c4;      // += : the destination holds the running gradient
+    const float4 o = *d;
+    *d = make_float4(o.x + acc.x, o.y + acc.y, o.z + acc.z, o.w + acc.w);
 }
 extern "C" int spe_bicubic(const float* src, float* dst, int gh, int gw, int h, int w, int C, int backward, hipStream_t st) {
     if (C & 3) return -2;
     const long total = (long)h * w * (C / 4);
     if (total <= 0) return 0;
     long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
-    if (backward) hipLaunchKernelGGL(bicubic_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, src, dst, gh, gw, h, w, C);
-    else hipLaunchKernelGGL(bicubic_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, src, dst, gh, gw, h, w, C);
+    if (backward) {
+        const long cells = (long)gh * gw * (C / 4);
+        hipLaunchKernelGGL(bicubic_bwd_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, src, dst, gh, gw, h, w, C);
+    } else hipLaunchKernelGGL(bicubic_kernel, dim3((unsigned)nb), dim3(256), 0, st, src, dst, gh, gw, h, w, C);
     SPE_CHECK_LAUNCH();
     return 0;
 }
@@ -147,7 +176,24 @@ extern "C" int spe_occupy(int nwg, long micros, float* buf, long buf_floats, hip
     return 0;
 }
 
-extern "C" int spe_abi_version(void) { return 3; }    // 2: round 2 (signatures of spe_hungarian, spe_adamw_flat, spe_layernorm_fwd, spe_attn_contract, spe_talking_fused_plan changed; new entry points)
+// ---- reduction workspace of the deterministic cross-workgroup sums (det_reduce.h) -------------------------------------
+static DetWs g_detws = {nullptr, nullptr, 0, 0};
+DetWs spe_detws() { return g_detws; }
+// C-ABI: see include/spe_hip.h.  The first 64 KiB hold the tickets (zeroed here, on `st`), the rest the partial-sum slabs.
+extern "C" int spe_set_reduce_workspace(void* ws, size_t bytes, hipStream_t st) {
+    if (!ws) { g_detws = DetWs{nullptr, nullptr, 0, 0}; return 0; }
+    const size_t tbytes = 64 * 1024;
+    if ((reinterpret_cast<uintptr_t>(ws) & 255) || bytes < tbytes + (1u << 20)) return -2;
+    hipError_t e = hipMemsetAsync(ws, 0, tbytes, st);
+    if (e != hipSuccess) return (int)e;
+    g_detws.tickets = reinterpret_cast<unsigned*>(ws);
+    g_detws.ntickets = (int)(tbytes / sizeof(unsigned));
+    g_detws.slab = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + tbytes);
+    g_detws.slab_floats = (long)((bytes - tbytes) / sizeof(float));
+    return 0;
+}
+
+extern "C" int spe_abi_version(void) { return 4; }    // 2: round 2 (signatures of spe_hungarian, spe_adamw_flat, spe_layernorm_fwd, spe_attn_contract, spe_talking_fused_plan changed; new entry points)
 
 
 // ------------------------------------------------------------------------------------------

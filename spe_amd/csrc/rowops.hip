@@ -4,6 +4,7 @@
 // every lane moves 16 B per access where the row length allows it.
 #include <cstdlib>
 #include "common.h"
+#include "det_reduce.h"
 
 // ------------------------------------------------------------------------------------------
 // LayerNorm (reference: nn.LayerNorm at models/cait.py:403,407 eps=1e-6; transformer.py:264-265,
@@ -67,15 +68,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
-// dx per row; dgamma/dbeta accumulated per wave in registers over a grid-stride row loop,
-// combined through LDS, then one atomicAdd per column per block into pre-zeroed buffers.
+// dx per row; dgamma/dbeta accumulated per wave in registers over a grid-stride row loop, combined through LDS, then across
+// the workgroups in a fixed order (det_reduce.h) and added to the running gradient.
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      long R, int C, const float* __restrict__ add, float* __restrict__ dz,
-                                                     float p, uint64_t seed, uint64_t offset) {
+                                                     float p, uint64_t seed, uint64_t offset, DetWs ws) {
     extern __shared__ float red_raw[];                 // [2][NW][C + 4]
     const int ldr = C + 4;
     auto red = [&](int k, int wv, int c) -> float& { return red_raw[((long)k * NW + wv) * ldr + c]; };
@@ -134,17 +135,16 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * C; c += NW * 64) {
-        const int k = c >= C, cc = k ? c - C : c;
-        float t = 0.f;
+    // the 16 waves' column sums in wave order, then across workgroups in a fixed order (det_reduce.h): dgamma / dbeta += total
+    det_reduce(ws, 0, blockIdx.x, gridDim.x, 2 * C, threadIdx.x, NW * 64,
+               [&](int c) {
+                   const int k = c >= C, cc = k ? c - C : c;
+                   float t = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < NW; ++wv) t += red(k, wv, cc);
-#ifndef SPE_DBG_LN_NOATOMIC
-        atomicAdd((k ? dbeta : dgamma) + cc, t);
-#else
-        if (t == 12345.678f) dgamma[cc] = t;
-#endif
-    }
+                   for (int wv = 0; wv < NW; ++wv) t += red(k, wv, cc);
+                   return t;
+               },
+               [&](int c, float t) { float* d = (c >= C) ? dbeta + (c - C) : dgamma + c; *d += t; });
 }
 
 // Post-norm residual site of the DETR encoder / decoder layers, `norm(x + dropout(z))` (reference models/transformer.py:
@@ -331,8 +331,7 @@ static int ln_bwd_launch(const float* dy, const float* x, const float* gamma, co
                          uint64_t offset, hipStream_t st) {
     if (R <= 0) return 0;
     if ((C & 3) || C > 256 * LN_MAXV) return -2;
-    // 16 waves per workgroup, at most 256 workgroups: every workgroup ends with 2*C atomics on the same addresses, and
-    // those serialise (512 x 4 waves: 21 us per call at cfg2; 2048 x 4: 42 us; 256 x 16: 15 us)
+    // 16 waves per workgroup, at most 256 workgroups: every workgroup ends with a 2*C-value partial for the cross-workgroup sum
     constexpr int NW = 16;
     static bool attr = false;
     if (!attr) {
@@ -342,8 +341,10 @@ static int ln_bwd_launch(const float* dy, const float* x, const float* gamma, co
         attr = true;
     }
     long nb = (R + NW - 1) / NW; if (nb > 256) nb = 256;
+    const DetWs ws = spe_detws();
+    DET_CHECK(ws, 1, nb, 2 * C);
     hipLaunchKernelGGL(ln_bwd_kernel<NW>, dim3((unsigned)nb), dim3(NW * 64), 2 * NW * (C + 4) * (int)sizeof(float), st, dy, x, gamma, mean,
-                       rstd, dx, dgamma, dbeta, R, C, add, dz, p, seed, offset);
+                       rstd, dx, dgamma, dbeta, R, C, add, dz, p, seed, offset, ws);
     SPE_CHECK_LAUNCH();
     return 0;
 }
@@ -446,7 +447,7 @@ extern "C" int spe_softmax_bwd(const float* dPd, const float* P, float* dS, int 
 // Two shapes occur: a few very wide rows (the split-K slabs of a weight gradient: R <= 32, C ~ 1e5..1e6) and
 // tall narrow matrices (bias gradients: R ~ 1e4, C <= 2048).
 //   wide: one thread per 4 columns, float4 loads down the R rows, plain read-modify-write of out (no atomics)
-//   tall: block = 16 column quads (64 columns) x 16 row lanes, float4 loads, LDS reduce, one atomic per column
+//   tall: block = 16 column quads (64 columns) x 16 row lanes, float4 loads, LDS reduce, fixed-order sum over the row segments
 __global__ __launch_bounds__(256) void colsum_wide_kernel(const float* __restrict__ in, float* __restrict__ out, int R, long C, long ld,
                                                           int accumulate) {
     const long c = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -459,7 +460,8 @@ __global__ __launch_bounds__(256) void colsum_wide_kernel(const float* __restric
     }
     *reinterpret_cast<float4*>(out + c) = acc;
 }
-__global__ __launch_bounds__(256) void colsum_tall4_kernel(const float* __restrict__ in, float* __restrict__ out, long R, int C, long ld) {
+__global__ __launch_bounds__(256) void colsum_tall4_kernel(const float* __restrict__ in, float* __restrict__ out, long R, int C, long ld,
+                                                           int accumulate, DetWs ws) {
     __shared__ float4 red[16][16];
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = (blockIdx.x * 16 + cq) * 4;
@@ -471,18 +473,19 @@ __global__ __launch_bounds__(256) void colsum_tall4_kernel(const float* __restri
         }
     red[rl][cq] = acc;
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int q = threadIdx.x >> 2, e = threadIdx.x & 3;
-        float s = 0.f;
+    // 16 row lanes in order, then the row segments (blockIdx.y) in order: det_reduce.h
+    det_reduce(ws, blockIdx.x, blockIdx.y, gridDim.y, 64, threadIdx.x, 256,
+               [&](int cl) {
+                   float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s += reinterpret_cast<const float*>(&red[i][q])[e];
-        const int cc = (blockIdx.x * 16 + q) * 4 + e;
-        if (cc < C) atomicAdd(out + cc, s);
-    }
+                   for (int i = 0; i < 16; ++i) s += reinterpret_cast<const float*>(&red[i][cl >> 2])[cl & 3];
+                   return s;
+               },
+               [&](int cl, float s) { const int cc = blockIdx.x * 64 + cl; if (cc < C) out[cc] = accumulate ? out[cc] + s : s; });
 }
 // generic fallback (unaligned pointers / leading dimension): block = 64 columns x 4 row lanes
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, long R, int C,
-                                                     long ld) {
+                                                     long ld, int accumulate, DetWs ws) {
     __shared__ float red[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -491,17 +494,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
         for (long r = (long)blockIdx.y * 4 + rl; r < R; r += (long)gridDim.y * 4) acc += in[r * ld + c];
     red[rl][cl] = acc;
     __syncthreads();
-    if (rl == 0 && c < C) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+    det_reduce(ws, blockIdx.x, blockIdx.y, gridDim.y, 64, threadIdx.x, 256,
+               [&](int k) { return red[0][k] + red[1][k] + red[2][k] + red[3][k]; },
+               [&](int k, float s) { const int cc = blockIdx.x * 64 + k; if (cc < C) out[cc] = accumulate ? out[cc] + s : s; });
 }
 extern "C" int spe_colsum(const float* in, float* out, long R, int C, long ld, int accumulate, hipStream_t st) {
     if (C <= 0) return 0;
     if (R <= 0) { if (!accumulate) { hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, st); if (e != hipSuccess) return (int)e; } return 0; }
     const bool al4 = (C % 4 == 0) && (ld % 4 == 0) && ((((uintptr_t)in) | ((uintptr_t)out)) % 16 == 0);
     const bool wide = al4 && R <= 64 && C >= 4096;
-    if (!accumulate && !wide) {        // the tall kernels add their partial sums atomically: they need a zeroed destination
-        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, st);
-        if (e != hipSuccess) return (int)e;
-    }
+    const DetWs ws = spe_detws();
     if (wide) {
         hipLaunchKernelGGL(colsum_wide_kernel, dim3((unsigned)((C / 4 + 255) / 256)), dim3(256), 0, st, in, out, (int)R, (long)C, ld, accumulate);
     } else if (al4) {
@@ -509,10 +511,12 @@ extern "C" int spe_colsum(const float* in, float* out, long R, int C, long ld, i
         long ry = (R + 63) / 64;                       // >= 4 rows per thread
         const long cap = (2048 + gx - 1) / gx;         // ~8 blocks per CU overall
         if (ry > cap) ry = cap; if (ry < 1) ry = 1;
-        hipLaunchKernelGGL(colsum_tall4_kernel, dim3(gx, (unsigned)ry), dim3(256), 0, st, in, out, R, C, ld);
+        DET_CHECK(ws, gx, ry, 64);
+        hipLaunchKernelGGL(colsum_tall4_kernel, dim3(gx, (unsigned)ry), dim3(256), 0, st, in, out, R, C, ld, accumulate, ws);
     } else {
         long ry = (R + 255) / 256; if (ry > 64) ry = 64; if (ry < 1) ry = 1;
-        hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, (unsigned)ry), dim3(256), 0, st, in, out, R, C, ld);
+        DET_CHECK(ws, (C + 63) / 64, ry, 64);
+        hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, (unsigned)ry), dim3(256), 0, st, in, out, R, C, ld, accumulate, ws);
     }
     SPE_CHECK_LAUNCH();
     return 0;
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(256) void lsres_fwd_kernel(const float4* __restrict
 __global__ __launch_bounds__(256) void lsres_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ sample_scale,
                                                         float* __restrict__ dy, float* __restrict__ dgamma, long R, int C,
-                                                        long rows_per_sample) {
+                                                        long rows_per_sample, DetWs ws) {
     __shared__ float red[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -553,7 +557,9 @@ __global__ __launch_bounds__(256) void lsres_bwd_kernel(const float* __restrict_
     }
     red[rl][cl] = acc;
     __syncthreads();
-    if (rl == 0 && c < C) atomicAdd(dgamma + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+    det_reduce(ws, blockIdx.x, blockIdx.y, gridDim.y, 64, threadIdx.x, 256,
+               [&](int k) { return red[0][k] + red[1][k] + red[2][k] + red[3][k]; },
+               [&](int k, float s) { const int cc = blockIdx.x * 64 + k; if (cc < C) dgamma[cc] += s; });
 }
 // The same, one wave per row with 16-B accesses and per-lane column accumulators (C % 4 == 0, C <= 256 * LN_MAXV):
 // NW = 16 waves per workgroup so that few workgroups (few atomics per column) still fill the SIMDs.
@@ -561,7 +567,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void lsres_bwd_rows_kernel(const float* __restrict__ dout, const float* __restrict__ y,
                                                                  const float* __restrict__ gamma, const float* __restrict__ sample_scale,
                                                                  float* __restrict__ dy, float* __restrict__ dgamma, long R, int C,
-                                                                 long rows_per_sample) {
+                                                                 long rows_per_sample, DetWs ws) {
     extern __shared__ float red_raw[];                 // [NW][C + 4]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int C4 = C >> 2, ldr = C + 4;
@@ -596,12 +602,14 @@ __global__ __launch_bounds__(NW * 64) void lsres_bwd_rows_kernel(const float* __
         if (c < C4) *reinterpret_cast<float4*>(red_raw + (long)w * ldr + 4 * c) = acc[i];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += NW * 64) {
-        float t = 0.f;
+    det_reduce(ws, 0, blockIdx.x, gridDim.x, C, threadIdx.x, NW * 64,
+               [&](int c) {
+                   float t = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < NW; ++wv) t += red_raw[(long)wv * ldr + c];
-        atomicAdd(dgamma + c, t);
-    }
+                   for (int wv = 0; wv < NW; ++wv) t += red_raw[(long)wv * ldr + c];
+                   return t;
+               },
+               [&](int c, float t) { dgamma[c] += t; });
 }
 // LayerScale backward feeding a Linear backward directly: dy = gamma * dout is never written in fp32 - the kernel emits
 // what the weight / input gradient GEMMs of the preceding Linear consume, dy16 [R][C] and dy16T [C][ldt] (zero padded
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(NW * 64) void lsres_bwd_rows_kernel(const float* __
 __global__ __launch_bounds__(1024) void lsres_bwd16_kernel(const float* __restrict__ dout, const float* __restrict__ y,
                                                            const float* __restrict__ gamma, unsigned short* __restrict__ dy16,
                                                            unsigned short* __restrict__ dy16T, long ldt, float* __restrict__ db,
-                                                           float* __restrict__ dgamma, long R, int C) {
+                                                           float* __restrict__ dgamma, long R, int C, DetWs ws) {
     extern __shared__ unsigned short lsT[];            // [64][C + 8] bf16 tile ; reused as float [16][C + 4] x 2 at the end
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int C4 = C >> 2, ldl = C + 8;
@@ -668,7 +676,7 @@ __global__ __launch_bounds__(1024) void lsres_bwd16_kernel(const float* __restri
         }
         __syncthreads();
     }
-    // column sums of the 16 waves through LDS, one atomic per column and workgroup
+    // column sums of the 16 waves through LDS, then across the workgroups in a fixed order (det_reduce.h)
     float* red = reinterpret_cast<float*>(lsT);
     const int ldr = C + 4;
 #pragma unroll
@@ -680,14 +688,15 @@ __global__ __launch_bounds__(1024) void lsres_bwd16_kernel(const float* __restri
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * C; c += 1024) {
-        const int k = c >= C, cc = k ? c - C : c;
-        float t = 0.f;
+    det_reduce(ws, 0, blockIdx.x, gridDim.x, 2 * C, threadIdx.x, 1024,
+               [&](int c) {
+                   const int k = c >= C, cc = k ? c - C : c;
+                   float t = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < 16; ++wv) t += red[(long)(16 * k + wv) * ldr + cc];
-        float* dst = k ? db : dgamma;
-        if (dst) atomicAdd(dst + cc, t);
-    }
+                   for (int wv = 0; wv < 16; ++wv) t += red[(long)(16 * k + wv) * ldr + cc];
+                   return t;
+               },
+               [&](int c, float t) { float* dst = (c >= C) ? db : dgamma; if (dst) dst[c >= C ? c - C : c] += t; });
 }
 
 // C-ABI: see include/spe_hip.h (spe_layerscale_residual_bwd16).  -2: C % 4 != 0, C > 1024, ldt not a multiple of 64
@@ -708,8 +717,10 @@ extern "C" int spe_layerscale_residual_bwd16(const float* dout, const float* y, 
         attr = true;
     }
     long nb = (ldt + 63) / 64; if (nb > 256) nb = 256;
+    const DetWs ws = spe_detws();
+    DET_CHECK(ws, 1, nb, 2 * C);
     hipLaunchKernelGGL(lsres_bwd16_kernel, dim3((unsigned)nb), dim3(1024), smem, st, dout, y, gamma,
-                       reinterpret_cast<unsigned short*>(dy16), reinterpret_cast<unsigned short*>(dy16T), ldt, db, dgamma, R, C);
+                       reinterpret_cast<unsigned short*>(dy16), reinterpret_cast<unsigned short*>(dy16T), ldt, db, dgamma, R, C, ws);
     SPE_CHECK_LAUNCH();
     return 0;
 }
@@ -728,17 +739,20 @@ extern "C" int spe_layerscale_residual_fwd(const float* x, const float* y, const
 extern "C" int spe_layerscale_residual_bwd(const float* dout, const float* y, const float* gamma, const float* sample_scale,
                                            float* dy, float* dgamma, long R, int C, long rows_per_sample, hipStream_t st) {
     if (R <= 0) return 0;
+    const DetWs ws = spe_detws();
     if ((C & 3) == 0 && C <= 256 * LN_MAXV && ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(y) |
                                                            reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(gamma)) & 15) == 0) {
         long nb = (R + 15) / 16; if (nb > 128) nb = 128;
+        DET_CHECK(ws, 1, nb, C);
         hipLaunchKernelGGL(lsres_bwd_rows_kernel<16>, dim3((unsigned)nb), dim3(1024), 16 * (C + 4) * (int)sizeof(float), st, dout, y,
-                           gamma, sample_scale, dy, dgamma, R, C, rows_per_sample);
+                           gamma, sample_scale, dy, dgamma, R, C, rows_per_sample, ws);
         SPE_CHECK_LAUNCH();
         return 0;
     }
     long ry = (R + 63) / 64; if (ry > 256) ry = 256; if (ry < 1) ry = 1;
+    DET_CHECK(ws, (C + 63) / 64, ry, 64);
     hipLaunchKernelGGL(lsres_bwd_kernel, dim3((C + 63) / 64, (unsigned)ry), dim3(256), 0, st, dout, y, gamma, sample_scale,
-                       dy, dgamma, R, C, rows_per_sample);
+                       dy, dgamma, R, C, rows_per_sample, ws);
     SPE_CHECK_LAUNCH();
     return 0;
 }

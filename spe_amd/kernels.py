@@ -92,7 +92,22 @@ def timing_results():
 _GEMM_DIMS = {"spe_gemm_bf16nt": (7, 8, 9), "spe_gemm_bf16nt_ex": (16, 17, 18)}
 
 
+# Reduction workspace of the deterministic cross-workgroup sums (include/spe_hip.h: spe_set_reduce_workspace; csrc/det_reduce.h):
+# 16 MiB of device memory registered with the library on the first launch of this process (one process per GPU).
+_RWS = None
+_RWS_BYTES = 16 << 20
+
+
+def _register_reduce_ws():
+    global _RWS
+    dev = torch.device("cuda", torch.cuda.current_device())
+    _RWS = torch.zeros((_RWS_BYTES,), device=dev, dtype=torch.uint8)
+    lib.call("spe_set_reduce_workspace", _RWS.data_ptr(), _RWS_BYTES, _st())
+
+
 def _call(name, *args):
+    if _RWS is None:
+        _register_reduce_ws()
     if not _TIMED:
         return lib.call(name, *args)
     ev = _TIMED.get(name)
@@ -872,7 +887,7 @@ def box_loss(pred_boxes, srow_i64, tbox, w, lidx_i32, L):
     sums = torch.zeros((L, 2), device=pred_boxes.device, dtype=torch.float32)
     g1 = torch.empty((n, 4), device=pred_boxes.device, dtype=torch.float32)
     g2 = torch.empty_like(g1)
-    _call("spe_box_loss", _p(pred_boxes), _p(srow_i64), _p(tbox), _p(w), _p(lidx_i32), _p(sums), _p(g1), _p(g2), n, _st())
+    _call("spe_box_loss", _p(pred_boxes), _p(srow_i64), _p(tbox), _p(w), _p(lidx_i32), _p(sums), _p(g1), _p(g2), n, int(L), _st())
     return sums, g1, g2
 
 

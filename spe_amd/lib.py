@@ -12,7 +12,7 @@ LIBPATH = os.environ.get("SPE_HIP_LIB") or os.path.join(HERE, "libspe_hip.so")
 
 _CTYPES = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
-    "uint64_t": ctypes.c_uint64, "spe_stream_t": ctypes.c_void_p,
+    "uint64_t": ctypes.c_uint64, "size_t": ctypes.c_size_t, "spe_stream_t": ctypes.c_void_p,
 }
 
 
