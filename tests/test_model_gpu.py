@@ -87,11 +87,33 @@ def test_forward_and_losses_match_reference(dev, name, prec):
             for p, r in zip(pr, ev["pseudo"]):
                 assert torch.equal(p["labels"].cpu(), r["labels"])
                 assert rel(p["scores"], r["scores"]) < OUT_TOL[prec] and rel(p["boxes"], r["boxes"]) < OUT_TOL[prec]
-            if prec == "bf16x3":
+            if prec in ("bf16x3", "bf16s"):
+                # PostProcess top-k (reference models/conditional_detr.py:592-623) in the exact AND in the benchmark mode: the
+                # sorted scores must agree everywhere; labels / boxes rank by rank (exact mode) or detection by detection (below)
                 post = pp["bbox"](out[0], orig, 10)
                 for p, r in zip(post, ev["postprocess"]):
-                    assert torch.equal(p["labels"].cpu(), r["labels"])
-                    assert rel(p["scores"], r["scores"]) < OUT_TOL[prec] and rel(p["boxes"], r["boxes"]) < OUT_TOL[prec]
+                    assert rel(p["scores"], r["scores"]) < OUT_TOL[prec]
+                    if prec == "bf16x3":
+                        assert torch.equal(p["labels"].cpu(), r["labels"])
+                        assert rel(p["boxes"], r["boxes"]) < OUT_TOL[prec]
+                        continue
+                    # benchmark mode: the fixture's top scores are nearly tied (gaps down to 1e-4), so neighbours may swap - match
+                    # every reference detection whose score clears the k-th one to the product's detection of the same class with
+                    # the nearest box, whatever its rank
+                    sc, kth = r["scores"].double(), float(r["scores"][-1])
+                    pb, pl, ps = p["boxes"].double().cpu(), p["labels"].cpu(), p["scores"].double().cpu()
+                    matched = 0
+                    for i in range(len(sc)):
+                        if float(sc[i]) - kth < 4 * OUT_TOL[prec]:
+                            continue            # could legitimately drop out of the top k
+                        same = (pl == r["labels"][i]).nonzero().flatten()
+                        assert len(same) > 0, ("class missing from the top k", i, int(r["labels"][i]))
+                        dist = (pb[same] - r["boxes"][i].double()).norm(dim=1)
+                        j = same[int(dist.argmin())]
+                        assert float(dist.min()) <= OUT_TOL[prec] * float(r["boxes"][i].double().norm()), (i, float(dist.min()))
+                        assert abs(float(ps[j]) - float(sc[i])) <= OUT_TOL[prec] * float(sc[i])
+                        matched += 1
+                    assert matched >= 3, "fixture leaves nothing to check"
     finally:
         K.set_precision("bf16")
 
