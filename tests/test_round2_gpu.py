@@ -259,8 +259,11 @@ def test_fused_attention_at_config_token_counts(dev, B, N):
         errs[nm] = float(a.abs().max() / grads[1].abs().max()) if nm == "dbl" else rel(a, b_)
     print(f"[fused attention B={B} N={N}] " + ", ".join(f"{k} {v:.3e}" for k, v in errs.items()))
     assert torch.isfinite(out).all() and all(torch.isfinite(t).all() for t in grads)
-    assert errs["out"] < 1e-2 and errs["dqkv"] < 2e-2 and errs["dWl"] < 2e-2 and errs["dWw"] < 2e-2 and errs["dbw"] < 2e-2, errs
-    assert errs["dbl"] < 2e-2, errs          # softmax is shift invariant: the exact gradient is 0
+    # forward (fp16 operands, fp32 statistics): north_star's 1e-3 on unit-variance random inputs (measured 3.4e-4 at 2 x 4150);
+    # backward (single bf16 operands, bf16 dS / P'd blocks): ~2.5x the measured 3.0e-3 .. 4.0e-3
+    assert errs["out"] < 1e-3, errs
+    assert errs["dqkv"] < 1e-2 and errs["dWl"] < 1e-2 and errs["dWw"] < 1e-2 and errs["dbw"] < 1e-2, errs
+    assert errs["dbl"] < 1e-4, errs          # softmax is shift invariant: the exact gradient is 0
 
 
 def _dense_from_blocks(T, N):
