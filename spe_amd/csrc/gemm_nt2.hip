@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(Gemm16Args p) {
     constexpr int PA = BM / RPP, PB = BN / RPP;   // pieces of an A / B tile
     constexpr int NP = (PA + PB) * (SPLIT ? 2 : 1), PW = NP / 4;
     constexpr int STE = NP * 512;                 // bf16 elements per stage
-    static_assert(PA % 4 == 0 && PB % 4 == 0 && (BK == 32 || BK == 64) && NST >= 2, "tile geometry");
+    static_assert(NP % 4 == 0 && BM % 32 == 0 && BN % 32 == 0 && (BK == 32 || BK == 64) && NST >= 2, "tile geometry");
 
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     int tm, tn;
@@ -92,11 +92,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(Gemm16Args p) {
         const long k0 = (long)tc * BK;
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
-            const int piece = i * 4 + ws;         // PA, PB are multiples of 4: the array a piece belongs to depends on i only
+            const int piece = i * 4 + ws;         // wave-uniform: which array a piece belongs to is a scalar decision
             constexpr int HALF = PA + PB;
-            const bool lo = SPLIT && (i * 4 >= HALF);
+            const bool lo = SPLIT && (piece >= HALF);
             const int ph = lo ? piece - HALF : piece;
-            const bool isA = (i * 4 - (lo ? HALF : 0)) < PA;
+            const bool isA = ph < PA;
             const int r = (isA ? ph : ph - PA) * RPP + pr;
             const int gc = pc ^ nt2_swz<CPR>(r);
             const unsigned short* base = isA ? (lo ? p.Alo : p.A) : (lo ? p.Blo : p.B);
@@ -208,6 +208,15 @@ int spe_nt2_dispatch(const Gemm16Args& p, bool ex, hipStream_t stream) {
         if (ex) return wide ? launch_nt2<128, 128, BK_, NST_, SP_, true>(p, stream) : launch_nt2<128, 64, BK_, NST_, SP_, true>(p, stream);   \
         return wide ? launch_nt2<128, 128, BK_, NST_, SP_, false>(p, stream) : launch_nt2<128, 64, BK_, NST_, SP_, false>(p, stream);         \
     } while (0)
+    // Tile quantisation: 8300 rows make 65 row tiles of 128; 65 x 9 = 585 tiles (qkv forward) take 2 rounds on the 512 resident workgroup
+    // slots for 1.14 rounds of work.  160-row tiles (52 x 9 = 468) fit one round of 1.25x larger tiles.  Plain epilogue only (the staged
+    // epilogue of a 160 x 128 tile does not fit two workgroups per CU).
+    static const int tall = getenv("SPE_NT2_TALL") ? atoi(getenv("SPE_NT2_TALL")) : 1;      // developer knob (A/B)
+    if (tall && !ex && wide && cfg == 0) {
+        const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128), t160 = (long)((p.M + 159) / 160) * ((p.N + 127) / 128);
+        const long c128 = ((t128 + 511) / 512) * 128, c160 = ((t160 + 511) / 512) * 160;
+        if (c160 < c128) return split ? launch_nt2<160, 128, 32, 2, true, false>(p, stream) : launch_nt2<160, 128, 64, 2, false, false>(p, stream);
+    }
     if (split) {
         if (cfg == 1) NT2_GO(32, 3, true);
         if (cfg == 2) NT2_GO(32, 4, true);
