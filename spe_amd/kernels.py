@@ -188,6 +188,9 @@ def _chk(*ts):
             raise TypeError(f"expected float32, got {t.dtype}")
 
 
+TN_SMALL_TILES = os.environ.get("SPE_TN_SMALL_TILES", "1") != "0"      # developer knob (A/B)
+
+
 def auto_splitk(M, N, K, batch):
     """Split-K factor for long contractions with few output tiles (the dW GEMMs).  Sized for 128x128 tiles
     (half the L2 re-reads of 64x64: 45 vs 74 us for fc1's dW) and ~2 workgroups per CU; the partial results go to
@@ -197,7 +200,13 @@ def auto_splitk(M, N, K, batch):
         return 1
     # tiles * splits must FIT the 512 resident workgroup slots (2 per CU): 36 tiles x 15 = 540 leaves 28 workgroups for a
     # second, nearly empty round (fc1 / fc2 dW: 29 -> 24 us with 14 splits)
-    return max(1, min(512 // tiles, K // 512, 16))
+    sk = max(1, min(512 // tiles, K // 512, 16))
+    if TN_SMALL_TILES and batch == 1 and tiles * sk < 256:
+        # few output tiles even at the largest split (a 384 x 384 weight: 9 tiles x 16 = 144 workgroups on 512 slots): 64 x 64 tiles
+        # (spe_gemm_bf16tn picks them when 128-tiles x splits < 256) quadruple the tile count; the split is sized for THEM
+        t64 = ((M + 63) // 64) * ((N + 63) // 64)
+        sk = max(1, min(512 // t64, K // 512, 16))
+    return sk
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, C2=None,
