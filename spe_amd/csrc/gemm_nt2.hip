@@ -226,6 +226,8 @@ int spe_nt2_dispatch(const Gemm16Args& p, bool ex, hipStream_t stream) {
     if (cfg == 2) NT2_GO(64, 4, false);
     if (cfg == 3) NT2_GO(32, 4, false);
     if (cfg == 4) NT2_GO(32, 6, false);
+    if (cfg == 5) NT2_GO(32, 2, false);
+    if (cfg == 6) NT2_GO(32, 3, false);
     NT2_GO(64, 2, false);
 #undef NT2_GO
 }
