@@ -134,11 +134,13 @@ int spe_gemm_bf16tn(const void* A16, const void* B16, float* C, int M, int N, in
  * C = v (optional fp32) ; out16[M][ld16] = bf16(v) ; out16T[N][ld16t] = bf16(v)^T with columns M..ld16t-1 zero
  * (ld16t <= M rounded up to 64) ; colsum[n] += sum_m v.  Any output may be NULL.  res/rgamma != NULL (act 0, no aux):
  * the LayerScale residual of the block is applied by the epilogue, C = res[m][n] + rgamma[n] * v (res [M][ldc]), while C2
- * keeps v for the gamma gradient.  Used by the fused MLP of the backbone block (reference models/cait.py:405-416 = timm
- * Mlp fc1 -> GELU -> fc2 inside x + gamma_2 * mlp(norm2(x)), and its autograd). */
+ * keeps v for the gamma gradient.  half_flags bit 0: C2 is stored as IEEE fp16 [M][ldc] (saturating) instead of fp32; bit 1: aux
+ * holds IEEE fp16 [M][ldc] - the saved pre-activation of the MLP, of which only gelu'(.) is ever taken.  Used by the fused MLP of the
+ * backbone block (reference models/cait.py:405-416 = timm Mlp fc1 -> GELU -> fc2 inside x + gamma_2 * mlp(norm2(x)), and its autograd). */
 int spe_gemm_bf16nt_ex(const void* A16, const void* B16, const void* A16lo, const void* B16lo, float* C, const float* bias,
                        float* C2, void* out16, void* out16lo, long ld16, void* out16T, long ld16t, float* colsum, const float* aux,
-                       const float* res, const float* rgamma, int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, spe_stream_t stream);
+                       const float* res, const float* rgamma, int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act,
+                       int half_flags, spe_stream_t stream);
 int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, void* out_lo, long ldo, void* outT, long ldt, float* colsum,
                  const float* aux, int act, spe_stream_t stream);
 /* spe_cvt_bf16_multi: the row-major and transposed bf16 copies of njobs contiguous fp32 matrices in ONE launch (every

@@ -29,9 +29,23 @@ struct Gemm16Args {
     float* colsum;                         // [N] += sum_m v (row tiles added in a fixed order: det_reduce.h)
     DetWs ws;                              // reduction workspace of the column sums
     const float* aux;                      // [M][ldc]: v *= act'(aux) (act 1: aux = forward output, 2: pre-activation)
+    int half_flags;                        // bit 0: C2 is written as IEEE fp16 [M][ldc] ; bit 1: aux holds IEEE fp16 [M][ldc]  (the saved
+                                           // pre-activation of the fused MLP: only act'(.) is ever taken of it - fp16 costs the gradient
+                                           // ~3e-4 relative, an order below its bf16 operand rounding, and halves 51 MB per block each way)
     const float* res; const float* rgamma; // LayerScale residual: C = res[m][n] + rgamma[n] * v  (C2 still gets v)
 };
 
+typedef _Float16 ep_h4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 ep_f2h4(float a, float b, float c, float d) {
+    ep_h4_t h;
+    h[0] = (_Float16)fminf(fmaxf(a, -65504.f), 65504.f); h[1] = (_Float16)fminf(fmaxf(b, -65504.f), 65504.f);
+    h[2] = (_Float16)fminf(fmaxf(c, -65504.f), 65504.f); h[3] = (_Float16)fminf(fmaxf(d, -65504.f), 65504.f);
+    return __builtin_bit_cast(uint2, h);
+}
+__device__ __forceinline__ float4 ep_h2f4(uint2 u) {
+    const ep_h4_t h = __builtin_bit_cast(ep_h4_t, u);
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
 __device__ __forceinline__ float gelu_erf16(float x) { return 0.5f * x * (1.0f + spe_erff(x * 0.70710678118654752f)); }
 
 
@@ -66,12 +80,17 @@ __device__ __forceinline__ void gemm16_epilogue_ex(const Gemm16Args& p, f32x4_t 
     const bool interior = vst && (m0 + BM <= p.M) && (n0 + BN <= p.N);
     float4 hq[NFN][NFM];
     const float* pre_src = p.aux ? p.aux : p.res;              // aux and res are mutually exclusive
+    const bool aux16 = p.aux && (p.half_flags & 2), c216 = p.half_flags & 1;
     if (pre_src && interior) {
 #pragma unroll
         for (int j = 0; j < NFN; ++j)
 #pragma unroll
             for (int i = 0; i < NFM; ++i)
-                hq[j][i] = *reinterpret_cast<const float4*>(pre_src + (long)(m0 + wm * WM + i * 16 + fr) * p.ldc + n0 + wn * WN + j * 16 + (lane >> 4) * 4);
+            {
+                const long o = (long)(m0 + wm * WM + i * 16 + fr) * p.ldc + n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+                if (aux16) hq[j][i] = ep_h2f4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.aux) + o));
+                else hq[j][i] = *reinterpret_cast<const float4*>(pre_src + o);
+            }
     }
 #pragma unroll
     for (int j = 0; j < NFN; ++j) {
@@ -97,7 +116,16 @@ __device__ __forceinline__ void gemm16_epilogue_ex(const Gemm16Args& p, f32x4_t 
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha + bv[r];
             if (p.C2 && rowv) {
-                if (full) spe_store4_stream(p.C2 + off, v[0], v[1], v[2], v[3]);
+                if (c216) {
+                    unsigned short* c2h = reinterpret_cast<unsigned short*>(p.C2);
+                    const uint2 u = ep_f2h4(v[0], v[1], v[2], v[3]);
+                    if (full) *reinterpret_cast<uint2*>(c2h + off) = u;
+                    else {
+                        const unsigned short e[4] = {(unsigned short)(u.x & 0xffff), (unsigned short)(u.x >> 16), (unsigned short)(u.y & 0xffff), (unsigned short)(u.y >> 16)};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) c2h[(long)m * p.ldc + n + r] = e[r];
+                    }
+                } else if (full) spe_store4_stream(p.C2 + off, v[0], v[1], v[2], v[3]);
                 else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (n + r < p.N) p.C2[(long)m * p.ldc + n + r] = v[r];
@@ -106,10 +134,16 @@ __device__ __forceinline__ void gemm16_epilogue_ex(const Gemm16Args& p, f32x4_t 
             if (p.aux) {
                 float h[4] = {0.f, 0.f, 0.f, 0.f};
                 if (interior) { h[0] = hq[j][i].x; h[1] = hq[j][i].y; h[2] = hq[j][i].z; h[3] = hq[j][i].w; }
-                else if (full) { const float4 q = *reinterpret_cast<const float4*>(p.aux + off); h[0] = q.x; h[1] = q.y; h[2] = q.z; h[3] = q.w; }
-                else if (rowv) {
+                else if (full) {
+                    const float4 q = aux16 ? ep_h2f4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.aux) + off))
+                                           : *reinterpret_cast<const float4*>(p.aux + off);
+                    h[0] = q.x; h[1] = q.y; h[2] = q.z; h[3] = q.w;
+                } else if (rowv) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < p.N) h[r] = p.aux[(long)m * p.ldc + n + r];
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N)
+                            h[r] = aux16 ? (float)__builtin_bit_cast(_Float16, reinterpret_cast<const unsigned short*>(p.aux)[(long)m * p.ldc + n + r])
+                                         : p.aux[(long)m * p.ldc + n + r];
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {

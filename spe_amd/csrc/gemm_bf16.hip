@@ -337,7 +337,7 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, const void* A16
     p.Alo = reinterpret_cast<const unsigned short*>(A16lo); p.Blo = reinterpret_cast<const unsigned short*>(B16lo); p.out16lo = nullptr;
     p.C = C; p.C2 = C2; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.act = act; p.slab = 0;
-    p.ws = DetWs{nullptr, nullptr, 0, 0};
+    p.ws = DetWs{nullptr, nullptr, 0, 0}; p.half_flags = 0;
     p.out16 = nullptr; p.out16T = nullptr; p.colsum = nullptr; p.aux = nullptr; p.ld16 = 0; p.ld16t = 0; p.res = nullptr; p.rgamma = nullptr;
     const int ktiles = (K + GB_BK - 1) / GB_BK;
     if (splitk < 0) {           // slab mode: C holds |splitk| slabs of M*ldc floats
@@ -395,7 +395,7 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, const void* A16
 extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, const void* A16lo, const void* B16lo, float* C, const float* bias,
                                   float* C2, void* out16, void* out16lo, long ld16, void* out16T, long ld16t, float* colsum,
                                   const float* aux, const float* res, const float* rgamma,
-                                  int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, hipStream_t stream) {
+                                  int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int half_flags, hipStream_t stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0) return -4;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -414,6 +414,8 @@ extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, const void* 
     p.out16 = reinterpret_cast<unsigned short*>(out16); p.ld16 = ld16;
     p.out16T = reinterpret_cast<unsigned short*>(out16T); p.ld16t = ld16t;
     p.colsum = colsum; p.aux = aux; p.res = res; p.rgamma = rgamma;
+    if (half_flags & ~3) return -2;
+    p.half_flags = half_flags;
     p.ws = spe_detws();
     if (colsum) DET_CHECK(p.ws, (N + 63) / 64, (M + 63) / 64, 64);      // bound for the smallest tiles
     // the transposed copy's zero columns M..ld16t-1 are written by the last row tile: it must reach ld16t

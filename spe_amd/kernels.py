@@ -413,10 +413,12 @@ def gemm16_ex(A16, B16, M, N, K, lda, ldb, bias=None, C=None, C2=None, out16=Non
               alpha=1.0, act=0, res=None, rgamma=None, Alo=None, Blo=None, out16lo=None):
     """spe_gemm_bf16nt_ex: v = alpha * A16 @ B16.T + bias; C2 = v; v = act(v) or v * act'(aux); optional fp32 C [M,N], bf16
     out16 [M,N], bf16 transposed out16T [N, ldt] (zero padded), colsum [N] += column sums.  All fp32 tensors have ld = N.
-    Alo / Blo: low parts of split operands; out16lo [M,N]: bf16(v - out16), the low part of the result for the next split GEMM."""
+    Alo / Blo: low parts of split operands; out16lo [M,N]: bf16(v - out16), the low part of the result for the next split GEMM.
+    C2 / aux may be fp16 tensors (the saved pre-activation of the fused MLP): flagged to the library by their dtype."""
+    half_flags = (1 if (C2 is not None and C2.dtype == torch.float16) else 0) | (2 if (aux is not None and aux.dtype == torch.float16) else 0)
     _call("spe_gemm_bf16nt_ex", _p(A16), _p(B16), _p(Alo), _p(Blo), _p(C), _p(bias), _p(C2), _p(out16), _p(out16lo), N, _p(out16T),
           out16T.shape[1] if out16T is not None else 0, _p(colsum), _p(aux), _p(res), _p(rgamma), M, N, K, lda, ldb, N,
-          float(alpha), int(act), _st())
+          float(alpha), int(act), half_flags, _st())
 
 
 def mlp16_ok(R, K, Hd, N):
@@ -477,6 +479,9 @@ def linear_res_bwd(dout2, saved, W, gamma, need_dx=True, grad_bufs=(None, None, 
     return dx, dW, db, dg
 
 
+MLP_PRE_F16 = os.environ.get("SPE_MLP_PRE_F16", "1") != "0"      # developer knob (A/B)
+
+
 def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True, src=None):
     """y = fc2(gelu(fc1(x2))) with every intermediate that the next GEMM needs emitted as bf16 by the producing GEMM's
     epilogue: fc1 writes the fp32 pre-activation (for the backward) and the bf16 activation h16 / h16T, never the fp32
@@ -488,7 +493,9 @@ def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True, src=None):
     sp = split_fwd()                         # bf16s forward: both products on (hi, lo) operand pairs, fc1 emits gelu(pre) as a pair
     x16, x16T, x16lo = act16(x2, save and not DW_TN, src, want_lo=sp)
     Rp = ((R + 63) // 64) * 64
-    pre = torch.empty((R, Hd), device=dev, dtype=torch.float32) if save else None
+    # the pre-activation is kept for gelu'(.) of the backward only: fp16 (11 significant bits: the derivative is exact to ~3e-4,
+    # an order below the bf16 operand rounding of the backward products) - half the bytes of the largest activation of the block
+    pre = torch.empty((R, Hd), device=dev, dtype=torch.float16 if MLP_PRE_F16 else torch.float32) if save else None
     h16 = torch.empty((R, Hd), device=dev, dtype=torch.bfloat16)
     h16lo = torch.empty((R, Hd), device=dev, dtype=torch.bfloat16) if sp else None
     h16T = torch.empty((Hd, Rp), device=dev, dtype=torch.bfloat16) if (save and not DW_TN) else None
