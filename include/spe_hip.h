@@ -240,8 +240,9 @@ int spe_layerscale_residual_bwd(const float* dout, const float* y, const float* 
 /* spe_layerscale_residual_bwd16: the same backward when the branch ends in a Linear on the bf16-copy GEMMs (proj / fc2 of
  * the backbone block, cait.py:390,412): dy = gamma * dout is emitted only as the bf16 operands of that Linear's backward
  * GEMMs - dy16 [R][C] and dy16T [C][ldt] (ldt = R rounded up to 64, padding zero) - with db[c] += sum_r dy (the Linear's
- * bias gradient, fp32 before rounding) and dgamma[c] += sum_r dout * y.  No per-sample scale (drop_path = 0). */
-int spe_layerscale_residual_bwd16(const float* dout, const float* y, const float* gamma, void* dy16, void* dy16T, long ldt,
+ * bias gradient, fp32 before rounding) and dgamma[c] += sum_r dout * y.  No per-sample scale (drop_path = 0).  y_f16 != 0: y holds
+ * IEEE fp16 [R][C] (written by spe_gemm_bf16nt_ex with half_flags bit 0: y only ever enters this sum). */
+int spe_layerscale_residual_bwd16(const float* dout, const void* y, int y_f16, const float* gamma, void* dy16, void* dy16T, long ldt,
                                   float* db, float* dgamma, long R, int C, spe_stream_t stream);
 
 /* ---- activation backward: mode 1 ReLU (aux = forward output), mode 2 GELU (aux = pre-activation);

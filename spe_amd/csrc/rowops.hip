@@ -619,7 +619,7 @@ __global__ __launch_bounds__(NW * 64) void lsres_bwd_rows_kernel(const float* __
 __global__ __launch_bounds__(1024) void lsres_bwd16_kernel(const float* __restrict__ dout, const float* __restrict__ y,
                                                            const float* __restrict__ gamma, unsigned short* __restrict__ dy16,
                                                            unsigned short* __restrict__ dy16T, long ldt, float* __restrict__ db,
-                                                           float* __restrict__ dgamma, long R, int C, DetWs ws) {
+                                                           float* __restrict__ dgamma, long R, int C, DetWs ws, int y_f16) {
     extern __shared__ unsigned short lsT[];            // [64][C + 8] bf16 tile ; reused as float [16][C + 4] x 2 at the end
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int C4 = C >> 2, ldl = C + 8;
@@ -642,12 +642,20 @@ __global__ __launch_bounds__(1024) void lsres_bwd16_kernel(const float* __restri
             const bool rv = row < R;
             const float4* dr = reinterpret_cast<const float4*>(dout + (rv ? row : 0) * C);
             const float4* yr = reinterpret_cast<const float4*>(y + (rv ? row : 0) * C);
+            const uint2* yh = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(y) + (rv ? row : 0) * C);
 #pragma unroll
             for (int i = 0; i < LN_MAXV; ++i) {
                 const int c = lane + 64 * i;
                 if (c < C4) {
                     float4 d = make_float4(0, 0, 0, 0), yv = d;
-                    if (rv) { d = dr[c]; yv = yr[c]; }
+                    if (rv) {
+                        d = dr[c];
+                        if (y_f16) {          // y saved as IEEE fp16 by the producing GEMM's epilogue: it only enters the gamma gradient
+                            typedef _Float16 ls_h4_t __attribute__((ext_vector_type(4)));
+                            const ls_h4_t h = __builtin_bit_cast(ls_h4_t, yh[c]);
+                            yv = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+                        } else yv = yr[c];
+                    }
                     ag[i].x += d.x * yv.x; ag[i].y += d.y * yv.y; ag[i].z += d.z * yv.z; ag[i].w += d.w * yv.w;
                     const float4 o = make_float4(d.x * g[i].x, d.y * g[i].y, d.z * g[i].z, d.w * g[i].w);
                     ab[i].x += o.x; ab[i].y += o.y; ab[i].z += o.z; ab[i].w += o.w;
@@ -701,7 +709,7 @@ __global__ __launch_bounds__(1024) void lsres_bwd16_kernel(const float* __restri
 
 // C-ABI: see include/spe_hip.h (spe_layerscale_residual_bwd16).  -2: C % 4 != 0, C > 1024, ldt not a multiple of 64
 // or smaller than R, misaligned pointers.
-extern "C" int spe_layerscale_residual_bwd16(const float* dout, const float* y, const float* gamma, void* dy16, void* dy16T, long ldt,
+extern "C" int spe_layerscale_residual_bwd16(const float* dout, const void* y, int y_f16, const float* gamma, void* dy16, void* dy16T, long ldt,
                                              float* db, float* dgamma, long R, int C, hipStream_t st) {
     if (R <= 0) return 0;
     if ((C & 3) || C > 256 * LN_MAXV || (ldt & 63) || ldt < R) return -2;
@@ -719,8 +727,8 @@ extern "C" int spe_layerscale_residual_bwd16(const float* dout, const float* y, 
     long nb = (ldt + 63) / 64; if (nb > 256) nb = 256;
     const DetWs ws = spe_detws();
     DET_CHECK(ws, 1, nb, 2 * C);
-    hipLaunchKernelGGL(lsres_bwd16_kernel, dim3((unsigned)nb), dim3(1024), smem, st, dout, y, gamma,
-                       reinterpret_cast<unsigned short*>(dy16), reinterpret_cast<unsigned short*>(dy16T), ldt, db, dgamma, R, C, ws);
+    hipLaunchKernelGGL(lsres_bwd16_kernel, dim3((unsigned)nb), dim3(1024), smem, st, dout, reinterpret_cast<const float*>(y), gamma,
+                       reinterpret_cast<unsigned short*>(dy16), reinterpret_cast<unsigned short*>(dy16T), ldt, db, dgamma, R, C, ws, y_f16);
     SPE_CHECK_LAUNCH();
     return 0;
 }

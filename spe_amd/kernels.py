@@ -440,7 +440,8 @@ def layerscale_residual_bwd16(dout2, y2, gamma, Rp, db_out=None, dg_out=None, wa
     dy16T = torch.empty((C, Rp), device=dev, dtype=torch.bfloat16) if want_T else None
     db = _zeros_or(db_out, C, dev)
     dg = _zeros_or(dg_out, C, dev)
-    _call("spe_layerscale_residual_bwd16", _p(dout2), _p(y2), _p(gamma), _p(dy16), _p(dy16T), Rp, _p(db), _p(dg), R, C, _st())
+    _call("spe_layerscale_residual_bwd16", _p(dout2), _p(y2), int(y2.dtype == torch.float16), _p(gamma), _p(dy16), _p(dy16T), Rp, _p(db), _p(dg),
+          R, C, _st())
     return dy16, dy16T, db, dg
 
 
@@ -452,7 +453,8 @@ def linear_res_fwd(x2, W, b, res, gamma, save=True, src=None):
     sp = split_fwd()
     x16, x16T, x16lo = act16(x2, save and not DW_TN, src, want_lo=sp)
     out = torch.empty((R, N), device=dev, dtype=torch.float32)
-    y = torch.empty((R, N), device=dev, dtype=torch.float32) if save else None
+    # the branch output y is kept for the LayerScale gamma gradient only (dgamma = sum dout * y): fp16, like the MLP's pre-activation
+    y = torch.empty((R, N), device=dev, dtype=torch.float16 if MLP_PRE_F16 else torch.float32) if save else None
     Wt = weight16(W, lo=sp)
     gemm16_ex(x16, Wt[0], R, N, K, K, K, bias=b, C=out, C2=y, res=res, rgamma=gamma, Alo=x16lo, Blo=Wt[2] if sp else None)
     return out, ((x16 if DW_TN else x16T), y)
@@ -510,6 +512,8 @@ def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True, src=None):
         return y, (x16T, pre, h16T)
     # LayerScale residual in the fc2 epilogue: out = res + gamma * y ; y is kept for the gamma gradient
     out = torch.empty((R, N), device=dev, dtype=torch.float32)
+    if MLP_PRE_F16:
+        y = torch.empty((R, N), device=dev, dtype=torch.float16)        # kept for the gamma gradient only
     gemm16_ex(h16, W2t[0], R, N, Hd, Hd, Hd, bias=b2, C=out, C2=y if save else None, res=res, rgamma=gamma, Alo=h16lo, Blo=W2lo)
     return out, (x16T, pre, h16T, y)
 

@@ -605,30 +605,43 @@ def test_fused_mlp_residual_matches_composite(dev):
     xn = torch.randn(2, R // 2, C, generator=g).to(dev).requires_grad_()
     xr = torch.randn(2, R // 2, C, generator=g).to(dev).requires_grad_()
     go = torch.randn(2, R // 2, C, generator=g).to(dev)
-    out = ops.mlp_gelu_residual(xn, W1, b1, W2, b2, xr, gamma)
-    assert out.grad_fn.name().startswith("_MlpGeluRes")
-    gr = torch.autograd.grad(out, [xn, xr] + params, go)
-    ref = ops.layerscale_residual(xr, ops.mlp_gelu(xn, W1, b1, W2, b2), gamma)
-    g0 = torch.autograd.grad(ref, [xn, xr] + params, go)
-    assert rel(out, ref) < 1e-6
-    for a, b, nm in zip(gr, g0, ["xn", "xres", "W1", "b1", "W2", "b2", "gamma"]):
-        assert rel(a, b) < 5e-6, (nm, rel(a, b))
-    # with a reducer: every parameter gradient lands in its bucket view without a copy
-    red = GradAllReducer(params, flatten_params=False)
-    red.reset()
-    ops.mlp_gelu_residual(xn, W1, b1, W2, b2, xr, gamma).backward(go)
-    red.finish()
-    for p, b in zip(params, g0[2:]):
-        assert p.grad.data_ptr() == red._views[p].data_ptr() and rel(p.grad, b) < 5e-6
-    # no gradient wanted (inference): same output, nothing saved
-    with torch.no_grad():
-        oi = ops.mlp_gelu_residual(xn.detach(), W1.detach(), b1.detach(), W2.detach(), b2.detach(), xr.detach(), gamma.detach())
-    assert torch.equal(oi, out.detach())
-    # DropPath scale present -> composite path
-    ss = torch.tensor([1.25, 0.0], device=dev)
-    o2 = ops.mlp_gelu_residual(xn, W1, b1, W2, b2, xr, gamma, ss)
-    assert not o2.grad_fn.name().startswith("_MlpGeluRes")
-    assert rel(o2, ops.layerscale_residual(xr, ops.mlp_gelu(xn, W1, b1, W2, b2), gamma, ss)) < 1e-6
+    saved16 = K.MLP_PRE_F16
+    K.MLP_PRE_F16 = False                  # fp32 saves: the fused node must reproduce the composite to summation order
+    try:
+        out = ops.mlp_gelu_residual(xn, W1, b1, W2, b2, xr, gamma)
+        assert out.grad_fn.name().startswith("_MlpGeluRes")
+        gr = torch.autograd.grad(out, [xn, xr] + params, go)
+        ref = ops.layerscale_residual(xr, ops.mlp_gelu(xn, W1, b1, W2, b2), gamma)
+        g0 = torch.autograd.grad(ref, [xn, xr] + params, go)
+        assert rel(out, ref) < 1e-6
+        for a, b, nm in zip(gr, g0, ["xn", "xres", "W1", "b1", "W2", "b2", "gamma"]):
+            assert rel(a, b) < 5e-6, (nm, rel(a, b))
+        # the default: pre-activation and branch output saved as fp16 (they only enter gelu'(.) and the gamma gradient) - same
+        # output bit for bit, gradients within 1e-3 of the fp32-save ones
+        K.MLP_PRE_F16 = True
+        out16 = ops.mlp_gelu_residual(xn, W1, b1, W2, b2, xr, gamma)
+        assert torch.equal(out16, out)
+        for a, b, nm in zip(torch.autograd.grad(out16, [xn, xr] + params, go), g0, ["xn", "xres", "W1", "b1", "W2", "b2", "gamma"]):
+            assert rel(a, b) < 1e-3, (nm, rel(a, b))
+        K.MLP_PRE_F16 = False
+        # with a reducer: every parameter gradient lands in its bucket view without a copy
+        red = GradAllReducer(params, flatten_params=False)
+        red.reset()
+        ops.mlp_gelu_residual(xn, W1, b1, W2, b2, xr, gamma).backward(go)
+        red.finish()
+        for p, b in zip(params, g0[2:]):
+            assert p.grad.data_ptr() == red._views[p].data_ptr() and rel(p.grad, b) < 5e-6
+        # no gradient wanted (inference): same output, nothing saved
+        with torch.no_grad():
+            oi = ops.mlp_gelu_residual(xn.detach(), W1.detach(), b1.detach(), W2.detach(), b2.detach(), xr.detach(), gamma.detach())
+        assert torch.equal(oi, out.detach())
+        # DropPath scale present -> composite path
+        ss = torch.tensor([1.25, 0.0], device=dev)
+        o2 = ops.mlp_gelu_residual(xn, W1, b1, W2, b2, xr, gamma, ss)
+        assert not o2.grad_fn.name().startswith("_MlpGeluRes")
+        assert rel(o2, ops.layerscale_residual(xr, ops.mlp_gelu(xn, W1, b1, W2, b2), gamma, ss)) < 1e-6
+    finally:
+        K.MLP_PRE_F16 = saved16
 
 
 @pytest.mark.parametrize("B,H,N,dh", [(2, 8, 4150, 48), (1, 8, 8200, 48), (2, 4, 300, 32), (3, 8, 2100, 64)])
@@ -682,7 +695,8 @@ def test_fused_linear_residual_matches_composite(dev):
     g0 = torch.autograd.grad(ref, [xa, xr, W, b, gamma], go)
     assert rel(out, ref) < 1e-6
     for a, c, nm in zip(gr, g0, ["x", "xres", "W", "b", "gamma"]):
-        assert rel(a, c) < 5e-6, (nm, rel(a, c))
+        # the branch output is saved as fp16 for the gamma gradient (the only place it is used): 1e-3 there, summation order elsewhere
+        assert rel(a, c) < (1e-3 if (nm == "gamma" and K.MLP_PRE_F16) else 5e-6), (nm, rel(a, c))
     with torch.no_grad():
         assert torch.equal(ops.linear_residual(xa.detach(), W.detach(), b.detach(), xr.detach(), gamma.detach()), out.detach())
     ss = torch.tensor([1.25, 0.0], device=dev)
