@@ -347,7 +347,8 @@ class _TalkingHeadsAttentionFused(Function):
     """Same operator on the fused score kernels (csrc/attn_fused.hip): no fp32 N x N tensor in HBM.
     forward : pack q*scale*log2e, k, v (fp16) -> statistics pass -> write pass (P'd * 2^8, blocked fp16) -> O = P'd V (streaming contraction)
     backward: dV = P'd^T dO ; pass 1 (D, dWw, dbw) ; pass 2 (dS blocked bf16, dWl, dbl) ; dQ, dK contractions.
-    Saved for backward: qkv, the packed q/k fragments (fp16), P'd (fp16) and the row statistics."""
+    Saved for backward: the packed q / k fragments (fp16 for the score recompute, bf16 for the gradient contractions), the bf16 v
+    fragments, P'd (fp16) and the row statistics - not qkv itself."""
 
     @staticmethod
     def forward(ctx, qkv, Wl, bl, Ww, bw, H, scale, p_drop):
@@ -361,7 +362,14 @@ class _TalkingHeadsAttentionFused(Function):
         spw0, _ = K.fused_plan(B, N, 0)
         # the fused kernels work in the log2 domain: scale * log2(e) is folded into the Q fragments
         # forward operands in fp16 (O(1) values: 3 more mantissa bits than bf16 at the same size and MFMA rate)
-        Qf, Kf, V16 = K.attn_pack_multi([(q, scale * K.LOG2E, 32 + K.F16), (k, 1.0, 32 + K.F16), (v, 1.0, 16 + K.F16)])
+        # ... and, when a backward will follow, its bf16 fragments of q / k / v from the same read of qkv (one launch; the fp32
+        # qkv - 38 MB per block at cfg2 - is then neither re-read nor kept)
+        train = any(ctx.needs_input_grad)
+        jobs = [(q, scale * K.LOG2E, 32 + K.F16), (k, 1.0, 32 + K.F16), (v, 1.0, 16 + K.F16)]
+        if train:
+            jobs += [(v, 1.0, 32), (k, 1.0, 16), (q, 1.0, 16)]
+        packed = K.attn_pack_multi(jobs)
+        Qf, Kf, V16 = packed[:3]
         Wl, bl, Ww, bw = Wl.contiguous(), bl.contiguous(), Ww.contiguous(), bw.contiguous()
         ws_stats = torch.empty((B * nt * 8 * H * 32,), device=qkv.device, dtype=torch.float32)
         seed, off = K.next_rng() if p_drop > 0 else (0, 0)
@@ -377,29 +385,28 @@ class _TalkingHeadsAttentionFused(Function):
             K.attach16(O, O16, O16lo)        # the output projection's operand, written by the contraction's epilogue
         ctx.meta = (B, N, C, H, dh, nt, scale, p_drop, seed, off)
         ctx.wparams = (Wl, bl, Ww, bw)      # leaves: looked up in backward for their gradient buckets
-        ctx.save_for_backward(qkv, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw)
+        if train:
+            ctx.save_for_backward(packed[3], packed[4], packed[5], Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw)
         return O
 
     @staticmethod
     @K.backward_scope
     def backward(ctx, dO):
-        qkv, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw = ctx.saved_tensors
+        Vf, K16, Q16, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw = ctx.saved_tensors
         B, N, C, H, dh, nt, scale, p_drop, seed, off = ctx.meta
         spw, nwg = K.fused_plan(B, N, 2)
         dO = dO.contiguous()
-        v5 = qkv.view(B, N, 3, H, dh)
-        q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
-        dqkv = torch.empty_like(qkv)
+        dqkv = torch.empty((B, N, 3 * C), device=dO.device, dtype=torch.float32)
         d5 = dqkv.view(B, N, 3, H, dh)
         dq, dk, dv = d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]
         dO4 = dO.view(B, N, H, dh)
-        Vf, dOf, dO16, K16, Q16 = K.attn_pack_multi([(v, 1.0, 32), (dO4, 1.0, 32), (dO4, 1.0, 16), (k, 1.0, 16), (q, 1.0, 16)])
+        dOf, dO16 = K.attn_pack_multi([(dO4, 1.0, 32), (dO4, 1.0, 16)])
         nw = 2 * (H * H + H)
-        ws_stats = torch.empty((B * nt * 8 * H * 32,), device=qkv.device, dtype=torch.float32)
-        ws_w = torch.empty((nwg, nw), device=qkv.device, dtype=torch.float32)
+        ws_stats = torch.empty((B * nt * 8 * H * 32,), device=dO.device, dtype=torch.float32)
+        ws_w = torch.empty((nwg, nw), device=dO.device, dtype=torch.float32)
         K.talking_fused(2, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, None, ws_stats, ws_w, None, B, H, N, dh, p_drop, seed, off)
         D, _ = K.attn_merge(ws_stats, B, H, N, spw, 2)
-        dS = K.score_blocks(B, H, N, qkv.device)
+        dS = K.score_blocks(B, H, N, dO.device)
         K.talking_fused(3, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, None, ws_w, dS, B, H, N, dh, p_drop, seed, off)
         # dV[key,d] = sum_q P'd[q,key] dO[q,d] - issued here, between backward pass 2 and the contractions that re-read
         # its 554 MB of dS: a streaming read right after a pass that wrote that much runs ~20 % slower (measured)
