@@ -201,7 +201,11 @@ int spe_nt2_dispatch(const Gemm16Args& p, bool ex, hipStream_t stream) {
     const bool split = p.Alo != nullptr;
     if (!enabled || p.M < 2048 || p.splitk != 1 || p.out16T || (p.K % 64) != 0 || p.K < 128 || p.N < 64) return SPE_NT2_NA;
     static const int wide_min = getenv("SPE_NT2_WIDE_MIN") ? atoi(getenv("SPE_NT2_WIDE_MIN")) : 1024;     // developer knob
-    const bool wide = p.N >= wide_min;
+    // single-term products with the extended epilogue (fc2 dh: GELU derivative from the saved pre-activation, bf16 output, column
+    // sums) are bound by that epilogue: 128 x 64 tiles at three workgroups per CU overlap it with other workgroups' main loops
+    // (8300 x 1536 x 384: 63 -> 51 us); the split forward products and the plain-epilogue ones are faster on the wide tiles
+    static const int wide_min_ex1 = getenv("SPE_NT2_WIDE_MIN_EX1") ? atoi(getenv("SPE_NT2_WIDE_MIN_EX1")) : 2048;      // developer knob
+    const bool wide = p.N >= ((ex && !split) ? wide_min_ex1 : wide_min);
     static const int cfg = getenv("SPE_NT2_CFG") ? atoi(getenv("SPE_NT2_CFG")) : 0;      // developer knob: ring depth / stage depth variants
 #define NT2_GO(BK_, NST_, SP_)                                                                                                   \
     do {                                                                                                                         \
