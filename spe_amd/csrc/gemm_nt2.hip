@@ -221,6 +221,17 @@ int spe_nt2_dispatch(const Gemm16Args& p, bool ex, hipStream_t stream) {
         const long c128 = ((t128 + 511) / 512) * 128, c160 = ((t160 + 511) / 512) * 160;
         if (c160 < c128) return split ? launch_nt2<160, 128, 32, 2, true, false>(p, stream) : launch_nt2<160, 128, 64, 2, false, false>(p, stream);
     }
+    // Narrow outputs (N = 384: the input-gradient products, proj / fc2 forward): 8300 x 384 is 390 tiles of 128 x 64 - 1.5 workgroups
+    // per CU.  64 x 64 tiles (780 workgroups, three to four per CU) hide each other's load latency: qkv dx 19.4 -> 17.0 us, fc1 dx
+    // 24.0 -> 21.5, the stacked decoder dx (K = 4608) 59.3 -> 53.1.  SPE_NT2_SHORT: bit 0 single-term plain, bit 1 split plain,
+    // bit 2 split extended epilogue, bit 3 single-term extended epilogue (developer knob, A/B).
+    static const int short_rows = getenv("SPE_NT2_SHORT") ? atoi(getenv("SPE_NT2_SHORT")) : 1;
+    if (!wide && cfg == 0) {
+        if ((short_rows & 1) && !ex && !split) return launch_nt2<64, 64, 64, 2, false, false>(p, stream);
+        if ((short_rows & 2) && !ex && split) return launch_nt2<64, 64, 32, 2, true, false>(p, stream);
+        if ((short_rows & 4) && ex && split) return launch_nt2<64, 64, 32, 2, true, true>(p, stream);
+        if ((short_rows & 8) && ex && !split) return launch_nt2<64, 64, 64, 2, false, true>(p, stream);
+    }
     if (split) {
         if (cfg == 1) NT2_GO(32, 3, true);
         if (cfg == 2) NT2_GO(32, 4, true);
