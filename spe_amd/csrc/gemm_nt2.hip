@@ -205,7 +205,10 @@ int spe_nt2_dispatch(const Gemm16Args& p, bool ex, hipStream_t stream) {
     // sums) are bound by that epilogue: 128 x 64 tiles at three workgroups per CU overlap it with other workgroups' main loops
     // (8300 x 1536 x 384: 63 -> 51 us); the split forward products and the plain-epilogue ones are faster on the wide tiles
     static const int wide_min_ex1 = getenv("SPE_NT2_WIDE_MIN_EX1") ? atoi(getenv("SPE_NT2_WIDE_MIN_EX1")) : 2048;      // developer knob
-    const bool wide = p.N >= ((ex && !split) ? wide_min_ex1 : wide_min);
+    // ... and so are the split forward products with the extended epilogue (fc1 + GELU: fp16 pre-activation + hi / lo bf16 outputs):
+    // 85 -> 73 us INSIDE the step on 128 x 64 tiles (the isolated launch prefers the wide tiles, 69 vs 76 us: measured in the step)
+    static const int wide_min_ex3 = getenv("SPE_NT2_WIDE_MIN_EX3") ? atoi(getenv("SPE_NT2_WIDE_MIN_EX3")) : 2048;           // developer knob
+    const bool wide = p.N >= (ex ? (split ? wide_min_ex3 : wide_min_ex1) : wide_min);
     static const int cfg = getenv("SPE_NT2_CFG") ? atoi(getenv("SPE_NT2_CFG")) : 0;      // developer knob: ring depth / stage depth variants
 #define NT2_GO(BK_, NST_, SP_)                                                                                                   \
     do {                                                                                                                         \
@@ -225,7 +228,7 @@ int spe_nt2_dispatch(const Gemm16Args& p, bool ex, hipStream_t stream) {
     // per CU.  64 x 64 tiles (780 workgroups, three to four per CU) hide each other's load latency: qkv dx 19.4 -> 17.0 us, fc1 dx
     // 24.0 -> 21.5, the stacked decoder dx (K = 4608) 59.3 -> 53.1.  SPE_NT2_SHORT: bit 0 single-term plain, bit 1 split plain,
     // bit 2 split extended epilogue, bit 3 single-term extended epilogue (developer knob, A/B).
-    static const int short_rows = getenv("SPE_NT2_SHORT") ? atoi(getenv("SPE_NT2_SHORT")) : 1;
+    static const int short_rows = getenv("SPE_NT2_SHORT") ? atoi(getenv("SPE_NT2_SHORT")) : 9;      // in the step: fc2 dh 64.5 -> 56.3 us with bit 3; bits 1, 2 no gain
     if (!wide && cfg == 0) {
         if ((short_rows & 1) && !ex && !split) return launch_nt2<64, 64, 64, 2, false, false>(p, stream);
         if ((short_rows & 2) && !ex && split) return launch_nt2<64, 64, 32, 2, true, false>(p, stream);
