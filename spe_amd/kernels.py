@@ -188,7 +188,9 @@ def _chk(*ts):
             raise TypeError(f"expected float32, got {t.dtype}")
 
 
-TN_SMALL_TILES = os.environ.get("SPE_TN_SMALL_TILES", "1") != "0"      # developer knob (A/B)
+_tn_small = int(os.environ.get("SPE_TN_SMALL_TILES", "1"))             # developer knob (A/B): 0 off, 1 default threshold, n threshold
+TN_SMALL_TILES = _tn_small != 0
+TN_SMALL_MAX = 256 if _tn_small <= 1 else _tn_small
 
 
 def auto_splitk(M, N, K, batch):
@@ -201,7 +203,7 @@ def auto_splitk(M, N, K, batch):
     # tiles * splits must FIT the 512 resident workgroup slots (2 per CU): 36 tiles x 15 = 540 leaves 28 workgroups for a
     # second, nearly empty round (fc1 / fc2 dW: 29 -> 24 us with 14 splits)
     sk = max(1, min(512 // tiles, K // 512, 16))
-    if TN_SMALL_TILES and batch == 1 and tiles * sk < 256:
+    if TN_SMALL_TILES and batch == 1 and tiles * sk < TN_SMALL_MAX:
         # few output tiles even at the largest split (a 384 x 384 weight: 9 tiles x 16 = 144 workgroups on 512 slots): 64 x 64 tiles
         # (spe_gemm_bf16tn picks them when 128-tiles x splits < 256) quadruple the tile count; the split is sized for THEM
         t64 = ((M + 63) // 64) * ((N + 63) // 64)
