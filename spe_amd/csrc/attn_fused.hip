@@ -365,8 +365,10 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
     constexpr int JBW = (MODE == 3) ? SPE_FUSED_JB3 : (GWM ? SPE_FUSED_JB2G * SPE_FUSED_JB2 : SPE_FUSED_JB2);
     constexpr int JB = (MODE >= 2) ? ((H >= JBW) ? JBW : ((H >= SPE_FUSED_JB2) ? SPE_FUSED_JB2 : H)) : H;
     // request the next macro step's first batch before the VALU phases (its registers stay live through them)
+// (round 3: the prefetch of modes 1 and 2 is OFF - measured INSIDE the training step, interleaved same-box runs: 57.22 -> 56.68 ms per
+    // step without it; the isolated launches it was tuned on preferred it.  The registers it holds through the VALU phases cost more there.)
 #ifndef SPE_FUSED_PREF1
-#define SPE_FUSED_PREF1 1
+#define SPE_FUSED_PREF1 0
 #endif
 #ifndef SPE_FUSED_QG
 #define SPE_FUSED_QG 2
@@ -375,10 +377,13 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
     // room and read them (and dO) from LDS in groups of QG jobs
     constexpr bool QREG = (MODE <= 1) && SPE_FUSED_QREG01;
     constexpr int QG = QREG ? ((JB >= 4) ? 4 : JB) : ((JB >= SPE_FUSED_QG) ? SPE_FUSED_QG : JB);
-    #ifndef SPE_FUSED_PREF2
-#define SPE_FUSED_PREF2 1
+#ifndef SPE_FUSED_PREF2
+#define SPE_FUSED_PREF2 0
 #endif
-    constexpr bool PREF = (MODE == 0) || (MODE == 1 && SPE_FUSED_PREF1) || (MODE == 2 && !DROP && SPE_FUSED_PREF2) || (MODE == 3 && !DROP && SPE_FUSED_PREF3);
+#ifndef SPE_FUSED_PREF0
+#define SPE_FUSED_PREF0 1
+#endif
+    constexpr bool PREF = (MODE == 0 && SPE_FUSED_PREF0) || (MODE == 1 && SPE_FUSED_PREF1) || (MODE == 2 && !DROP && SPE_FUSED_PREF2) || (MODE == 3 && !DROP && SPE_FUSED_PREF3);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int QP = (MODE <= 1) ? SPE_FUSED_QP : 1, WPQ = 4 / QP;        // q-tiles per workgroup, waves per q-tile
     u32x4_t* sQ = reinterpret_cast<u32x4_t*>(smem_raw);    // [QP][NFR][64]
