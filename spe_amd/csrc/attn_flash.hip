@@ -1,0 +1,443 @@
+// Flash-style talking-heads attention (K4 of SURVEY.md section 2.2; reference models/cait.py:377-389 and its autograd): the
+// kernels of this file keep the N x N tensors out of HBM altogether.
+//
+//   forward  (spe_talking_flash_fwd):  O = dropout(Ww softmax_k(Wl S + bl) + bw) V, S = scale q k^T, with the row statistics of
+//            the statistics pass (spe_talking_fused mode 0 + spe_attn_merge) - the P'd tensor the materialising write pass stored
+//            (554 MB per block at cfg2) and the streaming P'd V contraction are gone: P' goes from the mix straight into the
+//            P' V matrix instructions, O accumulates in registers.
+//   backward (spe_talking_flash_bwd):  key-major.  A wave owns 16 keys and walks over the query tiles, recomputing S, P, P' and
+//            dP' = dO V^T, dP = Ww^T dP', dS' = P (dP - D), dS = Wl^T dS' per step and accumulating dV += P'd^T dO and
+//            dK += dS^T Q in registers; dWl / dbl partials as in attn_fused.hip.  Only dS leaves the kernel (bf16 blocks, transposed
+//            ownership: lane = (key, 4 queries)) for the one remaining streaming contraction dQ = scale dS K.
+//
+// Both kernels run ONE wave per SIMD with the whole 512-entry register file (the accumulators live in its AccVGPR half) and stage
+// the streamed operand tiles of a step in LDS with global_load_lds_dwordx4, double-buffered: the DMA of step i + 1 is issued
+// right after the barrier that admits step i and has the whole step to land.  Work is split by a flattened (batch, major tile
+// group, streamed tile) numbering cut into equal ranges (attn_flash_common.h: fl_plan), so 260 tile groups on 256 CUs cost no
+// second round; a range's partial O / dV / dK go to slot workspaces that one small merge kernel sums in fixed order
+// (bitwise reproducible: no floating-point atomics anywhere).
+#include "attn_flash_common.h"
+
+// =====================================================================================================================
+// forward
+// =====================================================================================================================
+struct FlashFwdArgs {
+    const unsigned char* Qf; const unsigned char* Kf; const unsigned char* V16;     // fp16 fragment records (DT * 512 B each)
+    const float* Wl; const float* Ww; const float* bw;
+    const float* c0;                     // [B][N][H]: bl * log2(e) - m + log2(1 / l)   (spe_talking_flash_rows mode 0)
+    float* ws_o;                         // partial O * 2^8: [B * nmaj][FL_MAXSLOT][NW waves][QS][H][DT][64 lanes][4]
+    int B, N, nt, nmaj, spw; long total;
+    float p_drop; uint64_t seed, offset;
+};
+
+// Geometry: FLF_NW waves per workgroup, FLF_QS q-tiles per wave, 8 q-tiles = 128 queries per workgroup either way (the K / V
+// tiles a workgroup streams are 24 KB per step at cfg2 and a CU loads ~10 B / clk: fewer queries per workgroup would make the
+// kernel load-bound).
+//   (4, 2): ONE wave per SIMD with the 512-entry register file: the 2 x 96 O accumulators live in AccVGPRs, everything else must
+//           stay under 256 VGPRs (otherwise hipcc parks values in AccVGPRs around every matrix instruction) - so each q-tile's half
+//           steps are kept apart: H1(u) ends in 16 registers of packed fp16 probabilities, H2(u) starts from them.
+//           hipcc (ROCm 7.2) nevertheless gives every matrix result an AccVGPR and copies it out for the vector instructions
+//           (1060 v_accvgpr moves per step): built, not used.
+//   (8, 1): two waves per SIMD, <= 256 registers each, all of them ordinary VGPRs: clean code, 210 registers.  The default.
+// SKEW (8-wave geometry).  A step has a matrix-heavy half H1 (K Q^T, the fp32 Wl mix: ~1000 matrix cycles, few vector instructions)
+// and a vector-heavy half H2 (the fp16 Ww mix, dropout, packs, P' V).  With every wave running H1, H2 between the same barriers the
+// two waves of a SIMD are in lock step: they queue on the matrix pipe in H1 and leave it idle in H2 (measured, rocprofv3 SQ
+// counters at cfg2: matrix pipe 53 % + vector 46 % busy = no overlap).  So the two wave groups place their ONE barrier per step at
+// different points of the same instruction stream - waves 0-3 in front of H1, waves 4-7 in front of H2 - which holds the groups
+// half a step apart: between two barriers group 0 runs H1(k), H2(k) and group 1 H2(k), H1(k + 1).  Three K buffers, two V buffers.
+#ifndef FLF_NW
+#define FLF_NW 8
+#endif
+#ifndef FLF_SKEW
+#define FLF_SKEW 1
+#endif
+#ifndef FLF_SCHED
+#define FLF_SCHED 1
+#endif
+#define FLF_MAJ 8                        // q-tiles per workgroup
+#ifndef FLF_HB
+#define FLF_HB 4                         // heads per operand-fragment batch of the K Q^T products
+#endif
+#ifndef SPE_ABLATE
+#undef FLF_DBG_NOS
+#undef FLF_DBG_NOMIX1
+#undef FLF_DBG_NOEXP
+#undef FLF_DBG_NOMIX2
+#undef FLF_DBG_NOPV
+#undef FLF_DBG_NODMA
+#undef FLF_DBG_NOBAR
+#endif
+#define FLF_QS (FLF_MAJ / FLF_NW)
+
+template <int H, int DSTEPS, bool TAIL16, bool DROP>
+__global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_kernel(FlashFwdArgs a) {
+    constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
+    constexpr int NW = FLF_NW, QS = FLF_QS;
+    constexpr int TILEB = H * REC;                 // one operand, one 16-row tile, all heads
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];           // [K 0][K 1][K 2][V 0][V 1][8 q-tiles x TILEB of Q]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
+    const unsigned char* sQ = smem + 5 * TILEB + wave * (QS * TILEB);
+    const unsigned ldsQ = lds0 + 5 * TILEB + wave * (QS * TILEB);
+    const int grp = (FLF_SKEW && NW == 8) ? (wave >> 2) : 0;      // 1: this wave's barrier sits between H1 and H2
+    const int nt = a.nt, N = a.N;
+
+    float Al4[H / 4][H];
+    fl_mixA_f32<H, false>(a.Wl, lane, Al4);
+    fls16x4_t Aw[H / 4][H / 4];
+    fl_mixA_16<H, false, true>(a.Ww, lane, 1.0f, Aw);
+    f32x4_t vbws[H / 4];                           // bw * 2^8: the mix runs on P * 2^8
+#pragma unroll
+    for (int gh = 0; gh < H / 4; ++gh)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vbws[gh][i] = a.bw[4 * gh + i] * FL_PD_SCALE;
+    constexpr int NP = TILEB / 1024, NPW = (NP + NW - 1) / NW;     // 1-KB pieces of an operand tile, pieces per wave
+    unsigned voff[NPW];                                            // byte offset of this lane's 16 B of piece i * NW + wave inside a (b, tile) image
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int o = (i * NW + wave) * 1024 + lane * 16;
+        voff[i] = (unsigned)((o / REC) * nt * REC + o % REC);
+    }
+
+    const long s_begin = (long)blockIdx.x * a.spw;
+    long s_end = s_begin + a.spw; if (s_end > a.total) s_end = a.total;
+    long s = s_begin;
+    while (s < s_end) {
+        const int bm = (int)(s / nt), kt0 = (int)(s % nt);
+        int seg = nt - kt0; if (seg > s_end - s) seg = (int)(s_end - s);
+        const int b = bm / a.nmaj, mj = bm % a.nmaj;
+        const int qt0 = (mj * NW + wave) * QS;                  // this wave's first q-tile (wave-uniform)
+        const bool wvalid = qt0 < nt;
+
+        // ---- this wave's Q records -> its LDS area (QS x H records; a 1-KB piece may straddle two records: per-lane source offset)
+#pragma unroll
+        for (int u = 0; u < QS; ++u) {
+            constexpr int NPQ = TILEB / 1024;
+            const unsigned char* qbase = a.Qf + ((long)b * H * nt + min(qt0 + u, nt - 1)) * REC;          // wave-uniform
+#pragma unroll
+            for (int p = 0; p < NPQ; ++p) {
+                const int o = p * 1024 + lane * 16;
+                fl_glds16_s(qbase, (unsigned)((o / REC) * nt * REC + o % REC), ldsQ + u * TILEB + p * 1024);
+            }
+        }
+        // one operand tile (all heads) of key tile kt -> LDS byte address dst: TILEB / 1024 pieces shared by the waves.  The source is
+        // (uniform base of the (b, tile)) + (per-lane 32-bit offset of the piece, computed once): no 64-bit vector arithmetic per piece
+        auto issue_tile = [&](const unsigned char* base, int kt, unsigned dst) {
+            const unsigned char* tb = base + ((long)b * H * nt + kt) * REC;
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) {
+                const int p = i * NW + wave;
+                if (NP % NW != 0 && p >= NP) break;
+                fl_glds16_s(tb, voff[i], dst + p * 1024);
+            }
+        };
+        issue_tile(a.Kf, kt0, lds0);
+
+        // ---- row constants and accumulators
+        f32x4_t c0v[QS][H / 4];
+        int qrow[QS];
+#pragma unroll
+        for (int u = 0; u < QS; ++u) {
+            qrow[u] = (qt0 + u) * 16 + (lane & 15);
+            const float* cp = a.c0 + ((long)b * N + (wvalid ? min(qrow[u], N - 1) : 0)) * H;
+#pragma unroll
+            for (int gh = 0; gh < H / 4; ++gh) {
+                c0v[u][gh] = *reinterpret_cast<const f32x4_t*>(cp + 4 * gh);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c0v[u][gh][i] += 8.0f;           // exp2(. + 8) = P * 2^8
+            }
+        }
+        f32x4_t O[QS][H][DT];
+#pragma unroll
+        for (int u = 0; u < QS; ++u)
+#pragma unroll
+            for (int g = 0; g < H; ++g)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) O[u][g][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        // barrier j admits K(j) / V(j - 1) and everything older; after it this wave's share of K(j + 1) and V(j) goes out, with a whole
+        // step to land.  Group 0 passes barrier i + 1 in front of H1(i), group 1 between H1(i) and H2(i); barrier 0 is common.
+        auto step_barrier = [&](int j) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA pieces (and its Q records) have landed
+#ifdef FLF_DBG_NOBAR
+            if (j == 0)
+#endif
+            __builtin_amdgcn_s_barrier();                                // everybody's have, and the buffers refilled below have been read
+            asm volatile("" ::: "memory");
+#ifdef FLF_DBG_NODMA
+            if (j == 0)
+#endif
+            {
+            if (j + 1 < seg) issue_tile(a.Kf, kt0 + j + 1, lds0 + ((j + 1) % 3) * TILEB);
+            if (j < seg) issue_tile(a.V16, kt0 + j, lds0 + (3 + (j & 1)) * TILEB);
+            }
+        };
+        step_barrier(0);
+        for (int i = 0; i < seg; ++i) {
+            if (grp == 0) step_barrier(i + 1);
+            if (!wvalid) { if (grp != 0) step_barrier(i + 1); continue; }
+            const unsigned char* sK = smem + (i % 3) * TILEB;
+            const unsigned char* sV = smem + (3 + (i & 1)) * TILEB;
+            fls16x4_t bv[QS][4][H / 4];             // fp16(P * 2^8): [q-tile][key r][4 heads] - all that crosses from H1 to H2
+            // ---- H1: S^T = K Q^T (M = keys, N = queries): lane = (query l & 15, keys 4 (l >> 4) + r) ; P * 2^8 = exp2(Wl S + c0 + 8)
+#pragma unroll
+            for (int u = 0; u < QS; ++u) {
+                f32x4_t acc[H];
+#ifndef FLF_DBG_NOS
+                // operand fragments of FLF_HB heads are requested together (one LDS round trip per batch, not per head); the 16-wide tail
+                // step runs as a 16x16x16 instruction on its 8-B operands into its OWN accumulator (no zero-extended copies, and an
+                // accumulate chain never mixes two MFMA shapes - see attn_fused.hip), added on the vector pipe
+#pragma unroll
+                for (int h0 = 0; h0 < H; h0 += FLF_HB) {
+                    flu32x4_t kf[FLF_HB][FULL ? FULL : 1], qf[FLF_HB][FULL ? FULL : 1];
+                    fls16x4_t kt16[FLF_HB], qt16[FLF_HB];
+#pragma unroll
+                    for (int hb = 0; hb < FLF_HB; ++hb) {
+                        const unsigned char* kr = sK + (h0 + hb) * REC;
+                        const unsigned char* qr = sQ + (u * H + h0 + hb) * REC;
+#pragma unroll
+                        for (int st = 0; st < FULL; ++st) {
+                            kf[hb][st] = *reinterpret_cast<const flu32x4_t*>(kr + st * 1024 + lane * 16);
+                            qf[hb][st] = *reinterpret_cast<const flu32x4_t*>(qr + st * 1024 + lane * 16);
+                        }
+                        if constexpr (TAIL16) {
+                            kt16[hb] = *reinterpret_cast<const fls16x4_t*>(kr + FULL * 1024 + lane * 8);
+                            qt16[hb] = *reinterpret_cast<const fls16x4_t*>(qr + FULL * 1024 + lane * 8);
+                        }
+                    }
+#pragma unroll
+                    for (int hb = 0; hb < FLF_HB; ++hb) {
+                        f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int st = 0; st < FULL; ++st) c = fl_mfma32<true>(kf[hb][st], qf[hb][st], c);
+                        if constexpr (TAIL16) {
+                            const f32x4_t t = fl_mfma16<true>(kt16[hb], qt16[hb], (f32x4_t){0.f, 0.f, 0.f, 0.f});
+                            c = (FULL > 0) ? c + t : t;
+                        }
+                        acc[h0 + hb] = c;
+                    }
+                }
+#else
+#pragma unroll
+                for (int h = 0; h < H; ++h) acc[h] = (f32x4_t){(float)(i + h), 0.f, 0.f, 0.f};
+#endif
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f32x4_t sp[H / 4];
+#pragma unroll
+                    for (int gh = 0; gh < H / 4; ++gh) {
+                        f32x4_t d = c0v[u][gh];
+#ifndef FLF_DBG_NOMIX1
+#pragma unroll
+                        for (int h = 0; h < H; ++h) d = __builtin_amdgcn_mfma_f32_4x4x1f32(Al4[gh][h], acc[h][r], d, 0, 0, 0);
+#else
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) d[k] += acc[4 * gh + k][r];
+#endif
+                        sp[gh] = d;
+                    }
+#pragma unroll
+                    for (int hh = 0; hh < H / 4; ++hh)          // P * 2^8 <= 256: no saturation needed
+#ifndef FLF_DBG_NOEXP
+                        bv[u][r][hh] = fl_pack4_f16(fl_exp2(sp[hh][0]), fl_exp2(sp[hh][1]), fl_exp2(sp[hh][2]), fl_exp2(sp[hh][3]));
+#else
+                        bv[u][r][hh] = fl_pack4_f16(sp[hh][0], sp[hh][1], sp[hh][2], sp[hh][3]);
+#endif
+                }
+                if (FLF_SCHED) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (grp != 0) step_barrier(i + 1);
+            // ---- H2: P' * 2^8 = Ww (P * 2^8) + bw * 2^8 ; dropout ; fp16 B operands ; O^T[d][q] += V^T[d][key] P'^T[key][q]
+#pragma unroll
+            for (int u = 0; u < QS; ++u) {
+                f32x4_t pr[4][H / 4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int gh = 0; gh < H / 4; ++gh) {
+                        f32x4_t d = vbws[gh];
+#ifndef FLF_DBG_NOMIX2
+#pragma unroll
+                        for (int hh = 0; hh < H / 4; ++hh)
+                            d = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(flf16x4_t, Aw[gh][hh]), __builtin_bit_cast(flf16x4_t, bv[u][r][hh]), d, 0, 0, 0);
+#else
+                        { const flf16x4_t t = __builtin_bit_cast(flf16x4_t, bv[u][r][gh]); d[0] += (float)t[0]; d[1] += (float)t[1]; d[2] += (float)t[2]; d[3] += (float)t[3]; }
+#endif
+                        pr[r][gh] = d;
+                    }
+                if constexpr (DROP) {
+                    const uint32_t thr = (uint32_t)(a.p_drop * 65536.0f);
+                    const float inv = 1.0f / (1.0f - a.p_drop);
+#pragma unroll
+                    for (int hp = 0; hp < H / 2; ++hp) {
+                        uint32_t o[4];
+                        fl_keep_lots<H>(a.seed, a.offset, b, hp, qrow[u], (kt0 + i) * 16 + 4 * (lane >> 4), N, o);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int g0 = 2 * hp, g1 = 2 * hp + 1;
+                            pr[r][g0 >> 2][g0 & 3] *= (fl_lot(o, 0, r) >= thr) ? inv : 0.f;
+                            pr[r][g1 >> 2][g1 & 3] *= (fl_lot(o, 1, r) >= thr) ? inv : 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < H; ++g) {
+                    const fls16x4_t pk = fl_pack4<true>(pr[0][g >> 2][g & 3], pr[1][g >> 2][g & 3], pr[2][g >> 2][g & 3], pr[3][g >> 2][g & 3]);
+#ifndef FLF_DBG_NOPV
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)     // A = the V16 record (lane: d = dt*16 + (l & 15), keys 4 (l >> 4) + i), B = pk
+                        O[u][g][dt] = fl_mfma16<true>(*reinterpret_cast<const fls16x4_t*>(sV + g * REC + dt * 512 + lane * 8), pk, O[u][g][dt]);
+#else
+                    { const flf16x4_t t = __builtin_bit_cast(flf16x4_t, pk); O[u][g][0][0] += (float)t[0] + (float)t[1] + (float)t[2] + (float)t[3]; }
+#endif
+                }
+                if (FLF_SCHED) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_s_barrier();              // the last tiles have been read by everybody: the next segment may refill the buffers
+
+        // ---- partial O of this segment -> the major's slot (fragment order: one coalesced 1-KB store per accumulator register group)
+        if (wvalid) {
+            const int first_wg = (int)(((long)bm * nt) / a.spw);
+            const int slot = (int)blockIdx.x - first_wg;
+#pragma unroll
+            for (int u = 0; u < QS; ++u) {
+                if (qt0 + u >= nt) continue;
+                float* dst = a.ws_o + ((((long)bm * FL_MAXSLOT + slot) * NW + wave) * QS + u) * (long)(H * DT * 256);
+#pragma unroll
+                for (int g = 0; g < H; ++g)
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4_t*>(dst + (g * DT + dt) * 256 + lane * 4) = O[u][g][dt];
+            }
+        }
+        s += seg;
+    }
+}
+
+// Sum of the partial O slots of each (major, wave, q-tile), times 2^-8 -> O [B, N, H * dh] fp32 (+ its bf16 copy / low part: the
+// operand of the output projection).  One thread per float4 of the fragment-ordered workspace.
+__global__ __launch_bounds__(256) void flash_fwd_merge_kernel(const float* __restrict__ ws, float* __restrict__ O, unsigned short* __restrict__ O16,
+                                                              unsigned short* __restrict__ O16lo, int B, int H, int N, int nt, int dh, int DT,
+                                                              int nmaj, int spw, long nvec) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    constexpr int QS = FLF_QS;
+    const int lane = (int)(i & 63);
+    long r = i >> 6;
+    const int dt = (int)(r % DT); r /= DT;
+    const int g = (int)(r % H); r /= H;
+    const int u = (int)(r % QS); r /= QS;
+    const int wave = (int)(r % FLF_NW); r /= FLF_NW;
+    const int bm = (int)r;
+    const int b = bm / nmaj, mj = bm % nmaj;
+    const int qt = (mj * FLF_NW + wave) * QS + u;
+    const int q = qt * 16 + (lane & 15), d = dt * 16 + 4 * (lane >> 4);
+    if (qt >= nt || q >= N || d >= dh) return;
+    const int first_wg = (int)(((long)bm * nt) / spw), last_wg = (int)(((long)(bm + 1) * nt - 1) / spw);
+    const long slot_stride = (long)FLF_MAJ * H * DT * 256;
+    const float* src = ws + (long)bm * FL_MAXSLOT * slot_stride + (((long)wave * QS + u) * H + g) * (long)(DT * 256) + dt * 256 + lane * 4;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl <= last_wg - first_wg; ++sl) acc += *reinterpret_cast<const f32x4_t*>(src + sl * slot_stride);
+    acc *= (1.0f / FL_PD_SCALE);
+    const long C = (long)H * dh;
+    const long oi = ((long)b * N + q) * C + (long)g * dh + d;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (d + k >= dh) break;
+        O[oi + k] = acc[k];
+        if (O16) {
+            const unsigned short hi = spe_f2bf(acc[k]);
+            O16[oi + k] = hi;
+            if (O16lo) O16lo[oi + k] = spe_f2bf(acc[k] - spe_bf2f(hi));
+        }
+    }
+}
+
+// =====================================================================================================================
+// row constants
+// =====================================================================================================================
+// mode 0: c0[b][q][g] = bl[g] * log2(e) - M[b][g][q] + log2(IL[b][g][q])      (the addend that turns Wl S into log2 P)
+// mode 1: out[b][q][g] = in0[b][g][q]                                            (D of backward pass 1, query-major)
+__global__ __launch_bounds__(256) void flash_rows_kernel(const float* __restrict__ in0, const float* __restrict__ in1, const float* __restrict__ bl,
+                                                         float* __restrict__ out, int B, int H, int N, int mode) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * N * H) return;
+    const int g = (int)(i % H); const long bq = i / H; const int q = (int)(bq % N), b = (int)(bq / N);
+    const long si = ((long)b * H + g) * N + q;
+    out[i] = (mode == 0) ? bl[g] * FL_LOG2E - in0[si] + __builtin_amdgcn_logf(in1[si]) : in0[si];
+}
+
+template <int H, int DSTEPS, bool TAIL16>
+static int launch_flash_fwd(const FlashFwdArgs& a, int nwg, bool drop, hipStream_t st) {
+    constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
+    constexpr int smem = 5 * H * REC + FLF_MAJ * H * REC;
+    if (smem > 160 * 1024) return -2;              // H * head dim too large for the resident Q tiles + two stages: use the materialising path
+    static bool attr_set[2] = {false, false};
+    const void* fn = drop ? reinterpret_cast<const void*>(&talking_flash_fwd_kernel<H, DSTEPS, TAIL16, true>)
+                          : reinterpret_cast<const void*>(&talking_flash_fwd_kernel<H, DSTEPS, TAIL16, false>);
+    if (!attr_set[drop]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set[drop] = true;
+    }
+    if (drop) hipLaunchKernelGGL((talking_flash_fwd_kernel<H, DSTEPS, TAIL16, true>), dim3(nwg), dim3(64 * FLF_NW), smem, st, a);
+    else hipLaunchKernelGGL((talking_flash_fwd_kernel<H, DSTEPS, TAIL16, false>), dim3(nwg), dim3(64 * FLF_NW), smem, st, a);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+static inline int flash_dsteps(int dh, int* tail) {
+    const int rem = dh % 32, full = dh / 32 + (rem > 16 ? 1 : 0);
+    *tail = (rem > 0 && rem <= 16) ? 1 : 0;
+    return full + *tail;
+}
+
+// C-ABI: see include/spe_hip.h
+extern "C" int spe_talking_flash_plan(int B, int N, int nwg, int pass, int* steps_per_wg, int* nwg_used, int* nmajor) {
+    const int nt = (N + 15) / 16;
+    if ((long)B * nt <= 0 || nwg <= 0) { *steps_per_wg = 0; *nwg_used = 0; *nmajor = 0; return 0; }
+    const FlashPlan p = fl_plan(B, nt, (pass == 0) ? FLF_MAJ : 4, nt, nwg);
+    *steps_per_wg = p.spw; *nwg_used = p.nwg; *nmajor = p.nmaj;
+    return 0;
+}
+
+extern "C" int spe_talking_flash_rows(const float* in0, const float* in1, const float* bl, float* out, int B, int H, int N, int mode,
+                                      hipStream_t st) {
+    const long n = (long)B * N * H;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(flash_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in0, in1, bl, out, B, H, N, mode);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int spe_talking_flash_fwd(const void* Qf, const void* Kf, const void* V16, const float* Wl, const float* Ww, const float* bw,
+                                     const float* c0, float* ws_o, float* O, void* O16, void* O16lo, int B, int H, int N, int dh, int nwg,
+                                     float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
+    const int nt = (N + 15) / 16;
+    if ((long)B * nt <= 0) return 0;
+    if (dh < 1 || dh > 64 || nwg <= 0 || (O16lo && !O16)) return -2;
+    int tail; const int ds = flash_dsteps(dh, &tail);
+    const FlashPlan p = fl_plan(B, nt, FLF_MAJ, nt, nwg);
+    FlashFwdArgs a;
+    a.Qf = (const unsigned char*)Qf; a.Kf = (const unsigned char*)Kf; a.V16 = (const unsigned char*)V16;
+    a.Wl = Wl; a.Ww = Ww; a.bw = bw; a.c0 = c0; a.ws_o = ws_o;
+    a.B = B; a.N = N; a.nt = nt; a.nmaj = p.nmaj; a.spw = p.spw; a.total = p.total;
+    a.p_drop = p_drop; a.seed = seed; a.offset = offset;
+    const bool drop = p_drop > 0.f;
+    int rc = -2;
+#define SPE_FLASH_FWD(HH)                                                                  \
+    if (H == HH && ds == 2 && tail) rc = launch_flash_fwd<HH, 2, true>(a, p.nwg, drop, st);       \
+    else if (H == HH && ds == 2 && !tail) rc = launch_flash_fwd<HH, 2, false>(a, p.nwg, drop, st); \
+    else if (H == HH && ds == 1 && tail) rc = launch_flash_fwd<HH, 1, true>(a, p.nwg, drop, st);  \
+    else if (H == HH && ds == 1 && !tail) rc = launch_flash_fwd<HH, 1, false>(a, p.nwg, drop, st);
+    SPE_FLASH_FWD(8)
+    else SPE_FLASH_FWD(4)
+#undef SPE_FLASH_FWD
+    if (rc != 0) return rc;
+    const int DT = (dh + 15) / 16;
+    const long nvec = (long)B * p.nmaj * FLF_MAJ * H * DT * 64;
+    hipLaunchKernelGGL(flash_fwd_merge_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, ws_o, O,
+                       reinterpret_cast<unsigned short*>(O16), reinterpret_cast<unsigned short*>(O16lo), B, H, N, nt, dh, DT, p.nmaj, p.spw, nvec);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}

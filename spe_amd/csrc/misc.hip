@@ -193,7 +193,7 @@ extern "C" int spe_set_reduce_workspace(void* ws, size_t bytes, hipStream_t st) 
     return 0;
 }
 
-extern "C" int spe_abi_version(void) { return 4; }    // 2: round 2 (signatures of spe_hungarian, spe_adamw_flat, spe_layernorm_fwd, spe_attn_contract, spe_talking_fused_plan changed; new entry points)
+extern "C" int spe_abi_version(void) { return 5; }    // 2: round 2 (signatures of spe_hungarian, spe_adamw_flat, spe_layernorm_fwd, spe_attn_contract, spe_talking_fused_plan changed; new entry points)
 
 
 // ------------------------------------------------------------------------------------------

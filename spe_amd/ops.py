@@ -375,10 +375,19 @@ class _TalkingHeadsAttentionFused(Function):
         seed, off = K.next_rng() if p_drop > 0 else (0, 0)
         K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws_stats, None, None, B, H, N, dh, 0.0, 0, 0)
         M, IL = K.attn_merge(ws_stats, B, H, N, spw0, 0)
+        want16 = K.produces16(B * N, C)
+        if not train and K.flash_supported(H, dh):
+            # no backward will follow: P' goes from the head mix straight into the P' V products (csrc/attn_flash.hip) - the 554 MB
+            # (cfg2) P'd tensor of the write pass is neither stored nor streamed back
+            c0 = K.flash_rows(M, IL, bl, B, H, N, 0)
+            O, O16, O16lo = K.talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, off, want16, K.split_fwd())
+            if O16 is not None:
+                K.attach16(O, O16, O16lo)
+            return O
         Pd = K.score_blocks(B, H, N, qkv.device, torch.float16)          # fp16(P'd * PD_SCALE)
         K.talking_fused(1, Qf, Kf, None, None, Wl, bl, Ww, bw, M, IL, None, None, None, Pd, B, H, N, dh, p_drop, seed, off)
         O = torch.empty((B, N, C), device=qkv.device, dtype=torch.float32)
-        O16 = torch.empty((B * N, C), device=qkv.device, dtype=torch.bfloat16) if K.produces16(B * N, C) else None
+        O16 = torch.empty((B * N, C), device=qkv.device, dtype=torch.bfloat16) if want16 else None
         O16lo = torch.empty((B * N, C), device=qkv.device, dtype=torch.bfloat16) if (O16 is not None and K.split_fwd()) else None
         K.attn_contract(Pd, V16, O.view(B, N, H, dh), False, alpha=1.0 / K.PD_SCALE, out16=O16, out16lo=O16lo)
         if O16 is not None:

@@ -843,3 +843,40 @@ def test_nms_known_answers(dev):
     assert out["labels"].tolist() == [1, 1, 2, 2, 2, 2]
     assert torch.allclose(out["scores"].cpu(), torch.tensor([.90, .80, .95, .85, .75, .60]))
     assert torch.equal(out["boxes"].cpu(), boxes[[0, 1, 4, 5, 6, 3]])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: flash-style talking-heads forward (csrc/attn_flash.hip) - no N x N tensor in HBM
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,N,dh,p", [(1, 4, 12, 8, 0.0), (2, 4, 35, 8, 0.1), (2, 4, 196, 48, 0.0), (1, 8, 130, 48, 0.1),
+                                        (2, 8, 1100, 48, 0.0), (1, 4, 300, 32, 0.05), (1, 4, 257, 64, 0.0), (1, 4, 77, 24, 0.1)])
+def test_flash_forward_equals_materialising_path(dev, B, H, N, dh, p):
+    """spe_talking_flash_fwd against the write pass + streaming contraction it replaces (spe_talking_fused mode 1 +
+    spe_attn_contract; reference models/cait.py:377-389) on the same fragments, statistics and dropout stream: the two compute
+    the same fp16-operand products in a different summation order, so they agree to fp32 accumulation noise - with dropout too
+    (identical Philox counters).  Ragged N, both head counts, every head-dim decomposition (tail only, full + tail, full only)."""
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(17 * N + H)
+    C = H * dh
+    qkv = torch.randn(B, N, 3 * C, generator=g).to(dev)
+    Wl = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g)).to(dev); bl = (0.1 * torch.randn(H, generator=g)).to(dev)
+    Ww = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g)).to(dev); bw = (0.1 * torch.randn(H, generator=g)).to(dev)
+    scale = dh ** -0.5
+    v5 = qkv.view(B, N, 3, H, dh)
+    Qf, Kf, V16 = K.attn_pack_multi([(v5[:, :, 0], scale * K.LOG2E, 32 + K.F16), (v5[:, :, 1], 1.0, 32 + K.F16), (v5[:, :, 2], 1.0, 16 + K.F16)])
+    nt = (N + 15) // 16
+    spw0, _ = K.fused_plan(B, N, 0)
+    ws = torch.zeros(B * nt * 8 * H * 32, device=dev)
+    K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws, None, None, B, H, N, dh, 0.0, 0, 0)
+    M, IL = K.attn_merge(ws, B, H, N, spw0, 0)
+    Pd = K.score_blocks(B, H, N, dev, torch.float16)
+    K.talking_fused(1, Qf, Kf, None, None, Wl, bl, Ww, bw, M, IL, None, None, None, Pd, B, H, N, dh, p, 11, 5)
+    Oref = torch.empty(B, N, C, device=dev)
+    K.attn_contract(Pd, V16, Oref.view(B, N, H, dh), False, alpha=1.0 / K.PD_SCALE)
+    c0 = K.flash_rows(M, IL, bl, B, H, N, 0)
+    O, O16, O16lo = K.talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p, 11, 5, True, True)
+    O2, _, _ = K.talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p, 11, 5)
+    assert torch.isfinite(O).all()
+    assert torch.equal(O, O2)                                       # fixed summation order: bitwise reproducible
+    assert rel(O, Oref) < 2e-5, rel(O, Oref)
+    assert float((O16.float().view_as(O) + O16lo.float().view_as(O) - O).abs().max()) <= 2e-5 * float(O.abs().max())
