@@ -205,23 +205,31 @@ int spe_talking_wgrad_reduce(const float* ws_w, int nwg, int H, float* dWl, floa
                              spe_stream_t stream);
 
 /* ---- flash-style talking-heads attention (reference models/cait.py:377-389 + autograd): the same operator as spe_talking_fused
- * with NO N x N tensor in HBM at all - P' goes from the head mix straight into the P' V matrix instructions.
- * spe_talking_flash_rows: query-major row constants.  mode 0: out[b][q][g] = bl[g] log2(e) - in0[b][g][q] + log2(in1[b][g][q])
- *   from the M / IL of spe_attn_merge (the addend that turns Wl S into log2 P); mode 1: out[b][q][g] = in0[b][g][q] (D).
- * spe_talking_flash_plan(pass): the launcher's flattened work split - pass 0 = forward (a workgroup keeps 8 q-tiles resident and
- *   streams key tiles), pass 1 = backward (4 key tiles resident, q-tiles streamed): steps per workgroup, workgroups launched for
- *   an `nwg` budget, major tile groups per image.  Partial-result workspaces hold 8 (= slots) rows per major.
+ * with NO N x N tensor in HBM for the forward and for dV - P' goes from the head mix straight into the matrix instructions that
+ * consume it, the result accumulates in registers.
+ * spe_talking_flash_plan: the launcher's flattened work split for an `nwg` workgroup budget (a workgroup keeps 8 tiles of 16 rows
+ *   resident and streams the tiles of the other axis): steps per workgroup, workgroups launched, major tile groups per image, and
+ *   Np = the padded row count of the row-constant arrays.  The partial-result workspace `ws` holds
+ *   B * nmajor * 8 (slots) * 128 * H * 16 * ceil(dh / 16) floats.
+ * spe_talking_flash_rows: query-major row constants [B][Np][H], rows >= N zero.  mode 0: out[b][q][g] = bl[g] log2(e) - in0[b][g][q]
+ *   + log2(in1[b][g][q]) from the M / IL of spe_attn_merge (the addend that turns Wl S into log2 P); mode 1: out = in0 transposed.
  * spe_talking_flash_fwd: O[b, q, g*dh + d] = sum_key P'd[b,g][q,key] v[b, key, g, d] with P'd = attn_drop(proj_w(softmax(proj_l(
  *   scale q k^T)))); Qf / Kf fp16 fragments (spe_attn_pack_multi kind 0 + 16, Qf packed with scale * log2(e)), V16 fp16 (kind
- *   1 + 16), c0 from spe_talking_flash_rows mode 0.  ws_o: B * nmajor * 8 * 128 * H * 16 * ceil(dh / 16) floats.  O16 / O16lo
- *   (optional): bf16(O) and bf16(O - bf16(O)), same addressing - the operand of the output projection.
- * Supported: H in {4, 8}, head dim <= 64; -2 otherwise. */
-int spe_talking_flash_rows(const float* in0, const float* in1, const float* bl, float* out, int B, int H, int N, int mode,
+ *   1 + 16), c0 from spe_talking_flash_rows mode 0.  O16 / O16lo (optional): bf16(O) and bf16(O - bf16(O)), same addressing - the
+ *   operand of the output projection.
+ * spe_talking_flash_dv: dv[b, key, g, :] = sum_q P'd[b,g][q,key] dO[b, q, g, :] (element strides ob, on, oh of dv) - the same walk
+ *   with the key tiles resident: P'd is RECOMPUTED from the forward's fragments, statistics and dropout stream (nothing N x N is
+ *   saved for the backward); dO16 = spe_attn_pack_multi kind 1 (bf16).
+ * Supported: H in {4, 8}, 13 * H * ceil(dh / 16) * 512 + 3072 bytes of LDS <= 160 KB; -2 otherwise. */
+int spe_talking_flash_rows(const float* in0, const float* in1, const float* bl, float* out, int B, int H, int N, int Np, int mode,
                            spe_stream_t stream);
-int spe_talking_flash_plan(int B, int N, int nwg, int pass, int* steps_per_wg, int* nwg_used, int* nmajor);
+int spe_talking_flash_plan(int B, int N, int nwg, int* steps_per_wg, int* nwg_used, int* nmajor, int* rows_padded);
 int spe_talking_flash_fwd(const void* Qf, const void* Kf, const void* V16, const float* Wl, const float* Ww, const float* bw,
-                          const float* c0, float* ws_o, float* O, void* O16, void* O16lo, int B, int H, int N, int dh, int nwg,
+                          const float* c0, int Np, float* ws, float* O, void* O16, void* O16lo, int B, int H, int N, int dh, int nwg,
                           float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
+int spe_talking_flash_dv(const void* Qf, const void* Kf, const void* dO16, const float* Wl, const float* Ww, const float* bw,
+                         const float* c0, int Np, float* ws, float* dv, long ob, long on, long oh, int B, int H, int N, int dh, int nwg,
+                         float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
 
 /* ---- streaming contractions of a blocked 16-bit score tensor T (written by spe_talking_fused modes 1/3):
  *   trans = 0: out[b, q, h, :]   = alpha * sum_key T[b,h][q,key] x[b, key, h, :]   (`attn @ v`, cait.py:388; dQ)

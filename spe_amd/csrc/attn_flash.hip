@@ -22,9 +22,12 @@
 // forward
 // =====================================================================================================================
 struct FlashFwdArgs {
-    const unsigned char* Qf; const unsigned char* Kf; const unsigned char* V16;     // fp16 fragment records (DT * 512 B each)
+    // fragment records (DT * 512 B each).  forward: Qf = q (resident tiles, fp16), Kf = k (streamed, fp16), V16 = v (streamed, fp16);
+    // dV pass (KV): Qf = k (resident), Kf = q (streamed), V16 = dO in the 16-wide layout (streamed, bf16)
+    const unsigned char* Qf; const unsigned char* Kf; const unsigned char* V16;
     const float* Wl; const float* Ww; const float* bw;
-    const float* c0;                     // [B][N][H]: bl * log2(e) - m + log2(1 / l)   (spe_talking_flash_rows mode 0)
+    const float* c0;                     // [B][Np][H]: bl * log2(e) - m + log2(1 / l), rows >= N zero (spe_talking_flash_rows mode 0)
+    int Np;                              // rows per image of c0 (>= 16 nt + 64: the dV pass fetches whole 1-KB pieces of it)
     float* ws_o;                         // partial O * 2^8: [B * nmaj][FL_MAXSLOT][NW waves][QS][H][DT][64 lanes][4]
     int B, N, nt, nmaj, spw; long total;
     float p_drop; uint64_t seed, offset;
@@ -69,12 +72,17 @@ struct FlashFwdArgs {
 #endif
 #define FLF_QS (FLF_MAJ / FLF_NW)
 
-template <int H, int DSTEPS, bool TAIL16, bool DROP>
+// KV = false: the forward pass (a wave keeps q-tiles, streams key tiles: O = P'd V).
+// KV = true : the dV pass of the backward - the SAME walk on the transposed problem: a wave keeps KEY tiles and streams q-tiles,
+//             S = Q K^T lands as lane = (key l & 15, queries 4 (l >> 4) + r), the addend c0 belongs to the streamed rows (fetched per
+//             step into LDS), and the last product is dV^T[d][key] += dO^T[d][q] P'd[q][key] on bf16 operands.  P'd is recomputed
+//             from the forward's own fp16 fragments and statistics: nothing N x N was saved for it.
+template <int H, int DSTEPS, bool TAIL16, bool DROP, bool KV>
 __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_kernel(FlashFwdArgs a) {
     constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
     constexpr int NW = FLF_NW, QS = FLF_QS;
     constexpr int TILEB = H * REC;                 // one operand, one 16-row tile, all heads
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];           // [K 0][K 1][K 2][V 0][V 1][8 q-tiles x TILEB of Q]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];           // [K 0][K 1][K 2][V 0][V 1][8 resident tiles x TILEB][KV: c0 rows 0 1 2, 1 KB each]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
     const unsigned char* sQ = smem + 5 * TILEB + wave * (QS * TILEB);
@@ -131,20 +139,29 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
                 fl_glds16_s(tb, voff[i], dst + p * 1024);
             }
         };
+        // dV pass: the addend rows of streamed q-tile t (16 x H floats; the 1-KB piece reaches into the next tiles' rows / the padding)
+        auto issue_c0 = [&](int t, int buf) {
+            if constexpr (KV) {
+                if (wave == 0) fl_glds16_s(a.c0 + ((long)b * a.Np + t * 16) * H, (unsigned)(lane * 16), lds0 + (5 + FLF_MAJ) * TILEB + buf * 1024);
+            }
+        };
         issue_tile(a.Kf, kt0, lds0);
+        issue_c0(kt0, 0);
 
         // ---- row constants and accumulators
-        f32x4_t c0v[QS][H / 4];
+        f32x4_t c0v[KV ? 1 : QS][H / 4];
         int qrow[QS];
 #pragma unroll
         for (int u = 0; u < QS; ++u) {
-            qrow[u] = (qt0 + u) * 16 + (lane & 15);
-            const float* cp = a.c0 + ((long)b * N + (wvalid ? min(qrow[u], N - 1) : 0)) * H;
+            qrow[u] = (qt0 + u) * 16 + (lane & 15);                         // forward: this lane's query ; dV pass: this lane's KEY
+            if constexpr (!KV) {
+                const float* cp = a.c0 + ((long)b * a.Np + (wvalid ? min(qrow[u], N - 1) : 0)) * H;
 #pragma unroll
-            for (int gh = 0; gh < H / 4; ++gh) {
-                c0v[u][gh] = *reinterpret_cast<const f32x4_t*>(cp + 4 * gh);
+                for (int gh = 0; gh < H / 4; ++gh) {
+                    c0v[u][gh] = *reinterpret_cast<const f32x4_t*>(cp + 4 * gh);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) c0v[u][gh][i] += 8.0f;           // exp2(. + 8) = P * 2^8
+                    for (int i = 0; i < 4; ++i) c0v[u][gh][i] += 8.0f;       // exp2(. + 8) = P * 2^8
+                }
             }
         }
         f32x4_t O[QS][H][DT];
@@ -168,7 +185,7 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
             if (j == 0)
 #endif
             {
-            if (j + 1 < seg) issue_tile(a.Kf, kt0 + j + 1, lds0 + ((j + 1) % 3) * TILEB);
+            if (j + 1 < seg) { issue_tile(a.Kf, kt0 + j + 1, lds0 + ((j + 1) % 3) * TILEB); issue_c0(kt0 + j + 1, (j + 1) % 3); }
             if (j < seg) issue_tile(a.V16, kt0 + j, lds0 + (3 + (j & 1)) * TILEB);
             }
         };
@@ -226,7 +243,12 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
                     f32x4_t sp[H / 4];
 #pragma unroll
                     for (int gh = 0; gh < H / 4; ++gh) {
-                        f32x4_t d = c0v[u][gh];
+                        f32x4_t d;
+                        if constexpr (KV) {     // the streamed row 4 (l >> 4) + r: broadcast LDS read
+                            d = *reinterpret_cast<const f32x4_t*>(smem + (5 + FLF_MAJ) * TILEB + (i % 3) * 1024 + ((4 * (lane >> 4) + r) * H + 4 * gh) * 4);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) d[k] += 8.0f;
+                        } else d = c0v[u][gh];
 #ifndef FLF_DBG_NOMIX1
 #pragma unroll
                         for (int h = 0; h < H; ++h) d = __builtin_amdgcn_mfma_f32_4x4x1f32(Al4[gh][h], acc[h][r], d, 0, 0, 0);
@@ -270,23 +292,33 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
                     const float inv = 1.0f / (1.0f - a.p_drop);
 #pragma unroll
                     for (int hp = 0; hp < H / 2; ++hp) {
-                        uint32_t o[4];
-                        fl_keep_lots<H>(a.seed, a.offset, b, hp, qrow[u], (kt0 + i) * 16 + 4 * (lane >> 4), N, o);
+                        const int g0 = 2 * hp, g1 = 2 * hp + 1;
+                        if constexpr (!KV) {        // lane = (query, 4 consecutive keys): one counter, lots r
+                            uint32_t o[4];
+                            fl_keep_lots<H>(a.seed, a.offset, b, hp, qrow[u], (kt0 + i) * 16 + 4 * (lane >> 4), N, o);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int g0 = 2 * hp, g1 = 2 * hp + 1;
-                            pr[r][g0 >> 2][g0 & 3] *= (fl_lot(o, 0, r) >= thr) ? inv : 0.f;
-                            pr[r][g1 >> 2][g1 & 3] *= (fl_lot(o, 1, r) >= thr) ? inv : 0.f;
+                            for (int r = 0; r < 4; ++r) {
+                                pr[r][g0 >> 2][g0 & 3] *= (fl_lot(o, 0, r) >= thr) ? inv : 0.f;
+                                pr[r][g1 >> 2][g1 & 3] *= (fl_lot(o, 1, r) >= thr) ? inv : 0.f;
+                            }
+                        } else {                    // lane = (key, 4 consecutive queries): the counter of each query, lot key & 3
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                uint32_t o[4];
+                                fl_keep_lots<H>(a.seed, a.offset, b, hp, (kt0 + i) * 16 + 4 * (lane >> 4) + r, qrow[u], N, o);
+                                pr[r][g0 >> 2][g0 & 3] *= (fl_lot(o, 0, qrow[u] & 3) >= thr) ? inv : 0.f;
+                                pr[r][g1 >> 2][g1 & 3] *= (fl_lot(o, 1, qrow[u] & 3) >= thr) ? inv : 0.f;
+                            }
                         }
                     }
                 }
 #pragma unroll
                 for (int g = 0; g < H; ++g) {
-                    const fls16x4_t pk = fl_pack4<true>(pr[0][g >> 2][g & 3], pr[1][g >> 2][g & 3], pr[2][g >> 2][g & 3], pr[3][g >> 2][g & 3]);
+                    const fls16x4_t pk = fl_pack4<!KV>(pr[0][g >> 2][g & 3], pr[1][g >> 2][g & 3], pr[2][g >> 2][g & 3], pr[3][g >> 2][g & 3]);
 #ifndef FLF_DBG_NOPV
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt)     // A = the V16 record (lane: d = dt*16 + (l & 15), keys 4 (l >> 4) + i), B = pk
-                        O[u][g][dt] = fl_mfma16<true>(*reinterpret_cast<const fls16x4_t*>(sV + g * REC + dt * 512 + lane * 8), pk, O[u][g][dt]);
+                        O[u][g][dt] = fl_mfma16<!KV>(*reinterpret_cast<const fls16x4_t*>(sV + g * REC + dt * 512 + lane * 8), pk, O[u][g][dt]);
 #else
                     { const flf16x4_t t = __builtin_bit_cast(flf16x4_t, pk); O[u][g][0][0] += (float)t[0] + (float)t[1] + (float)t[2] + (float)t[3]; }
 #endif
@@ -314,11 +346,12 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
     }
 }
 
-// Sum of the partial O slots of each (major, wave, q-tile), times 2^-8 -> O [B, N, H * dh] fp32 (+ its bf16 copy / low part: the
-// operand of the output projection).  One thread per float4 of the fragment-ordered workspace.
-__global__ __launch_bounds__(256) void flash_fwd_merge_kernel(const float* __restrict__ ws, float* __restrict__ O, unsigned short* __restrict__ O16,
-                                                              unsigned short* __restrict__ O16lo, int B, int H, int N, int nt, int dh, int DT,
-                                                              int nmaj, int spw, long nvec) {
+// Sum of the partial result slots of each (major, wave, tile), times 2^-8 -> out[b, row, g, d] (element strides ob, on, oh; the
+// forward's O [B, N, H * dh], or the v slice of dqkv for the dV pass) fp32 (+ its bf16 copy / low part with the same addressing:
+// the operand of the output projection).  One thread per float4 of the fragment-ordered workspace; fixed summation order.
+__global__ __launch_bounds__(256) void flash_merge_kernel(const float* __restrict__ ws, float* __restrict__ O, long ob, long on, long oh,
+                                                          unsigned short* __restrict__ O16, unsigned short* __restrict__ O16lo,
+                                                          int B, int H, int N, int nt, int dh, int DT, int nmaj, int spw, long nvec) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= nvec) return;
     constexpr int QS = FLF_QS;
@@ -339,8 +372,7 @@ __global__ __launch_bounds__(256) void flash_fwd_merge_kernel(const float* __res
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     for (int sl = 0; sl <= last_wg - first_wg; ++sl) acc += *reinterpret_cast<const f32x4_t*>(src + sl * slot_stride);
     acc *= (1.0f / FL_PD_SCALE);
-    const long C = (long)H * dh;
-    const long oi = ((long)b * N + q) * C + (long)g * dh + d;
+    const long oi = (long)b * ob + (long)q * on + (long)g * oh + d;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (d + k >= dh) break;
@@ -356,32 +388,34 @@ __global__ __launch_bounds__(256) void flash_fwd_merge_kernel(const float* __res
 // =====================================================================================================================
 // row constants
 // =====================================================================================================================
-// mode 0: c0[b][q][g] = bl[g] * log2(e) - M[b][g][q] + log2(IL[b][g][q])      (the addend that turns Wl S into log2 P)
+// out [B][Np][H], rows q >= N zero.
+// mode 0: out[b][q][g] = bl[g] * log2(e) - M[b][g][q] + log2(IL[b][g][q])     (the addend that turns Wl S into log2 P)
 // mode 1: out[b][q][g] = in0[b][g][q]                                            (D of backward pass 1, query-major)
 __global__ __launch_bounds__(256) void flash_rows_kernel(const float* __restrict__ in0, const float* __restrict__ in1, const float* __restrict__ bl,
-                                                         float* __restrict__ out, int B, int H, int N, int mode) {
+                                                         float* __restrict__ out, int B, int H, int N, int Np, int mode) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)B * N * H) return;
-    const int g = (int)(i % H); const long bq = i / H; const int q = (int)(bq % N), b = (int)(bq / N);
+    if (i >= (long)B * Np * H) return;
+    const int g = (int)(i % H); const long bq = i / H; const int q = (int)(bq % Np), b = (int)(bq / Np);
+    if (q >= N) { out[i] = 0.f; return; }
     const long si = ((long)b * H + g) * N + q;
     out[i] = (mode == 0) ? bl[g] * FL_LOG2E - in0[si] + __builtin_amdgcn_logf(in1[si]) : in0[si];
 }
 
-template <int H, int DSTEPS, bool TAIL16>
+template <int H, int DSTEPS, bool TAIL16, bool KV>
 static int launch_flash_fwd(const FlashFwdArgs& a, int nwg, bool drop, hipStream_t st) {
     constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
-    constexpr int smem = 5 * H * REC + FLF_MAJ * H * REC;
-    if (smem > 160 * 1024) return -2;              // H * head dim too large for the resident Q tiles + two stages: use the materialising path
+    constexpr int smem = (5 + FLF_MAJ) * H * REC + (KV ? 3 * 1024 : 0);
+    if (smem > 160 * 1024) return -2;              // H * head dim too large for the resident tiles + the stage buffers: use the materialising path
     static bool attr_set[2] = {false, false};
-    const void* fn = drop ? reinterpret_cast<const void*>(&talking_flash_fwd_kernel<H, DSTEPS, TAIL16, true>)
-                          : reinterpret_cast<const void*>(&talking_flash_fwd_kernel<H, DSTEPS, TAIL16, false>);
+    const void* fn = drop ? reinterpret_cast<const void*>(&talking_flash_fwd_kernel<H, DSTEPS, TAIL16, true, KV>)
+                          : reinterpret_cast<const void*>(&talking_flash_fwd_kernel<H, DSTEPS, TAIL16, false, KV>);
     if (!attr_set[drop]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set[drop] = true;
     }
-    if (drop) hipLaunchKernelGGL((talking_flash_fwd_kernel<H, DSTEPS, TAIL16, true>), dim3(nwg), dim3(64 * FLF_NW), smem, st, a);
-    else hipLaunchKernelGGL((talking_flash_fwd_kernel<H, DSTEPS, TAIL16, false>), dim3(nwg), dim3(64 * FLF_NW), smem, st, a);
+    if (drop) hipLaunchKernelGGL((talking_flash_fwd_kernel<H, DSTEPS, TAIL16, true, KV>), dim3(nwg), dim3(64 * FLF_NW), smem, st, a);
+    else hipLaunchKernelGGL((talking_flash_fwd_kernel<H, DSTEPS, TAIL16, false, KV>), dim3(nwg), dim3(64 * FLF_NW), smem, st, a);
     SPE_CHECK_LAUNCH();
     return 0;
 }
@@ -393,51 +427,65 @@ static inline int flash_dsteps(int dh, int* tail) {
 }
 
 // C-ABI: see include/spe_hip.h
-extern "C" int spe_talking_flash_plan(int B, int N, int nwg, int pass, int* steps_per_wg, int* nwg_used, int* nmajor) {
+extern "C" int spe_talking_flash_plan(int B, int N, int nwg, int* steps_per_wg, int* nwg_used, int* nmajor, int* rows_padded) {
     const int nt = (N + 15) / 16;
-    if ((long)B * nt <= 0 || nwg <= 0) { *steps_per_wg = 0; *nwg_used = 0; *nmajor = 0; return 0; }
-    const FlashPlan p = fl_plan(B, nt, (pass == 0) ? FLF_MAJ : 4, nt, nwg);
-    *steps_per_wg = p.spw; *nwg_used = p.nwg; *nmajor = p.nmaj;
+    if ((long)B * nt <= 0 || nwg <= 0) { *steps_per_wg = 0; *nwg_used = 0; *nmajor = 0; *rows_padded = 0; return 0; }
+    const FlashPlan p = fl_plan(B, nt, FLF_MAJ, nt, nwg);
+    *steps_per_wg = p.spw; *nwg_used = p.nwg; *nmajor = p.nmaj; *rows_padded = nt * 16 + 64;
     return 0;
 }
 
-extern "C" int spe_talking_flash_rows(const float* in0, const float* in1, const float* bl, float* out, int B, int H, int N, int mode,
+extern "C" int spe_talking_flash_rows(const float* in0, const float* in1, const float* bl, float* out, int B, int H, int N, int Np, int mode,
                                       hipStream_t st) {
-    const long n = (long)B * N * H;
+    const long n = (long)B * Np * H;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(flash_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in0, in1, bl, out, B, H, N, mode);
+    if (Np < N) return -2;
+    hipLaunchKernelGGL(flash_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in0, in1, bl, out, B, H, N, Np, mode);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// forward (kv = 0): R = Qf, S1 = Kf, S2 = V16, out = O.   dV pass (kv = 1): R = Kf, S1 = Qf, S2 = dO16 (bf16), out = dv.
+static int flash_run(int kv, const void* R, const void* S1, const void* S2, const float* Wl, const float* Ww, const float* bw, const float* c0,
+                     int Np, float* ws, float* out, long ob, long on, long oh, void* O16, void* O16lo, int B, int H, int N, int dh, int nwg,
+                     float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
+    const int nt = (N + 15) / 16;
+    if ((long)B * nt <= 0) return 0;
+    if (dh < 1 || dh > 64 || nwg <= 0 || (O16lo && !O16) || Np < nt * 16 + 64) return -2;
+    int tail; const int ds = flash_dsteps(dh, &tail);
+    const FlashPlan p = fl_plan(B, nt, FLF_MAJ, nt, nwg);
+    FlashFwdArgs a;
+    a.Qf = (const unsigned char*)R; a.Kf = (const unsigned char*)S1; a.V16 = (const unsigned char*)S2;
+    a.Wl = Wl; a.Ww = Ww; a.bw = bw; a.c0 = c0; a.Np = Np; a.ws_o = ws;
+    a.B = B; a.N = N; a.nt = nt; a.nmaj = p.nmaj; a.spw = p.spw; a.total = p.total;
+    a.p_drop = p_drop; a.seed = seed; a.offset = offset;
+    const bool drop = p_drop > 0.f;
+    int rc = -2;
+#define SPE_FLASH_FWD(HH, KVV)                                                                   \
+    if (H == HH && ds == 2 && tail) rc = launch_flash_fwd<HH, 2, true, KVV>(a, p.nwg, drop, st);       \
+    else if (H == HH && ds == 2 && !tail) rc = launch_flash_fwd<HH, 2, false, KVV>(a, p.nwg, drop, st); \
+    else if (H == HH && ds == 1 && tail) rc = launch_flash_fwd<HH, 1, true, KVV>(a, p.nwg, drop, st);  \
+    else if (H == HH && ds == 1 && !tail) rc = launch_flash_fwd<HH, 1, false, KVV>(a, p.nwg, drop, st);
+    if (kv) { SPE_FLASH_FWD(8, true) else SPE_FLASH_FWD(4, true) }
+    else { SPE_FLASH_FWD(8, false) else SPE_FLASH_FWD(4, false) }
+#undef SPE_FLASH_FWD
+    if (rc != 0) return rc;
+    const int DT = (dh + 15) / 16;
+    const long nvec = (long)B * p.nmaj * FLF_MAJ * H * DT * 64;
+    hipLaunchKernelGGL(flash_merge_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, ws, out, ob, on, oh,
+                       reinterpret_cast<unsigned short*>(O16), reinterpret_cast<unsigned short*>(O16lo), B, H, N, nt, dh, DT, p.nmaj, p.spw, nvec);
     SPE_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int spe_talking_flash_fwd(const void* Qf, const void* Kf, const void* V16, const float* Wl, const float* Ww, const float* bw,
-                                     const float* c0, float* ws_o, float* O, void* O16, void* O16lo, int B, int H, int N, int dh, int nwg,
+                                     const float* c0, int Np, float* ws, float* O, void* O16, void* O16lo, int B, int H, int N, int dh, int nwg,
                                      float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
-    const int nt = (N + 15) / 16;
-    if ((long)B * nt <= 0) return 0;
-    if (dh < 1 || dh > 64 || nwg <= 0 || (O16lo && !O16)) return -2;
-    int tail; const int ds = flash_dsteps(dh, &tail);
-    const FlashPlan p = fl_plan(B, nt, FLF_MAJ, nt, nwg);
-    FlashFwdArgs a;
-    a.Qf = (const unsigned char*)Qf; a.Kf = (const unsigned char*)Kf; a.V16 = (const unsigned char*)V16;
-    a.Wl = Wl; a.Ww = Ww; a.bw = bw; a.c0 = c0; a.ws_o = ws_o;
-    a.B = B; a.N = N; a.nt = nt; a.nmaj = p.nmaj; a.spw = p.spw; a.total = p.total;
-    a.p_drop = p_drop; a.seed = seed; a.offset = offset;
-    const bool drop = p_drop > 0.f;
-    int rc = -2;
-#define SPE_FLASH_FWD(HH)                                                                  \
-    if (H == HH && ds == 2 && tail) rc = launch_flash_fwd<HH, 2, true>(a, p.nwg, drop, st);       \
-    else if (H == HH && ds == 2 && !tail) rc = launch_flash_fwd<HH, 2, false>(a, p.nwg, drop, st); \
-    else if (H == HH && ds == 1 && tail) rc = launch_flash_fwd<HH, 1, true>(a, p.nwg, drop, st);  \
-    else if (H == HH && ds == 1 && !tail) rc = launch_flash_fwd<HH, 1, false>(a, p.nwg, drop, st);
-    SPE_FLASH_FWD(8)
-    else SPE_FLASH_FWD(4)
-#undef SPE_FLASH_FWD
-    if (rc != 0) return rc;
-    const int DT = (dh + 15) / 16;
-    const long nvec = (long)B * p.nmaj * FLF_MAJ * H * DT * 64;
-    hipLaunchKernelGGL(flash_fwd_merge_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, ws_o, O,
-                       reinterpret_cast<unsigned short*>(O16), reinterpret_cast<unsigned short*>(O16lo), B, H, N, nt, dh, DT, p.nmaj, p.spw, nvec);
-    SPE_CHECK_LAUNCH();
-    return 0;
+    return flash_run(0, Qf, Kf, V16, Wl, Ww, bw, c0, Np, ws, O, (long)N * H * dh, (long)H * dh, dh, O16, O16lo, B, H, N, dh, nwg, p_drop, seed, offset, st);
+}
+
+extern "C" int spe_talking_flash_dv(const void* Qf, const void* Kf, const void* dO16, const float* Wl, const float* Ww, const float* bw,
+                                    const float* c0, int Np, float* ws, float* dv, long ob, long on, long oh, int B, int H, int N, int dh, int nwg,
+                                    float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
+    return flash_run(1, Kf, Qf, dO16, Wl, Ww, bw, c0, Np, ws, dv, ob, on, oh, nullptr, nullptr, B, H, N, dh, nwg, p_drop, seed, offset, st);
 }

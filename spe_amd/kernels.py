@@ -1094,31 +1094,33 @@ def attn_contract(T, X16, out4, trans, alpha=1.0, out16=None, out16lo=None):
 
 
 # ---- flash-style talking-heads attention (csrc/attn_flash.hip): no N x N tensor in HBM -------------------------------------
-# workgroups per pass: the forward runs 8-wave workgroups (two waves per SIMD), one per CU; the backward 4-wave workgroups
-FLASH_NWG = {0: int(os.environ.get("SPE_FLASH_NWG0", 256)), 1: int(os.environ.get("SPE_FLASH_NWG1", 256))}
+# workgroups: 8-wave workgroups (two waves per SIMD), one per CU
+FLASH_NWG = int(os.environ.get("SPE_FLASH_NWG", 256))
 FLASH_SLOTS = 8
 
 
 def flash_supported(H, dh):
-    """The flash kernels keep 8 q-tiles of Q fragments and 5 K / V tile buffers in LDS: 13 * H * ceil(dh / 16) * 512 B <= 160 KB."""
-    return H in (4, 8) and dh <= 64 and 13 * H * ((dh + 15) // 16) * 512 <= 160 * 1024 and os.environ.get("SPE_FLASH", "1") != "0"
+    """The flash kernels keep 8 resident tiles and 5 stage buffers (+ 3 KB of row constants) in LDS."""
+    return (H in (4, 8) and dh <= 64 and 13 * H * ((dh + 15) // 16) * 512 + 3072 <= 160 * 1024
+            and os.environ.get("SPE_FLASH", "1") != "0")
 
 
-def flash_plan(B, N, pass_):
-    """(steps per workgroup, workgroups, major tile groups per image) of spe_talking_flash_fwd (pass 0) / _bwd (pass 1)."""
-    spw, nwg, nmaj = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-    lib.call("spe_talking_flash_plan", B, N, FLASH_NWG[pass_], int(pass_), ctypes.byref(spw), ctypes.byref(nwg), ctypes.byref(nmaj))
-    return spw.value, nwg.value, nmaj.value
+def flash_plan(B, N):
+    """(steps per workgroup, workgroups, major tile groups per image, padded rows of the row-constant arrays)."""
+    spw, nwg, nmaj, npad = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    lib.call("spe_talking_flash_plan", B, N, FLASH_NWG, ctypes.byref(spw), ctypes.byref(nwg), ctypes.byref(nmaj), ctypes.byref(npad))
+    return spw.value, nwg.value, nmaj.value, npad.value
 
 
 def flash_rows(in0, in1, bl, B, H, N, mode):
-    """mode 0: c0 [B,N,H] = bl log2(e) - M + log2(IL) ; mode 1: the [B,H,N] rows of in0 as [B,N,H]."""
-    out = torch.empty((B, N, H), device=in0.device, dtype=torch.float32)
-    _call("spe_talking_flash_rows", _p(in0), _p(in1), _p(bl), _p(out), B, H, N, int(mode), _st())
+    """mode 0: c0 [B,Np,H] = bl log2(e) - M + log2(IL) ; mode 1: the [B,H,N] rows of in0 as [B,Np,H]; rows >= N zero."""
+    Np = flash_plan(B, N)[3]
+    out = torch.empty((B, Np, H), device=in0.device, dtype=torch.float32)
+    _call("spe_talking_flash_rows", _p(in0), _p(in1), _p(bl), _p(out), B, H, N, Np, int(mode), _st())
     return out
 
 
-_FLASH_WS = {}         # (device, floats) -> partial-result workspace shared by every flash launch of the stream (24 blocks reuse one)
+_FLASH_WS = {}         # device -> partial-result workspace shared by every flash launch of the stream (all blocks reuse one)
 
 
 def _flash_ws(device, floats):
@@ -1132,15 +1134,26 @@ def _flash_ws(device, floats):
 def talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, offset, want16=False, want16lo=False):
     """-> O [B,N,H*dh] fp32 (+ bf16 copy, + its low part)."""
     dev = Qf.device
-    _, _, nmaj = flash_plan(B, N, 0)
+    nmaj = flash_plan(B, N)[2]
     ws = _flash_ws(dev, B * nmaj * FLASH_SLOTS * 128 * H * 16 * ((dh + 15) // 16))
     C = H * dh
     O = torch.empty((B, N, C), device=dev, dtype=torch.float32)
     O16 = torch.empty((B * N, C), device=dev, dtype=torch.bfloat16) if want16 else None
     O16lo = torch.empty((B * N, C), device=dev, dtype=torch.bfloat16) if (want16 and want16lo) else None
-    _call("spe_talking_flash_fwd", _p(Qf), _p(Kf), _p(V16), _p(Wl), _p(Ww), _p(bw), _p(c0), _p(ws), _p(O), _p(O16), _p(O16lo),
-          B, H, N, dh, FLASH_NWG[0], float(p_drop), seed, offset, _st())
+    _call("spe_talking_flash_fwd", _p(Qf), _p(Kf), _p(V16), _p(Wl), _p(Ww), _p(bw), _p(c0), c0.shape[1], _p(ws), _p(O), _p(O16), _p(O16lo),
+          B, H, N, dh, FLASH_NWG, float(p_drop), seed, offset, _st())
     return O, O16, O16lo
+
+
+def talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, c0, dv4, p_drop, seed, offset):
+    """dv4 [B,N,H,dh] (fp32 view, unit last stride) = P'd^T dO with P'd recomputed from the forward's fragments and statistics."""
+    B, N, H, dh = dv4.shape
+    assert dv4.stride(3) == 1
+    nmaj = flash_plan(B, N)[2]
+    ws = _flash_ws(dv4.device, B * nmaj * FLASH_SLOTS * 128 * H * 16 * ((dh + 15) // 16))
+    _call("spe_talking_flash_dv", _p(Qf), _p(Kf), _p(dO16), _p(Wl), _p(Ww), _p(bw), _p(c0), c0.shape[1], _p(ws), _p(dv4),
+          dv4.stride(0), dv4.stride(1), dv4.stride(2), B, H, N, dh, FLASH_NWG, float(p_drop), seed, offset, _st())
+    return dv4
 
 
 def attn_merge(ws_stats, B, H, N, spw, mode):

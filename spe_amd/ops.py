@@ -376,23 +376,23 @@ class _TalkingHeadsAttentionFused(Function):
         K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws_stats, None, None, B, H, N, dh, 0.0, 0, 0)
         M, IL = K.attn_merge(ws_stats, B, H, N, spw0, 0)
         want16 = K.produces16(B * N, C)
-        if not train and K.flash_supported(H, dh):
-            # no backward will follow: P' goes from the head mix straight into the P' V products (csrc/attn_flash.hip) - the 554 MB
-            # (cfg2) P'd tensor of the write pass is neither stored nor streamed back
+        flash = K.flash_supported(H, dh)
+        if flash:
+            # P' goes from the head mix straight into the P' V products (csrc/attn_flash.hip): the 554 MB (cfg2) P'd tensor of the
+            # write pass is neither stored, streamed back nor saved - the backward recomputes it inside its dV pass
             c0 = K.flash_rows(M, IL, bl, B, H, N, 0)
             O, O16, O16lo = K.talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, off, want16, K.split_fwd())
-            if O16 is not None:
-                K.attach16(O, O16, O16lo)
-            return O
-        Pd = K.score_blocks(B, H, N, qkv.device, torch.float16)          # fp16(P'd * PD_SCALE)
-        K.talking_fused(1, Qf, Kf, None, None, Wl, bl, Ww, bw, M, IL, None, None, None, Pd, B, H, N, dh, p_drop, seed, off)
-        O = torch.empty((B, N, C), device=qkv.device, dtype=torch.float32)
-        O16 = torch.empty((B * N, C), device=qkv.device, dtype=torch.bfloat16) if want16 else None
-        O16lo = torch.empty((B * N, C), device=qkv.device, dtype=torch.bfloat16) if (O16 is not None and K.split_fwd()) else None
-        K.attn_contract(Pd, V16, O.view(B, N, H, dh), False, alpha=1.0 / K.PD_SCALE, out16=O16, out16lo=O16lo)
+            Pd = c0                                                        # what the backward needs instead of P'd
+        else:
+            Pd = K.score_blocks(B, H, N, qkv.device, torch.float16)          # fp16(P'd * PD_SCALE)
+            K.talking_fused(1, Qf, Kf, None, None, Wl, bl, Ww, bw, M, IL, None, None, None, Pd, B, H, N, dh, p_drop, seed, off)
+            O = torch.empty((B, N, C), device=qkv.device, dtype=torch.float32)
+            O16 = torch.empty((B * N, C), device=qkv.device, dtype=torch.bfloat16) if want16 else None
+            O16lo = torch.empty((B * N, C), device=qkv.device, dtype=torch.bfloat16) if (O16 is not None and K.split_fwd()) else None
+            K.attn_contract(Pd, V16, O.view(B, N, H, dh), False, alpha=1.0 / K.PD_SCALE, out16=O16, out16lo=O16lo)
         if O16 is not None:
             K.attach16(O, O16, O16lo)        # the output projection's operand, written by the contraction's epilogue
-        ctx.meta = (B, N, C, H, dh, nt, scale, p_drop, seed, off)
+        ctx.meta = (B, N, C, H, dh, nt, scale, p_drop, seed, off, flash)
         ctx.wparams = (Wl, bl, Ww, bw)      # leaves: looked up in backward for their gradient buckets
         if train:
             ctx.save_for_backward(packed[3], packed[4], packed[5], Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw)
@@ -402,7 +402,7 @@ class _TalkingHeadsAttentionFused(Function):
     @K.backward_scope
     def backward(ctx, dO):
         Vf, K16, Q16, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw = ctx.saved_tensors
-        B, N, C, H, dh, nt, scale, p_drop, seed, off = ctx.meta
+        B, N, C, H, dh, nt, scale, p_drop, seed, off, flash = ctx.meta
         spw, nwg = K.fused_plan(B, N, 2)
         dO = dO.contiguous()
         dqkv = torch.empty((B, N, 3 * C), device=dO.device, dtype=torch.float32)
@@ -419,7 +419,10 @@ class _TalkingHeadsAttentionFused(Function):
         K.talking_fused(3, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, None, ws_w, dS, B, H, N, dh, p_drop, seed, off)
         # dV[key,d] = sum_q P'd[q,key] dO[q,d] - issued here, between backward pass 2 and the contractions that re-read
         # its 554 MB of dS: a streaming read right after a pass that wrote that much runs ~20 % slower (measured)
-        K.attn_contract(Pd, dO16, dv, True, alpha=1.0 / K.PD_SCALE)
+        if flash:       # Pd holds the row constants c0: P'd is recomputed tile by tile inside the dV pass
+            K.talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, Pd, dv, p_drop, seed, off)
+        else:
+            K.attn_contract(Pd, dO16, dv, True, alpha=1.0 / K.PD_SCALE)
         dWl, dbl, dWw, dbw = K.talking_wgrad_reduce(ws_w, H, ctx.wparams)
         # dQ[q,d] = scale * sum_key dS[q,key] K[key,d] ; dK[key,d] = scale * sum_q dS[q,key] Q[q,d]
         K.attn_contract(dS, K16, dq, False, alpha=scale)

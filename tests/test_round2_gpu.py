@@ -880,3 +880,12 @@ def test_flash_forward_equals_materialising_path(dev, B, H, N, dh, p):
     assert torch.equal(O, O2)                                       # fixed summation order: bitwise reproducible
     assert rel(O, Oref) < 2e-5, rel(O, Oref)
     assert float((O16.float().view_as(O) + O16lo.float().view_as(O) - O).abs().max()) <= 2e-5 * float(O.abs().max())
+    # the dV pass of the backward (spe_talking_flash_dv: P'd recomputed, key tiles resident) against the streaming contraction of the
+    # STORED P'd it replaces: same fp16 P'd products, bf16 rounding of P'd in both (fp16 -> bf16 there, fp32 -> bf16 here)
+    dO = torch.randn(B, N, C, generator=g).to(dev)
+    dO16 = K.attn_pack_multi([(dO.view(B, N, H, dh), 1.0, 16)])[0]
+    dref = torch.zeros(B, N, 3 * C, device=dev); dnew = torch.zeros(B, N, 3 * C, device=dev)
+    K.attn_contract(Pd, dO16, dref.view(B, N, 3, H, dh)[:, :, 2], True, alpha=1.0 / K.PD_SCALE)
+    K.talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, c0, dnew.view(B, N, 3, H, dh)[:, :, 2], p, 11, 5)
+    assert torch.isfinite(dnew).all() and float(dnew[..., :2 * C].abs().max()) == 0.0
+    assert rel(dnew, dref) < 3e-3, rel(dnew, dref)            # two independent bf16 roundings of P'd (2^-9 each, averaged over N terms)

@@ -43,7 +43,15 @@ def case(B, H, N, dh, p_drop=0.0, time=False):
     K.attn_contract(Pd, V16, Oref.view(B, N, H, dh), False, alpha=1.0 / K.PD_SCALE)
     c0 = K.flash_rows(M, IL, bl, B, H, N, 0)
     O, O16, O16lo = K.talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, off, True, True)
+    # dV = P'd^T dO: streaming contraction of the stored P'd against the flash dV pass
+    dO = torch.randn(B, N, C, generator=g).to(dev)
+    dO16 = K.attn_pack_multi([(dO.view(B, N, H, dh), 1.0, 16)])[0]
+    dref = torch.zeros(B, N, 3 * C, device=dev); dnew = torch.zeros(B, N, 3 * C, device=dev)
+    K.attn_contract(Pd, dO16, dref.view(B, N, 3, H, dh)[:, :, 2], True, alpha=1.0 / K.PD_SCALE)
+    K.talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, c0, dnew.view(B, N, 3, H, dh)[:, :, 2], p_drop, seed, off)
     torch.cuda.synchronize()
+    errv = (dnew - dref).norm() / dref.norm()
+    print(f"      dV rel {errv.item():.3e} max {float((dnew - dref).abs().max()):.3e} (|dV| max {float(dref.abs().max()):.2f})")
     err = (O - Oref).norm() / Oref.norm()
     e16 = (O16.float().view_as(O) + O16lo.float().view_as(O) - O).abs().max() / O.abs().max()
     print(f"B={B} H={H} N={N} dh={dh} p={p_drop}: O rel {err.item():.3e} max {float((O - Oref).abs().max()):.3e}  hi+lo residual {e16.item():.2e}"
@@ -53,8 +61,11 @@ def case(B, H, N, dh, p_drop=0.0, time=False):
                                 K.attn_contract(Pd, V16, Oref.view(B, N, H, dh), False, alpha=1.0 / K.PD_SCALE)))
         t_new = timeit(lambda: K.talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, off, True, True))
         t_rows = timeit(lambda: K.flash_rows(M, IL, bl, B, H, N, 0))
+        t_dvo = timeit(lambda: K.attn_contract(Pd, dO16, dref.view(B, N, 3, H, dh)[:, :, 2], True, alpha=1.0 / K.PD_SCALE))
+        t_dvn = timeit(lambda: K.talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, c0, dnew.view(B, N, 3, H, dh)[:, :, 2], p_drop, seed, off))
+        print(f"   dV contraction {t_dvo:.3f} ms ; flash dV (+ merge) {t_dvn:.3f} ms")
         print(f"   write pass + PV contraction {t_old:.3f} ms ; flash forward (+ merge) {t_new:.3f} ms ; row constants {t_rows:.3f} ms")
-    return err.item()
+    return max(err.item(), errv.item() / 100)
 
 
 if __name__ == "__main__":
