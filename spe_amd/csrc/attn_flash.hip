@@ -58,6 +58,12 @@ struct FlashFwdArgs {
 #define FLF_SCHED 1
 #endif
 #define FLF_MAJ 8                        // q-tiles per workgroup
+#ifndef FLF_MIXH
+#define FLF_MIXH 1
+#endif
+#ifndef FLF_TAILMIX
+#define FLF_TAILMIX 0
+#endif
 #ifndef FLF_HB
 #define FLF_HB 4                         // heads per operand-fragment batch of the K Q^T products
 #endif
@@ -69,6 +75,9 @@ struct FlashFwdArgs {
 #undef FLF_DBG_NOPV
 #undef FLF_DBG_NODMA
 #undef FLF_DBG_NOBAR
+#undef FLF_DBG_Q1
+#undef FLF_DBG_K1
+#undef FLF_DBG_NOTAIL
 #endif
 #define FLF_QS (FLF_MAJ / FLF_NW)
 
@@ -199,11 +208,22 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
             // ---- H1: S^T = K Q^T (M = keys, N = queries): lane = (query l & 15, keys 4 (l >> 4) + r) ; P * 2^8 = exp2(Wl S + c0 + 8)
 #pragma unroll
             for (int u = 0; u < QS; ++u) {
-                f32x4_t acc[H];
-#ifndef FLF_DBG_NOS
-                // operand fragments of FLF_HB heads are requested together (one LDS round trip per batch, not per head); the 16-wide tail
-                // step runs as a 16x16x16 instruction on its 8-B operands into its OWN accumulator (no zero-extended copies, and an
-                // accumulate chain never mixes two MFMA shapes - see attn_fused.hip), added on the vector pipe
+#if FLF_MIXH
+                // head-outer order: as soon as the raw scores of head h exist, its 4 x H / 4 contributions to the fp32 Wl mix are issued -
+                // 8 independent 4x4x1 instructions per head that fill the matrix pipe while the next head's K Q^T products wait for
+                // their LDS operands; the mix accumulators (32 registers) replace the 32 registers of raw scores, which now live for
+                // one head only.  (The key-outer order below ends the K Q^T phase in a dependency wall: every mix chain needs all heads.)
+                f32x4_t sp[4][H / 4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int gh = 0; gh < H / 4; ++gh) {
+                        if constexpr (KV) {     // the streamed row 4 (l >> 4) + r: broadcast LDS read
+                            sp[r][gh] = *reinterpret_cast<const f32x4_t*>(smem + (5 + FLF_MAJ) * TILEB + (i % 3) * 1024 + ((4 * (lane >> 4) + r) * H + 4 * gh) * 4);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) sp[r][gh][k] += 8.0f;
+                        } else sp[r][gh] = c0v[u][gh];
+                    }
 #pragma unroll
                 for (int h0 = 0; h0 < H; h0 += FLF_HB) {
                     flu32x4_t kf[FLF_HB][FULL ? FULL : 1], qf[FLF_HB][FULL ? FULL : 1];
@@ -228,6 +248,70 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
 #pragma unroll
                         for (int st = 0; st < FULL; ++st) c = fl_mfma32<true>(kf[hb][st], qf[hb][st], c);
                         if constexpr (TAIL16) {
+                            // the 16-wide tail step as a 16x16x16 instruction into its OWN accumulator (an accumulate chain never mixes two MFMA
+                            // shapes - attn_fused.hip); the mix is linear, so the two parts go into it one after the other: no vector add
+                            const f32x4_t t = fl_mfma16<true>(kt16[hb], qt16[hb], (f32x4_t){0.f, 0.f, 0.f, 0.f});
+                            if constexpr (FULL > 0 && FLF_TAILMIX) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                    for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = __builtin_amdgcn_mfma_f32_4x4x1f32(Al4[gh][h0 + hb], t[r], sp[r][gh], 0, 0, 0);
+                            } else c = (FULL > 0) ? c + t : t;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = __builtin_amdgcn_mfma_f32_4x4x1f32(Al4[gh][h0 + hb], c[r], sp[r][gh], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int hh = 0; hh < H / 4; ++hh)          // P * 2^8 <= 256: no saturation needed
+                        bv[u][r][hh] = fl_pack4_f16(fl_exp2(sp[r][hh][0]), fl_exp2(sp[r][hh][1]), fl_exp2(sp[r][hh][2]), fl_exp2(sp[r][hh][3]));
+#else
+                f32x4_t acc[H];
+#ifndef FLF_DBG_NOS
+                // operand fragments of FLF_HB heads are requested together (one LDS round trip per batch, not per head); the 16-wide tail
+                // step runs as a 16x16x16 instruction on its 8-B operands into its OWN accumulator (no zero-extended copies, and an
+                // accumulate chain never mixes two MFMA shapes - see attn_fused.hip), added on the vector pipe
+#pragma unroll
+                for (int h0 = 0; h0 < H; h0 += FLF_HB) {
+                    flu32x4_t kf[FLF_HB][FULL ? FULL : 1], qf[FLF_HB][FULL ? FULL : 1];
+                    fls16x4_t kt16[FLF_HB], qt16[FLF_HB];
+#pragma unroll
+                    for (int hb = 0; hb < FLF_HB; ++hb) {
+#ifdef FLF_DBG_K1
+                        const unsigned char* kr = sK;
+#else
+                        const unsigned char* kr = sK + (h0 + hb) * REC;
+#endif
+#ifdef FLF_DBG_Q1
+                        const unsigned char* qr = sQ;
+#else
+                        const unsigned char* qr = sQ + (u * H + h0 + hb) * REC;
+#endif
+#pragma unroll
+                        for (int st = 0; st < FULL; ++st) {
+                            kf[hb][st] = *reinterpret_cast<const flu32x4_t*>(kr + st * 1024 + lane * 16);
+                            qf[hb][st] = *reinterpret_cast<const flu32x4_t*>(qr + st * 1024 + lane * 16);
+                        }
+                        if constexpr (TAIL16) {
+                            kt16[hb] = *reinterpret_cast<const fls16x4_t*>(kr + FULL * 1024 + lane * 8);
+                            qt16[hb] = *reinterpret_cast<const fls16x4_t*>(qr + FULL * 1024 + lane * 8);
+                        }
+                    }
+#pragma unroll
+                    for (int hb = 0; hb < FLF_HB; ++hb) {
+                        f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int st = 0; st < FULL; ++st) c = fl_mfma32<true>(kf[hb][st], qf[hb][st], c);
+#ifndef FLF_DBG_NOTAIL
+                        if constexpr (TAIL16)
+#else
+                        if constexpr (false)
+#endif
+                        {
                             const f32x4_t t = fl_mfma16<true>(kt16[hb], qt16[hb], (f32x4_t){0.f, 0.f, 0.f, 0.f});
                             c = (FULL > 0) ? c + t : t;
                         }
@@ -266,6 +350,7 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
                         bv[u][r][hh] = fl_pack4_f16(sp[hh][0], sp[hh][1], sp[hh][2], sp[hh][3]);
 #endif
                 }
+#endif
                 if (FLF_SCHED) __builtin_amdgcn_sched_barrier(0);
             }
             if (grp != 0) step_barrier(i + 1);
@@ -301,13 +386,28 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
                                 pr[r][g0 >> 2][g0 & 3] *= (fl_lot(o, 0, r) >= thr) ? inv : 0.f;
                                 pr[r][g1 >> 2][g1 & 3] *= (fl_lot(o, 1, r) >= thr) ? inv : 0.f;
                             }
-                        } else {                    // lane = (key, 4 consecutive queries): the counter of each query, lot key & 3
+                        } else {
+                            // lane = (key, 4 consecutive queries 4 (l >> 4) + r): element (q, key) uses lot (key & 3) of the counter of
+                            // (q, key >> 2).  The 4 lanes of a quad hold the 4 keys of one key group, so lane (l & 3) = t evaluates the
+                            // counter of query 4 (l >> 4) + t ONCE, keeps its own key's two lots, and the quad exchanges them
+                            // (quad-permute DPP): one Philox call per lane and head pair, as in the forward
+                            uint32_t o[4];
+                            fl_keep_lots<H>(a.seed, a.offset, b, hp, (kt0 + i) * 16 + 4 * (lane >> 4) + (lane & 3), qrow[u] & ~3, N, o);
+                            // lots of query t for the 4 keys of the group, both heads: word w[k] = lot(head 0, k) | lot(head 1, k) << 16
+                            uint32_t w[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) w[k] = fl_lot(o, 0, k) | (fl_lot(o, 1, k) << 16);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                uint32_t o[4];
-                                fl_keep_lots<H>(a.seed, a.offset, b, hp, (kt0 + i) * 16 + 4 * (lane >> 4) + r, qrow[u], N, o);
-                                pr[r][g0 >> 2][g0 & 3] *= (fl_lot(o, 0, qrow[u] & 3) >= thr) ? inv : 0.f;
-                                pr[r][g1 >> 2][g1 & 3] *= (fl_lot(o, 1, qrow[u] & 3) >= thr) ? inv : 0.f;
+                                // from lane t = r of the quad: its w[my key & 3]
+                                uint32_t got = 0;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const uint32_t x = fl_quad_bcast(w[k], r);
+                                    got = ((lane & 3) == k) ? x : got;
+                                }
+                                pr[r][g0 >> 2][g0 & 3] *= ((got & 0xffffu) >= thr) ? inv : 0.f;
+                                pr[r][g1 >> 2][g1 & 3] *= ((got >> 16) >= thr) ? inv : 0.f;
                             }
                         }
                     }

@@ -173,3 +173,13 @@ __device__ __forceinline__ uint32_t fl_lot(const uint32_t (&o)[4], int head, int
     const uint32_t w = o[2 * head + (i >> 1)];
     return (i & 1) ? (w >> 16) : (w & 0xffffu);
 }
+
+// value of lane (l & ~3) + t of every quad (quad-permute DPP, t = 0..3)
+__device__ __forceinline__ uint32_t fl_quad_bcast(uint32_t v, int t) {
+    switch (t) {
+        case 0: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xf, 0xf, false);
+        case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x55, 0xf, 0xf, false);
+        case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xaa, 0xf, 0xf, false);
+        default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xff, 0xf, 0xf, false);
+    }
+}
