@@ -52,6 +52,8 @@ class RcclComm:
     """The process' communicator.  rank / world default to RANK / WORLD_SIZE; the unique id travels through `store`
     (a torch.distributed.Store; default: TCPStore on MASTER_ADDR:MASTER_PORT, rank 0 hosts it)."""
 
+    _generation = 0        # communicators created by this process so far (every rank creates them in the same order)
+
     def __init__(self, rank=None, world=None, store=None, device=None, port=None, timeout_s=300):
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
@@ -70,11 +72,15 @@ class RcclComm:
                     port = int(port or os.environ.get("SPE_COMM_PORT") or int(os.environ.get("MASTER_PORT", "29533")) + 1)
                     store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, self.world, self.rank == 0,
                                           timeout=datetime.timedelta(seconds=timeout_s))
+            # every communicator of the job gets its own key: the n-th RcclComm a process creates meets the n-th of every other rank
+            # (a re-created reducer, several groups) - a fixed key would hand a later communicator the stale id of an earlier one
+            RcclComm._generation += 1
+            key = "spe_comm_id/%d" % RcclComm._generation
             if self.rank == 0:
                 _call("spe_comm_unique_id", buf)
-                store.set("spe_comm_id", buf.raw)
+                store.set(key, buf.raw)
             else:
-                buf = ctypes.create_string_buffer(store.get("spe_comm_id"), ID_BYTES)
+                buf = ctypes.create_string_buffer(store.get(key), ID_BYTES)
         else:
             _call("spe_comm_unique_id", buf)
         _call("spe_comm_init", self.rank, self.world, buf)

@@ -28,13 +28,15 @@ typedef __bf16 flbf16x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float fl_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// saturating fp16 conversion; a NaN stays a NaN (a diverged run must stay visible)
+__device__ __forceinline__ _Float16 fl_f2h_sat(float f) { return (_Float16)((f != f) ? f : __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f)); }
+
 // 4 floats -> one 8-B MFMA operand: saturating fp16 (forward quantities, O(1)) or bf16 (anything that carries a gradient)
 template <bool F16>
 __device__ __forceinline__ fls16x4_t fl_pack4(float a, float b, float c, float d) {
     if constexpr (F16) {
         flf16x4_t v;
-        v[0] = (_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f); v[1] = (_Float16)__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
-        v[2] = (_Float16)__builtin_amdgcn_fmed3f(c, -65504.f, 65504.f); v[3] = (_Float16)__builtin_amdgcn_fmed3f(d, -65504.f, 65504.f);
+        v[0] = fl_f2h_sat(a); v[1] = fl_f2h_sat(b); v[2] = fl_f2h_sat(c); v[3] = fl_f2h_sat(d);
         return __builtin_bit_cast(fls16x4_t, v);
     } else {
         flbf16x4_t v; v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;

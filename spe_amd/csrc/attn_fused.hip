@@ -147,7 +147,7 @@ __device__ __forceinline__ void mix_rows(const f32x4_t (&s)[H], const float (&w)
 typedef short s16x4m_t __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4m_t __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8m_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ _Float16 f2h_sat(float f) { return (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f); }
+__device__ __forceinline__ _Float16 f2h_sat(float f) { return (_Float16)((f != f) ? f : __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f)); }      // NaN stays NaN
 // 4 floats -> one 8-B MFMA operand (F16: saturating fp16, else bf16), both round to nearest even
 template <bool F16>
 __device__ __forceinline__ s16x4m_t pack4(float a, float b, float c, float d) {

@@ -10,7 +10,8 @@
 #include "common.h"
 
 __device__ __forceinline__ unsigned short spe_f2h_sat(float f) {
-    const _Float16 h = (_Float16)fminf(fmaxf(f, -65504.f), 65504.f);      // v_cvt_f16_f32: round to nearest even
+    // v_med3_f32 keeps a NaN (fminf / fmaxf would turn it into +-65504 and hide a diverged run); v_cvt_f16_f32: round to nearest even
+    const _Float16 h = (_Float16)((f != f) ? f : __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f));
     return __builtin_bit_cast(unsigned short, h);
 }
 // 4 floats -> 4 x 16 bit (bf16 RNE or saturating fp16 RNE) as one 8-B unit

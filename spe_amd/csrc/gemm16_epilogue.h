@@ -38,8 +38,9 @@ struct Gemm16Args {
 typedef _Float16 ep_h4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 ep_f2h4(float a, float b, float c, float d) {
     ep_h4_t h;
-    h[0] = (_Float16)fminf(fmaxf(a, -65504.f), 65504.f); h[1] = (_Float16)fminf(fmaxf(b, -65504.f), 65504.f);
-    h[2] = (_Float16)fminf(fmaxf(c, -65504.f), 65504.f); h[3] = (_Float16)fminf(fmaxf(d, -65504.f), 65504.f);
+    // saturating, but a NaN stays a NaN (fminf / fmaxf would turn it into +-65504 and hide a diverged run)
+    h[0] = (_Float16)((a != a) ? a : __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f)); h[1] = (_Float16)((b != b) ? b : __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f));
+    h[2] = (_Float16)((c != c) ? c : __builtin_amdgcn_fmed3f(c, -65504.f, 65504.f)); h[3] = (_Float16)((d != d) ? d : __builtin_amdgcn_fmed3f(d, -65504.f, 65504.f));
     return __builtin_bit_cast(uint2, h);
 }
 __device__ __forceinline__ float4 ep_h2f4(uint2 u) {

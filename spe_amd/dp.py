@@ -58,8 +58,10 @@ class GradAllReducer:
         if cu_reserve is None:
             cu_reserve = int(os.environ.get("NCCL_MAX_NCHANNELS", "32")) if self.world > 1 else 0
         self.cu_reserve = cu_reserve
+        self._cu_reserve_prev = None
         if self.params and self.params[0].is_cuda:
             from . import kernels as _K
+            self._cu_reserve_prev = _K.get_cu_reserve()        # restored by remove(): the grids are global to the process
             _K.set_cu_reserve(cu_reserve)
         self.average = average
         # set by FlatAdamW (and only by it): the 1/world is folded into its update launch (no div_ per bucket); p.grad / the
@@ -131,7 +133,7 @@ class GradAllReducer:
     # Gradients of parameters with more than ZERO_MAX elements are always OVERWRITTEN by their producer (GEMM stores, split-K slab
     # sums with accumulate = 0, or the copy in _on_grad); only the small ones (biases, LayerNorm / LayerScale vectors, head mixers:
     # their kernels add partial sums atomically into a zeroed view) and the statically unused ones need zeros.
-    ZERO_MAX = 16384
+    ZERO_MAX = 16384         # == spe_amd.kernels.ACC_ZERO_MAX (kernels._zeros_or zeroes larger accumulate-into views itself)
 
     def reset(self):
         """Call before every backward (after the optimizer consumed the gradients): re-arm the buckets and detach the .grad
@@ -251,3 +253,7 @@ class GradAllReducer:
     def remove(self):
         for h in self._hooks:
             h.remove()
+        if self._cu_reserve_prev is not None:
+            from . import kernels as _K
+            _K.set_cu_reserve(self._cu_reserve_prev)
+            self._cu_reserve_prev = None

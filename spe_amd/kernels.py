@@ -17,32 +17,51 @@ from . import lib
 #   2 "bf16s"  FORWARD products on split operands (what north_star's 1e-3 on logits / losses needs), BACKWARD products on
 #              single bf16 operands (gradients carry bf16 rounding like any mixed-precision trainer) - the benchmark mode
 _PRECISION = 2       # default: the benchmark mode
-_IN_BWD = False      # set by @backward_scope around every autograd backward of spe_amd.ops
+import functools as _functools
+import threading as _threading
+
+_TLS = _threading.local()      # .in_bwd: set by @backward_scope around every autograd backward of spe_amd.ops - per THREAD (autograd
+#                                runs backward on its own worker threads)
+
+
+def _in_bwd():
+    return getattr(_TLS, "in_bwd", False)
 
 
 def backward_scope(fn):
     """Decorator of the `backward` staticmethods: products issued inside run at the mode's BACKWARD operand precision."""
-    import functools
-
-    @functools.wraps(fn)
+    @_functools.wraps(fn)
     def wrapped(ctx, *grads):
-        global _IN_BWD
-        prev, _IN_BWD = _IN_BWD, True
+        prev, _TLS.in_bwd = _in_bwd(), True
         try:
             return fn(ctx, *grads)
         finally:
-            _IN_BWD = prev
+            _TLS.in_bwd = prev
+    return wrapped
+
+
+def forward_scope(fn):
+    """Decorator of the `forward` staticmethods: a forward entered from INSIDE a backward (torch.utils.checkpoint recomputes the
+    block in the saved-tensor unpack hook of the wrapped backward) runs at the mode's FORWARD operand precision, so the recomputed
+    activations equal the original ones."""
+    @_functools.wraps(fn)
+    def wrapped(ctx, *args):
+        prev, _TLS.in_bwd = _in_bwd(), False
+        try:
+            return fn(ctx, *args)
+        finally:
+            _TLS.in_bwd = prev
     return wrapped
 
 
 def split_now():
     """True when the product about to be issued takes split (hi + lo) bf16 operands."""
-    return _PRECISION == 1 or (_PRECISION == 2 and not _IN_BWD)
+    return _PRECISION == 1 or (_PRECISION == 2 and not _in_bwd())
 
 
 def split_fwd():
     """bf16s forward: the bf16-copy GEMMs run on (hi, lo) operand pairs and every producer of such an operand also writes lo."""
-    return _PRECISION == 2 and not _IN_BWD
+    return _PRECISION == 2 and not _in_bwd()
 # Philox stream for dropout: (seed, running offset).  Each dropout site draws a fresh offset.
 # seed None = not set by the caller: derived on first use from torch's seed (the reference's main.py:161-164 seeds torch
 # with args.seed + rank and nothing else, so its dropout masks differ per rank and per run; ours then do too).
@@ -98,6 +117,9 @@ _RWS = None
 _RWS_BYTES = 16 << 20
 
 
+_RWS_STREAM = None     # raw handle of the stream the last launch went to: the ticket / slab workspace is only safe for stream-ordered launches
+
+
 def _register_reduce_ws():
     global _RWS
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -105,9 +127,28 @@ def _register_reduce_ws():
     lib.call("spe_set_reduce_workspace", _RWS.data_ptr(), _RWS_BYTES, _st())
 
 
-def _call(name, *args):
+def _guard_reduce_ws():
+    """The deterministic reductions (csrc/det_reduce.h) share ONE ticket / slab workspace per process: launches must come from the
+    device it lives on (one process per GPU) and be stream-ordered.  A launch from another stream first waits for everything the
+    previous stream was given (an event edge, once per switch); another device is an error."""
+    global _RWS_STREAM
     if _RWS is None:
         _register_reduce_ws()
+    cur = torch.cuda.current_device()
+    if cur != _RWS.device.index:
+        raise lib.SpeLibraryError(f"spe_amd kernels were first used on cuda:{_RWS.device.index} and are now launched on cuda:{cur}: "
+                                  "the reduction workspace is per process (one process per GPU)")
+    st = _st()
+    if st != _RWS_STREAM:
+        if _RWS_STREAM is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.ExternalStream(_RWS_STREAM, device=_RWS.device) if _RWS_STREAM else torch.cuda.default_stream(_RWS.device))
+            torch.cuda.current_stream().wait_event(ev)
+        _RWS_STREAM = st
+
+
+def _call(name, *args):
+    _guard_reduce_ws()
     if not _TIMED:
         return lib.call(name, *args)
     ev = _TIMED.get(name)
@@ -159,8 +200,20 @@ def grad_buffer(param):
     return buf.view_as(buf)            # fresh alias: AccumulateGrad only steals a tensor nobody else references
 
 
+ACC_ZERO_MAX = 16384       # == spe_amd.dp.GradAllReducer.ZERO_MAX: bucket views up to this size are zeroed by reducer.reset() every step
+
+
 def _zeros_or(buf, n, device):
-    return buf.view(-1) if buf is not None else zeros_small(n, device)
+    """Destination of an ACCUMULATE-INTO gradient (bias / LayerNorm / LayerScale column sums: their kernels add partial sums onto
+    what is there): the parameter's bucket view, or a zeroed temporary.  The reducer pre-zeroes only views of <= ACC_ZERO_MAX
+    elements from the second step on (larger gradients are overwritten by their producers), so a larger accumulate-into view - a
+    bias of a wide class / vocabulary head - is zeroed here, at hand-out time."""
+    if buf is None:
+        return zeros_small(n, device)
+    v = buf.view(-1)
+    if v.numel() > ACC_ZERO_MAX:
+        v.zero_()
+    return v
 
 
 def _p(t):
@@ -935,8 +988,17 @@ def set_cu_reserve(n):
     a 512-workgroup launch would need a second, nearly empty round (measured with tools/dp_proxy.py: +8 % per step for ANY
     number of foreign workgroups from 8 to 64).  With the grids cut to 512 - n the launches stay single-round.
     spe_amd.dp.GradAllReducer calls this with its channel budget when world > 1; 0 restores the solo grids."""
+    global _CU_RESERVE
+    _CU_RESERVE = int(n)
     for m in FUSED_NWG:
         FUSED_NWG[m] = max(8, (_FUSED_NWG_SOLO[m] - int(n)) & ~7) if n > 0 else _FUSED_NWG_SOLO[m]
+
+
+_CU_RESERVE = 0
+
+
+def get_cu_reserve():
+    return _CU_RESERVE
 
 
 def fused_supported(H, dh):

@@ -18,6 +18,7 @@ class _Linear(Function):
     cait.py:376,390, timm Mlp."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, x, W, b, act):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
@@ -62,6 +63,7 @@ class _MultiLinear(Function):
     blocks of the stacked bf16 dy, the bias gradients ride on the n conversion passes."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, x, *wb):
         n = len(wb) // 2
         Ws, bs = wb[:n], wb[n:]
@@ -128,6 +130,7 @@ def multi_linear(x, Ws, bs):
 # ---------------------------------------------------------------------------------------------
 class _LayerNorm(Function):
     @staticmethod
+    @K.forward_scope
     def forward(ctx, x, g, b, eps):
         x2 = x.reshape(-1, x.shape[-1])
         if not x2.is_contiguous():
@@ -158,6 +161,7 @@ class _ResDropLayerNorm(Function):
     models/transformer.py:279-287, 384-386, 420-421, 426-427) as one kernel each way instead of dropout, add and LayerNorm."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, x, z, g, b, eps, p):
         x2 = x.reshape(-1, x.shape[-1])
         z2 = z.reshape(-1, z.shape[-1])
@@ -192,6 +196,7 @@ class _LayerNormSkip(Function):
     skip path - meet in THIS node and are summed inside the LayerNorm backward kernel instead of by an extra autograd add."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, x, g, b, eps):
         x2 = x.reshape(-1, x.shape[-1])
         if not x2.is_contiguous():
@@ -236,6 +241,7 @@ class _LayerScaleResidual(Function):
     """out = x + s_b * gamma * y   (cait.py:413-416; s_b = DropPath keep-scale per sample)."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, x, y, gamma, sample_scale):
         B = x.shape[0]
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
@@ -271,6 +277,7 @@ def drop_path_scale(B, p, training, device):
 # ---------------------------------------------------------------------------------------------
 class _Dropout(Function):
     @staticmethod
+    @K.forward_scope
     def forward(ctx, x, p):
         seed, off = K.next_rng()
         ctx.p, ctx.seed, ctx.off = p, seed, off
@@ -295,6 +302,7 @@ class _TalkingHeadsAttention(Function):
     dropout row kernel -> PV GEMM; the saved tensors are P and Pd ([B,H,N,N] each)."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, qkv, Wl, bl, Ww, bw, H, scale, p_drop):
         B, N, C3 = qkv.shape
         C = C3 // 3
@@ -351,6 +359,7 @@ class _TalkingHeadsAttentionFused(Function):
     fragments, P'd (fp16) and the row statistics - not qkv itself."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, qkv, Wl, bl, Ww, bw, H, scale, p_drop):
         B, N, C3 = qkv.shape
         C = C3 // 3
@@ -436,6 +445,7 @@ class _MlpGelu(Function):
     producing GEMM epilogues write the bf16 (and transposed bf16) operands of the following GEMMs and the bias gradient."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, x, W1, b1, W2, b2):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
@@ -470,6 +480,7 @@ class _LinearRes(Function):
     operands of the projection's gradient GEMMs."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, x, W, b, xres, gamma):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
@@ -514,6 +525,7 @@ class _MlpGeluRes(Function):
     the backward the branch gradient gamma * dout emitted directly as the bf16 operands of the fc2 gradient GEMMs."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, x, W1, b1, W2, b2, xres, gamma):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
@@ -590,6 +602,7 @@ class _Attention(Function):
     (cait.py:120-131, map saved at :130)."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, q, k, v, mask_u8, scale, p_drop, need_map):
         B, Lq, H, dk = q.shape
         Lk, dv = k.shape[1], v.shape[3]
@@ -643,6 +656,7 @@ class _AttentionFlash(Function):
     Used in bf16 mode when no attention map is requested and the head dims fit (q/k <= 96, v <= 64)."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, q, k, v, mask_u8, scale, p_drop):
         B, Lq, H, dk = q.shape
         Lk, dv = k.shape[1], v.shape[3]
@@ -698,6 +712,7 @@ class _PatchEmbed(Function):
     """Conv2d(3,C,16,16) patch embedding as gather + GEMM (reference cait.py:518-528)."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, img, W, b, P):
         B, Cin, Hi, Wi = img.shape
         cols = K.patchify(img.contiguous(), P)
@@ -724,6 +739,7 @@ class _AddRows(Function):
     """x [B,N,C] + table [N,C] (pos-embed add, cait.py:623-624)."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, x, table):
         ctx.B = x.shape[0]
         return K.add_rows(x.contiguous(), table.contiguous())
@@ -747,6 +763,7 @@ class _Add(Function):
     """a + b for equally shaped activations (residual / positional adds), one float4 pass."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, a, b):
         a, b = a.contiguous(), b.contiguous()
         return K.add_rows(a, b)
@@ -766,6 +783,7 @@ class _BicubicGrid(Function):
     """pos_embed [1, gh*gw, C] -> [1, h*w, C] (cait.py:598-613)."""
 
     @staticmethod
+    @K.forward_scope
     def forward(ctx, pe, gh, gw, h, w):
         ctx.g = (gh, gw, h, w)
         return K.bicubic(pe[0].contiguous(), gh, gw, h, w).unsqueeze(0)

@@ -1,0 +1,97 @@
+"""Round-4 GPU tests of the host-side contracts the advisor flagged: accumulate-into gradients larger than the
+reducer's pre-zeroed views, forward precision of a block recomputed inside a backward (torch.utils.checkpoint), launches from a
+second stream next to the shared reduction workspace."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_wide_bias_gradient_does_not_accumulate_across_steps(dev):
+    """A bias of > 16384 elements (a wide class / vocabulary head) is an ACCUMULATE-INTO gradient (column sums added onto the
+    bucket view) that GradAllReducer.reset() does not pre-zero from the second step on (dp.py: ZERO_MAX): kernels._zeros_or zeroes
+    such a view at hand-out time.  Three steps with different inputs, a parameter that fires only in step 1 included: every
+    step's gradients equal the fp64 reference of THAT step (not the running sum).  Reference: the autograd of nn.Linear at
+    models/conditional_detr.py:104-110 under DDP (main.py:172), whose buckets start every backward from zero."""
+    from spe_amd import kernels as K, ops
+    from spe_amd.dp import GradAllReducer
+    K.set_precision("bf16x3")
+    g = torch.Generator().manual_seed(5)
+    Nout, Kin, R = 20000, 64, 256
+    W = torch.nn.Parameter((0.05 * torch.randn(Nout, Kin, generator=g)).to(dev))
+    b = torch.nn.Parameter(torch.zeros(Nout, device=dev))
+    W2 = torch.nn.Parameter((0.05 * torch.randn(Nout, Kin, generator=g)).to(dev))          # used in step 0 only
+    b2 = torch.nn.Parameter(torch.zeros(Nout, device=dev))
+    red = GradAllReducer([W, b, W2, b2])
+    assert b.numel() > red.ZERO_MAX == K.ACC_ZERO_MAX
+    try:
+        for step in range(3):
+            x = torch.randn(R, Kin, generator=g).to(dev)
+            go = torch.randn(R, Nout, generator=g).to(dev)
+            red.reset()
+            y = ops.linear(x, W, b)
+            if step == 0:
+                y = y + ops.linear(x, W2, b2)
+            (y * go).sum().backward()
+            red.finish()
+            db_ref = go.double().sum(0)
+            dW_ref = go.double().t() @ x.double()
+            assert (b.grad.double() - db_ref).abs().max() <= 1e-4 * db_ref.abs().max(), step
+            assert (W.grad.double() - dW_ref).abs().max() <= 1e-4 * dW_ref.abs().max(), step
+            if step == 0:
+                assert (b2.grad.double() - db_ref).abs().max() <= 1e-4 * db_ref.abs().max()
+            else:       # no gradient this step: zeros, like DDP's unused-parameter path - not step 0's leftovers
+                assert float(b2.grad.abs().max()) == 0.0 and float(W2.grad.abs().max()) == 0.0, step
+    finally:
+        red.remove()
+
+
+def test_checkpointed_block_recomputes_at_forward_precision(dev):
+    """bf16s runs forward products on split operands and backward products on single bf16 operands; which one a launch gets is a
+    thread-local flag set around every backward (kernels.backward_scope).  torch.utils.checkpoint(use_reentrant=False) recomputes
+    the block INSIDE the wrapped backward: kernels.forward_scope makes that recomputation a forward again, so the recomputed
+    activations - and with them every gradient - are bitwise those of the run without checkpointing."""
+    from torch.utils.checkpoint import checkpoint
+    from spe_amd import kernels as K, ops
+    K.set_precision("bf16s")
+    g = torch.Generator().manual_seed(9)
+    C, R = 384, 2304
+    W1 = (0.05 * torch.randn(4 * C, C, generator=g)).to(dev).requires_grad_(); b1 = torch.zeros(4 * C, device=dev, requires_grad=True)
+    W2 = (0.05 * torch.randn(C, 4 * C, generator=g)).to(dev).requires_grad_(); b2 = torch.zeros(C, device=dev, requires_grad=True)
+    gam = torch.ones(C, device=dev, requires_grad=True); bet = torch.zeros(C, device=dev, requires_grad=True)
+    x = torch.randn(1, R, C, generator=g).to(dev).requires_grad_()
+    go = torch.randn(1, R, C, generator=g).to(dev)
+
+    def block(t):
+        return t + ops.mlp_gelu(ops.layer_norm(t, gam, bet, 1e-6), W1, b1, W2, b2)
+
+    outs = []
+    for use_ckpt in (False, True):
+        y = checkpoint(block, x, use_reentrant=False) if use_ckpt else block(x)
+        grads = torch.autograd.grad(y, (x, W1, b1, W2, gam), go)
+        outs.append([y.detach().clone()] + [t.clone() for t in grads])
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)
+
+
+def test_launch_from_second_stream_is_ordered_behind_the_first(dev):
+    """The deterministic reductions share one ticket / slab workspace per process (csrc/det_reduce.h): kernels._call orders a launch
+    from another stream behind everything the previous stream was given.  Column sums issued alternately from two streams stay
+    bitwise equal to the single-stream result; a launch on another DEVICE index is refused."""
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(8300, 1536, generator=g).to(dev)
+    ref = K.colsum(x, torch.empty(1536, device=dev), accumulate=False).clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    outs = []
+    for t in range(8):
+        if t % 2:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                outs.append(K.colsum(x, torch.empty(1536, device=dev), accumulate=False))
+        else:
+            outs.append(K.colsum(x, torch.empty(1536, device=dev), accumulate=False))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, ref)
