@@ -117,6 +117,7 @@ _RWS = None
 _RWS_BYTES = 16 << 20
 
 
+_RWS_DEVIDX = -1
 _RWS_STREAM = None     # raw handle of the stream the last launch went to: the ticket / slab workspace is only safe for stream-ordered launches
 
 
@@ -127,28 +128,27 @@ def _register_reduce_ws():
     lib.call("spe_set_reduce_workspace", _RWS.data_ptr(), _RWS_BYTES, _st())
 
 
-def _guard_reduce_ws():
-    """The deterministic reductions (csrc/det_reduce.h) share ONE ticket / slab workspace per process: launches must come from the
-    device it lives on (one process per GPU) and be stream-ordered.  A launch from another stream first waits for everything the
-    previous stream was given (an event edge, once per switch); another device is an error."""
-    global _RWS_STREAM
+def _guard_reduce_ws(cur, st):
+    """Slow path of _st(): the launch stream or device changed.  The deterministic reductions (csrc/det_reduce.h) share ONE ticket /
+    slab workspace per process: launches must come from the device it lives on (one process per GPU) and be stream-ordered.  A
+    launch from another stream first waits for everything the previous stream was given (an event edge, once per switch); another
+    device is an error."""
+    global _RWS_STREAM, _RWS_DEVIDX
     if _RWS is None:
         _register_reduce_ws()
-    cur = torch.cuda.current_device()
     if cur != _RWS.device.index:
         raise lib.SpeLibraryError(f"spe_amd kernels were first used on cuda:{_RWS.device.index} and are now launched on cuda:{cur}: "
                                   "the reduction workspace is per process (one process per GPU)")
-    st = _st()
-    if st != _RWS_STREAM:
-        if _RWS_STREAM is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.ExternalStream(_RWS_STREAM, device=_RWS.device) if _RWS_STREAM else torch.cuda.default_stream(_RWS.device))
-            torch.cuda.current_stream().wait_event(ev)
-        _RWS_STREAM = st
+    if _RWS_STREAM is not None and st != _RWS_STREAM:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.ExternalStream(_RWS_STREAM, device=_RWS.device) if _RWS_STREAM else torch.cuda.default_stream(_RWS.device))
+        torch.cuda.current_stream().wait_event(ev)
+    _RWS_STREAM, _RWS_DEVIDX = st, cur
 
 
 def _call(name, *args):
-    _guard_reduce_ws()
+    if _RWS is None:
+        _register_reduce_ws()
     if not _TIMED:
         return lib.call(name, *args)
     ev = _TIMED.get(name)
@@ -225,10 +225,13 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def _st():
-    """Current HIP stream handle of the current device (the raw-handle query skips building a torch.cuda.Stream object)."""
-    if _raw_stream is not None:
-        return _raw_stream(torch.cuda.current_device())
-    return torch.cuda.current_stream().cuda_stream
+    """Current HIP stream handle of the current device (the raw-handle query skips building a torch.cuda.Stream object).  Every
+    wrapper fetches its launch stream here, so this is also where a change of stream or device is noticed (_guard_reduce_ws)."""
+    cur = torch.cuda.current_device()
+    st = _raw_stream(cur) if _raw_stream is not None else torch.cuda.current_stream().cuda_stream
+    if st != _RWS_STREAM or cur != _RWS_DEVIDX:
+        _guard_reduce_ws(cur, st)
+    return st
 
 
 def _chk(*ts):

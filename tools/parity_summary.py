@@ -1,4 +1,4 @@
-"""gpurun_out/parity_<case>_<precision>.json (written by tests/test_config_golden.py on the GPU box) -> profiles/parity_r03.json:
+"""gpurun_out/parity_<case>_<precision>.json (written by tests/test_config_golden.py on the GPU box) -> profiles/parity_r04.json:
 per precision mode the worst measured error over the cases at BASELINE.json's own dimensions, against the REFERENCE.
 bench.py copies the entry of the precision it runs into its JSON line ("precision_contract")."""
 import glob
@@ -29,7 +29,9 @@ tol = {"bf16s": "asserted: every output 1e-3, every loss key 1e-3, total loss 1e
                "operand): NOT within north_star's 1e-3"}
 for k in out:
     out[k]["asserted_tolerances"] = tol.get(k)
-path = os.path.join(ROOT, "profiles", "parity_r03.json")
+out["label"] = (sys.argv[1] if len(sys.argv) > 1 else "round 4") + ": tests/test_config_golden.py on the GPU box, product vs reference fixtures"
+path = os.path.join(ROOT, "profiles", "parity_r04.json")
 json.dump(out, open(path, "w"), indent=1, sort_keys=True)
 for k, v in out.items():
-    print(k, json.dumps(v["worst"]))
+    if isinstance(v, dict):
+        print(k, json.dumps(v["worst"]))

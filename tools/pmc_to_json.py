@@ -23,6 +23,9 @@ KERNELS = {
     "talking_fused_mode3": "talking_fused_kernel<8, 2, true, 3,",
     "attn_contract": "attn_contract_kernel<3, false",
     "attn_contract_T": "attn_contract_kernel<3, true",
+    "flash_fwd": "talking_flash_fwd_kernel<8, 2, true, false, false>",
+    "flash_dv": "talking_flash_fwd_kernel<8, 2, true, false, true>",
+    "flash_merge": "flash_merge_kernel",
 }
 
 
@@ -44,7 +47,7 @@ def main():
     note = sys.argv[4] if len(sys.argv) > 4 else ""
     fe, nf = per_launch(fetch_dir, "FETCH_SIZE")
     wr, nw = per_launch(write_dir, "WRITE_SIZE")
-    res = {"note": note, "units": "bytes per launch; fetch = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE", "kernels": {}}
+    res = {"note": note, "label": note, "units": "bytes per launch; fetch = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE", "kernels": {}}
     prev = out if os.path.exists(out) else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "roofline_inputs.json")
     if os.path.exists(prev):
         old = json.load(open(prev))
