@@ -275,3 +275,39 @@ def test_training_trajectory_matches_reference(dev, name, prec):
         if red is not None:
             red.remove()
         K.set_precision("bf16s")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["bf16s", "bf16x3"])
+def test_train_mode_criteria_at_full_depth(dev, prec):
+    """cfg2_full (24 blocks, batch 2, N = 4150, padded second image) with BOTH criteria in TRAIN mode - the 5x one-to-many jitter
+    and Hungarian matching of reference models/conditional_detr.py:399-466 on 35 / 25 targets per image - against the reference's
+    record (tools/gen_traj_golden.py cfg2_full:train: forward without autograd, the jittered targets_cp of both stages captured at
+    its matcher calls and injected here): every loss key of both criteria and the weighted total within north_star's 1e-3."""
+    from spe_amd import kernels as K
+    from spe_amd.util.misc import NestedTensor
+    name = "cfg2_full"
+    blob = torch.load(os.path.join(GOLD, f"cfg_{name}_train.pt"), weights_only=False)
+    args, (model, crit, crit_r, pp, rpp), tensors, mask, targets = cc.build_case(name)
+    chk = float(sum(v.detach().double().abs().sum() for v in model.state_dict().values() if v.is_floating_point()))
+    assert abs(chk - blob["sd_checksum"]) <= 1e-9 * blob["sd_checksum"]
+    K.set_precision(prec)
+    try:
+        model.to(dev).train(); crit.to(dev).train(); crit_r.to(dev).train()
+        with torch.no_grad():
+            out = model(NestedTensor(tensors.to(dev), mask.to(dev)))
+            l0 = crit(out[0], _to_dev(targets, dev), targets_cp=_to_dev(blob["targets_cp0"], dev))
+            l1 = crit_r(out[1], _to_dev(blob["pseudo"], dev), targets_cp=_to_dev(blob["targets_cp1"], dev))
+        wd = blob["weight_dict"]
+        total = sum(l0[k] * wd[k] for k in l0 if k in wd) + sum(l1[k] * wd[k] for k in l1 if k in wd)
+        errs = {}
+        for tag, ld, ref in (("0", l0, blob["loss0"]), ("1", l1, blob["loss1"])):
+            for k, v in ref.items():
+                if k in wd:
+                    errs[f"{tag}.{k}"] = abs(float(ld[k]) - float(v)) / max(abs(float(v)), 1e-2)
+        te = abs(float(total) - float(blob["total"])) / abs(float(blob["total"]))
+        worst = max(errs.items(), key=lambda kv: kv[1])
+        print(f"[train-mode criteria {name} {prec}] total {te:.2e}, worst key {worst}, targets per image {[len(t['labels']) for t in blob['targets_cp0']]}")
+        assert worst[1] < 1e-3 and te < 1e-3, (worst, te)
+    finally:
+        K.set_precision("bf16s")

@@ -107,7 +107,56 @@ def run_case(name):
     print(name, "bytes", os.path.getsize(path))
 
 
+def train_criterion_record(name):
+    """TRAIN-mode criteria (5x one-to-many jitter, conditional_detr.py:410-431) of the reference on a FULL-DEPTH case: the
+    forward runs without autograd (the backward of these cases is pinned by cfg_<case>.pt with eval-mode criteria), then both
+    criteria in train mode with what they hand to their matchers captured -> tests/golden/cfg_<case>_train.pt."""
+    from models import build_model as ref_build
+    import util.misc as um
+    args, (pmodel, *_), tensors, mask, targets = cc.build_case(name)
+    sd = {k: v.detach().clone() for k, v in pmodel.state_dict().items()}
+    del pmodel
+    with contextlib.redirect_stdout(io.StringIO()):
+        model, crit, crit_r, pp, rpp = ref_build(copy.deepcopy(args))
+    model.load_state_dict(sd, strict=True)
+    model.train(); crit.train(); crit_r.train()
+    for blk in model.backbone[0].body.blocks:                # drop the per-block attention_map clone (cait.py:392): harness-side memory only
+        blk.attn.register_forward_hook(lambda m, i, o: setattr(m, "attention_map", None))
+    captured = {}
+    for c, tag in ((crit, "crit"), (crit_r, "crit_r")):
+        calls = []
+
+        def fwd(outputs, tg, _inner=c.matcher.forward, _calls=calls):
+            _calls.append(copy.deepcopy(tg))
+            return _inner(outputs, tg)
+        c.matcher.forward = fwd
+        captured[tag] = calls
+    torch.manual_seed(cc.ALL_CASES[name]["seed"] + 78)
+    orig = torch.stack([t["orig_size"] for t in targets])
+    with torch.no_grad():
+        out = model(um.NestedTensor(tensors, mask))
+        pr = rpp["bbox"](out[0], orig, targets)
+        pseudo = []
+        for t, r in zip(targets, pr):
+            p = copy.deepcopy(t)
+            p.update({"labels": r["labels"].clone(), "boxes": r["boxes"].clone(), "scores": r["scores"].clone()})
+            pseudo.append(p)
+        l0 = crit(out[0], targets)
+        l1 = crit_r(out[1], pseudo)
+    wd = crit.weight_dict
+    total = sum(l0[k] * wd[k] for k in l0 if k in wd) + sum(l1[k] * wd[k] for k in l1 if k in wd)
+    blob = {"case": name, "loss0": {k: v.detach().clone() for k, v in l0.items()}, "loss1": {k: v.detach().clone() for k, v in l1.items()},
+            "total": total.detach().clone(), "targets_cp0": captured["crit"][0], "targets_cp1": captured["crit_r"][0], "pseudo": pseudo,
+            "weight_dict": dict(wd), "sd_checksum": float(sum(v.double().abs().sum() for v in sd.values() if v.is_floating_point()))}
+    path = os.path.join(OUT, f"cfg_{name}_train.pt")
+    torch.save(blob, path)
+    print(name, "train-mode criteria: total", float(total), "targets per image", [len(t["labels"]) for t in blob["targets_cp0"]], "bytes", os.path.getsize(path))
+
+
 if __name__ == "__main__":
     gcg.register_reference_backbones()
     for n in (sys.argv[1:] or ["cfg1", "cfg2_depth2"]):
-        run_case(n)
+        if n.endswith(":train"):
+            train_criterion_record(n[:-6])
+        else:
+            run_case(n)
