@@ -3,7 +3,7 @@ statistics): forward O, and - once built - the backward gradients.  Prints max /
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from spe_amd import kernels as K
 
