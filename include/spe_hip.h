@@ -105,7 +105,11 @@ int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const
  * A16 / B16) hold bf16(x - bf16(x)) of the fp32 operands, written next to the high parts by every producer (out_lo of
  * spe_cvt_bf16 / spe_cvt_bf16_multi, y16lo of spe_layernorm_fwd, out16lo of spe_attn_contract and spe_gemm_bf16nt_ex); the
  * product is then A_hi B_hi + A_lo B_hi + A_hi B_lo - ~16 significant operand bits instead of 8 at 3x the MFMA work of kernels
- * that are load / store bound (no split-K with split operands). */
+ * that are load / store bound (no split-K with split operands).  * act bits 8 / 9 (round 4, the decoder's memory-side projections - north_star's "decoder cross-attention GEMM", reference
+ * models/transformer.py:389-396): bit 8 = A16 / B16 hold IEEE fp16 and the product is single-term on v_mfma_f32_16x16x32_f16 (no lo
+ * parts); bit 9 = C is an IEEE fp16 [M][ldc] matrix (saturating) - what spe_attn_pack_multi's fp16-source jobs consume.  Both need
+ * splitk = 1, no C2, ldc % 4 == 0; bit 8 needs M >= 2048 and K % 64 == 0.  spe_cvt_f16: fp32 [R, C] -> IEEE fp16 (C, ldx, ldo % 4 == 0). */
+int spe_cvt_f16(const float* x, long ldx, int R, int C, void* out, long ldo, spe_stream_t stream);
 int spe_gemm_bf16nt(const void* A16, const void* B16, const void* A16lo, const void* B16lo, float* C, const float* bias,
                     float* C2, int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int splitk,
                     spe_stream_t stream);

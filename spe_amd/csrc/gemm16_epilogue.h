@@ -33,6 +33,7 @@ struct Gemm16Args {
                                            // pre-activation of the fused MLP: only act'(.) is ever taken of it - fp16 costs the gradient
                                            // ~3e-4 relative, an order below its bf16 operand rounding, and halves 51 MB per block each way)
     const float* res; const float* rgamma; // LayerScale residual: C = res[m][n] + rgamma[n] * v  (C2 still gets v)
+    int h16;                               // bit 0: A / B hold IEEE fp16 (single-term product on v_mfma_f32_16x16x32_f16) ; bit 1: C is IEEE fp16 [M][ldc] (plain epilogue)
 };
 
 typedef _Float16 ep_h4_t __attribute__((ext_vector_type(4)));
@@ -308,6 +309,17 @@ __device__ __forceinline__ void gemm16_epilogue_plain(const Gemm16Args& p, f32x4
                     for (int r = 0; r < 4; ++r) v[r] = gelu_erf16(v[r]);
                 }
             }
+            if (p.h16 & 2) {        // fp16 output (saturating, NaN kept): the consumer packs these values into fp16 MFMA operands anyway
+                unsigned short* C16 = reinterpret_cast<unsigned short*>(C);
+                const uint2 h = ep_f2h4(v[0], v[1], v[2], v[3]);
+                if (full) __builtin_nontemporal_store(h.x | ((unsigned long long)h.y << 32), reinterpret_cast<unsigned long long*>(C16 + off));
+                else {
+                    const unsigned short e[4] = {(unsigned short)(h.x & 0xffff), (unsigned short)(h.x >> 16), (unsigned short)(h.y & 0xffff), (unsigned short)(h.y >> 16)};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) C16[off + r] = e[r];
+                }
+                continue;
+            }
             // split-K: the private slab of this split (zeros if the split was empty), summed by the caller
             if (full) spe_store4_stream(C + off, v[0], v[1], v[2], v[3]);
             else {
@@ -315,5 +327,41 @@ __device__ __forceinline__ void gemm16_epilogue_plain(const Gemm16Args& p, f32x4
                 for (int r = 0; r < 4; ++r) if (n + r < p.N) C[off + r] = v[r];
             }
         }
+    }
+}
+
+
+// ---- fp16-output epilogue of the 128-wide LDS-DMA kernels (Gemm16Args::h16 bit 1): v = alpha * acc + bias -> IEEE fp16 (saturating,
+// NaN kept), staged through LDS (the operand ring is free by now; the caller has synchronised the workgroup) so that the tile leaves
+// as 16-B stores of whole 256-B row segments - a lane's own 4 columns would be 8-B stores in 32-B pieces (measured: slower than the
+// fp32 stores they replace).  Needs N % 8 == 0, ldc % 8 == 0 and a 16-B aligned C.
+template <int BM, int BN>
+__device__ __forceinline__ void gemm16_epilogue_h16(const Gemm16Args& p, f32x4_t (&acc)[BM / 32][BN / 32], unsigned short* smem16, const int m0, const int n0) {
+    constexpr int NFM = BM / 32, NFN = BN / 32, WM = BM / 2, WN = BN / 2, LR = BN + 8;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int fr = lane & 15;
+#pragma unroll
+    for (int j = 0; j < NFN; ++j) {
+        const int nl = wn * WN + j * 16 + (lane >> 4) * 4, n = n0 + nl;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = p.bias[min(n + r, p.N - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < NFM; ++i) {
+            const int ml = wm * WM + i * 16 + fr;
+            *reinterpret_cast<uint2*>(smem16 + ml * LR + nl) = ep_f2h4(acc[i][j][0] * p.alpha + bv[0], acc[i][j][1] * p.alpha + bv[1],
+                                                                      acc[i][j][2] * p.alpha + bv[2], acc[i][j][3] * p.alpha + bv[3]);
+        }
+    }
+    __syncthreads();
+    unsigned short* C16 = reinterpret_cast<unsigned short*>(p.C);
+    for (int idx = threadIdx.x; idx < BM * (BN / 8); idx += 256) {
+        const int r = idx / (BN / 8), c8 = idx % (BN / 8);
+        const int m = m0 + r, n = n0 + c8 * 8;
+        if (m >= p.M || n >= p.N) continue;
+        spe_store16_stream(C16 + (long)m * p.ldc + n, *reinterpret_cast<const spe_u32x4_t*>(smem16 + r * LR + c8 * 8));
     }
 }

@@ -336,10 +336,15 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, const void* A16
     p.A = reinterpret_cast<const unsigned short*>(A16); p.B = reinterpret_cast<const unsigned short*>(B16);
     p.Alo = reinterpret_cast<const unsigned short*>(A16lo); p.Blo = reinterpret_cast<const unsigned short*>(B16lo); p.out16lo = nullptr;
     p.C = C; p.C2 = C2; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    // act bits 8, 9: IEEE fp16 operands (single-term, v_mfma_f32_16x16x32_f16) / IEEE fp16 output C [M][ldc] - the 128-wide LDS-DMA
+    // kernels only (gemm_nt2.hip); -2 when the problem is outside their domain
+    p.h16 = (act >> 8) & 3; act &= 0xff;
     p.alpha = alpha; p.act = act; p.slab = 0;
     p.ws = DetWs{nullptr, nullptr, 0, 0}; p.half_flags = 0;
     p.out16 = nullptr; p.out16T = nullptr; p.colsum = nullptr; p.aux = nullptr; p.ld16 = 0; p.ld16t = 0; p.res = nullptr; p.rgamma = nullptr;
     const int ktiles = (K + GB_BK - 1) / GB_BK;
+    if (p.h16 && (splitk != 1 || C2 || (ldc & 3))) return -2;
+    if ((p.h16 & 1) && A16lo) return -2;
     if (splitk < 0) {           // slab mode: C holds |splitk| slabs of M*ldc floats
         splitk = -splitk; p.slab = (long)M * ldc;
         if (splitk > ktiles) return -5;
@@ -350,6 +355,7 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, const void* A16
     if (splitk > 1 && (act != 0 || C2 != nullptr || bias != nullptr)) return -3;
     if (p.Alo && splitk != 1) return -3;
     { const int rc = spe_nt2_dispatch(p, false, stream); if (rc != SPE_NT2_NA) return rc; }
+    if (p.h16 & 1) return -2;
     if (p.Alo) {            // split operands: 64x64 tiles at two workgroups per CU (73 KB of LDS each); 128x64 when that fills the chip less
         if (splitk != 1) return -3;
         return launch_gemm16<64, 64, false, 0, 0, true>(p, stream);
@@ -405,6 +411,7 @@ extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, const void* 
     if (aux && act != 1 && act != 2) return -2;
     if ((res != nullptr) != (rgamma != nullptr) || (res && (!C || act != 0 || aux))) return -2;
     Gemm16Args p;
+    p.h16 = 0;
     p.A = reinterpret_cast<const unsigned short*>(A16); p.B = reinterpret_cast<const unsigned short*>(B16);
     p.C = C; p.C2 = C2; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.act = act; p.slab = 0; p.splitk = 1;

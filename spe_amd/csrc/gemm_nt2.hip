@@ -38,7 +38,8 @@ __device__ __forceinline__ int nt2_swz(int r) {
     else return (0x78 >> (2 * ((r >> 2) & 3))) & 3;
 }
 
-template <int BM, int BN, int BK, int NST, bool SPLIT, bool EX>
+// F16: the operands hold IEEE fp16 (single-term product on v_mfma_f32_16x16x32_f16: same bytes and rate as bf16, 3 more mantissa bits)
+template <int BM, int BN, int BK, int NST, bool SPLIT, bool EX, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(Gemm16Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     constexpr int NFM = BM / 32, NFN = BN / 32, WM = BM / 2, WN = BN / 2;
@@ -147,7 +148,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(Gemm16Args p) {
 #pragma unroll
             for (int i = 0; i < NFM; ++i)
 #pragma unroll
-                for (int j = 0; j < NFN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NFN; ++j) {
+                    if constexpr (F16) {
+                        typedef _Float16 nt2_h8_t __attribute__((ext_vector_type(8)));
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(nt2_h8_t, b[j]), __builtin_bit_cast(nt2_h8_t, a[i]), acc[i][j], 0, 0, 0);
+                    } else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the (unused) tail stages before the epilogue reuses the ring
@@ -160,17 +166,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(Gemm16Args p) {
     return;
 #endif
     if constexpr (EX) gemm16_epilogue_ex<BM, BN, SPLIT, false>(p, acc, smem16, m0, n0);
+    else if (F16 && (p.h16 & 2) && (p.N & 7) == 0 && (p.ldc & 7) == 0) gemm16_epilogue_h16<BM, BN>(p, acc, smem16, m0, n0);
     else gemm16_epilogue_plain<BM, BN>(p, acc, p.C, m0, n0);
 }
 
-template <int BM, int BN, int BK, int NST, bool SPLIT, bool EX>
+template <int BM, int BN, int BK, int NST, bool SPLIT, bool EX, bool F16 = false>
 static int launch_nt2(const Gemm16Args& p, hipStream_t stream) {
     constexpr int ring = NST * ((BM + BN) / (64 / (BK / 8))) * (SPLIT ? 2 : 1) * 1024;
     constexpr int epi = EX ? BM * (BN + 8) * 2 * (SPLIT ? 2 : 1) : 0;
     constexpr int smem = ring > epi ? ring : epi;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt2_kernel<BM, BN, BK, NST, SPLIT, EX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt2_kernel<BM, BN, BK, NST, SPLIT, EX, F16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -187,7 +194,7 @@ static int launch_nt2(const Gemm16Args& p, hipStream_t stream) {
     int tiles = tiles_m * tiles_n;
     if (q.xcd_bind == 1) tiles = 8 * ((tiles_m + 7) / 8) * tiles_n;
     if (q.xcd_bind == 2) tiles = 8 * ((tiles_n + 7) / 8) * tiles_m;
-    hipLaunchKernelGGL((gemm_nt2_kernel<BM, BN, BK, NST, SPLIT, EX>), dim3(tiles), dim3(256), smem, stream, q);
+    hipLaunchKernelGGL((gemm_nt2_kernel<BM, BN, BK, NST, SPLIT, EX, F16>), dim3(tiles), dim3(256), smem, stream, q);
     SPE_CHECK_LAUNCH();
     return 0;
 }
@@ -200,6 +207,12 @@ int spe_nt2_dispatch(const Gemm16Args& p, bool ex, hipStream_t stream) {
     static const int enabled = getenv("SPE_GEMM_NT2") ? atoi(getenv("SPE_GEMM_NT2")) : 1;      // developer knob (A/B against gemm_bf16.hip)
     const bool split = p.Alo != nullptr;
     if (!enabled || p.M < 2048 || p.splitk != 1 || p.out16T || (p.K % 64) != 0 || p.K < 128 || p.N < 64) return SPE_NT2_NA;
+    if (p.h16 & 1) {        // fp16 single-term operands (the decoder's memory-side projections): wide tiles, plain epilogue only
+        if (ex || split) return -2;
+        const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128), t160 = (long)((p.M + 159) / 160) * ((p.N + 127) / 128);
+        if (((t160 + 511) / 512) * 160 < ((t128 + 511) / 512) * 128) return launch_nt2<160, 128, 64, 2, false, false, true>(p, stream);
+        return launch_nt2<128, 128, 64, 2, false, false, true>(p, stream);
+    }
     static const int wide_min = getenv("SPE_NT2_WIDE_MIN") ? atoi(getenv("SPE_NT2_WIDE_MIN")) : 1024;     // developer knob
     // single-term products with the extended epilogue (fc2 dh: GELU derivative from the saved pre-activation, bf16 output, column
     // sums) are bound by that epilogue: 128 x 64 tiles at three workgroups per CU overlap it with other workgroups' main loops

@@ -237,3 +237,27 @@ extern "C" int spe_pos_sine(const void* mask_u8, const float* dim_t, float* out,
     SPE_CHECK_LAUNCH();
     return 0;
 }
+
+
+// fp32 [R, C] (row stride ldx) -> IEEE fp16 [R, C] (row stride ldo), saturating at +-65504, NaN kept: the single-term operands of
+// the decoder's memory-side projections (spe_gemm_bf16nt with act bit 8; reference models/transformer.py:389-396).
+__global__ __launch_bounds__(256) void cvt_f16_kernel(const float* __restrict__ x, long ldx, int R, int C4, unsigned short* __restrict__ out, long ldo) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)R * C4; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / C4), c = (int)(i % C4) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + (long)r * ldx + c);
+        typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+        h4_t h;
+        h[0] = (_Float16)((v.x != v.x) ? v.x : __builtin_amdgcn_fmed3f(v.x, -65504.f, 65504.f)); h[1] = (_Float16)((v.y != v.y) ? v.y : __builtin_amdgcn_fmed3f(v.y, -65504.f, 65504.f));
+        h[2] = (_Float16)((v.z != v.z) ? v.z : __builtin_amdgcn_fmed3f(v.z, -65504.f, 65504.f)); h[3] = (_Float16)((v.w != v.w) ? v.w : __builtin_amdgcn_fmed3f(v.w, -65504.f, 65504.f));
+        *reinterpret_cast<uint2*>(out + (long)r * ldo + c) = __builtin_bit_cast(uint2, h);
+    }
+}
+extern "C" int spe_cvt_f16(const float* x, long ldx, int R, int C, void* out, long ldo, hipStream_t st) {
+    if (R <= 0 || C <= 0) return 0;
+    if ((C & 3) || (ldx & 3) || (ldo & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 7)) return -2;
+    const long n = (long)R * (C / 4);
+    long nb = (n + 255) / 256; if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, ldx, R, C / 4, reinterpret_cast<unsigned short*>(out), ldo);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}

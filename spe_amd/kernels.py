@@ -461,6 +461,15 @@ def gemm16(A16, B16, C, M, N, K, lda, ldb, ldc, bias=None, C2=None, alpha=1.0, a
     return C
 
 
+def cvt_f16(x2, out=None):
+    """IEEE fp16 copy (saturating) of a contiguous fp32 [R, C], C % 4 == 0."""
+    R, C = x2.shape
+    if out is None:
+        out = torch.empty((R, C), device=x2.device, dtype=torch.float16)
+    _call("spe_cvt_f16", _p(x2), x2.stride(0), R, C, _p(out), out.stride(0), _st())
+    return out
+
+
 def gemm16_tn(A16, B16, C, M, N, R, lda, ldb, ldc, alpha=1.0, splitk=1):
     """C[M,N] = alpha * A16[:R,:M].T @ B16[:R,:N] on row-major bf16 operands (spe_gemm_bf16tn); splitk < 0: slabs."""
     _call("spe_gemm_bf16tn", _p(A16), _p(B16), _p(C), M, N, R, lda, ldb, ldc, float(alpha), int(splitk), _st())
