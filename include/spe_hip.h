@@ -341,6 +341,25 @@ int spe_box_loss(const float* pred_boxes, const long* srow, const float* tbox, c
 int spe_box_loss_bwd(const long* srow, const int* lidx, const float* g_l1, const float* g_giou, const float* c1,
                      const float* c2, float* dpred, long n, spe_stream_t stream);
 
+/* ---- memory side of the decoder's conditional cross attention for ALL layers (reference models/transformer.py:389-419):
+ * spe_kv_frags turns the fp16 outputs of the two stacked projection GEMMs (spe_gemm_bf16nt with act bits 8 + 9) -
+ *   ym16 [B*S][ldm]: column block 2l = ca_kcontent_proj_l(memory), 2l + 1 = ca_v_proj_l(memory);  yp16 [B*S][ldp]: block l =
+ *   ca_kpos_proj_l(pos); d = H * dh columns per block -
+ * into the operand fragments spe_mha_fwd / spe_mha_bwd consume, stacked over the layers ([L][B][H][ceil(S/16)] records):
+ *   Kf  fp16, 32-wide steps of the 2 dh key dims [k_content | k_pos] of a head (spe_attn_pack_multi kind 2 + 16 layout)
+ *   V16 fp16, 16-wide (kind 1 + 16);   K16 bf16, 16-wide (kind 1) and Vf bf16, 32-wide steps (kind 2): backward only, both or neither.
+ * No fp32 key / value tensor, concatenation or per-layer pack.  dh % 8 == 0, dh <= 64, ldm / ldp % 8 == 0.
+ * spe_kv_grad_scatter: dk [B,S,H,2 dh] / dv [B,S,H,dh] (fp32, spe_mha_bwd) of one layer -> bf16 column blocks 2l (content half of
+ *   dk), 2l + 1 (dv) of dYm [B*S][ldm] and block l (pos half of dk) of dYp [B*S][ldp]: the stacked dY operands of the projection
+ *   GEMMs' backward. */
+int spe_kv_frags(const void* ym16, long ldm, const void* yp16, long ldp, void* Kf, void* V16, void* K16, void* Vf,
+                 int L, int B, int S, int H, int dh, spe_stream_t stream);
+int spe_kv_grad_scatter(const float* dk, const float* dv, void* dYm, long ldm, void* dYp, long ldp, int layer, int B, int S,
+                        int H, int dh, spe_stream_t stream);
+/* column sums of a bf16 matrix [R][ld] made of nblk (<= 32) column blocks of blkC columns, block i into its own fp32 vector outs[i]
+ * (HOST array of device pointers): the bias gradients of the stacked projections, fixed summation order. */
+int spe_colsum_bf16_blocks(const void* x, long ld, long R, int nblk, int blkC, float* const* outs, int accumulate, spe_stream_t stream);
+
 /* ---- flash-style multi-head attention (reference models/attention.py:277-383; nn.MultiheadAttention core of the
  * encoder, models/transformer.py:275-277): softmax(scale q k^T + key_padding_mask), dropout, . v, forward and backward
  * without the [B,H,Lq,Lk] score tensor.  Operands are fragments from spe_attn_pack_multi: kind 2 (32-wide steps) of

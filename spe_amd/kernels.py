@@ -470,6 +470,54 @@ def cvt_f16(x2, out=None):
     return out
 
 
+_WCATH = {}     # fp16 stacks of weights sharing an input: key -> (owner weakrefs, epoch, versions, Wcat fp16 [n*N, K], bcat fp32)
+
+
+def weightcat_f16(Ws, bs):
+    """IEEE fp16 copy of several [N, K] weights stacked along the output axis + the stacked fp32 biases: the single-term fp16 operand
+    of the decoder's memory-side projection GEMM (spe_gemm_bf16nt, act bit 8).  Rebuilt when a weight changed (one concatenation +
+    one conversion launch)."""
+    import weakref
+    key = tuple((W.data_ptr(), tuple(W.shape)) for W in Ws)
+    vers = tuple(W._version for W in Ws) + tuple(b._version for b in bs)
+    ent = _WCATH.get(key)
+    if ent is not None and ent[1] == _W16_EPOCH and ent[2] == vers:
+        owners = [r() for r in ent[0]]
+        if all(o is not None and _owns(o, W.data_ptr()) for o, W in zip(owners, Ws)):
+            return ent[3], ent[4]
+    with torch.no_grad():
+        Wh = cvt_f16(torch.cat([W.detach() for W in Ws], 0))
+        bc = torch.cat([b.detach() for b in bs])
+    if len(_WCATH) > 64:
+        _WCATH.clear()
+    _WCATH[key] = ([weakref.ref(W._base if W._base is not None else W) for W in Ws], _W16_EPOCH, vers, Wh, bc)
+    return Wh, bc
+
+
+def kv_frags(ym16, yp16, L, B, S, H, dh, train):
+    """fp16 outputs of the stacked memory-side projections -> (Kf, V16, K16, Vf) fragment stacks [L, B, H, nt, ...] (csrc/decoder_kv.hip);
+    K16 / Vf (the backward's bf16 operands) only when `train`."""
+    dev = ym16.device
+    nt, dk = (S + 15) // 16, 2 * dh
+    Kf = torch.empty((L, B, H, nt, (dk + 31) // 32, 64, 8), device=dev, dtype=torch.float16)
+    V16 = torch.empty((L, B, H, nt, (dh + 15) // 16, 64, 4), device=dev, dtype=torch.float16)
+    K16 = torch.empty((L, B, H, nt, (dk + 15) // 16, 64, 4), device=dev, dtype=torch.bfloat16) if train else None
+    Vf = torch.empty((L, B, H, nt, (dh + 31) // 32, 64, 8), device=dev, dtype=torch.bfloat16) if train else None
+    _call("spe_kv_frags", _p(ym16), ym16.stride(0), _p(yp16), yp16.stride(0), _p(Kf), _p(V16), _p(K16), _p(Vf), L, B, S, H, dh, _st())
+    return Kf, V16, K16, Vf
+
+
+def kv_grad_scatter(dk, dv, dYm, dYp, layer, B, S, H, dh):
+    _call("spe_kv_grad_scatter", _p(dk), _p(dv), _p(dYm), dYm.stride(0), _p(dYp), dYp.stride(0), int(layer), B, S, H, dh, _st())
+
+
+def colsum_bf16_blocks(x16, blkC, outs):
+    """Column sums of the bf16 matrix x16 [R, n*blkC], block i -> outs[i] (fp32 [blkC], overwritten)."""
+    n = len(outs)
+    ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    _call("spe_colsum_bf16_blocks", _p(x16), x16.stride(0), x16.shape[0], n, int(blkC), ptrs, 0, _st())
+
+
 def gemm16_tn(A16, B16, C, M, N, R, lda, ldb, ldc, alpha=1.0, splitk=1):
     """C[M,N] = alpha * A16[:R,:M].T @ B16[:R,:N] on row-major bf16 operands (spe_gemm_bf16tn); splitk < 0: slabs."""
     _call("spe_gemm_bf16tn", _p(A16), _p(B16), _p(C), M, N, R, lda, ldb, ldc, float(alpha), int(splitk), _st())

@@ -155,9 +155,22 @@ class TransformerDecoderLayer(nn.Module):
         if is_first:
             q = q + self.ca_qpos_proj(query_pos)
         qs = self.ca_qpos_sine_proj(query_sine_embed)
-        q = torch.cat([q.view(B, RQ, H, dh), qs.view(B, RQ, H, dh)], dim=3).view(B, RQ, 2 * d)
-        k, v = mem_kv
-        tgt2 = self.cross_attn(q, k, v, key_padding_mask=memory_key_padding_mask)[0]
+        if isinstance(mem_kv[0], ops.MemoryKV):
+            # keys / values are operand fragments of the flash MHA kernels, key layout [k_content | k_pos] for EVERY layer.  The first
+            # layer's k_content + k_pos (transformer.py:400-406) is carried by the query instead:
+            # q_c (k_c + k_p) + q_s k_p = q_c k_c + (q_s + q_c) k_p
+            holder, tok, layer_id = mem_kv
+            if is_first:
+                qs = qs + q
+            q = torch.cat([q.view(B, RQ, H, dh), qs.view(B, RQ, H, dh)], dim=3)
+            ca = self.cross_attn
+            o = ops.cross_attention_kv(q, tok, holder, layer_id, memory_key_padding_mask, float(ca.head_dim) ** -0.5,
+                                       ca.dropout if ca.training else 0.0)
+            tgt2 = ca.out_proj(o)
+        else:
+            q = torch.cat([q.view(B, RQ, H, dh), qs.view(B, RQ, H, dh)], dim=3).view(B, RQ, 2 * d)
+            k, v = mem_kv
+            tgt2 = self.cross_attn(q, k, v, key_padding_mask=memory_key_padding_mask)[0]
         tgt = self.norm2.residual(tgt, tgt2, self.dropout2)
         # ---- FFN
         tgt2 = self.linear2(self.dropout(self.linear1(tgt, ops.ACT_RELU)))
@@ -189,6 +202,12 @@ class TransformerDecoder(nn.Module):
             return
         B, S, d = memory.shape
         H, dh = self.layers[0].nhead, d // self.layers[0].nhead
+        if ops.memory_side_kv_ok(memory, Wm, Wp, H):
+            # fragments straight from two fp16 GEMMs and one fragment launch: no fp32 keys / values, no concatenation, no per-layer pack
+            holder, toks = ops.memory_side_kv(memory, pos, H, Wm, Wp, bm, bp)
+            for l in range(len(self.layers)):
+                mem_cache[l] = (holder, toks[l], l)
+            return
         ym = ops.multi_linear(memory, Wm, bm)                 # 2*L column blocks [B, S, d] of one [B, S, 2*L*d] buffer
         yp = ops.multi_linear(pos, Wp, bp)                    # L column blocks
         for l in range(len(self.layers)):

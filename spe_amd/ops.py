@@ -690,6 +690,164 @@ class _AttentionFlash(Function):
         return dq, dk_, dv_, None, None, None
 
 
+class MemoryKV:
+    """What the memory-side node hands to the cross-attention nodes of the decoder layers (not a tensor: fragments + the shared
+    gradient buffers the layers' backward passes fill)."""
+
+    def __init__(self):
+        self.Kf = self.V16 = self.K16 = self.Vf = None
+        self.dYm = self.dYp = None          # bf16 [B*S, 2*L*d] / [B*S, L*d]: allocated by the first layer's backward of a step
+        self.written = set()
+        self.dims = None                    # (L, B, S, H, dh)
+        self.ztok = None
+
+
+class _MemorySideKV(Function):
+    """ca_kcontent_proj / ca_v_proj (of `memory`) and ca_kpos_proj (of `pos`) of ALL decoder layers and the per-head key layout
+    [k_content | k_pos] (reference models/transformer.py:389-419) -> the operand fragments of the flash MHA kernels, without an fp32
+    key / value tensor: two stacked GEMMs on IEEE fp16 single-term operands with fp16 outputs (north_star's "decoder cross-attention
+    GEMM": spe_gemm_bf16nt act bits 8 + 9) and ONE fragment launch (spe_kv_frags).  Outputs: one scalar token per layer - the
+    autograd edges to the layers' cross-attention nodes, which write their key / value gradients straight into the bf16 dY operands
+    of this node's backward GEMMs (MemoryKV.dYm / dYp) and return a zero for the token."""
+
+    @staticmethod
+    @K.forward_scope
+    def forward(ctx, holder, memory, pos, H, *wb):
+        L = len(wb) // 6
+        Wm, Wp, bm, bp = wb[:2 * L], wb[2 * L:3 * L], wb[3 * L:5 * L], wb[5 * L:]
+        B, S, d = memory.shape
+        dh = d // H
+        m2, p2 = memory.reshape(B * S, d), pos.reshape(B * S, d)
+        m2 = m2 if m2.is_contiguous() else m2.contiguous()
+        p2 = p2 if p2.is_contiguous() else p2.contiguous()
+        train = any(ctx.needs_input_grad)
+        Wmh, bmc = K.weightcat_f16(Wm, bm)
+        Wph, bpc = K.weightcat_f16(Wp, bp)
+        ym = torch.empty((B * S, 2 * L * d), device=memory.device, dtype=torch.float16)
+        yp = torch.empty((B * S, L * d), device=memory.device, dtype=torch.float16)
+        K.gemm16(K.cvt_f16(m2), Wmh, ym, B * S, 2 * L * d, d, d, d, 2 * L * d, bias=bmc, act=0x300)
+        K.gemm16(K.cvt_f16(p2), Wph, yp, B * S, L * d, d, d, d, L * d, bias=bpc, act=0x300)
+        holder.Kf, holder.V16, holder.K16, holder.Vf = K.kv_frags(ym, yp, L, B, S, H, dh, train)
+        holder.dims = (L, B, S, H, dh)
+        holder.ztok = torch.zeros((1,), device=memory.device, dtype=torch.float32)
+        ctx.holder = holder
+        ctx.params = (Wm, Wp, bm, bp)
+        if train:
+            # the backward runs on single bf16 operands like every other Linear backward: bf16 copies of the inputs (shared with the
+            # other consumers of `memory` / `pos`) and the transposed bf16 weight stack for the input gradient
+            m16, _, _ = K.act16(m2, False, memory)
+            p16, _, _ = K.act16(p2, False, pos)
+            ctx.save_for_backward(m16, p16, K.weightcat16(Wm, bm)[1])
+        toks = tuple(torch.zeros((1,), device=memory.device, dtype=torch.float32) for _ in range(L))
+        return toks
+
+    @staticmethod
+    @K.backward_scope
+    def backward(ctx, *dtoks):
+        m16, p16, WmT = ctx.saved_tensors
+        h = ctx.holder
+        L, B, S, H, dh = h.dims
+        d, R = H * dh, B * S
+        Wm, Wp, bm, bp = ctx.params
+        dev = m16.device
+        if h.dYm is None:
+            h.dYm = torch.zeros((R, 2 * L * d), device=dev, dtype=torch.bfloat16)
+            h.dYp = torch.zeros((R, L * d), device=dev, dtype=torch.bfloat16)
+            h.written = set(range(L))
+        for l in range(L):           # a layer whose cross attention got no gradient this step: zeros
+            if l not in h.written:
+                h.dYm[:, 2 * l * d:(2 * l + 2) * d].zero_()
+                h.dYp[:, l * d:(l + 1) * d].zero_()
+        dbm = [K.grad_buffer(b) for b in bm]
+        dbm = [g.view(-1) if g is not None else torch.empty((d,), device=dev, dtype=torch.float32) for g in dbm]
+        dbp = [K.grad_buffer(b) for b in bp]
+        dbp = [g.view(-1) if g is not None else torch.empty((d,), device=dev, dtype=torch.float32) for g in dbp]
+        K.colsum_bf16_blocks(h.dYm, d, dbm)
+        K.colsum_bf16_blocks(h.dYp, d, dbp)
+        dWm = [K._dw16_tn(h.dYm[:, i * d:(i + 1) * d], m16, d, d, R, K.grad_buffer(Wm[i]), lda=2 * L * d) for i in range(2 * L)]
+        dWp = [K._dw16_tn(h.dYp[:, i * d:(i + 1) * d], p16, d, d, R, K.grad_buffer(Wp[i]), lda=L * d) for i in range(L)]
+        dmem = None
+        if ctx.needs_input_grad[1]:
+            dmem = torch.empty((R, d), device=dev, dtype=torch.float32)
+            K.gemm16(h.dYm, WmT, dmem, R, d, 2 * L * d, 2 * L * d, 2 * L * d, d)
+            dmem = dmem.view(B, S, d)
+        dpos = None
+        if ctx.needs_input_grad[2]:
+            dpos = torch.empty((R, d), device=dev, dtype=torch.float32)
+            K.gemm16(h.dYp, K.weightcat16(Wp, bp)[1], dpos, R, d, L * d, L * d, L * d, d)
+            dpos = dpos.view(B, S, d)
+        h.dYm = h.dYp = None
+        h.written = set()
+        return (None, dmem, dpos, None, *dWm, *dWp, *[g.view_as(b) for g, b in zip(dbm, bm)], *[g.view_as(b) for g, b in zip(dbp, bp)])
+
+
+class _CrossAttentionKV(Function):
+    """softmax(scale q k^T + key_padding_mask) [dropout] v for one decoder layer (reference models/attention.py:277-383) on the
+    fragments of _MemorySideKV: q [B,Lq,H,2 dh] fp32, keys / values by (holder, layer).  The key / value gradients do not travel
+    through autograd as fp32 tensors: they are scattered as bf16 into the memory-side node's dY buffers (spe_kv_grad_scatter)."""
+
+    @staticmethod
+    @K.forward_scope
+    def forward(ctx, q, tok, holder, layer, mask_u8, scale, p_drop):
+        B, Lq, H, dk = q.shape
+        L, _, S, _, dh = holder.dims
+        sc = scale * K.LOG2E
+        need_bwd = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        jobs = [(q, sc, 322 + K.F16)] + ([(q, sc, 16)] if need_bwd else [])
+        packs = K.attn_pack_multi(jobs)
+        nch = K.mha_plan(B, H, Lq, S)
+        seed, off = K.next_rng() if p_drop > 0 else (0, 0)
+        O, lse, keep = K.mha_fwd(packs[0], holder.Kf[layer], holder.V16[layer], mask_u8, B, H, Lq, S, dk, dh, nch, p_drop, seed, off)
+        ctx.meta = (B, Lq, S, H, dk, dh, nch, scale, p_drop, layer)
+        ctx.holder = holder
+        if need_bwd:
+            ctx.save_for_backward(packs[0], packs[1], O, lse, mask_u8, keep)
+        return O
+
+    @staticmethod
+    @K.backward_scope
+    def backward(ctx, dO):
+        Qf, Q16, O, lse, mask_u8, keep = ctx.saved_tensors
+        B, Lq, S, H, dk, dh, nch, scale, p_drop, layer = ctx.meta
+        h = ctx.holder
+        L = h.dims[0]
+        d = H * dh
+        dO = dO.contiguous()
+        dO4 = dO.view(B, Lq, H, dh)
+        D = (dO4 * O.view(B, Lq, H, dh)).sum(-1).permute(0, 2, 1).contiguous()          # [B,H,Lq] = rowsum(dO . O)
+        dOf, dO16 = K.attn_pack_multi([(dO4, 1.0, 322), (dO4, 1.0, 16)])
+        dq, dk_, dv_ = K.mha_bwd(Qf, h.Kf[layer], h.Vf[layer], dOf, h.K16[layer], Q16, dO16, mask_u8, lse, D, keep, B, H, Lq, S, dk, dh, nch,
+                                 scale, p_drop)
+        if h.dYm is None:
+            h.dYm = torch.empty((B * S, 2 * L * d), device=dO.device, dtype=torch.bfloat16)
+            h.dYp = torch.empty((B * S, L * d), device=dO.device, dtype=torch.bfloat16)
+            h.written = set()
+        K.kv_grad_scatter(dk_, dv_, h.dYm, h.dYp, layer, B, S, H, dh)
+        h.written.add(layer)
+        return dq, h.ztok, None, None, None, None, None
+
+
+def memory_side_kv_ok(memory, Wm, Wp, H):
+    """The fragment path of the decoder's memory side: benchmark precision modes, flash-MHA shapes, GEMM alignment."""
+    B, S, d = memory.shape
+    dh = d // H
+    return (FLASH_MHA and MEMKV and memory.is_cuda and K.get_precision() != "bf16x3" and B * S >= 2048 and S >= FLASH_MIN_KEYS and d % 64 == 0
+            and dh % 8 == 0 and dh <= 48 and len(Wm) <= 32 and all(W.shape == (d, d) and W.is_contiguous() for W in list(Wm) + list(Wp)))
+
+
+def memory_side_kv(memory, pos, H, Wm, Wp, bm, bp):
+    """-> (holder, tokens): see _MemorySideKV.  Wm = [kcontent_0, v_0, kcontent_1, v_1, ...], Wp = [kpos_0, ...]."""
+    holder = MemoryKV()
+    toks = _MemorySideKV.apply(holder, memory, pos, H, *Wm, *Wp, *bm, *bp)
+    return holder, toks
+
+
+def cross_attention_kv(q, tok, holder, layer, key_padding_mask, scale, p_drop):
+    m = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
+    return _CrossAttentionKV.apply(q, tok, holder, layer, m, float(scale), float(p_drop))
+
+
+MEMKV = __import__("os").environ.get("SPE_MEMKV", "1") != "0"
 FLASH_MHA = __import__("os").environ.get("SPE_FLASH_MHA", "1") != "0"
 FLASH_MIN_KEYS = 512
 
