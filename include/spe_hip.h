@@ -341,6 +341,21 @@ int spe_box_loss(const float* pred_boxes, const long* srow, const float* tbox, c
 int spe_box_loss_bwd(const long* srow, const int* lidx, const float* g_l1, const float* g_giou, const float* c1,
                      const float* c2, float* dpred, long n, spe_stream_t stream);
 
+/* ---- multi-head attention over a few rows: the decoder's query self-attention (reference models/transformer.py:368-386 through
+ * models/attention.py:277-383; 100 queries per proposal stage) as ONE launch each way, the whole (batch, head) problem in the LDS of
+ * one workgroup, plain fp32: softmax(scale q k^T + key_padding_mask), dropout, . v.  q / k / v: [B, L, H, d] views (element strides
+ * batch, row, head; unit d stride); O [B, Lq, H*dv]; P [B, H, Lq, ld] (ld = Lk rounded up to 4): the softmax output, saved for the
+ * backward; dq [B, Lq, H*dk], dk [B, Lk, H*dk], dv [B, Lk, H*dv] dense.  Dropout stream: element index ((b H + h) Lq + q) ld + key.
+ * -2 when the problem does not fit 160 KB of LDS (callers keep the GEMM + softmax path). */
+int spe_mha_small_fwd(const float* q, long qb, long qn, long qh, const float* k, long kb, long kn, long kh,
+                      const float* v, long vb, long vn, long vh, const void* mask, float* O, float* P,
+                      int B, int H, int Lq, int Lk, int dk, int dv, float scale, float p_drop, uint64_t seed, uint64_t offset,
+                      spe_stream_t stream);
+int spe_mha_small_bwd(const float* q, long qb, long qn, long qh, const float* k, long kb, long kn, long kh,
+                      const float* v, long vb, long vn, long vh, const float* P, const float* dO, float* dq, float* dk_out, float* dv_out,
+                      int B, int H, int Lq, int Lk, int dk, int dv, float scale, float p_drop, uint64_t seed, uint64_t offset,
+                      spe_stream_t stream);
+
 /* ---- memory side of the decoder's conditional cross attention for ALL layers (reference models/transformer.py:389-419):
  * spe_kv_frags turns the fp16 outputs of the two stacked projection GEMMs (spe_gemm_bf16nt with act bits 8 + 9) -
  *   ym16 [B*S][ldm]: column block 2l = ca_kcontent_proj_l(memory), 2l + 1 = ca_v_proj_l(memory);  yp16 [B*S][ldp]: block l =

@@ -1188,6 +1188,38 @@ def mha_bwd(Qf, Kf, Vf, dOf, K16, Q16, dO16, mask_u8, lse, D, keep, B, H, Lq, Lk
     return dq, dk_, dv_
 
 
+def mha_small_ok(Lq, Lk, dk, dv):
+    f = (Lq + Lk) * (dk + 1) + Lk * dv + Lq * dv + 2 * Lq * (Lk + 1)
+    # OFF by default: measured inside the cfg2 step (same box, interleaved) the one-launch kernel is SLOWER than the GEMM + softmax
+    # launches it replaces - 56.5 / 56.8 ms against 55.5 / 56.0 ms per step: 32 workgroups, every product read straight from LDS (two
+    # ds_read per FMA: LDS-bandwidth bound, ~14 us per contraction phase).  Kept behind SPE_MHA_SMALL=1 with its parity test.
+    return 4 * f <= 160 * 1024 and os.environ.get("SPE_MHA_SMALL", "0") == "1"
+
+
+def mha_small_fwd(q, k, v, mask_u8, scale, p_drop, seed, offset):
+    """q [B,Lq,H,dk], k [B,Lk,H,dk], v [B,Lk,H,dv] fp32 views (unit last stride) -> O [B,Lq,H*dv], P [B,H,Lq,ld]."""
+    B, Lq, H, dk = q.shape
+    Lk, dv = k.shape[1], v.shape[3]
+    O = torch.empty((B, Lq, H * dv), device=q.device, dtype=torch.float32)
+    P = torch.empty((B, H, Lq, pad4(Lk)), device=q.device, dtype=torch.float32)
+    _call("spe_mha_small_fwd", _p(q), q.stride(0), q.stride(1), q.stride(2), _p(k), k.stride(0), k.stride(1), k.stride(2),
+          _p(v), v.stride(0), v.stride(1), v.stride(2), _p(mask_u8), _p(O), _p(P), B, H, Lq, Lk, dk, dv, float(scale), float(p_drop),
+          seed, offset, _st())
+    return O, P
+
+
+def mha_small_bwd(q, k, v, P, dO, scale, p_drop, seed, offset):
+    B, Lq, H, dk = q.shape
+    Lk, dv = k.shape[1], v.shape[3]
+    dq = torch.empty((B, Lq, H, dk), device=q.device, dtype=torch.float32)
+    dk_ = torch.empty((B, Lk, H, dk), device=q.device, dtype=torch.float32)
+    dv_ = torch.empty((B, Lk, H, dv), device=q.device, dtype=torch.float32)
+    _call("spe_mha_small_bwd", _p(q), q.stride(0), q.stride(1), q.stride(2), _p(k), k.stride(0), k.stride(1), k.stride(2),
+          _p(v), v.stride(0), v.stride(1), v.stride(2), _p(P), _p(dO), _p(dq), _p(dk_), _p(dv_), B, H, Lq, Lk, dk, dv, float(scale),
+          float(p_drop), seed, offset, _st())
+    return dq, dk_, dv_
+
+
 _CONTRACT_WS = {}      # device -> (scratch floats, zeroed counters) shared by every contraction launch of the stream
 
 

@@ -690,6 +690,29 @@ class _AttentionFlash(Function):
         return dq, dk_, dv_, None, None, None
 
 
+class _AttentionSmall(Function):
+    """softmax(scale q k^T + key_padding_mask) [dropout] v over a few rows (the decoder's 100-query self-attention, reference
+    models/transformer.py:368-386): one launch each way, everything in the LDS of one workgroup per (batch, head), plain fp32
+    (csrc/mha_small.hip) - instead of two GEMMs + a softmax launch forward and four GEMMs + a softmax launch backward."""
+
+    @staticmethod
+    @K.forward_scope
+    def forward(ctx, q, k, v, mask_u8, scale, p_drop):
+        seed, off = K.next_rng() if p_drop > 0 else (0, 0)
+        O, P = K.mha_small_fwd(q, k, v, mask_u8, scale, p_drop, seed, off)
+        ctx.meta = (scale, p_drop, seed, off)
+        ctx.save_for_backward(q, k, v, P)
+        return O
+
+    @staticmethod
+    @K.backward_scope
+    def backward(ctx, dO):
+        q, k, v, P = ctx.saved_tensors
+        scale, p_drop, seed, off = ctx.meta
+        dq, dk_, dv_ = K.mha_small_bwd(q, k, v, P, dO.contiguous(), scale, p_drop, seed, off)
+        return dq, dk_, dv_, None, None, None
+
+
 class MemoryKV:
     """What the memory-side node hands to the cross-attention nodes of the decoder layers (not a tensor: fragments + the shared
     gradient buffers the layers' backward passes fill)."""
@@ -862,6 +885,9 @@ def attention(q, k, v, key_padding_mask=None, scale=1.0, p_drop=0.0, need_map=Fa
     if (FLASH_MHA and not need_map and K.get_precision() != "bf16x3" and q.is_cuda and q.shape[3] <= 96 and v.shape[3] <= 64
             and k.shape[1] >= FLASH_MIN_KEYS and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1):
         return _AttentionFlash.apply(q, k, v, m, float(scale), float(p_drop)), None
+    if (not need_map and q.is_cuda and q.dtype == torch.float32 and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+            and K.mha_small_ok(q.shape[1], k.shape[1], q.shape[3], v.shape[3])):
+        return _AttentionSmall.apply(q, k, v, m, float(scale), float(p_drop)), None
     return _Attention.apply(q, k, v, m, float(scale), float(p_drop), need_map)
 
 

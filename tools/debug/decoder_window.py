@@ -12,8 +12,14 @@ w = rows[a:b]
 def short(n):
     n = n.replace("void ", "")
     return n[:70]
-m1 = max(i for i, r in enumerate(w) if "talking_fused_kernel" in r[2] and ", 1, " in r[2].split("<")[1][:20])
-fwd_end = max(i for i, r in enumerate(w) if "attn_contract_kernel<3, false" in r[2] and i < m1 + 3)
+def is_flash_fwd(n):          # talking_flash_fwd_kernel<H, DSTEPS, TAIL16, DROP, KV = false>: the forward pass (round 4)
+    return "talking_flash_fwd_kernel" in n and n.split("<")[1].split(">")[0].split(",")[4].strip() == "false"
+if any(is_flash_fwd(r[2]) for r in w):
+    m1 = max(i for i, r in enumerate(w) if is_flash_fwd(r[2]))
+    fwd_end = max(i for i, r in enumerate(w) if "flash_merge_kernel" in r[2] and i < m1 + 3)
+else:
+    m1 = max(i for i, r in enumerate(w) if "talking_fused_kernel" in r[2] and ", 1, " in r[2].split("<")[1][:20])
+    fwd_end = max(i for i, r in enumerate(w) if "attn_contract_kernel<3, false" in r[2] and i < m1 + 3)
 m2 = min(i for i, r in enumerate(w) if "talking_fused_kernel" in r[2] and r[2].split("<")[1].split(",")[3].strip() == "2")
 m3 = max(i for i, r in enumerate(w) if "talking_fused_kernel" in r[2] and r[2].split("<")[1].split(",")[3].strip() == "3")
 for title, lo, hi in (("backbone forward", 0, fwd_end + 1), ("decoder + criteria + class attention (fwd and bwd)", fwd_end + 1, m2), ("backbone backward", m2, m3 + 1), ("tail: stem backward, optimiser", m3 + 1, len(w))):
