@@ -20,6 +20,10 @@ ws = torch.zeros(B * nt * 8 * H * 32, device=dev)
 K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws, None, None, B, H, N, dh, 0.0, 0, 0)
 M, IL = K.attn_merge(ws, B, H, N, spw0, 0)
 c0 = K.flash_rows(M, IL, bl, B, H, N, 0)
+dO = torch.randn(B, N, C, generator=g).to(dev)
+dO16 = K.attn_pack_multi([(dO.view(B, N, H, dh), 1.0, 16)])[0]
+dqkv = torch.zeros(B, N, 3 * C, device=dev)
 for _ in range(int(os.environ.get("REP", 3))):
     K.talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, 0.0, 0, 0, True, True)
+    K.talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, c0, dqkv.view(B, N, 3, H, dh)[:, :, 2], 0.0, 0, 0)
 torch.cuda.synchronize()
