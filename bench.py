@@ -334,6 +334,7 @@ def main():
         last = step()
     sync()
     dt_local = time.perf_counter() - t0
+    peak_mem = torch.cuda.max_memory_allocated(dev)
     K_res = K.timing_results()
     K.enable_timing([])
     reducer.measure = False
@@ -426,6 +427,7 @@ def main():
             "dp": {"cu_reserve": reducer.cu_reserve, "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
                    "fused_attention_workgroups": K.FUSED_NWG[3]},
             "dist": dist_info,
+            "hbm_peak_allocated_gb": round(peak_mem / 1e9, 2),           # torch allocator high-water mark through the timed steps (of 288 GB)
             "allreduce_exposed_ms_per_step": max(exposed), "allreduce_exposed_ms_per_rank": exposed,
             "roofline": {"bound": "mfma", "kernel": "talking_fused_kernel<8,2,3> (attention backward pass 2)", "launches": launches,
                          # algorithmic work only (dP' = dO V^T); the recomputed S = Q K^T is reported as `executed`

@@ -126,6 +126,18 @@ int spe_linear_small_fwd(const float* x, long ldx, const void* W16, const void* 
                          void* x16_out, int R, int N, int K, long ldc, int act, spe_stream_t stream);
 int spe_linear_small_bwd(const float* dy, const float* aux, int act, const void* x16, const void* WT16, float* dx, float* dW,
                          float* db, int R, int N, int K, spe_stream_t stream);
+/* Group form (round 4): nblk Linears of equal shape [N][K] applied to ONE input - the decoder layer's query-side projections
+ * (reference models/transformer.py:368-372: sa_qcontent / sa_kcontent / sa_v of tgt; 369-371, 399: sa_qpos / sa_kpos of every layer and
+ * ca_qpos of the first on query_pos) - as one launch each way; every Linear keeps its own cached weight copies, output and gradient
+ * buffers: the arguments are HOST arrays of nblk device pointers, nothing is stacked.  nblk <= 16.
+ * spe_linear_small_group_fwd: y[i] [R][N] = x W_i^T + bias[i] (W16lo != NULL: split operands, every element non-NULL); N % 32 == 0.
+ * spe_linear_small_group_bwd: dx [R][K] = sum_i dy[i] W_i (WT16[i] = bf16 W_i^T [K][N]), dW[i] [N][K] = dy[i]^T x16, db[i] [N] =
+ *   colsum(dy[i]), overwritten, fixed summation order; dy[i] == NULL: output i received no gradient - it adds nothing to dx and its
+ *   dW[i] / db[i] are not written.  dx, dW, db (or single elements of dW / db) may be NULL.  N % 128 == 0. */
+int spe_linear_small_group_fwd(const float* x, long ldx, const void* const* W16, const void* const* W16lo, const float* const* bias,
+                               float* const* y, void* x16_out, int R, int nblk, int N, int K, spe_stream_t stream);
+int spe_linear_small_group_bwd(const float* const* dy, const void* x16, const void* const* WT16, float* dx, float* const* dW,
+                               float* const* db, int R, int nblk, int N, int K, spe_stream_t stream);
 /* spe_gemm_bf16tn: C[m][n] = alpha * sum_r A16[r][m] * B16[r][n] - the weight gradient dW = dy^T x of a Linear (autograd of
  * reference models/cait.py:376,390,409, models/transformer.py:368-425) on ROW-MAJOR bf16 operands A16 [R, lda] (M columns)
  * and B16 [R, ldb] (N columns): the contraction runs over rows, the MFMA operands are formed by LDS transpose reads
@@ -205,6 +217,10 @@ int spe_talking_fused(int mode, const void* Qf, const void* Kf, const void* Vf, 
                       spe_stream_t stream);
 int spe_attn_merge(const float* ws, float* out0, float* out1, int B, int H, int N, int steps_per_wg, int mode,
                    spe_stream_t stream);
+/* mode-0 merge that ALSO writes the flash kernels' row constants rows [B][Np][H] = bl[g] log2(e) - M + log2(IL), zero for the rows
+ * N .. Np-1 (what spe_talking_flash_rows mode 0 computes from M / IL in a launch of its own).  Np: multiple of 16, >= 16 ceil(N / 16). */
+int spe_attn_merge_rows(const float* ws, float* M, float* IL, const float* bl, float* rows, int Np, int B, int H, int N,
+                        int steps_per_wg, spe_stream_t stream);
 int spe_talking_wgrad_reduce(const float* ws_w, int nwg, int H, float* dWl, float* dbl, float* dWw, float* dbw,
                              spe_stream_t stream);
 

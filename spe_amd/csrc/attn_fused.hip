@@ -1172,13 +1172,18 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
 }
 
 // Merge the per-slot partial statistics of each (b, q-tile): mode 0 -> M = max, IL = 1/sum; mode 2 -> D = sum.
+// rows (mode 0, optional): [B][Np][H] row constants of the flash kernels, bl[g] * log2(e) - max - log2(sum) (the addend that turns
+// Wl S into log2 P), zero for the rows N .. Np-1 - written here instead of by a launch of its own (spe_talking_flash_rows)
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ ws, float* __restrict__ out0, float* __restrict__ out1,
-                                                         int B, int H, int N, int nt, int steps_per_wg, int mode) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;          // over B*nt*H*16
-    if (i >= (long)B * nt * H * 16) return;
-    const int ql = (int)(i & 15); const int g = (int)((i >> 4) % H); const int bq = (int)(i / (16L * H));
-    const int b = bq / nt, qt = bq % nt, q = qt * 16 + ql;
-    if (q >= N) return;
+                                                         int B, int H, int N, int nt, int steps_per_wg, int mode,
+                                                         const float* __restrict__ bl, float* __restrict__ rows, int Np) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;          // over B*ntr*H*16, ntr = nt (or Np / 16 with rows)
+    const int ntr = rows ? Np / 16 : nt;
+    if (i >= (long)B * ntr * H * 16) return;
+    const int ql = (int)(i & 15); const int g = (int)((i >> 4) % H);
+    const int b = (int)(i / (16L * H * ntr)), qt = (int)((i / (16L * H)) % ntr), q = qt * 16 + ql;
+    const int bq = b * nt + qt;
+    if (q >= N) { if (rows) rows[((long)b * Np + q) * H + g] = 0.f; return; }
     const float* base = ws + (((long)bq * FUSED_MAXSLOT) * H * 16 + (long)g * 16 + ql) * 2;
     const long stride = (long)H * 16 * 2;
     const long o = ((long)b * H + g) * N + q;
@@ -1198,7 +1203,11 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
                 else l += e[1] * EXP2(e[0] - mn);
             }
         }
-    if (mode == 0) { out0[o] = mn; out1[o] = 1.f / l; }
+    if (mode == 0) {
+        const float il = 1.f / l;
+        out0[o] = mn; out1[o] = il;
+        if (rows) rows[((long)b * Np + q) * H + g] = bl[g] * 1.4426950408889634f - mn + __builtin_amdgcn_logf(il);
+    }
     else out0[o] = d;
 }
 
@@ -1229,7 +1238,19 @@ extern "C" int spe_attn_merge(const float* ws, float* out0, float* out1, int B, 
     const long n = (long)B * nt * H * 16;
     if (n <= 0) return 0;
     hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws, out0, out1, B, H, N, nt,
-                       steps_per_wg, mode);
+                       steps_per_wg, mode, nullptr, nullptr, 0);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// C-ABI: see include/spe_hip.h.  Mode-0 merge that also writes the flash kernels' row constants [B][Np][H] (Np a multiple of 16, >= N).
+extern "C" int spe_attn_merge_rows(const float* ws, float* M, float* IL, const float* bl, float* rows, int Np, int B, int H, int N,
+                                   int steps_per_wg, hipStream_t st) {
+    const int nt = (N + 15) / 16;
+    if ((long)B * nt * H <= 0) return 0;
+    if (!rows || !bl || Np < nt * 16 || (Np & 15)) return -2;
+    const long n = (long)B * (Np / 16) * H * 16;
+    hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws, M, IL, B, H, N, nt, steps_per_wg, 0, bl, rows, Np);
     SPE_CHECK_LAUNCH();
     return 0;
 }

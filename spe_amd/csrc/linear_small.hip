@@ -29,6 +29,7 @@
 // sides); LDS rows of KC + 8 bf16 = 196 / 68 dwords: 16 consecutive rows start 4 dwords apart (conflict-free b128 reads).
 // Row chunk RC of the row-contraction product: 512 / 256 likewise.
 #define LS_LDT (LS_T + 8)
+#define LS_MAXBLK 16
 
 typedef short s16x4l_t __attribute__((ext_vector_type(4)));
 typedef short s16x8l_t __attribute__((ext_vector_type(8)));
@@ -42,6 +43,11 @@ struct LinSmallArgs {
     const unsigned short* xs16;     // backward dW part: x_hi [R, K]
     float* dW; float* db;           // [N, K], [N]
     int R, N, K, tiles_dx;
+    // group mode (nblk > 0): nblk Linears [Nblk, K] sharing the input x - the column blocks of one stacked product, each with its own
+    // weight / bias / output (forward) and dy / W^T / dW / db (backward) pointers: no stacked copies of anything
+    int nblk, Nblk;
+    const unsigned short* Wb[LS_MAXBLK]; const unsigned short* Wlob[LS_MAXBLK]; const float* biasb[LS_MAXBLK]; float* yb[LS_MAXBLK];
+    const float* dyb[LS_MAXBLK]; const unsigned short* WTb[LS_MAXBLK]; float* dWb[LS_MAXBLK]; float* dbb[LS_MAXBLK];
 };
 
 __device__ __forceinline__ float ls_dact(float v, float h, int act) {
@@ -60,10 +66,13 @@ __device__ __forceinline__ uint2 ls_pack4(float a, float b, float c, float d) {
 
 // ---- C[r][n] = sum_k A[r][k] B[n][k] on a 32 x 32 tile: A fp32 [rows][lda] (rounded / split to bf16 while staged, optionally times
 // act'(aux)), B bf16 [ncols][K] (+ low part).  DACT: backward dx part.  Returns the tile in acc (one 16 x 16 MFMA tile per wave).
+// Ab / Bb (group backward, dx part): the contraction runs over the nblk column blocks of width Nblk; chunk k0 lies in block k0 / Nblk,
+// whose A rows (dy_i [R][Nblk]) and B rows (W_i^T [K][Nblk]) have row stride Nblk; a NULL A block contributes nothing.
 template <int LS_KC, bool SPLIT, bool DACT>
 __device__ __forceinline__ void ls_nt_tile(const float* __restrict__ A, long lda, const float* __restrict__ aux, int act, int r0, int R,
                                            const unsigned short* __restrict__ B, const unsigned short* __restrict__ Blo, int n0, int N, int K,
-                                           unsigned short* x16, bool write_x16, unsigned short* smem, f32x4_t& acc) {
+                                           unsigned short* x16, bool write_x16, unsigned short* smem, f32x4_t& acc,
+                                           const float* const* Ab = nullptr, const unsigned short* const* Bb = nullptr, int Nblk = 0) {
     constexpr int LS_LD = LS_KC + 8, LS_NA = LS_KC / 32, LS_NB = LS_KC / 64;      // float4 / 16-B chunks per thread of a 32 x KC fp32 / bf16 slab
     unsigned short* sA = smem;                         // [32][LS_LD]
     unsigned short* sB = sA + LS_T * LS_LD;
@@ -76,20 +85,22 @@ __device__ __forceinline__ void ls_nt_tile(const float* __restrict__ A, long lda
     // thread t: float4 columns (t & 31) + 32 m of rows (t >> 5) + 8 j of the fp32 slab; 16-B chunks (t & 15) + 16 m of rows (t >> 4) + 16 j of the bf16 slab
     auto load = [&](int k0) {
         const int kw = min(LS_KC, K - k0), n4 = kw >> 2, n8 = kw >> 3;           // K % 8 == 0
+        const float* Ak = A; const unsigned short* Bk = B; long lda_ = lda, ldb_ = K; int kk = k0;
+        if (Ab) { const int blk = k0 / Nblk; kk = k0 - blk * Nblk; Ak = Ab[blk]; Bk = Bb[blk]; lda_ = ldb_ = Nblk; }
 #pragma unroll
         for (int i = 0; i < LS_NA; ++i) {
             const int rl = (t >> 5) + 8 * (i & 3), c4 = (t & 31) + 32 * (i >> 2);
             if (c4 >= n4) continue;
-            const long off = (long)min(r0 + rl, R - 1) * lda + k0 + c4 * 4;
-            xa[i] = *reinterpret_cast<const float4*>(A + off);
+            const long off = (long)min(r0 + rl, R - 1) * lda_ + kk + c4 * 4;
+            xa[i] = Ak ? *reinterpret_cast<const float4*>(Ak + off) : make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (DACT) { if (aux) ha[i] = *reinterpret_cast<const float4*>(aux + off); }
         }
 #pragma unroll
         for (int i = 0; i < LS_NB; ++i) {
             const int nl = (t >> 4) + 16 * (i & 1), c8 = (t & 15) + 16 * (i >> 1);
             if (c8 >= n8) continue;
-            const long off = (long)min(n0 + nl, N - 1) * K + k0 + c8 * 8;
-            wb[i] = *reinterpret_cast<const u32x4g_t*>(B + off);
+            const long off = (long)min(n0 + nl, N - 1) * ldb_ + kk + c8 * 8;
+            wb[i] = *reinterpret_cast<const u32x4g_t*>(Bk + off);
             if constexpr (SPLIT) wl[i] = *reinterpret_cast<const u32x4g_t*>(Blo + off);
         }
     };
@@ -150,6 +161,16 @@ __global__ __launch_bounds__(256) void linear_small_fwd_kernel(LinSmallArgs p) {
     const int tiles_r = (p.g.M + LS_T - 1) / LS_T;
     const int tr = blockIdx.x % tiles_r, tn = blockIdx.x / tiles_r;
     f32x4_t acc1;
+    if (p.nblk > 0) {                   // group: column tile tn lies in block tn * 32 / Nblk, which has its own weight, bias and output
+        const int blk = tn * LS_T / p.Nblk, tl = tn - blk * (p.Nblk / LS_T);
+        ls_nt_tile<KC, SPLIT, false>(p.x, p.ldx, nullptr, 0, tr * LS_T, p.g.M, p.Wb[blk], p.Wlob[blk], tl * LS_T, p.Nblk, p.g.K, p.x16,
+                                 p.x16 != nullptr && tn == 0, ls_smem, acc1);
+        Gemm16Args g = p.g;
+        g.C = p.yb[blk]; g.bias = p.biasb[blk]; g.N = p.Nblk; g.ldc = p.Nblk;
+        f32x4_t accg[1][1] = {{acc1}};
+        gemm16_epilogue_plain<LS_T, LS_T>(g, accg, g.C, tr * LS_T, tl * LS_T);
+        return;
+    }
     ls_nt_tile<KC, SPLIT, false>(p.x, p.ldx, nullptr, 0, tr * LS_T, p.g.M, p.g.B, p.g.Blo, tn * LS_T, p.g.N, p.g.K, p.x16, p.x16 != nullptr && tn == 0,
                              ls_smem, acc1);
     f32x4_t acc[1][1] = {{acc1}};
@@ -178,7 +199,9 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(LinSmallArgs p) {
         const int tiles_r = (R + LS_T - 1) / LS_T;
         const int tr = blockIdx.x % tiles_r, tk = blockIdx.x / tiles_r;
         f32x4_t acc1;
-        ls_nt_tile<KC, false, true>(p.x, N, p.aux, p.act, tr * LS_T, R, p.g.B, nullptr, tk * LS_T, K, N, nullptr, false, ls_smem, acc1);
+        if (p.nblk > 0) ls_nt_tile<KC, false, true>(nullptr, 0, nullptr, 0, tr * LS_T, R, nullptr, nullptr, tk * LS_T, K, N, nullptr, false, ls_smem, acc1,
+                                                    p.dyb, p.WTb, p.Nblk);
+        else ls_nt_tile<KC, false, true>(p.x, N, p.aux, p.act, tr * LS_T, R, p.g.B, nullptr, tk * LS_T, K, N, nullptr, false, ls_smem, acc1);
         const int r = tr * LS_T + wm * 16 + fr, k = tk * LS_T + wn * 16 + (lane >> 4) * 4;
         if (r < R && k < K) *reinterpret_cast<float4*>(p.g.C + (long)r * K + k) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);     // K % 4 == 0
         return;
@@ -190,8 +213,15 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(LinSmallArgs p) {
     const int b2 = blockIdx.x - p.tiles_dx;
     const int tiles_n = (N + LS_T - 1) / LS_T;
     const int tn = b2 % tiles_n, tk = b2 / tiles_n;
-    const int n0 = tn * LS_T, k0 = tk * LS_T;
-    const bool want_dw = p.dW != nullptr, want_db = p.db != nullptr && tk == 0;
+    int n0 = tn * LS_T; const int k0 = tk * LS_T;
+    const float* dyp = p.x; float* dWp = p.dW; float* dbp = p.db; int Nld = N;
+    if (p.nblk > 0) {                   // group: this column tile's block has its own dy [R][Nblk], dW [Nblk][K] and db [Nblk]
+        const int blk = n0 / p.Nblk;
+        n0 -= blk * p.Nblk; Nld = p.Nblk;
+        dyp = p.dyb[blk]; dWp = p.dWb[blk]; dbp = p.dbb[blk];
+        if (!dyp) return;               // an output nobody differentiated: its parameter gradients are not touched
+    }
+    const bool want_dw = dWp != nullptr, want_db = dbp != nullptr && tk == 0;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 dv[LS_ND], hv[LS_ND]; u32x4g_t xv[LS_NX];
@@ -202,8 +232,8 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(LinSmallArgs p) {
         for (int i = 0; i < LS_ND; ++i) {
             const int r = rc0 + (t >> 3) + 32 * i;
             if (r >= R) continue;
-            const long off = (long)min(r, R - 1) * N + min(cn, N - 4);
-            dv[i] = *reinterpret_cast<const float4*>(p.x + off);
+            const long off = (long)min(r, R - 1) * Nld + min(cn, Nld - 4);
+            dv[i] = *reinterpret_cast<const float4*>(dyp + off);
             if (p.aux) hv[i] = *reinterpret_cast<const float4*>(p.aux + off);
         }
         if (want_dw) {
@@ -218,7 +248,7 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(LinSmallArgs p) {
     load(0);
     for (int rc0 = 0; rc0 < R; rc0 += LS_RC) {
         const int rows = min(LS_RC, R - rc0), rpad = (rows + 31) & ~31;
-        const bool cnv = n0 + (t & 7) * 4 < N, ckv = k0 + (t & 3) * 8 < K;
+        const bool cnv = n0 + (t & 7) * 4 < Nld, ckv = k0 + (t & 3) * 8 < K;
 #pragma unroll
         for (int i = 0; i < LS_ND; ++i) {
             const int rl = (t >> 3) + 32 * i;
@@ -250,17 +280,17 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(LinSmallArgs p) {
     }
     if (want_dw) {
         const int n = n0 + wm * 16 + fr, k = k0 + wn * 16 + (lane >> 4) * 4;
-        if (n < N && k < K) *reinterpret_cast<float4*>(p.dW + (long)n * K + k) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (n < Nld && k < K) *reinterpret_cast<float4*>(dWp + (long)n * K + k) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
     if (want_db) {          // 32 row lanes per column quad, added in a fixed order: deterministic, no atomics
         __syncthreads();
         *reinterpret_cast<float4*>(sred + (t >> 3) * 32 + (t & 7) * 4) = bsum;
         __syncthreads();
-        if (t < LS_T && n0 + t < N) {
+        if (t < LS_T && n0 + t < Nld) {
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < 32; ++i) s += sred[i * 32 + t];
-            p.db[n0 + t] = s;
+            dbp[n0 + t] = s;
         }
     }
 }
@@ -318,6 +348,83 @@ extern "C" int spe_linear_small_bwd(const float* dy, const float* aux, int act, 
     const int tiles_dw = dW ? tn * tk : (db ? tn : 0);          // bias gradient only: the k-tile-0 workgroups
     if (p.tiles_dx + tiles_dw == 0) return 0;
     const bool wide = p.tiles_dx + tiles_dw <= ls_latency_tiles();
+    auto smem_of = [](int kc, int rc) { const int a = 2 * LS_T * (kc + 8) * 2, b = 2 * rc * LS_LDT * 2 + 32 * 32 * 4; return a > b ? a : b; };
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_small_bwd_kernel<384, 512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           smem_of(384, 512));
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    if (wide) hipLaunchKernelGGL((linear_small_bwd_kernel<384, 512>), dim3(p.tiles_dx + tiles_dw), dim3(256), smem_of(384, 512), stream, p);
+    else hipLaunchKernelGGL((linear_small_bwd_kernel<128, 256>), dim3(p.tiles_dx + tiles_dw), dim3(256), smem_of(128, 256), stream, p);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- group entries: nblk Linears of equal shape [N, K] on ONE input (the decoder's query-side projections: reference models/transformer.py:
+// 368-372 sa_qcontent / sa_kcontent / sa_v of tgt, 369-371 + 399 sa_qpos / sa_kpos / ca_qpos of query_pos for every layer) - one launch each way
+// for all of them, every Linear keeping its own weight copies, output and gradient buffers (pointer tables, nothing is stacked).
+static bool ls_group_kc_wide(int N) { return N % 384 == 0; }
+extern "C" int spe_linear_small_group_fwd(const float* x, long ldx, const void* const* W16, const void* const* W16lo, const float* const* bias,
+                                          float* const* y, void* x16_out, int R, int nblk, int N, int K, hipStream_t stream) {
+    if (R <= 0 || N <= 0 || nblk <= 0) return 0;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (nblk > LS_MAXBLK || K <= 0 || (K & 7) || (N % LS_T) || (ldx & 3) || !al16(x) || !al16(x16_out)) return -2;
+    LinSmallArgs p = {};
+    const bool split = W16lo != nullptr;
+    for (int i = 0; i < nblk; ++i) {
+        if (!W16[i] || !y[i] || !al16(W16[i]) || !al16(y[i]) || (split && (!W16lo[i] || !al16(W16lo[i])))) return -2;
+        p.Wb[i] = reinterpret_cast<const unsigned short*>(W16[i]); p.Wlob[i] = split ? reinterpret_cast<const unsigned short*>(W16lo[i]) : nullptr;
+        p.biasb[i] = bias ? bias[i] : nullptr; p.yb[i] = y[i];
+    }
+    p.nblk = nblk; p.Nblk = N;
+    p.g.M = R; p.g.N = nblk * N; p.g.K = K; p.g.ldc = N; p.g.alpha = 1.f; p.g.act = 0; p.g.splitk = 1;
+    p.x = x; p.ldx = ldx; p.x16 = reinterpret_cast<unsigned short*>(x16_out);
+    const int tiles = ((R + LS_T - 1) / LS_T) * (nblk * N / LS_T);
+    const bool wide = tiles <= ls_latency_tiles();
+    const int smem = (split ? 4 : 2) * LS_T * ((wide ? 384 : 128) + 8) * (int)sizeof(unsigned short);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_small_fwd_kernel<384, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           4 * LS_T * 392 * (int)sizeof(unsigned short));
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    if (wide) {
+        if (split) hipLaunchKernelGGL((linear_small_fwd_kernel<384, true>), dim3(tiles), dim3(256), smem, stream, p);
+        else hipLaunchKernelGGL((linear_small_fwd_kernel<384, false>), dim3(tiles), dim3(256), smem, stream, p);
+    } else {
+        if (split) hipLaunchKernelGGL((linear_small_fwd_kernel<128, true>), dim3(tiles), dim3(256), smem, stream, p);
+        else hipLaunchKernelGGL((linear_small_fwd_kernel<128, false>), dim3(tiles), dim3(256), smem, stream, p);
+    }
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// dx [R][K] = sum_i dy_i W_i, dW_i [N][K] = dy_i^T x, db_i [N] = colsum(dy_i); dy[i] NULL: that output received no gradient (its dW / db are
+// not touched, it adds nothing to dx); dW / db NULL or with NULL elements: not wanted.  WT16[i]: bf16 W_i^T [K][N].  N % 128 == 0.
+extern "C" int spe_linear_small_group_bwd(const float* const* dy, const void* x16, const void* const* WT16, float* dx, float* const* dW,
+                                          float* const* db, int R, int nblk, int N, int K, hipStream_t stream) {
+    if (R <= 0 || N <= 0 || K <= 0 || nblk <= 0) return 0;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (nblk > LS_MAXBLK || (K & 7) || (N % 128) || !al16(x16) || !al16(dx) || (dx && !WT16) || (dW && !x16)) return -2;
+    LinSmallArgs p = {};
+    bool any_dw = false;
+    for (int i = 0; i < nblk; ++i) {
+        p.dyb[i] = dy[i]; p.WTb[i] = WT16 ? reinterpret_cast<const unsigned short*>(WT16[i]) : nullptr;
+        p.dWb[i] = dW ? dW[i] : nullptr; p.dbb[i] = db ? db[i] : nullptr;
+        if (!al16(p.dyb[i]) || !al16(p.WTb[i]) || !al16(p.dWb[i]) || (dx && !p.WTb[i])) return -2;
+        any_dw = any_dw || (p.dyb[i] && (p.dWb[i] || p.dbb[i]));
+    }
+    p.nblk = nblk; p.Nblk = N;
+    p.xs16 = reinterpret_cast<const unsigned short*>(x16); p.g.C = dx;
+    p.R = R; p.N = nblk * N; p.K = K;
+    const int tr = (R + LS_T - 1) / LS_T, tk = (K + LS_T - 1) / LS_T, tn = nblk * N / LS_T;
+    p.tiles_dx = dx ? tr * tk : 0;
+    const int tiles_dw = any_dw ? tn * tk : 0;
+    if (p.tiles_dx + tiles_dw == 0) return 0;
+    const bool wide = ls_group_kc_wide(N) && p.tiles_dx + tiles_dw <= ls_latency_tiles();
     auto smem_of = [](int kc, int rc) { const int a = 2 * LS_T * (kc + 8) * 2, b = 2 * rc * LS_LDT * 2 + 32 * 32 * 4; return a > b ? a : b; };
     static bool attr_set = false;
     if (!attr_set) {

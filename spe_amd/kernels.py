@@ -750,6 +750,63 @@ def linear_fwd(x2, W, b, act=0, want_pre=False, save_for_dw=True, src=None):
     return y, pre, x2
 
 
+LINEAR_GROUP = os.environ.get("SPE_LINEAR_GROUP", "1") != "0"
+
+
+def linear_group_ok(R, Ws, bs):
+    """Several Linears of one shape on one input of a few hundred rows: the one-launch group form of csrc/linear_small.hip."""
+    N, K = Ws[0].shape
+    return (LINEAR_GROUP and 2 <= len(Ws) <= 16 and _lin_small_ok(R, N, K) and N % 128 == 0
+            and all(W.shape == Ws[0].shape and W.is_contiguous() for W in Ws) and all(b is not None for b in bs))
+
+
+def _ptr_array(ptrs):
+    return (ctypes.c_void_p * len(ptrs))(*[(p if p else None) for p in ptrs])
+
+
+def linear_group_fwd(x2, Ws, bs, src=None):
+    """[x2 W_i^T + b_i] as n separate contiguous [R, N] tensors from ONE launch; -> (ys, x16 save for the backward)."""
+    _chk(x2, *Ws)
+    R, K = x2.shape
+    N = Ws[0].shape[0]
+    sp = split_fwd()
+    trip = [weight16(W, lo=sp) for W in Ws]
+    ent = getattr(src, "_spe16", None) if src is not None else None
+    x16 = ent[1] if (ent is not None and ent[0] == src._version and ent[1].shape == x2.shape) else None
+    x16_out = None
+    if x16 is None:
+        x16 = x16_out = torch.empty((R, K), device=x2.device, dtype=torch.bfloat16)
+        if src is not None:
+            src._spe16 = (src._version, x16, None, None)
+    ys = [torch.empty((R, N), device=x2.device, dtype=torch.float32) for _ in Ws]
+    _call("spe_linear_small_group_fwd", _p(x2), x2.stride(0), _ptr_array([t_[0].data_ptr() for t_ in trip]),
+          _ptr_array([t_[2].data_ptr() for t_ in trip]) if sp else None, _ptr_array([b.data_ptr() for b in bs]),
+          _ptr_array([y.data_ptr() for y in ys]), _p(x16_out), R, len(Ws), N, K, _st())
+    return ys, x16
+
+
+def linear_group_bwd(dys, x16, Ws, need_dx, dW_outs, db_outs):
+    """dys: list of contiguous fp32 [R, N] or None.  -> (dx or None, dWs, dbs); dW_outs / db_outs: bucket views (or None: fresh tensors);
+    entries of outputs without a gradient stay None."""
+    n = len(Ws)
+    N, K = Ws[0].shape
+    R = x16.shape[0]
+    dev = x16.device
+    dx = torch.empty((R, K), device=dev, dtype=torch.float32) if need_dx else None
+    dWs, dbs = [], []
+    for i in range(n):
+        if dys[i] is None:
+            dWs.append(None); dbs.append(None)
+            continue
+        dWs.append(dW_outs[i] if dW_outs[i] is not None else torch.empty((N, K), device=dev, dtype=torch.float32))
+        dbs.append(db_outs[i].view(-1) if db_outs[i] is not None else torch.empty((N,), device=dev, dtype=torch.float32))
+    _call("spe_linear_small_group_bwd", _ptr_array([0 if d is None else d.data_ptr() for d in dys]), _p(x16),
+          _ptr_array([weight16(W)[1].data_ptr() for W in Ws]) if need_dx else None, _p(dx),
+          _ptr_array([0 if w is None else w.data_ptr() for w in dWs]), _ptr_array([0 if b is None else b.data_ptr() for b in dbs]),
+          R, n, N, K, _st())
+    return dx, dWs, dbs
+
+
 def linear_bwd(dy2, xsave, W, need_dx=True, need_dw=True, need_db=True, dW_out=None, db_out=None, act=0, act_aux=None):
     """dx = dy @ W ; dW = dy.T @ x ; db = colsum(dy).  xsave: third result of linear_fwd.
     dW_out / db_out: zeroed destination buffers (grad_buffer).  act/act_aux: dy is the gradient w.r.t. the OUTPUT of
@@ -1315,6 +1372,16 @@ def attn_merge(ws_stats, B, H, N, spw, mode):
     out1 = torch.empty_like(out0) if mode == 0 else None
     _call("spe_attn_merge", _p(ws_stats), _p(out0), _p(out1), B, H, N, spw, mode, _st())
     return out0, out1
+
+
+def attn_merge_rows(ws_stats, bl, B, H, N, spw):
+    """Mode-0 merge -> (M, IL [B,H,N], c0 [B,Np,H]: the flash kernels' row constants) in one launch."""
+    Np = flash_plan(B, N)[3]
+    M = torch.empty((B, H, N), device=ws_stats.device, dtype=torch.float32)
+    IL = torch.empty_like(M)
+    c0 = torch.empty((B, Np, H), device=ws_stats.device, dtype=torch.float32)
+    _call("spe_attn_merge_rows", _p(ws_stats), _p(M), _p(IL), _p(bl), _p(c0), Np, B, H, N, spw, _st())
+    return M, IL, c0
 
 
 def talking_wgrad_reduce(ws_w, H, params):

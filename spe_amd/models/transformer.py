@@ -136,7 +136,7 @@ class TransformerDecoderLayer(nn.Module):
         k = torch.cat([k.view(B, S, H, dh), k_pos.view(B, S, H, dh)], dim=3)
         return k.view(B, S, 2 * d), v
 
-    def forward(self, tgt, mem_kv, memory_key_padding_mask, query_pos, query_sine_embed, is_first, n_stages=1):
+    def forward(self, tgt, mem_kv, memory_key_padding_mask, query_pos, query_sine_embed, is_first, n_stages=1, qp=None):
         """tgt [B, R*Q, d]: the R proposal stages are stacked along the query axis.  Cross attention, projections,
         FFN and LayerNorms are per-query, so they run once on all R*Q rows; only the query self-attention must not
         mix stages - it sees the same buffer as [B*R, Q, d]."""
@@ -144,16 +144,22 @@ class TransformerDecoderLayer(nn.Module):
         H, dh = self.nhead, d // self.nhead
         Q = RQ // n_stages
         # ---- self attention over the queries of each stage
-        q = self.sa_qcontent_proj(tgt) + self.sa_qpos_proj(query_pos)
-        k = self.sa_kcontent_proj(tgt) + self.sa_kpos_proj(query_pos)
-        v = self.sa_v_proj(tgt)
+        # qp: this layer's projections of query_pos (sa_qpos, sa_kpos, ca_qpos or None), evaluated for all layers at once by the decoder
+        q_pos, k_pos, ca_pos = qp if qp is not None else (self.sa_qpos_proj(query_pos), self.sa_kpos_proj(query_pos), None)
+        content = (self.sa_qcontent_proj, self.sa_kcontent_proj, self.sa_v_proj)
+        if ops.group_linear_ok(tgt, content):       # the three projections of tgt: one launch each way
+            q, k, v = ops.group_linear(tgt, content)
+        else:
+            q, k, v = (m(tgt) for m in content)
+        q = q + q_pos
+        k = k + k_pos
         sa = lambda t: t.view(B * n_stages, Q, d)
         tgt2 = self.self_attn(sa(q), sa(k), sa(v))[0].view(B, RQ, d)
         tgt = self.norm1.residual(tgt, tgt2, self.dropout1)
         # ---- conditional cross attention
         q = self.ca_qcontent_proj(tgt)
         if is_first:
-            q = q + self.ca_qpos_proj(query_pos)
+            q = q + (ca_pos if ca_pos is not None else self.ca_qpos_proj(query_pos))
         qs = self.ca_qpos_sine_proj(query_sine_embed)
         if isinstance(mem_kv[0], ops.MemoryKV):
             # keys / values are operand fragments of the flash MHA kernels, key layout [k_content | k_pos] for EVERY layer.  The first
@@ -216,6 +222,19 @@ class TransformerDecoder(nn.Module):
             k = torch.cat([k.view(B, S, H, dh), kp.view(B, S, H, dh)], dim=3)
             mem_cache[l] = (k.view(B, S, 2 * d), v)
 
+    def _query_pos_all(self, query_pos):
+        """query_pos is the same tensor in every layer (transformer.py:186-204): its 2 * num_layers + 1 projections (sa_qpos_proj and
+        sa_kpos_proj of every layer, ca_qpos_proj of the first) come from one group launch each way (<= 16 Linears per launch) instead
+        of 13 + 13 launches and 12 gradient accumulations.  -> per layer (sa_qpos, sa_kpos, ca_qpos or None), or None."""
+        mods = [m for layer in self.layers for m in (layer.sa_qpos_proj, layer.sa_kpos_proj)] + [self.layers[0].ca_qpos_proj]
+        if not ops.group_linear_ok(query_pos, mods[:2]):
+            return None
+        outs = []
+        for i in range(0, len(mods), 16):
+            chunk = mods[i:i + 16]
+            outs += list(ops.group_linear(query_pos, chunk)) if len(chunk) > 1 else [chunk[0](query_pos)]
+        return [(outs[2 * l], outs[2 * l + 1], outs[-1] if l == 0 else None) for l in range(len(self.layers))]
+
     def forward(self, tgt, memory, memory_key_padding_mask, pos, query_pos, mem_cache=None, n_stages=1):
         """tgt/query_pos [B, R*Q, d] (R stages stacked along the query axis); memory/pos [B,S,d].
         -> (hs [L,B,R*Q,d], reference_points [B,R*Q,2])."""
@@ -228,6 +247,7 @@ class TransformerDecoder(nn.Module):
         sine0 = gen_sineembed_for_position(reference_points[..., :2], self.d_model)
         if not mem_cache:
             self._memory_side_all(memory, pos, mem_cache)
+        qp_all = self._query_pos_all(query_pos)
         for layer_id, layer in enumerate(self.layers):
             if layer_id not in mem_cache:
                 mem_cache[layer_id] = layer.memory_side(memory, pos, layer_id == 0)
@@ -235,7 +255,7 @@ class TransformerDecoder(nn.Module):
             if layer_id > 0:
                 sine = sine0 * self.query_scale(output)
             output = layer(output, mem_cache[layer_id], memory_key_padding_mask, query_pos, sine, layer_id == 0,
-                           n_stages=n_stages)
+                           n_stages=n_stages, qp=None if qp_all is None else qp_all[layer_id])
             intermediate.append(self.norm(output))
         return torch.stack(intermediate), reference_points
 

@@ -127,6 +127,64 @@ def multi_linear(x, Ws, bs):
     return _MultiLinear.apply(x, *Ws, *bs)
 
 
+class _GroupLinear(Function):
+    """(x W_0^T + b_0, ..., x W_{n-1}^T + b_{n-1}) for n nn.Linear of one shape on ONE input of a few hundred rows - the query side of a
+    conditional-DETR decoder layer (reference models/transformer.py:368-372: sa_qcontent_proj / sa_kcontent_proj / sa_v_proj of tgt;
+    369-371, 399: sa_qpos_proj / sa_kpos_proj of every layer and the first layer's ca_qpos_proj of query_pos) - as ONE launch each way
+    (csrc/linear_small.hip group entries) instead of n forward launches, n backward launches and n - 1 gradient-accumulation adds;
+    same arithmetic per output as ops.linear on that path."""
+
+    @staticmethod
+    @K.forward_scope
+    def forward(ctx, x, *wb):
+        n = len(wb) // 2
+        Ws, bs = wb[:n], wb[n:]
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        ys, x16 = K.linear_group_fwd(x2, Ws, bs, src=x)
+        ctx.set_materialize_grads(False)          # an output outside the loss arrives as None, not as a zero tensor
+        ctx.params = (Ws, bs)
+        ctx.save_for_backward(x16)
+        N = Ws[0].shape[0]
+        return tuple(y.view(*shp[:-1], N) for y in ys)
+
+    @staticmethod
+    @K.backward_scope
+    def backward(ctx, *dys):
+        (x16,) = ctx.saved_tensors
+        Ws, bs = ctx.params
+        n, N = len(Ws), Ws[0].shape[0]
+        d2 = []
+        for d in dys:
+            if d is None:
+                d2.append(None)
+                continue
+            d = d.reshape(-1, N)
+            d2.append(d if d.is_contiguous() else d.contiguous())
+        # bucket views are claimed only for the outputs that received a gradient (a claimed view must be written)
+        dx, dWs, dbs = K.linear_group_bwd(d2, x16, Ws, ctx.needs_input_grad[0],
+                                          [K.grad_buffer(W) if d is not None else None for W, d in zip(Ws, d2)],
+                                          [K.grad_buffer(b) if d is not None else None for b, d in zip(bs, d2)])
+        if dx is not None:
+            ref = next(d for d in dys if d is not None)
+            dx = dx.view(*ref.shape[:-1], Ws[0].shape[1])
+        return (dx, *dWs, *[None if b is None else b.view_as(p) for b, p in zip(dbs, bs)])
+
+
+def group_linear_ok(x, mods):
+    """mods: nn.Linear-like modules (weight, bias) of one shape; True when the one-launch group form applies to x."""
+    if not x.is_cuda or len(mods) < 2:
+        return False
+    R = x.numel() // x.shape[-1]
+    return K.linear_group_ok(R, [m.weight for m in mods], [m.bias for m in mods])
+
+
+def group_linear(x, mods):
+    return _GroupLinear.apply(x, *[m.weight for m in mods], *[m.bias for m in mods])
+
+
 # ---------------------------------------------------------------------------------------------
 class _LayerNorm(Function):
     @staticmethod
@@ -383,13 +441,15 @@ class _TalkingHeadsAttentionFused(Function):
         ws_stats = torch.empty((B * nt * 8 * H * 32,), device=qkv.device, dtype=torch.float32)
         seed, off = K.next_rng() if p_drop > 0 else (0, 0)
         K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws_stats, None, None, B, H, N, dh, 0.0, 0, 0)
-        M, IL = K.attn_merge(ws_stats, B, H, N, spw0, 0)
         want16 = K.produces16(B * N, C)
         flash = K.flash_supported(H, dh)
         if flash:
+            M, IL, c0 = K.attn_merge_rows(ws_stats, bl, B, H, N, spw0)
+        else:
+            M, IL = K.attn_merge(ws_stats, B, H, N, spw0, 0)
+        if flash:
             # P' goes from the head mix straight into the P' V products (csrc/attn_flash.hip): the 554 MB (cfg2) P'd tensor of the
             # write pass is neither stored, streamed back nor saved - the backward recomputes it inside its dV pass
-            c0 = K.flash_rows(M, IL, bl, B, H, N, 0)
             O, O16, O16lo = K.talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, off, want16, K.split_fwd())
             Pd = c0                                                        # what the backward needs instead of P'd
         else:

@@ -92,10 +92,15 @@ class FlatAdamW(torch.optim.Optimizer):
                          b1, b2, eps, bc1, bc2, self._partials, clip, self.write_clipped_grads,
                          grad_scale=self.reducer.grad_scale())
         K.weights_changed()            # the update bypassed autograd's version counters: drop cached bf16 weight copies
+        return loss
+
+    def state_dict(self):
+        """torch's format carries a per-parameter `step` tensor: written here from the optimiser's own counter instead of
+        717 host-side tensor increments in every step."""
         for grp in self.param_groups:
             for p in grp["params"]:
-                self.state[p]["step"] += 1
-        return loss
+                self.state[p]["step"].fill_(float(self._step))
+        return super().state_dict()
 
     def zero_grad(self, set_to_none=True):
         """The reference loop calls optimizer.zero_grad() before backward (engine.py:161): the gradients live in the

@@ -140,3 +140,42 @@ def test_small_mha_matches_fp64(dev, B, H, Lq, Lk, dk, dv, p, masked):
     rel = lambda a, b: float((a.double() - b).norm() / b.norm())
     assert rel(O, Or) < 1e-5 and rel(P[..., :Lk], Pr) < 1e-5
     assert rel(dq, gq) < 1e-5 and rel(dk_, gk) < 1e-5 and rel(dv_, gv) < 1e-5, (rel(dq, gq), rel(dk_, gk), rel(dv_, gv))
+
+
+@pytest.mark.gpu
+def test_group_linear_matches_separate_linears():
+    """ops.group_linear (one launch each way for several Linears on one input: the decoder's query-side projections, reference
+    models/transformer.py:368-372, 399) against the same Linears evaluated one by one: outputs, weight and bias gradients bitwise
+    (same per-tile program), input gradient to rounding (one contraction over all blocks instead of a sum of n); an output
+    that receives no gradient leaves its parameters' gradients untouched."""
+    import torch.nn as nn
+    from spe_amd import kernels as K, ops
+    from spe_amd.models.layers import Linear
+    dev = torch.device("cuda:0")
+    K.set_precision("bf16s")
+    torch.manual_seed(3)
+    for n, R, d in ((3, 400, 384), (13, 400, 384), (2, 300, 256)):
+        mods = [Linear(d, d).to(dev) for _ in range(n)]
+        x = torch.randn(2, R // 2, d, device=dev, requires_grad=True)
+        assert ops.group_linear_ok(x, mods)
+        ws = [torch.randn(2, R // 2, d, device=dev) for _ in range(n)]
+        skip = n - 1 if n > 2 else None                     # this output is left out of the loss
+        ys = ops.group_linear(x, mods)
+        loss = sum((y * w).sum() for i, (y, w) in enumerate(zip(ys, ws)) if i != skip)
+        loss.backward()
+        got = (x.grad.clone(), [m.weight.grad for m in mods], [m.bias.grad for m in mods], [y.detach() for y in ys])
+        x.grad = None
+        for m in mods:
+            m.weight.grad = m.bias.grad = None
+        ys2 = [m(x) for m in mods]
+        loss2 = sum((y * w).sum() for i, (y, w) in enumerate(zip(ys2, ws)) if i != skip)
+        loss2.backward()
+        for i in range(n):
+            assert torch.equal(got[3][i], ys2[i].detach()), ("output", n, i)
+            if i == skip:
+                assert got[1][i] is None and got[2][i] is None
+                continue
+            assert torch.equal(got[1][i], mods[i].weight.grad), ("dW", n, i)
+            assert torch.equal(got[2][i], mods[i].bias.grad), ("db", n, i)
+        err = (got[0] - x.grad).norm() / x.grad.norm()
+        assert err < 2e-3, ("dx", n, float(err))        # bf16 single-term products, different summation order

@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--stack", action="store_true")
+    ap.add_argument("--copies", action="store_true", help="host-visible copy operators (H2D / D2D / D2H) with their call sites")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     lib.load()
@@ -52,9 +53,24 @@ def main():
         step()
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True,
-                 with_stack=a.stack) as prof:
+                 with_stack=a.stack or a.copies) as prof:
         step()
         torch.cuda.synchronize()
+    if a.copies:
+        names = {}
+        for e in prof.events():
+            if "emcpy" in e.name or "emset" in e.name:
+                names[e.name] = names.get(e.name, 0) + 1
+        print("memcpy / memset events:", names)
+        sites = {}
+        for e in prof.key_averages(group_by_stack_n=8):
+            if e.key in ("aten::_to_copy", "aten::copy_", "aten::item", "aten::_local_scalar_dense", "aten::tensor", "aten::lift_fresh",
+                         "aten::zeros", "aten::zero_", "aten::fill_", "aten::clone", "aten::contiguous"):
+                where = [s for s in e.stack if "spe_amd" in s or "bench" in s][:2]
+                sites[(e.key, tuple(w[-100:] for w in where))] = sites.get((e.key, tuple(w[-100:] for w in where)), 0) + e.count
+        for (k, w), n in sorted(sites.items(), key=lambda kv: -kv[1])[:a.top]:
+            print(f"{n:5d}  {k:26s} {' <- '.join(w)}")
+        return
     rows = []
     for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=6 if a.stack else 0):
         dt = getattr(e, "self_device_time_total", 0) or getattr(e, "self_cuda_time_total", 0)

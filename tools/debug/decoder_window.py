@@ -32,3 +32,14 @@ for title, lo, hi in (("backbone forward", 0, fwd_end + 1), ("decoder + criteria
             c[short(n)][0] += 1; c[short(n)][1] += (e - s) / 1e3
         for n, (k, t) in sorted(c.items(), key=lambda x: -x[1][1])[:28]:
             print("   %7.1f us %4d  %s" % (t, k, n))
+# ---- the launch sequence of ONE backbone block, forward (between two statistics passes) and backward (between two backward passes 1)
+def seq(title, idx):
+    if len(idx) < 14:
+        return
+    lo, hi = idx[12], idx[13]
+    print("== %s: one block = %d launches, %.1f us busy, %.1f us span" % (title, hi - lo, sum(e - s for s, e, _ in w[lo:hi]) / 1e3, (w[hi][0] - w[lo][0]) / 1e3))
+    for s, e, n in w[lo:hi]:
+        print("   %7.1f us  %s" % ((e - s) / 1e3, short(n)[:100]))
+mode = lambda r, k: "talking_fused_kernel" in r[2] and r[2].split("<")[1].split(",")[3].strip() == k
+seq("backbone forward", [i for i, r in enumerate(w) if mode(r, "0")])
+seq("backbone backward", [i for i, r in enumerate(w) if mode(r, "2")])
