@@ -239,7 +239,8 @@ int spe_talking_wgrad_reduce(const float* ws_w, int nwg, int H, float* dWl, floa
  *   operand of the output projection.
  * spe_talking_flash_dv: dv[b, key, g, :] = sum_q P'd[b,g][q,key] dO[b, q, g, :] (element strides ob, on, oh of dv) - the same walk
  *   with the key tiles resident: P'd is RECOMPUTED from the forward's fragments, statistics and dropout stream (nothing N x N is
- *   saved for the backward); dO16 = spe_attn_pack_multi kind 1 (bf16).
+ *   saved for the backward); dO16 = spe_attn_pack_multi kind 1 (bf16).  dv16 (optional): bf16(dv) with the same element strides - the
+ *   operand of the qkv Linear's backward GEMMs; dv may then be NULL (as `out` of spe_attn_contract may when out16 is given).
  * Supported: H in {4, 8}, 13 * H * ceil(dh / 16) * 512 + 3072 bytes of LDS <= 160 KB; -2 otherwise. */
 int spe_talking_flash_rows(const float* in0, const float* in1, const float* bl, float* out, int B, int H, int N, int Np, int mode,
                            spe_stream_t stream);
@@ -248,8 +249,8 @@ int spe_talking_flash_fwd(const void* Qf, const void* Kf, const void* V16, const
                           const float* c0, int Np, float* ws, float* O, void* O16, void* O16lo, int B, int H, int N, int dh, int nwg,
                           float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
 int spe_talking_flash_dv(const void* Qf, const void* Kf, const void* dO16, const float* Wl, const float* Ww, const float* bw,
-                         const float* c0, int Np, float* ws, float* dv, long ob, long on, long oh, int B, int H, int N, int dh, int nwg,
-                         float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
+                         const float* c0, int Np, float* ws, float* dv, void* dv16, long ob, long on, long oh, int B, int H, int N, int dh,
+                         int nwg, float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
 
 /* ---- streaming contractions of a blocked 16-bit score tensor T (written by spe_talking_fused modes 1/3):
  *   trans = 0: out[b, q, h, :]   = alpha * sum_key T[b,h][q,key] x[b, key, h, :]   (`attn @ v`, cait.py:388; dQ)

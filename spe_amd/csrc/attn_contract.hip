@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void attn_contract_kernel(const uint2* __restr
                     f32x4_t v = acc[r][d] + red[(r * DT + d) * 64 + lane];
                     v *= alpha;
                     const int dc = d * 16 + 4 * (lane >> 4);
-                    if (dc + 3 < dh && ((((uintptr_t)(dst + dc)) & 15) == 0)) {
+                    if (!out) {             // 16-bit result only (the gradient goes straight into the next GEMM's operand)
+                    } else if (dc + 3 < dh && ((((uintptr_t)(dst + dc)) & 15) == 0)) {
                         *reinterpret_cast<f32x4_t*>(dst + dc) = v;
                     } else {
 #pragma unroll

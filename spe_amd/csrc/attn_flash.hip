@@ -473,10 +473,28 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(const float* __restric
     for (int sl = 0; sl <= last_wg - first_wg; ++sl) acc += *reinterpret_cast<const f32x4_t*>(src + sl * slot_stride);
     acc *= (1.0f / FL_PD_SCALE);
     const long oi = (long)b * ob + (long)q * on + (long)g * oh + d;
+    if (d + 3 < dh && ((ob | on | oh) & 3) == 0) {        // the common case: one 16-B and up to two 8-B stores per lane
+        if (O && ((reinterpret_cast<uintptr_t>(O) & 15) == 0)) *reinterpret_cast<f32x4_t*>(O + oi) = acc;
+        else if (O) { O[oi] = acc[0]; O[oi + 1] = acc[1]; O[oi + 2] = acc[2]; O[oi + 3] = acc[3]; }
+        if (O16) {
+            unsigned short hi[4], lo[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { hi[k] = spe_f2bf(acc[k]); lo[k] = spe_f2bf(acc[k] - spe_bf2f(hi[k])); }
+            const uint2 h2 = make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
+            if ((reinterpret_cast<uintptr_t>(O16) & 7) == 0) *reinterpret_cast<uint2*>(O16 + oi) = h2;
+            else { O16[oi] = hi[0]; O16[oi + 1] = hi[1]; O16[oi + 2] = hi[2]; O16[oi + 3] = hi[3]; }
+            if (O16lo) {
+                const uint2 l2 = make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+                if ((reinterpret_cast<uintptr_t>(O16lo) & 7) == 0) *reinterpret_cast<uint2*>(O16lo + oi) = l2;
+                else { O16lo[oi] = lo[0]; O16lo[oi + 1] = lo[1]; O16lo[oi + 2] = lo[2]; O16lo[oi + 3] = lo[3]; }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (d + k >= dh) break;
-        O[oi + k] = acc[k];
+        if (O) O[oi + k] = acc[k];
         if (O16) {
             const unsigned short hi = spe_f2bf(acc[k]);
             O16[oi + k] = hi;
@@ -585,7 +603,8 @@ extern "C" int spe_talking_flash_fwd(const void* Qf, const void* Kf, const void*
 }
 
 extern "C" int spe_talking_flash_dv(const void* Qf, const void* Kf, const void* dO16, const float* Wl, const float* Ww, const float* bw,
-                                    const float* c0, int Np, float* ws, float* dv, long ob, long on, long oh, int B, int H, int N, int dh, int nwg,
-                                    float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
-    return flash_run(1, Kf, Qf, dO16, Wl, Ww, bw, c0, Np, ws, dv, ob, on, oh, nullptr, nullptr, B, H, N, dh, nwg, p_drop, seed, offset, st);
+                                    const float* c0, int Np, float* ws, float* dv, void* dv16, long ob, long on, long oh, int B, int H, int N, int dh,
+                                    int nwg, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
+    if (!dv && !dv16) return -2;
+    return flash_run(1, Kf, Qf, dO16, Wl, Ww, bw, c0, Np, ws, dv, ob, on, oh, dv16, nullptr, B, H, N, dh, nwg, p_drop, seed, offset, st);
 }

@@ -1294,14 +1294,15 @@ def attn_contract(T, X16, out4, trans, alpha=1.0, out16=None, out16lo=None):
     sum over q).  out4: [B,N,H,dh] fp32 view with unit last stride.  out16: optional bf16 tensor addressed with the SAME element
     strides (the bf16 copy of the result for the Linear that consumes it).  Element formats from the dtypes: bf16 T x bf16 X16;
     fp16 T x fp16 X16 (trans=False: the forward P'd V); fp16 T x bf16 X16 (trans=True: dV)."""
-    B, N, H, dh = out4.shape
-    assert out4.stride(3) == 1
+    ref = out4 if out4 is not None else out16          # out4 None: only the 16-bit result (out16: a view with the strides out4 would have)
+    B, N, H, dh = ref.shape
+    assert ref.stride(3) == 1
     tf, xf = T.dtype == torch.float16, X16.dtype == torch.float16
     fmt = {(False, False): 0, (True, True): 1, (True, False): 2}[(tf, xf)]
-    ws, cnt = _contract_ws(out4.device)
-    _call("spe_attn_contract", _p(T), _p(X16), _p(out4), out4.stride(0), out4.stride(1), out4.stride(2), B, H, N, dh,
+    ws, cnt = _contract_ws(ref.device)
+    _call("spe_attn_contract", _p(T), _p(X16), _p(out4), ref.stride(0), ref.stride(1), ref.stride(2), B, H, N, dh,
           int(trans), fmt, float(alpha), _p(ws), _p(cnt), ws.numel(), _p(out16), _p(out16lo), _st())
-    return out4
+    return ref
 
 
 # ---- flash-style talking-heads attention (csrc/attn_flash.hip): no N x N tensor in HBM -------------------------------------
@@ -1356,15 +1357,17 @@ def talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, of
     return O, O16, O16lo
 
 
-def talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, c0, dv4, p_drop, seed, offset):
-    """dv4 [B,N,H,dh] (fp32 view, unit last stride) = P'd^T dO with P'd recomputed from the forward's fragments and statistics."""
-    B, N, H, dh = dv4.shape
-    assert dv4.stride(3) == 1
+def talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, c0, dv4, p_drop, seed, offset, dv16=None):
+    """dv4 [B,N,H,dh] (fp32 view, unit last stride) = P'd^T dO with P'd recomputed from the forward's fragments and statistics.
+    dv16: bf16 view with the same element strides (then dv4 may be None: only the 16-bit result is written)."""
+    ref = dv4 if dv4 is not None else dv16
+    B, N, H, dh = ref.shape
+    assert ref.stride(3) == 1 and (dv4 is None or dv16 is None or dv4.stride() == dv16.stride())
     nmaj = flash_plan(B, N)[2]
-    ws = _flash_ws(dv4.device, B * nmaj * FLASH_SLOTS * 128 * H * 16 * ((dh + 15) // 16))
-    _call("spe_talking_flash_dv", _p(Qf), _p(Kf), _p(dO16), _p(Wl), _p(Ww), _p(bw), _p(c0), c0.shape[1], _p(ws), _p(dv4),
-          dv4.stride(0), dv4.stride(1), dv4.stride(2), B, H, N, dh, FLASH_NWG, float(p_drop), seed, offset, _st())
-    return dv4
+    ws = _flash_ws(ref.device, B * nmaj * FLASH_SLOTS * 128 * H * 16 * ((dh + 15) // 16))
+    _call("spe_talking_flash_dv", _p(Qf), _p(Kf), _p(dO16), _p(Wl), _p(Ww), _p(bw), _p(c0), c0.shape[1], _p(ws), _p(dv4), _p(dv16),
+          ref.stride(0), ref.stride(1), ref.stride(2), B, H, N, dh, FLASH_NWG, float(p_drop), seed, offset, _st())
+    return ref
 
 
 def attn_merge(ws_stats, B, H, N, spw, mode):

@@ -79,6 +79,10 @@ class Attention_talking_head(nn.Module):
 
     def context(self, x):
         """Attention output before the output projection."""
+        if ops.qkv_talking_attention_ok(x, self.qkv.weight, self.qkv.bias, self.num_heads):
+            # qkv Linear + attention as one autograd node: the gradient w.r.t. qkv only exists as the bf16 GEMM operand
+            return ops.qkv_talking_attention(x, self.qkv.weight, self.qkv.bias, self.proj_l.weight, self.proj_l.bias, self.proj_w.weight,
+                                             self.proj_w.bias, self.num_heads, self.scale, self.attn_drop if self.training else 0.0)
         qkv = self.qkv(x)
         return ops.talking_heads_attention(qkv, self.proj_l.weight, self.proj_l.bias, self.proj_w.weight,
                                            self.proj_w.bias, self.num_heads, self.scale,

@@ -4,6 +4,8 @@ libspe_hip.so kernel launches (spe_amd/kernels.py); torch only owns memory and t
 Layout convention inside spe_amd: activations are batch-first [B, L, D] (the reference's
 transformer uses [L, B, D]; only the public outputs follow the reference's layout).
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -419,6 +421,15 @@ class _TalkingHeadsAttentionFused(Function):
     @staticmethod
     @K.forward_scope
     def forward(ctx, qkv, Wl, bl, Ww, bw, H, scale, p_drop):
+        train = any(ctx.needs_input_grad)
+        O, saved = _TalkingHeadsAttentionFused._fwd(ctx, qkv, Wl, bl, Ww, bw, H, scale, p_drop, train)
+        if train:
+            ctx.save_for_backward(*saved)
+        return O
+
+    @staticmethod
+    def _fwd(ctx, qkv, Wl, bl, Ww, bw, H, scale, p_drop, train):
+        """-> (O, tensors the backward needs); also used by _QkvTalkingAttention (the qkv Linear inside the same node)."""
         B, N, C3 = qkv.shape
         C = C3 // 3
         dh = C // H
@@ -431,7 +442,6 @@ class _TalkingHeadsAttentionFused(Function):
         # forward operands in fp16 (O(1) values: 3 more mantissa bits than bf16 at the same size and MFMA rate)
         # ... and, when a backward will follow, its bf16 fragments of q / k / v from the same read of qkv (one launch; the fp32
         # qkv - 38 MB per block at cfg2 - is then neither re-read nor kept)
-        train = any(ctx.needs_input_grad)
         jobs = [(q, scale * K.LOG2E, 32 + K.F16), (k, 1.0, 32 + K.F16), (v, 1.0, 16 + K.F16)]
         if train:
             jobs += [(v, 1.0, 32), (k, 1.0, 16), (q, 1.0, 16)]
@@ -463,20 +473,27 @@ class _TalkingHeadsAttentionFused(Function):
             K.attach16(O, O16, O16lo)        # the output projection's operand, written by the contraction's epilogue
         ctx.meta = (B, N, C, H, dh, nt, scale, p_drop, seed, off, flash)
         ctx.wparams = (Wl, bl, Ww, bw)      # leaves: looked up in backward for their gradient buckets
-        if train:
-            ctx.save_for_backward(packed[3], packed[4], packed[5], Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw)
-        return O
+        saved = (packed[3], packed[4], packed[5], Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw) if train else ()
+        return O, saved
 
     @staticmethod
     @K.backward_scope
     def backward(ctx, dO):
-        Vf, K16, Q16, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw = ctx.saved_tensors
+        return (*_TalkingHeadsAttentionFused._bwd(ctx, ctx.saved_tensors, dO, False), None, None, None)
+
+    @staticmethod
+    def _bwd(ctx, saved, dO, out16):
+        """-> (dqkv, dWl, dbl, dWw, dbw).  out16: dqkv comes back as the bf16 [B, N, 3C] operand of the qkv Linear's backward GEMMs
+        (written by the contraction / merge epilogues); no fp32 copy exists then."""
+        Vf, K16, Q16, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw = saved
         B, N, C, H, dh, nt, scale, p_drop, seed, off, flash = ctx.meta
         spw, nwg = K.fused_plan(B, N, 2)
         dO = dO.contiguous()
-        dqkv = torch.empty((B, N, 3 * C), device=dO.device, dtype=torch.float32)
+        dqkv = torch.empty((B, N, 3 * C), device=dO.device, dtype=torch.bfloat16 if out16 else torch.float32)
         d5 = dqkv.view(B, N, 3, H, dh)
         dq, dk, dv = d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]
+        f32 = (lambda t: None) if out16 else (lambda t: t)          # the fp32 destination of a gradient (None: 16-bit only)
+        b16 = (lambda t: t) if out16 else (lambda t: None)
         dO4 = dO.view(B, N, H, dh)
         dOf, dO16 = K.attn_pack_multi([(dO4, 1.0, 32), (dO4, 1.0, 16)])
         nw = 2 * (H * H + H)
@@ -489,14 +506,72 @@ class _TalkingHeadsAttentionFused(Function):
         # dV[key,d] = sum_q P'd[q,key] dO[q,d] - issued here, between backward pass 2 and the contractions that re-read
         # its 554 MB of dS: a streaming read right after a pass that wrote that much runs ~20 % slower (measured)
         if flash:       # Pd holds the row constants c0: P'd is recomputed tile by tile inside the dV pass
-            K.talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, Pd, dv, p_drop, seed, off)
+            K.talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, Pd, f32(dv), p_drop, seed, off, dv16=b16(dv))
         else:
-            K.attn_contract(Pd, dO16, dv, True, alpha=1.0 / K.PD_SCALE)
+            K.attn_contract(Pd, dO16, f32(dv), True, alpha=1.0 / K.PD_SCALE, out16=b16(dv))
         dWl, dbl, dWw, dbw = K.talking_wgrad_reduce(ws_w, H, ctx.wparams)
         # dQ[q,d] = scale * sum_key dS[q,key] K[key,d] ; dK[key,d] = scale * sum_q dS[q,key] Q[q,d]
-        K.attn_contract(dS, K16, dq, False, alpha=scale)
-        K.attn_contract(dS, Q16, dk, True, alpha=scale)
-        return dqkv, dWl, dbl, dWw, dbw, None, None, None
+        K.attn_contract(dS, K16, f32(dq), False, alpha=scale, out16=b16(dq))
+        K.attn_contract(dS, Q16, f32(dk), True, alpha=scale, out16=b16(dk))
+        return dqkv, dWl, dbl, dWw, dbw
+
+
+class _QkvTalkingAttention(Function):
+    """qkv Linear + talking-heads attention of a backbone block (reference models/cait.py:376-389) as ONE autograd node: the gradient
+    w.r.t. qkv exists only as the bf16 operand of the Linear's backward GEMMs, written by the epilogues of the dQ / dK contractions and
+    the dV merge - no fp32 [B, N, 3C] gradient (38 MB per block at cfg2) is written, re-read and converted.  Same arithmetic as
+    ops.linear followed by _TalkingHeadsAttentionFused otherwise (the Linear's backward rounds that gradient to bf16 as well)."""
+
+    @staticmethod
+    @K.forward_scope
+    def forward(ctx, x, Wq, bq, Wl, bl, Ww, bw, H, scale, p_drop):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        y, _, xsave = K.linear_fwd(x2, Wq, bq, 0, want_pre=False, save_for_dw=True, src=x)
+        O, saved = _TalkingHeadsAttentionFused._fwd(ctx, y.view(*shp[:-1], Wq.shape[0]), Wl, bl, Ww, bw, H, scale, p_drop, True)
+        ctx.qparams = (Wq, bq)
+        ctx.save_for_backward(xsave, *saved)
+        return O
+
+    @staticmethod
+    @K.backward_scope
+    def backward(ctx, dO):
+        xsave, *saved = ctx.saved_tensors
+        Wq, bq = ctx.qparams
+        d16, dWl, dbl, dWw, dbw = _TalkingHeadsAttentionFused._bwd(ctx, saved, dO, True)
+        N3, Kd = Wq.shape
+        R = d16.numel() // N3
+        d16 = d16.view(R, N3)
+        dev = d16.device
+        gb = K.grad_buffer(bq)
+        db = gb.view(-1) if gb is not None else torch.empty((N3,), device=dev, dtype=torch.float32)
+        K.colsum_bf16_blocks(d16, N3, [db])                            # overwrites, fixed summation order
+        dW = K._dw16_tn(d16, xsave, N3, Kd, R, K.grad_buffer(Wq)) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((R, Kd), device=dev, dtype=torch.float32)
+            K.gemm16(d16, K.weight16(Wq)[1], dx, R, Kd, N3, N3, N3, Kd)
+            dx = dx.view(*dO.shape[:-1], Kd)
+        return dx, dW, db.view_as(bq), dWl, dbl, dWw, dbw, None, None, None
+
+
+QKV_FUSED = os.environ.get("SPE_QKV_FUSED", "1") != "0"
+
+
+def qkv_talking_attention_ok(x, Wq, bq, num_heads):
+    """The one-node form needs the bf16-operand Linear path with row-major saves, a bias, the fused attention kernels and gradients."""
+    C = x.shape[-1]
+    R = x.numel() // C
+    return (QKV_FUSED and x.is_cuda and bq is not None and Wq.is_contiguous() and torch.is_grad_enabled()
+            and (x.requires_grad or Wq.requires_grad) and Wq.requires_grad and bq.requires_grad
+            and K.get_precision() != "bf16x3" and K.DW_TN and K._lin16_ok(R, Wq.shape[0], C) and not K._lin_small_ok(R, Wq.shape[0], C)
+            and K.fused_supported(num_heads, C // num_heads))
+
+
+def qkv_talking_attention(x, Wq, bq, Wl, bl, Ww, bw, num_heads, scale, p_drop=0.0):
+    return _QkvTalkingAttention.apply(x, Wq, bq, Wl, bl, Ww, bw, num_heads, scale, p_drop)
 
 
 class _MlpGelu(Function):
