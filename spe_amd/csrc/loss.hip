@@ -155,11 +155,141 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float* __restrict__
     }
 }
 
+// The same algorithm with the per-column state (v, minv, way, p, used) in REGISTERS - lane t owns the columns t + 1 + 64 c, c < CPL - and
+// the problem's cost matrix staged once in LDS (transposed: a row's costs lie along the lanes) when it fits.  The LDS kernel above pays a
+// global-memory round trip for the cost row and several LDS round trips for the column state in EVERY step of the augmenting-path search,
+// and the search is one serial chain (round 3: 245 us per launch at 100 x 35, the GPU otherwise idle).  Identical arithmetic (fp64 potentials,
+// lowest column index on ties, same update order per value): the pairs are the same.  Row potentials u stay in LDS (indexed by row).
+#define HUNG_LDS_FLOATS (36 * 1024)
+template <int CPL>
+__global__ __launch_bounds__(64) void hungarian_reg_kernel(const float* __restrict__ cost, const int* __restrict__ toff,
+                                                           long* __restrict__ srow, long* __restrict__ gidx, int* __restrict__ lidx,
+                                                           int* __restrict__ err, int B, int Q) {
+    extern __shared__ float a_t[];                       // [n][m] when n * m <= HUNG_LDS_FLOATS
+    __shared__ double u[HUNG_QMAX + 1];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x, l = blockIdx.y;
+    const int total = toff[B];
+    const int n = toff[b + 1] - toff[b], m = Q;
+    if (n <= 0) return;
+    const float* a = cost + (long)l * Q * total + (long)Q * toff[b];      // a(i, j) = a[(j-1)*n + (i-1)]
+    const bool staged = (long)n * m <= HUNG_LDS_FLOATS;
+    if (staged)
+        for (int e = lane; e < n * m; e += 64) { const int j = e / n, i = e - j * n; a_t[i * m + j] = a[e]; }
+    for (int i = lane; i <= n; i += 64) u[i] = 0.0;
+    double v[CPL], minv[CPL]; int p[CPL], way[CPL]; bool used[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { v[c] = 0.0; p[c] = 0; way[c] = 0; }
+    // value of a per-column register of column j (1-based; uniform j) broadcast to the wave
+    auto col_i = [&](const int (&r)[CPL], int j) {
+        const int slot = (j - 1) >> 6, own = (j - 1) & 63;
+        int x = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) if (c == slot) x = r[c];
+        return __shfl(x, own, 64);
+    };
+    __syncthreads();
+    for (int i = 1; i <= n; ++i) {
+        const int p0 = i;                                 // the virtual column 0 holds the row being inserted
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { minv[c] = INFINITY; used[c] = false; }
+        int j0 = 0, pj0 = p0;
+        do {
+            if (j0 != 0) {
+                const int slot = (j0 - 1) >> 6, own = (j0 - 1) & 63;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) if (c == slot && lane == own) used[c] = true;
+            }
+            const int i0 = pj0;
+            const double ui0 = u[i0];
+            double best = INFINITY; int bj = 0x7fffffff;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int j = lane + 64 * c + 1;
+                if (j > m || used[c]) continue;
+                const float av = staged ? a_t[(i0 - 1) * m + (j - 1)] : a[(long)(j - 1) * n + (i0 - 1)];
+                const double cur = (double)av - ui0 - v[c];
+                if (cur < minv[c]) { minv[c] = cur; way[c] = j0; }
+                if (minv[c] < best) { best = minv[c]; bj = j; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o, 64); const int oj = __shfl_xor(bj, o, 64);
+                if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+            }
+            const double delta = best; const int j1 = bj;
+            if (j1 == 0x7fffffff || !(fabs(delta) <= 1.7e308)) {         // see hungarian_kernel: flag + identity assignment
+                if (err && lane == 0) atomicOr(err, 2);
+                const long ob = (long)l * total + toff[b];
+                for (int i2 = lane; i2 < n; i2 += 64) {
+                    srow[ob + i2] = ((long)l * B + b) * Q + i2;
+                    gidx[ob + i2] = toff[b] + i2;
+                    lidx[ob + i2] = l;
+                }
+                return;
+            }
+            __syncthreads();                              // every lane has read u[i0]
+            if (lane == 0) u[p0] += delta;                // column 0 is always in the tree
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int j = lane + 64 * c + 1;
+                if (j > m) continue;
+                if (used[c]) { u[p[c]] += delta; v[c] -= delta; }
+                else minv[c] -= delta;
+            }
+            j0 = j1;
+            pj0 = col_i(p, j0);
+            __syncthreads();
+        } while (pj0 != 0);
+        // augment along the alternating path (uniform walk; the owner of a column rewrites its p)
+        do {
+            const int j1 = col_i(way, j0);
+            const int pj1 = (j1 == 0) ? p0 : col_i(p, j1);
+            const int slot = (j0 - 1) >> 6, own = (j0 - 1) & 63;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) if (c == slot && lane == own) p[c] = pj1;
+            j0 = j1;
+        } while (j0);
+    }
+    const long obase = (long)l * total + toff[b];
+    int base = 0;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int j = lane + 64 * c + 1;
+        const bool has = j <= m && p[c] != 0;
+        const unsigned long long mask = __ballot(has);
+        if (has) {
+            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            srow[obase + pos] = ((long)l * B + b) * Q + (j - 1);
+            gidx[obase + pos] = toff[b] + (p[c] - 1);
+            lidx[obase + pos] = l;
+        }
+        base += __popcll(mask);
+    }
+}
+
+template <int CPL>
+static int launch_hungarian_reg(const float* cost, const int* toff, long* srow, long* gidx, int* lidx, int* err, int L, int B, int Q, hipStream_t st) {
+    constexpr int smem = HUNG_LDS_FLOATS * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hungarian_reg_kernel<CPL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(hungarian_reg_kernel<CPL>, dim3(B, L), dim3(64), smem, st, cost, toff, srow, gidx, lidx, err, B, Q);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
 // C-ABI: see include/spe_hip.h (spe_hungarian).  -2: Q above HUNG_QMAX (callers fall back to the host solver).
 extern "C" int spe_hungarian(const float* cost, const int* toff, long* srow, long* gidx, int* lidx, int* err, int L, int B,
                              int Q, hipStream_t st) {
     if (L <= 0 || B <= 0 || Q <= 0) return 0;
     if (Q > HUNG_QMAX) return -2;
+    static const bool reg_path = !(getenv("SPE_HUNGARIAN_LDS") && atoi(getenv("SPE_HUNGARIAN_LDS")));      // developer knob (A/B): 1 = the LDS-state kernel
+    if (reg_path && Q <= 128) return launch_hungarian_reg<2>(cost, toff, srow, gidx, lidx, err, L, B, Q, st);
+    if (reg_path && Q <= 320) return launch_hungarian_reg<5>(cost, toff, srow, gidx, lidx, err, L, B, Q, st);
     hipLaunchKernelGGL(hungarian_kernel, dim3(B, L), dim3(64), 0, st, cost, toff, srow, gidx, lidx, err, B, Q);
     SPE_CHECK_LAUNCH();
     return 0;
