@@ -173,12 +173,53 @@ __global__ __launch_bounds__(256) void colsum_bf16_blocks_kernel(ColsumBlkArgs a
                });
 }
 
+// The same sums with 16-byte loads: a workgroup owns 256 columns (32 lanes x 8) and 8 row lanes; thread (rl, cg) adds rows rl + 8 k of
+// its slab for its 8 columns, the 8 row lanes meet in LDS, the slabs across workgroups in a fixed order (det_reduce.h).
+__global__ __launch_bounds__(256) void colsum_bf16_blocks_v8_kernel(ColsumBlkArgs a, DetWs ws) {
+    __shared__ float red[8][256 + 8];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int C = a.nblk * a.blkC, c0 = blockIdx.x * 256 + cg * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 < C) {
+        const long rows_per = (a.R + gridDim.y - 1) / gridDim.y;
+        const long r0 = (long)blockIdx.y * rows_per, r1 = r0 + rows_per < a.R ? r0 + rows_per : a.R;
+        for (long r = r0 + rl; r < r1; r += 8) {
+            const uint4 q = *reinterpret_cast<const uint4*>(a.x + r * a.ld + c0);
+            const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[2 * i] += __uint_as_float(w[i] << 16); acc[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u); }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[rl][cg * 8 + i] = acc[i];
+    __syncthreads();
+    det_reduce(ws, blockIdx.x, blockIdx.y, gridDim.y, 256, threadIdx.x, 256,
+               [&](int k) { float t = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) t += red[j][k];
+                            return t; },
+               [&](int k, float s) {
+                   const int cc = blockIdx.x * 256 + k;
+                   if (cc < C) { float* o = a.out[cc / a.blkC] + cc % a.blkC; *o = a.accumulate ? *o + s : s; }
+               });
+}
+
 extern "C" int spe_colsum_bf16_blocks(const void* x, long ld, long R, int nblk, int blkC, float* const* outs, int accumulate, hipStream_t st) {
     if (nblk <= 0 || blkC <= 0 || R <= 0) return 0;
     if (nblk > KV_MAXBLK) return -2;
     ColsumBlkArgs a;
     a.x = (const unsigned short*)x; a.ld = ld; a.R = R; a.nblk = nblk; a.blkC = blkC; a.accumulate = accumulate;
     for (int i = 0; i < nblk; ++i) a.out[i] = outs[i];
+    if (((nblk * blkC) & 7) == 0 && (ld & 7) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const int gx = (nblk * blkC + 255) / 256;
+        long ry = (R + 63) / 64; if (ry > 96) ry = 96; if (ry < 1) ry = 1;
+        while (gx * ry > 1024 && ry > 16) ry /= 2;            // a few workgroups per CU are enough; the slabs cost a reduction each
+        const DetWs ws = spe_detws();
+        DET_CHECK(ws, gx, ry, 256);
+        hipLaunchKernelGGL(colsum_bf16_blocks_v8_kernel, dim3(gx, (unsigned)ry), dim3(256), 0, st, a, ws);
+        SPE_CHECK_LAUNCH();
+        return 0;
+    }
     const int gx = (nblk * blkC + 63) / 64;
     long ry = (R + 255) / 256; if (ry > 64) ry = 64; if (ry < 1) ry = 1;
     const DetWs ws = spe_detws();

@@ -179,3 +179,21 @@ def test_group_linear_matches_separate_linears():
             assert torch.equal(got[2][i], mods[i].bias.grad), ("db", n, i)
         err = (got[0] - x.grad).norm() / x.grad.norm()
         assert err < 2e-3, ("dx", n, float(err))        # bf16 single-term products, different summation order
+
+
+def test_colsum_bf16_blocks_matches_fp64(dev):
+    """Column sums of a bf16 matrix delivered block by block (the bias gradients of stacked projections: the decoder's memory side,
+    the qkv Linear inside the attention node) against fp64, for the 16-byte-load kernel (columns % 8 == 0) and the scalar one, with
+    and without accumulation; run twice: bitwise equal (fixed summation order)."""
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(11)
+    for R, nblk, blkC, ld in ((8300, 1, 1152, 1152), (8300, 18, 384, 18 * 384), (777, 3, 40, 128), (300, 2, 12, 24), (5, 1, 384, 384)):
+        x = torch.randn(R, ld, generator=g).to(dev).to(torch.bfloat16)
+        ref = x[:, :nblk * blkC].double().sum(0)
+        outs = [torch.full((blkC,), 7.0, device=dev) for _ in range(nblk)]
+        K.colsum_bf16_blocks(x, blkC, outs)
+        got = torch.cat(outs).double()
+        assert (got - ref).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max())) * R ** 0.5, (R, nblk, blkC)
+        outs2 = [torch.zeros((blkC,), device=dev) for _ in range(nblk)]
+        K.colsum_bf16_blocks(x, blkC, outs2)
+        assert torch.equal(torch.cat(outs2), torch.cat(outs)), "not reproducible"
