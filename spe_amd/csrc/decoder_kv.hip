@@ -13,6 +13,7 @@
 //                       q_c (k_c + k_p) + q_s k_p = q_c k_c + (q_s + q_c) k_p - models/transformer.py in this tree.)
 //   spe_kv_grad_scatter the backward's dk [B,S,H,2 dh] / dv [B,S,H,dh] (fp32, spe_mha_bwd) of one layer -> bf16 column blocks of the
 //                       stacked dY operands of the projection GEMMs' backward (dYm [B*S][2 L d], dYp [B*S][L d]).
+#include <cstdlib>
 #include "common.h"
 #include "attn_pack.h"
 #include "det_reduce.h"
@@ -212,7 +213,8 @@ extern "C" int spe_colsum_bf16_blocks(const void* x, long ld, long R, int nblk, 
     for (int i = 0; i < nblk; ++i) a.out[i] = outs[i];
     if (((nblk * blkC) & 7) == 0 && (ld & 7) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         const int gx = (nblk * blkC + 255) / 256;
-        long ry = (R + 63) / 64; if (ry > 96) ry = 96; if (ry < 1) ry = 1;
+        static const int ry_max = getenv("SPE_COLSUM_RY") ? atoi(getenv("SPE_COLSUM_RY")) : 96;       // developer knob (tuning)
+        long ry = (R + 63) / 64; if (ry > ry_max) ry = ry_max; if (ry < 1) ry = 1;
         while (gx * ry > 1024 && ry > 16) ry /= 2;            // a few workgroups per CU are enough; the slabs cost a reduction each
         const DetWs ws = spe_detws();
         DET_CHECK(ws, gx, ry, 256);
