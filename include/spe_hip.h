@@ -158,6 +158,16 @@ int spe_gemm_bf16nt_ex(const void* A16, const void* B16, const void* A16lo, cons
                        float* C2, void* out16, void* out16lo, long ld16, void* out16T, long ld16t, float* colsum, const float* aux,
                        const float* res, const float* rgamma, int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act,
                        int half_flags, spe_stream_t stream);
+/* spe_gemm_bf16nt_exd (round 4): spe_gemm_bf16nt_ex with the backbone block's training rates inside the epilogue (reference models/cait.py:
+ * 390-391 proj_drop, timm Mlp drop after GELU and after fc2, :404-416 drop_path): after the activation (or its derivative) v is multiplied
+ * by the dropout keep scale of element m * N + n - the (seed, offset) stream of spe_dropout on the row-major [M][N] result, N % 4 == 0 - and
+ * with res the epilogue writes C = res + sample_scale[m / rows_per_sample] * rgamma * v (sample_scale NULL: 1).  C2 keeps the RAW v: the
+ * backward (spe_layerscale_residual_bwd16d) applies the same mask and scale. */
+int spe_gemm_bf16nt_exd(const void* A16, const void* B16, const void* A16lo, const void* B16lo, float* C, const float* bias,
+                        float* C2, void* out16, void* out16lo, long ld16, void* out16T, long ld16t, float* colsum, const float* aux,
+                        const float* res, const float* rgamma, int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act,
+                        int half_flags, float p_drop, uint64_t seed, uint64_t offset, const float* sample_scale, long rows_per_sample,
+                        spe_stream_t stream);
 int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, void* out_lo, long ldo, void* outT, long ldt, float* colsum,
                  const float* aux, int act, spe_stream_t stream);
 /* spe_cvt_bf16_multi: the row-major and transposed bf16 copies of njobs contiguous fp32 matrices in ONE launch (every
@@ -293,6 +303,10 @@ int spe_layerscale_residual_bwd(const float* dout, const float* y, const float* 
  * IEEE fp16 [R][C] (written by spe_gemm_bf16nt_ex with half_flags bit 0: y only ever enters this sum). */
 int spe_layerscale_residual_bwd16(const float* dout, const void* y, int y_f16, const float* gamma, void* dy16, void* dy16T, long ldt,
                                   float* db, float* dgamma, long R, int C, spe_stream_t stream);
+/* ... when the forward was out = x + s_b * gamma * dropout(y) (spe_gemm_bf16nt_exd): dy = s_b * keep * gamma * dout, dgamma += sum s_b * keep * dout * y. */
+int spe_layerscale_residual_bwd16d(const float* dout, const void* y, int y_f16, const float* gamma, void* dy16, void* dy16T, long ldt,
+                                   float* db, float* dgamma, long R, int C, float p_drop, uint64_t seed, uint64_t offset,
+                                   const float* sample_scale, long rows_per_sample, spe_stream_t stream);
 
 /* ---- activation backward: mode 1 ReLU (aux = forward output), mode 2 GELU (aux = pre-activation);
  * autograd of F.relu (transformer.py:32,287,424) and nn.GELU (timm Mlp). n % 4 == 0. */

@@ -35,6 +35,11 @@ struct Gemm16Args {
                                            // pre-activation of the fused MLP: only act'(.) is ever taken of it - fp16 costs the gradient
                                            // ~3e-4 relative, an order below its bf16 operand rounding, and halves 51 MB per block each way)
     const float* res; const float* rgamma; // LayerScale residual: C = res[m][n] + rgamma[n] * v  (C2 still gets v)
+    // dropout / DropPath inside the extended epilogue (the backbone block with its training rates: reference models/cait.py:390-391 proj_drop,
+    // timm Mlp drop after GELU and after fc2, :404-416 drop_path): after the activation (or its derivative) v *= keepscale(element m * N + n) -
+    // the stream of spe_dropout on the row-major [M, N] tensor; with res: C = res + sscale[m / rps] * rgamma * v.  C2 keeps the raw v.
+    float drop_p; uint64_t drop_seed, drop_off;
+    const float* sscale; long rps;
     int h16;                               // bit 0: A / B hold IEEE fp16 (single-term product on v_mfma_f32_16x16x32_f16) ; bit 1: C is IEEE fp16 [M][ldc] (plain epilogue)
 };
 
@@ -165,6 +170,12 @@ __device__ __forceinline__ void gemm16_epilogue_ex(const Gemm16Args& p, f32x4_t 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = gelu_erf16(v[r]);
             }
+            if (p.drop_p > 0.f) {                     // same mask as spe_dropout on the [M, N] result (n % 4 == 0: one Philox call)
+                float ks[4];
+                spe_drop_scale4(p.drop_seed, p.drop_off, (uint64_t)min(m, p.M - 1) * (uint64_t)p.N + (uint64_t)n, p.drop_p, ks);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= ks[r];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = (rowv && n + r < p.N) ? v[r] : 0.f;      // padding rows / columns stage zeros
             if (p.C && rowv) {
@@ -177,8 +188,9 @@ __device__ __forceinline__ void gemm16_epilogue_ex(const Gemm16Args& p, f32x4_t 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) if (n + r < p.N) xr[r] = p.res[(long)m * p.ldc + n + r];
                     }
+                    const float ssb = p.sscale ? p.sscale[min(m, p.M - 1) / p.rps] : 1.f;      // DropPath keep scale of the row's sample
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = xr[r] + gv[r] * v[r];
+                    for (int r = 0; r < 4; ++r) o[r] = xr[r] + ssb * gv[r] * v[r];
                 }
                 if (full) spe_store4_stream(p.C + off, o[0], o[1], o[2], o[3]);
                 else {

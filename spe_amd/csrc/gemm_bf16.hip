@@ -342,6 +342,7 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, const void* A16
     p.alpha = alpha; p.act = act; p.slab = 0;
     p.ws = DetWs{nullptr, nullptr, 0, 0}; p.half_flags = 0;
     p.out16 = nullptr; p.out16T = nullptr; p.colsum = nullptr; p.aux = nullptr; p.ld16 = 0; p.ld16t = 0; p.res = nullptr; p.rgamma = nullptr;
+    p.drop_p = 0.f; p.drop_seed = p.drop_off = 0; p.sscale = nullptr; p.rps = 1;
     const int ktiles = (K + GB_BK - 1) / GB_BK;
     if (p.h16 && (splitk != 1 || C2 || (ldc & 3))) return -2;
     if ((p.h16 & 1) && A16lo) return -2;
@@ -398,10 +399,33 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, const void* A16
 }
 
 // C-ABI: see include/spe_hip.h (spe_gemm_bf16nt_ex).  -2: unsupported alignment / leading dimensions.
+static int gemm_bf16nt_ex_impl(const void* A16, const void* B16, const void* A16lo, const void* B16lo, float* C, const float* bias,
+                               float* C2, void* out16, void* out16lo, long ld16, void* out16T, long ld16t, float* colsum,
+                               const float* aux, const float* res, const float* rgamma,
+                               int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int half_flags,
+                               float p_drop, uint64_t seed, uint64_t offset, const float* sample_scale, long rows_per_sample, hipStream_t stream);
 extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, const void* A16lo, const void* B16lo, float* C, const float* bias,
                                   float* C2, void* out16, void* out16lo, long ld16, void* out16T, long ld16t, float* colsum,
                                   const float* aux, const float* res, const float* rgamma,
                                   int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int half_flags, hipStream_t stream) {
+    return gemm_bf16nt_ex_impl(A16, B16, A16lo, B16lo, C, bias, C2, out16, out16lo, ld16, out16T, ld16t, colsum, aux, res, rgamma, M, N, K, lda, ldb,
+                               ldc, alpha, act, half_flags, 0.f, 0, 0, nullptr, 1, stream);
+}
+// C-ABI: see include/spe_hip.h.  spe_gemm_bf16nt_ex with dropout after the activation (or its derivative) and a per-sample scale on the residual.
+extern "C" int spe_gemm_bf16nt_exd(const void* A16, const void* B16, const void* A16lo, const void* B16lo, float* C, const float* bias,
+                                   float* C2, void* out16, void* out16lo, long ld16, void* out16T, long ld16t, float* colsum,
+                                   const float* aux, const float* res, const float* rgamma,
+                                   int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int half_flags,
+                                   float p_drop, uint64_t seed, uint64_t offset, const float* sample_scale, long rows_per_sample, hipStream_t stream) {
+    if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && (N & 3)) || (sample_scale && (!res || rows_per_sample <= 0))) return -2;
+    return gemm_bf16nt_ex_impl(A16, B16, A16lo, B16lo, C, bias, C2, out16, out16lo, ld16, out16T, ld16t, colsum, aux, res, rgamma, M, N, K, lda, ldb,
+                               ldc, alpha, act, half_flags, p_drop, seed, offset, sample_scale, rows_per_sample, stream);
+}
+static int gemm_bf16nt_ex_impl(const void* A16, const void* B16, const void* A16lo, const void* B16lo, float* C, const float* bias,
+                               float* C2, void* out16, void* out16lo, long ld16, void* out16T, long ld16t, float* colsum,
+                               const float* aux, const float* res, const float* rgamma,
+                               int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int half_flags,
+                               float p_drop, uint64_t seed, uint64_t offset, const float* sample_scale, long rows_per_sample, hipStream_t stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0) return -4;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -411,7 +435,7 @@ extern "C" int spe_gemm_bf16nt_ex(const void* A16, const void* B16, const void* 
     if (aux && act != 1 && act != 2) return -2;
     if ((res != nullptr) != (rgamma != nullptr) || (res && (!C || act != 0 || aux))) return -2;
     Gemm16Args p;
-    p.h16 = 0;
+    p.h16 = 0; p.drop_p = p_drop; p.drop_seed = seed; p.drop_off = offset; p.sscale = sample_scale; p.rps = sample_scale ? rows_per_sample : 1;
     p.A = reinterpret_cast<const unsigned short*>(A16); p.B = reinterpret_cast<const unsigned short*>(B16);
     p.C = C; p.C2 = C2; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.act = act; p.slab = 0; p.splitk = 1;

@@ -619,7 +619,8 @@ __global__ __launch_bounds__(NW * 64) void lsres_bwd_rows_kernel(const float* __
 __global__ __launch_bounds__(1024) void lsres_bwd16_kernel(const float* __restrict__ dout, const float* __restrict__ y,
                                                            const float* __restrict__ gamma, unsigned short* __restrict__ dy16,
                                                            unsigned short* __restrict__ dy16T, long ldt, float* __restrict__ db,
-                                                           float* __restrict__ dgamma, long R, int C, DetWs ws, int y_f16) {
+                                                           float* __restrict__ dgamma, long R, int C, DetWs ws, int y_f16,
+                                                           float p_drop, uint64_t seed, uint64_t offset, const float* __restrict__ sscale, long rps) {
     extern __shared__ unsigned short lsT[];            // [64][C + 8] bf16 tile ; reused as float [16][C + 4] x 2 at the end
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int C4 = C >> 2, ldl = C + 8;
@@ -655,6 +656,12 @@ __global__ __launch_bounds__(1024) void lsres_bwd16_kernel(const float* __restri
                             const ls_h4_t h = __builtin_bit_cast(ls_h4_t, yh[c]);
                             yv = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
                         } else yv = yr[c];
+                    }
+                    if (sscale && rv) { const float ssb = sscale[row / rps]; d.x *= ssb; d.y *= ssb; d.z *= ssb; d.w *= ssb; }      // DropPath keep scale of the sample
+                    if (p_drop > 0.f) {           // the branch was dropout(y): the mask of the forward's epilogue (element row * C + 4 c)
+                        float ks[4];
+                        spe_drop_scale4(seed, offset, (uint64_t)(rv ? row : 0) * (uint64_t)C + 4u * (unsigned)c, p_drop, ks);
+                        d.x *= ks[0]; d.y *= ks[1]; d.z *= ks[2]; d.w *= ks[3];
                     }
                     ag[i].x += d.x * yv.x; ag[i].y += d.y * yv.y; ag[i].z += d.z * yv.z; ag[i].w += d.w * yv.w;
                     const float4 o = make_float4(d.x * g[i].x, d.y * g[i].y, d.z * g[i].z, d.w * g[i].w);
@@ -709,8 +716,24 @@ __global__ __launch_bounds__(1024) void lsres_bwd16_kernel(const float* __restri
 
 // C-ABI: see include/spe_hip.h (spe_layerscale_residual_bwd16).  -2: C % 4 != 0, C > 1024, ldt not a multiple of 64
 // or smaller than R, misaligned pointers.
+static int lsres_bwd16_launch(const float* dout, const void* y, int y_f16, const float* gamma, void* dy16, void* dy16T, long ldt,
+                              float* db, float* dgamma, long R, int C, float p_drop, uint64_t seed, uint64_t offset, const float* sscale, long rps,
+                              hipStream_t st);
 extern "C" int spe_layerscale_residual_bwd16(const float* dout, const void* y, int y_f16, const float* gamma, void* dy16, void* dy16T, long ldt,
                                              float* db, float* dgamma, long R, int C, hipStream_t st) {
+    return lsres_bwd16_launch(dout, y, y_f16, gamma, dy16, dy16T, ldt, db, dgamma, R, C, 0.f, 0, 0, nullptr, 1, st);
+}
+// C-ABI: see include/spe_hip.h.  The same backward when the forward was res + s_b * gamma * dropout(y) (spe_gemm_bf16nt_exd).
+extern "C" int spe_layerscale_residual_bwd16d(const float* dout, const void* y, int y_f16, const float* gamma, void* dy16, void* dy16T, long ldt,
+                                              float* db, float* dgamma, long R, int C, float p_drop, uint64_t seed, uint64_t offset,
+                                              const float* sample_scale, long rows_per_sample, hipStream_t st) {
+    if (p_drop < 0.f || p_drop >= 1.f || (sample_scale && rows_per_sample <= 0)) return -2;
+    return lsres_bwd16_launch(dout, y, y_f16, gamma, dy16, dy16T, ldt, db, dgamma, R, C, p_drop, seed, offset, sample_scale,
+                              sample_scale ? rows_per_sample : 1, st);
+}
+static int lsres_bwd16_launch(const float* dout, const void* y, int y_f16, const float* gamma, void* dy16, void* dy16T, long ldt,
+                              float* db, float* dgamma, long R, int C, float p_drop, uint64_t seed, uint64_t offset, const float* sscale, long rps,
+                              hipStream_t st) {
     if (R <= 0) return 0;
     if ((C & 3) || C > 256 * LN_MAXV || (ldt & 63) || ldt < R) return -2;
     if ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) |
@@ -728,7 +751,8 @@ extern "C" int spe_layerscale_residual_bwd16(const float* dout, const void* y, i
     const DetWs ws = spe_detws();
     DET_CHECK(ws, 1, nb, 2 * C);
     hipLaunchKernelGGL(lsres_bwd16_kernel, dim3((unsigned)nb), dim3(1024), smem, st, dout, reinterpret_cast<const float*>(y), gamma,
-                       reinterpret_cast<unsigned short*>(dy16), reinterpret_cast<unsigned short*>(dy16T), ldt, db, dgamma, R, C, ws, y_f16);
+                       reinterpret_cast<unsigned short*>(dy16), reinterpret_cast<unsigned short*>(dy16T), ldt, db, dgamma, R, C, ws, y_f16,
+                       p_drop, seed, offset, sscale, rps);
     SPE_CHECK_LAUNCH();
     return 0;
 }

@@ -525,12 +525,19 @@ def gemm16_tn(A16, B16, C, M, N, R, lda, ldb, ldc, alpha=1.0, splitk=1):
 
 
 def gemm16_ex(A16, B16, M, N, K, lda, ldb, bias=None, C=None, C2=None, out16=None, out16T=None, colsum=None, aux=None,
-              alpha=1.0, act=0, res=None, rgamma=None, Alo=None, Blo=None, out16lo=None):
+              alpha=1.0, act=0, res=None, rgamma=None, Alo=None, Blo=None, out16lo=None, drop=None, sscale=None, rps=1):
     """spe_gemm_bf16nt_ex: v = alpha * A16 @ B16.T + bias; C2 = v; v = act(v) or v * act'(aux); optional fp32 C [M,N], bf16
     out16 [M,N], bf16 transposed out16T [N, ldt] (zero padded), colsum [N] += column sums.  All fp32 tensors have ld = N.
     Alo / Blo: low parts of split operands; out16lo [M,N]: bf16(v - out16), the low part of the result for the next split GEMM.
     C2 / aux may be fp16 tensors (the saved pre-activation of the fused MLP): flagged to the library by their dtype."""
     half_flags = (1 if (C2 is not None and C2.dtype == torch.float16) else 0) | (2 if (aux is not None and aux.dtype == torch.float16) else 0)
+    if (drop is not None and drop[0] > 0) or sscale is not None:
+        # drop = (p, seed, offset): dropout after the activation / derivative; sscale [B] (+ rps rows per sample): DropPath scale on the residual
+        pd, sd, of = drop if (drop is not None and drop[0] > 0) else (0.0, 0, 0)
+        _call("spe_gemm_bf16nt_exd", _p(A16), _p(B16), _p(Alo), _p(Blo), _p(C), _p(bias), _p(C2), _p(out16), _p(out16lo), N, _p(out16T),
+              out16T.shape[1] if out16T is not None else 0, _p(colsum), _p(aux), _p(res), _p(rgamma), M, N, K, lda, ldb, N,
+              float(alpha), int(act), half_flags, float(pd), int(sd), int(of), _p(sscale), int(rps), _st())
+        return
     _call("spe_gemm_bf16nt_ex", _p(A16), _p(B16), _p(Alo), _p(Blo), _p(C), _p(bias), _p(C2), _p(out16), _p(out16lo), N, _p(out16T),
           out16T.shape[1] if out16T is not None else 0, _p(colsum), _p(aux), _p(res), _p(rgamma), M, N, K, lda, ldb, N,
           float(alpha), int(act), half_flags, _st())
@@ -546,7 +553,7 @@ def mlp16_ok(R, K, Hd, N):
 DW_TN = os.environ.get("SPE_DW_TN", "1") != "0"
 
 
-def layerscale_residual_bwd16(dout2, y2, gamma, Rp, db_out=None, dg_out=None, want_rowmajor=True, want_T=True):
+def layerscale_residual_bwd16(dout2, y2, gamma, Rp, db_out=None, dg_out=None, want_rowmajor=True, want_T=True, drop=None, sscale=None, rps=1):
     """Backward of out = x + gamma * y when y is the output of a Linear on the bf16-copy GEMMs: -> (dy16 [R,C], dy16T
     [C,Rp], db [C], dgamma [C]); dy = gamma * dout exists only as those bf16 operands."""
     R, C = dout2.shape
@@ -555,12 +562,17 @@ def layerscale_residual_bwd16(dout2, y2, gamma, Rp, db_out=None, dg_out=None, wa
     dy16T = torch.empty((C, Rp), device=dev, dtype=torch.bfloat16) if want_T else None
     db = _zeros_or(db_out, C, dev)
     dg = _zeros_or(dg_out, C, dev)
+    if (drop is not None and drop[0] > 0) or sscale is not None:       # the forward was x + s_b * gamma * dropout(y)
+        pd, sd, of = drop if (drop is not None and drop[0] > 0) else (0.0, 0, 0)
+        _call("spe_layerscale_residual_bwd16d", _p(dout2), _p(y2), int(y2.dtype == torch.float16), _p(gamma), _p(dy16), _p(dy16T), Rp, _p(db),
+              _p(dg), R, C, float(pd), int(sd), int(of), _p(sscale), int(rps), _st())
+        return dy16, dy16T, db, dg
     _call("spe_layerscale_residual_bwd16", _p(dout2), _p(y2), int(y2.dtype == torch.float16), _p(gamma), _p(dy16), _p(dy16T), Rp, _p(db), _p(dg),
           R, C, _st())
     return dy16, dy16T, db, dg
 
 
-def linear_res_fwd(x2, W, b, res, gamma, save=True, src=None):
+def linear_res_fwd(x2, W, b, res, gamma, save=True, src=None, drop=None, sscale=None, rps=1):
     """out = res + gamma * (x2 @ W.T + b) on the bf16-copy GEMM with the residual in its epilogue.  -> (out, (x16T, y))."""
     R, K = x2.shape
     N = W.shape[0]
@@ -571,11 +583,12 @@ def linear_res_fwd(x2, W, b, res, gamma, save=True, src=None):
     # the branch output y is kept for the LayerScale gamma gradient only (dgamma = sum dout * y): fp16, like the MLP's pre-activation
     y = torch.empty((R, N), device=dev, dtype=torch.float16 if MLP_PRE_F16 else torch.float32) if save else None
     Wt = weight16(W, lo=sp)
-    gemm16_ex(x16, Wt[0], R, N, K, K, K, bias=b, C=out, C2=y, res=res, rgamma=gamma, Alo=x16lo, Blo=Wt[2] if sp else None)
+    gemm16_ex(x16, Wt[0], R, N, K, K, K, bias=b, C=out, C2=y, res=res, rgamma=gamma, Alo=x16lo, Blo=Wt[2] if sp else None,
+              drop=drop, sscale=sscale, rps=rps)
     return out, ((x16 if DW_TN else x16T), y)
 
 
-def linear_res_bwd(dout2, saved, W, gamma, need_dx=True, grad_bufs=(None, None, None)):
+def linear_res_bwd(dout2, saved, W, gamma, need_dx=True, grad_bufs=(None, None, None), drop=None, sscale=None, rps=1):
     """Backward of linear_res_fwd: (dx, dW, db, dgamma); gamma * dout only exists as the bf16 operands of the two GEMMs."""
     xs, y = saved
     R, N = dout2.shape
@@ -583,11 +596,13 @@ def linear_res_bwd(dout2, saved, W, gamma, need_dx=True, grad_bufs=(None, None, 
     gW, gb, gg = grad_bufs
     if _is_rowmajor_save(xs, R):
         Rp = ((R + 63) // 64) * 64
-        dy16, _, db, dg = layerscale_residual_bwd16(dout2, y, gamma, Rp, db_out=gb, dg_out=gg, want_rowmajor=True, want_T=False)
+        dy16, _, db, dg = layerscale_residual_bwd16(dout2, y, gamma, Rp, db_out=gb, dg_out=gg, want_rowmajor=True, want_T=False,
+                                                    drop=drop, sscale=sscale, rps=rps)
         dW = _dw16_tn(dy16, xs, N, K, R, gW)
     else:
         Rp = xs.shape[1]
-        dy16, dy16T, db, dg = layerscale_residual_bwd16(dout2, y, gamma, Rp, db_out=gb, dg_out=gg, want_rowmajor=need_dx)
+        dy16, dy16T, db, dg = layerscale_residual_bwd16(dout2, y, gamma, Rp, db_out=gb, dg_out=gg, want_rowmajor=need_dx,
+                                                        drop=drop, sscale=sscale, rps=rps)
         dW = _dw16(dy16T, xs, N, K, Rp, gW)
     dx = None
     if need_dx:
@@ -599,7 +614,7 @@ def linear_res_bwd(dout2, saved, W, gamma, need_dx=True, grad_bufs=(None, None, 
 MLP_PRE_F16 = os.environ.get("SPE_MLP_PRE_F16", "1") != "0"      # developer knob (A/B)
 
 
-def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True, src=None):
+def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True, src=None, drop1=None, drop2=None, sscale=None, rps=1):
     """y = fc2(gelu(fc1(x2))) with every intermediate that the next GEMM needs emitted as bf16 by the producing GEMM's
     epilogue: fc1 writes the fp32 pre-activation (for the backward) and the bf16 activation h16 / h16T, never the fp32
     activation.  -> (y [R,N] fp32, saved = (x16T, pre, h16T))."""
@@ -618,7 +633,8 @@ def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True, src=None):
     h16T = torch.empty((Hd, Rp), device=dev, dtype=torch.bfloat16) if (save and not DW_TN) else None
     W1t, W2t = weight16(W1, lo=sp), weight16(W2, lo=sp)
     W1lo, W2lo = (W1t[2], W2t[2]) if sp else (None, None)
-    gemm16_ex(x16, W1t[0], R, Hd, K, K, K, bias=b1, C2=pre, out16=h16, out16T=h16T, act=2, Alo=x16lo, Blo=W1lo, out16lo=h16lo)
+    # drop1 = (p, seed, offset): timm Mlp's dropout after the activation - h16 then holds dropout(gelu(pre))
+    gemm16_ex(x16, W1t[0], R, Hd, K, K, K, bias=b1, C2=pre, out16=h16, out16T=h16T, act=2, Alo=x16lo, Blo=W1lo, out16lo=h16lo, drop=drop1)
     y = torch.empty((R, N), device=dev, dtype=torch.float32)
     if DW_TN:
         x16T, h16T = x16, h16            # what the backward gets: the row-major copies
@@ -629,7 +645,8 @@ def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True, src=None):
     out = torch.empty((R, N), device=dev, dtype=torch.float32)
     if MLP_PRE_F16:
         y = torch.empty((R, N), device=dev, dtype=torch.float16)        # kept for the gamma gradient only
-    gemm16_ex(h16, W2t[0], R, N, Hd, Hd, Hd, bias=b2, C=out, C2=y if save else None, res=res, rgamma=gamma, Alo=h16lo, Blo=W2lo)
+    gemm16_ex(h16, W2t[0], R, N, Hd, Hd, Hd, bias=b2, C=out, C2=y if save else None, res=res, rgamma=gamma, Alo=h16lo, Blo=W2lo,
+              drop=drop2, sscale=sscale, rps=rps)
     return out, (x16T, pre, h16T, y)
 
 
@@ -666,7 +683,8 @@ def _dw16_tn(dy16, x16, N, K, R, dW_out, lda=None):
     return dW
 
 
-def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, None), gamma=None, dg_out=None):
+def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, None), gamma=None, dg_out=None,
+                 drop1=None, drop2=None, sscale=None, rps=1):
     """Backward of mlp_gelu_fwd.  dy2 [R,N] fp32.  -> (dx, dW1, db1, dW2, db2).  The gradient w.r.t. the pre-activation
     exists only as the bf16 copies (row-major for dx, transposed for dW1) written by the dh GEMM's epilogue, which also
     applies gelu' and accumulates db1.  grad_bufs: zeroed bucket views for (dW1, db1, dW2, db2) or None."""
@@ -679,7 +697,8 @@ def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, 
     gW1, gb1, gW2, gb2 = grad_bufs
     dg = None
     if gamma is not None:        # residual form: dy2 is d(out); the branch gradient gamma * dout only exists in bf16
-        dy16, dy16T, db2, dg = layerscale_residual_bwd16(dy2, saved[3], gamma, Rp, db_out=gb2, dg_out=dg_out, want_T=not tn)
+        dy16, dy16T, db2, dg = layerscale_residual_bwd16(dy2, saved[3], gamma, Rp, db_out=gb2, dg_out=dg_out, want_T=not tn,
+                                                         drop=drop2, sscale=sscale, rps=rps)
     else:
         db2 = _zeros_or(gb2, N, dev)
         dy16, dy16T = cvt_bf16(dy2, True, not tn, ldt=Rp, colsum_out=db2)
@@ -688,7 +707,7 @@ def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, 
     db1 = _zeros_or(gb1, Hd, dev)
     dp16 = torch.empty((R, Hd), device=dev, dtype=torch.bfloat16) if (need_dx or tn) else None
     dp16T = torch.empty((Hd, Rp), device=dev, dtype=torch.bfloat16) if not tn else None
-    gemm16_ex(dy16, weight16(W2)[1], R, Hd, N, N, N, out16=dp16, out16T=dp16T, colsum=db1, aux=pre, act=2)
+    gemm16_ex(dy16, weight16(W2)[1], R, Hd, N, N, N, out16=dp16, out16T=dp16T, colsum=db1, aux=pre, act=2, drop=drop1)      # ... times the mask of drop1
     dW1 = _dw16_tn(dp16, x16T, Hd, K, R, gW1) if tn else _dw16(dp16T, x16T, Hd, K, Rp, gW1)
     dx = None
     if need_dx:

@@ -113,16 +113,17 @@ class LayerScale_Block(nn.Module):
         skip = isinstance(self.norm1, LayerNorm) and isinstance(self.norm2, LayerNorm)
         ss1 = ops.drop_path_scale(B, self.drop_path, self.training, x.device)
         y, xs = self.norm1.skip(x) if skip else (self.norm1(x), x)
-        if isinstance(self.attn, Attention_talking_head) and not (self.training and self.attn.proj_drop.p > 0.0):
-            # output projection + LayerScale residual as one node (same arithmetic)
-            x = ops.linear_residual(self.attn.context(y), self.attn.proj.weight, self.attn.proj.bias, xs, self.gamma_1, ss1)
+        if isinstance(self.attn, Attention_talking_head):
+            # output projection (+ proj_drop) + DropPath + LayerScale residual as one node (same arithmetic, same dropout stream)
+            x = ops.linear_residual(self.attn.context(y), self.attn.proj.weight, self.attn.proj.bias, xs, self.gamma_1, ss1,
+                                    self.attn.proj_drop.p if self.training else 0.0)
         else:
             x = ops.layerscale_residual(xs, self.attn(y), self.gamma_1, ss1)
         ss = ops.drop_path_scale(B, self.drop_path, self.training, x.device)
         y, xs = self.norm2.skip(x) if skip else (self.norm2(x), x)
-        if isinstance(self.mlp, Mlp) and not (self.training and self.mlp.drop.p > 0.0):
+        if isinstance(self.mlp, Mlp):
             return ops.mlp_gelu_residual(y, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight,
-                                         self.mlp.fc2.bias, xs, self.gamma_2, ss)
+                                         self.mlp.fc2.bias, xs, self.gamma_2, ss, self.mlp.drop.p if self.training else 0.0)
         return ops.layerscale_residual(xs, self.mlp(y), self.gamma_2, ss)
 
 

@@ -616,7 +616,7 @@ class _LinearRes(Function):
 
     @staticmethod
     @K.forward_scope
-    def forward(ctx, x, W, b, xres, gamma):
+    def forward(ctx, x, W, b, xres, gamma, sscale=None, p_drop=0.0):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         if not x2.is_contiguous():
@@ -625,33 +625,43 @@ class _LinearRes(Function):
         if not r2.is_contiguous():
             r2 = r2.contiguous()
         train = any(ctx.needs_input_grad)
-        out, saved = K.linear_res_fwd(x2, W, b, r2, gamma, save=train, src=x)
+        # training rates of the block (cait.py:391 proj_drop, :404 drop_path) ride on the epilogue: dropout mask of spe_dropout's stream,
+        # DropPath keep scale per sample
+        ctx.drop = (float(p_drop), *K.next_rng()) if p_drop > 0 else None
+        ctx.rps = r2.shape[0] // xres.shape[0]
+        out, saved = K.linear_res_fwd(x2, W, b, r2, gamma, save=train, src=x, drop=ctx.drop, sscale=sscale, rps=ctx.rps)
         ctx.params = (W, b, gamma)
+        ctx.has_ss = sscale is not None
         if train:
-            ctx.save_for_backward(*saved, W, gamma)
+            ctx.save_for_backward(*saved, W, gamma, *((sscale,) if sscale is not None else ()))
         return out.view(xres.shape)
 
     @staticmethod
     @K.backward_scope
     def backward(ctx, dout):
-        x16T, y, W, gamma = ctx.saved_tensors
+        x16T, y, W, gamma = ctx.saved_tensors[:4]
+        ss = ctx.saved_tensors[4] if ctx.has_ss else None
         d2 = dout.reshape(-1, W.shape[0])
         if not d2.is_contiguous():
             d2 = d2.contiguous()
         bufs = tuple(K.grad_buffer(p) for p in ctx.params)
-        dx, dW, db, dg = K.linear_res_bwd(d2, (x16T, y), W, gamma, ctx.needs_input_grad[0], bufs)
-        return (dx.view(*dout.shape[:-1], W.shape[1]) if dx is not None else None), dW, db, dout, dg.view_as(gamma)
+        dx, dW, db, dg = K.linear_res_bwd(d2, (x16T, y), W, gamma, ctx.needs_input_grad[0], bufs, drop=ctx.drop, sscale=ss, rps=ctx.rps)
+        return (dx.view(*dout.shape[:-1], W.shape[1]) if dx is not None else None), dW, db, dout, dg.view_as(gamma), None, None
 
 
-def linear_residual(x, W, b, xres, gamma, sample_scale=None):
-    """xres + s * gamma * linear(x): one fused node on the bf16-copy GEMM path without a per-sample DropPath scale, else
-    linear followed by layerscale_residual."""
+FUSE_DROP = os.environ.get("SPE_FUSE_DROP", "1") != "0"      # developer knob (A/B): dropout / DropPath inside the fused residual nodes
+
+
+def linear_residual(x, W, b, xres, gamma, sample_scale=None, p_drop=0.0):
+    """xres + s * gamma * dropout(linear(x)): one fused node on the bf16-copy GEMM path (the training rates ride on its epilogue), else
+    linear, dropout and layerscale_residual."""
     R = x.numel() // x.shape[-1]
     N, Kd = W.shape
-    if (FUSE_LINEAR_RES and sample_scale is None and b is not None and W.is_contiguous() and gamma.is_contiguous() and N % 4 == 0 and N <= 1024
-            and K._lin16_ok(R, N, Kd)):
-        return _LinearRes.apply(x, W, b, xres, gamma)
-    return layerscale_residual(xres, linear(x, W, b), gamma, sample_scale)
+    if (FUSE_LINEAR_RES and (FUSE_DROP or (sample_scale is None and p_drop <= 0)) and b is not None and W.is_contiguous()
+            and gamma.is_contiguous() and N % 4 == 0 and N <= 1024 and K._lin16_ok(R, N, Kd)
+            and (sample_scale is None or (sample_scale.is_contiguous() and R % xres.shape[0] == 0))):
+        return _LinearRes.apply(x, W, b, xres, gamma, sample_scale, p_drop)
+    return layerscale_residual(xres, dropout(linear(x, W, b), p_drop, p_drop > 0), gamma, sample_scale)
 
 
 class _MlpGeluRes(Function):
@@ -661,7 +671,7 @@ class _MlpGeluRes(Function):
 
     @staticmethod
     @K.forward_scope
-    def forward(ctx, x, W1, b1, W2, b2, xres, gamma):
+    def forward(ctx, x, W1, b1, W2, b2, xres, gamma, sscale=None, p_drop=0.0):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         if not x2.is_contiguous():
@@ -670,35 +680,48 @@ class _MlpGeluRes(Function):
         if not r2.is_contiguous():
             r2 = r2.contiguous()
         train = any(ctx.needs_input_grad)
-        out, saved = K.mlp_gelu_fwd(x2, W1, b1, W2, b2, res=r2, gamma=gamma, save=train, src=x)
+        # timm Mlp: fc1 -> GELU -> drop -> fc2 -> drop, then DropPath and the LayerScale residual (cait.py:405-416): the two dropout
+        # sites draw their streams in that order, like the unfused composition
+        ctx.drop1 = (float(p_drop), *K.next_rng()) if p_drop > 0 else None
+        ctx.drop2 = (float(p_drop), *K.next_rng()) if p_drop > 0 else None
+        ctx.rps = r2.shape[0] // xres.shape[0]
+        out, saved = K.mlp_gelu_fwd(x2, W1, b1, W2, b2, res=r2, gamma=gamma, save=train, src=x, drop1=ctx.drop1, drop2=ctx.drop2,
+                                    sscale=sscale, rps=ctx.rps)
         ctx.params = (W1, b1, W2, b2, gamma)
+        ctx.has_ss = sscale is not None
         if train:
-            ctx.save_for_backward(*saved, W1, W2, gamma)
+            ctx.save_for_backward(*saved, W1, W2, gamma, *((sscale,) if sscale is not None else ()))
         return out.view(xres.shape)
 
     @staticmethod
     @K.backward_scope
     def backward(ctx, dout):
-        x16T, pre, h16T, y, W1, W2, gamma = ctx.saved_tensors
+        x16T, pre, h16T, y, W1, W2, gamma = ctx.saved_tensors[:7]
+        ss = ctx.saved_tensors[7] if ctx.has_ss else None
         d2 = dout.reshape(-1, W2.shape[0])
         if not d2.is_contiguous():
             d2 = d2.contiguous()
         W1p, b1p, W2p, b2p, gp = ctx.params
         bufs = tuple(K.grad_buffer(p) for p in (W1p, b1p, W2p, b2p))
         dx, dW1, db1, dW2, db2, dg = K.mlp_gelu_bwd(d2, (x16T, pre, h16T, y), W1, W2, ctx.needs_input_grad[0], bufs,
-                                                     gamma=gamma, dg_out=K.grad_buffer(gp))
+                                                     gamma=gamma, dg_out=K.grad_buffer(gp), drop1=ctx.drop1, drop2=ctx.drop2,
+                                                     sscale=ss, rps=ctx.rps)
         return ((dx.view(*dout.shape[:-1], W1.shape[1]) if dx is not None else None), dW1, db1, dW2, db2, dout,
-                dg.view_as(gamma))
+                dg.view_as(gamma), None, None)
 
 
-def mlp_gelu_residual(x, W1, b1, W2, b2, xres, gamma, sample_scale=None):
-    """xres + s * gamma * mlp(x).  One fused node when the MLP takes the bf16-copy path and there is no per-sample DropPath
-    scale; otherwise mlp_gelu followed by layerscale_residual (same arithmetic)."""
+def mlp_gelu_residual(x, W1, b1, W2, b2, xres, gamma, sample_scale=None, p_drop=0.0):
+    """xres + s * gamma * drop(fc2(drop(gelu(fc1(x))))).  One fused node when the MLP takes the bf16-copy path (dropout and the per-sample
+    DropPath scale ride on the GEMM epilogues); otherwise the composition of the single operators (same arithmetic, same masks)."""
     R = x.numel() // x.shape[-1]
-    if (sample_scale is None and b1 is not None and b2 is not None and W1.is_contiguous() and W2.is_contiguous()
-            and gamma.is_contiguous() and W2.shape[0] % 4 == 0 and W2.shape[0] <= 1024
-            and K.mlp16_ok(R, W1.shape[1], W1.shape[0], W2.shape[0])):
-        return _MlpGeluRes.apply(x, W1, b1, W2, b2, xres, gamma)
+    if ((FUSE_DROP or (sample_scale is None and p_drop <= 0)) and b1 is not None and b2 is not None and W1.is_contiguous() and W2.is_contiguous()
+            and gamma.is_contiguous() and W2.shape[0] % 4 == 0 and W1.shape[0] % 4 == 0 and W2.shape[0] <= 1024
+            and K.mlp16_ok(R, W1.shape[1], W1.shape[0], W2.shape[0])
+            and (sample_scale is None or (sample_scale.is_contiguous() and R % xres.shape[0] == 0))):
+        return _MlpGeluRes.apply(x, W1, b1, W2, b2, xres, gamma, sample_scale, p_drop)
+    if p_drop > 0:
+        h = dropout(linear(x, W1, b1, ACT_GELU), p_drop, True)
+        return layerscale_residual(xres, dropout(linear(h, W2, b2), p_drop, True), gamma, sample_scale)
     return layerscale_residual(xres, mlp_gelu(x, W1, b1, W2, b2), gamma, sample_scale)
 
 

@@ -197,3 +197,44 @@ def test_colsum_bf16_blocks_matches_fp64(dev):
         outs2 = [torch.zeros((blkC,), device=dev) for _ in range(nblk)]
         K.colsum_bf16_blocks(x, blkC, outs2)
         assert torch.equal(torch.cat(outs2), torch.cat(outs)), "not reproducible"
+
+
+def test_block_with_training_rates_fused_equals_composite(dev):
+    """A backbone block with the launch scripts' rates (proj / MLP dropout, DropPath; reference models/cait.py:390-391, 404-416, timm Mlp):
+    the fused residual nodes - dropout masks and the per-sample DropPath scale inside the GEMM epilogues (spe_gemm_bf16nt_exd,
+    spe_layerscale_residual_bwd16d) - against the composition of the single operators run with the SAME Philox / torch RNG streams:
+    identical masks, so outputs and every gradient agree to the rounding order of the two paths."""
+    from spe_amd import kernels as K, ops
+    from spe_amd.models.cait import LayerScale_Block
+    K.set_precision("bf16s")
+    torch.manual_seed(21)
+    C, H, B, N = 384, 8, 2, 1100                         # 2200 rows: the bf16-copy GEMM path
+    blk = LayerScale_Block(C, H, drop=0.1, attn_drop=0.0, drop_path=0.3, init_values=0.5).to(dev).train()
+    x0 = torch.randn(B, N, C, device=dev)
+    w = torch.randn(B, N, C, device=dev)
+    res = {}
+    for fused in (True, False):
+        ops.FUSE_DROP = fused
+        try:
+            outs = []
+            for trial in range(3):                       # three DropPath draws (kept / dropped samples differ)
+                K.manual_seed(77 + trial); torch.manual_seed(5 + trial)
+                x = x0.clone().requires_grad_(True)
+                for p in blk.parameters():
+                    p.grad = None
+                y = blk(x)
+                (y * w).sum().backward()
+                outs.append((y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in blk.named_parameters()}))
+            res[fused] = outs
+        finally:
+            ops.FUSE_DROP = True
+    for (yf, dxf, gf), (yc, dxc, gc) in zip(res[True], res[False]):
+        assert (yf - yc).norm() <= 1e-5 * yc.norm(), float((yf - yc).norm() / yc.norm())
+        assert (dxf - dxc).norm() <= 3e-3 * dxc.norm(), float((dxf - dxc).norm() / dxc.norm())
+        for n in gc:
+            # (proj_l.bias shifts every score of a softmax row alike: its gradient is rounding noise around zero)
+            assert (gf[n] - gc[n]).norm() <= 5e-3 * gc[n].norm() + 1e-4, (n, float((gf[n] - gc[n]).norm() / gc[n].norm()))
+    # the rates are really applied: the dropped-branch output differs from the deterministic one
+    blk.eval()
+    with torch.no_grad():
+        assert (blk(x0) - res[True][0][0]).norm() > 1e-2 * res[True][0][0].norm()
