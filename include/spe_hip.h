@@ -225,6 +225,13 @@ int spe_talking_fused(int mode, const void* Qf, const void* Kf, const void* Vf, 
                       const float* M, const float* IL, const float* D, float* ws_stats, float* ws_w, void* outT,
                       int B, int H, int N, int dh, int nwg, float p_drop, uint64_t seed, uint64_t offset,
                       spe_stream_t stream);
+/* spe_talking_fused with the dropout keep flags of spe_talking_flash_fwd (keepbits; modes 2 and 3 with p_drop > 0): the masks are loaded -
+ * one dword per lane and tile - instead of regenerated; keepbits == NULL: identical to spe_talking_fused. */
+int spe_talking_fused_bits(int mode, const void* Qf, const void* Kf, const void* Vf, const void* dOf,
+                           const float* Wl, const float* bl, const float* Ww, const float* bw,
+                           const float* M, const float* IL, const float* D, float* ws_stats, float* ws_w, void* outT, const void* keepbits,
+                           int B, int H, int N, int dh, int nwg, float p_drop, uint64_t seed, uint64_t offset,
+                           spe_stream_t stream);
 int spe_attn_merge(const float* ws, float* out0, float* out1, int B, int H, int N, int steps_per_wg, int mode,
                    spe_stream_t stream);
 /* mode-0 merge that ALSO writes the flash kernels' row constants rows [B][Np][H] = bl[g] log2(e) - M + log2(IL), zero for the rows
@@ -246,7 +253,9 @@ int spe_talking_wgrad_reduce(const float* ws_w, int nwg, int H, float* dWl, floa
  * spe_talking_flash_fwd: O[b, q, g*dh + d] = sum_key P'd[b,g][q,key] v[b, key, g, d] with P'd = attn_drop(proj_w(softmax(proj_l(
  *   scale q k^T)))); Qf / Kf fp16 fragments (spe_attn_pack_multi kind 0 + 16, Qf packed with scale * log2(e)), V16 fp16 (kind
  *   1 + 16), c0 from spe_talking_flash_rows mode 0.  O16 / O16lo (optional): bf16(O) and bf16(O - bf16(O)), same addressing - the
- *   operand of the output projection.
+ *   operand of the output projection.  keepbits (optional, p_drop > 0): uint32 [B][nt][nt][64], nt = ceil(N / 16) - the dropout keep flags of
+ *   every 16 x 16 tile in the lane layout of the q-major passes (bit hp * 8 + 2 r + e: key 4 (lane >> 4) + r, head 2 hp + e of query lane & 15);
+ *   spe_talking_fused_bits then loads them in backward passes 1 and 2 instead of regenerating the masks.
  * spe_talking_flash_dv: dv[b, key, g, :] = sum_q P'd[b,g][q,key] dO[b, q, g, :] (element strides ob, on, oh of dv) - the same walk
  *   with the key tiles resident: P'd is RECOMPUTED from the forward's fragments, statistics and dropout stream (nothing N x N is
  *   saved for the backward); dO16 = spe_attn_pack_multi kind 1 (bf16).  dv16 (optional): bf16(dv) with the same element strides - the
@@ -256,8 +265,8 @@ int spe_talking_flash_rows(const float* in0, const float* in1, const float* bl, 
                            spe_stream_t stream);
 int spe_talking_flash_plan(int B, int N, int nwg, int* steps_per_wg, int* nwg_used, int* nmajor, int* rows_padded);
 int spe_talking_flash_fwd(const void* Qf, const void* Kf, const void* V16, const float* Wl, const float* Ww, const float* bw,
-                          const float* c0, int Np, float* ws, float* O, void* O16, void* O16lo, int B, int H, int N, int dh, int nwg,
-                          float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
+                          const float* c0, int Np, float* ws, float* O, void* O16, void* O16lo, void* keepbits, int B, int H, int N, int dh,
+                          int nwg, float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
 int spe_talking_flash_dv(const void* Qf, const void* Kf, const void* dO16, const float* Wl, const float* Ww, const float* bw,
                          const float* c0, int Np, float* ws, float* dv, void* dv16, long ob, long on, long oh, int B, int H, int N, int dh,
                          int nwg, float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);

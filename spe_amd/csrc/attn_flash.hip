@@ -31,6 +31,10 @@ struct FlashFwdArgs {
     float* ws_o;                         // partial O * 2^8: [B * nmaj][FL_MAXSLOT][NW waves][QS][H][DT][64 lanes][4]
     int B, N, nt, nmaj, spw; long total;
     float p_drop; uint64_t seed, offset;
+    // forward with dropout (optional): the keep flags of every 16 x 16 tile, one dword per lane - bit hp * 8 + 2 r + e = key 4 (lane >> 4) + r,
+    // head 2 hp + e of query lane & 15 - as [B][nt (q-tile)][nt (key tile)][64]: the lane layout of the q-major passes, which then load their
+    // masks (34 MB per block at cfg2) instead of regenerating them (4 Philox calls per lane and tile, ~60 us per pass)
+    unsigned* keepbits;
 };
 
 // Geometry: FLF_NW waves per workgroup, FLF_QS q-tiles per wave, 8 q-tiles = 128 queries per workgroup either way (the K / V
@@ -375,6 +379,7 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
                 if constexpr (DROP) {
                     const uint32_t thr = (uint32_t)(a.p_drop * 65536.0f);
                     const float inv = 1.0f / (1.0f - a.p_drop);
+                    uint32_t kbw = 0u;
 #pragma unroll
                     for (int hp = 0; hp < H / 2; ++hp) {
                         const int g0 = 2 * hp, g1 = 2 * hp + 1;
@@ -383,8 +388,10 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
                             fl_keep_lots<H>(a.seed, a.offset, b, hp, qrow[u], (kt0 + i) * 16 + 4 * (lane >> 4), N, o);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                pr[r][g0 >> 2][g0 & 3] *= (fl_lot(o, 0, r) >= thr) ? inv : 0.f;
-                                pr[r][g1 >> 2][g1 & 3] *= (fl_lot(o, 1, r) >= thr) ? inv : 0.f;
+                                const bool e0 = fl_lot(o, 0, r) >= thr, e1 = fl_lot(o, 1, r) >= thr;
+                                pr[r][g0 >> 2][g0 & 3] *= e0 ? inv : 0.f;
+                                pr[r][g1 >> 2][g1 & 3] *= e1 ? inv : 0.f;
+                                kbw |= ((e0 ? 1u : 0u) | (e1 ? 2u : 0u)) << (hp * 8 + 2 * r);
                             }
                         } else {
                             // lane = (key, 4 consecutive queries 4 (l >> 4) + r): element (q, key) uses lot (key & 3) of the counter of
@@ -410,6 +417,9 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
                                 pr[r][g1 >> 2][g1 & 3] *= ((got >> 16) >= thr) ? inv : 0.f;
                             }
                         }
+                    }
+                    if constexpr (!KV) {            // the q-major backward passes load this tile's flags instead of drawing them again
+                        if (a.keepbits && wvalid && qt0 + u < nt) a.keepbits[(((long)b * nt + (qt0 + u)) * nt + (kt0 + i)) * 64 + lane] = kbw;
                     }
                 }
 #pragma unroll
@@ -566,7 +576,7 @@ extern "C" int spe_talking_flash_rows(const float* in0, const float* in1, const 
 // forward (kv = 0): R = Qf, S1 = Kf, S2 = V16, out = O.   dV pass (kv = 1): R = Kf, S1 = Qf, S2 = dO16 (bf16), out = dv.
 static int flash_run(int kv, const void* R, const void* S1, const void* S2, const float* Wl, const float* Ww, const float* bw, const float* c0,
                      int Np, float* ws, float* out, long ob, long on, long oh, void* O16, void* O16lo, int B, int H, int N, int dh, int nwg,
-                     float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
+                     float p_drop, uint64_t seed, uint64_t offset, hipStream_t st, void* keepbits = nullptr) {
     const int nt = (N + 15) / 16;
     if ((long)B * nt <= 0) return 0;
     if (dh < 1 || dh > 64 || nwg <= 0 || (O16lo && !O16) || Np < nt * 16 + 64) return -2;
@@ -576,7 +586,7 @@ static int flash_run(int kv, const void* R, const void* S1, const void* S2, cons
     a.Qf = (const unsigned char*)R; a.Kf = (const unsigned char*)S1; a.V16 = (const unsigned char*)S2;
     a.Wl = Wl; a.Ww = Ww; a.bw = bw; a.c0 = c0; a.Np = Np; a.ws_o = ws;
     a.B = B; a.N = N; a.nt = nt; a.nmaj = p.nmaj; a.spw = p.spw; a.total = p.total;
-    a.p_drop = p_drop; a.seed = seed; a.offset = offset;
+    a.p_drop = p_drop; a.seed = seed; a.offset = offset; a.keepbits = reinterpret_cast<unsigned*>(keepbits);
     const bool drop = p_drop > 0.f;
     int rc = -2;
 #define SPE_FLASH_FWD(HH, KVV)                                                                   \
@@ -597,9 +607,10 @@ static int flash_run(int kv, const void* R, const void* S1, const void* S2, cons
 }
 
 extern "C" int spe_talking_flash_fwd(const void* Qf, const void* Kf, const void* V16, const float* Wl, const float* Ww, const float* bw,
-                                     const float* c0, int Np, float* ws, float* O, void* O16, void* O16lo, int B, int H, int N, int dh, int nwg,
-                                     float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
-    return flash_run(0, Qf, Kf, V16, Wl, Ww, bw, c0, Np, ws, O, (long)N * H * dh, (long)H * dh, dh, O16, O16lo, B, H, N, dh, nwg, p_drop, seed, offset, st);
+                                     const float* c0, int Np, float* ws, float* O, void* O16, void* O16lo, void* keepbits, int B, int H, int N,
+                                     int dh, int nwg, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
+    return flash_run(0, Qf, Kf, V16, Wl, Ww, bw, c0, Np, ws, O, (long)N * H * dh, (long)H * dh, dh, O16, O16lo, B, H, N, dh, nwg, p_drop, seed, offset, st,
+                     p_drop > 0.f ? keepbits : nullptr);
 }
 
 extern "C" int spe_talking_flash_dv(const void* Qf, const void* Kf, const void* dO16, const float* Wl, const float* Ww, const float* bw,

@@ -52,6 +52,7 @@ struct FusedArgs {
     int B, N, nt;                                         // nt = ceil(N/16) tiles per axis
     int steps_per_wg; long total_steps;
     float p_drop; uint64_t seed, offset;
+    const unsigned* keepbits;                             // modes 2, 3 with dropout (optional): the keep flags the flash forward stored, [B][nt][nt][64]
 };
 
 // H*H mixing weights -> SGPRs, once per register phase: H*H/16 s_load_dwordx16 through the scalar cache (no
@@ -249,6 +250,14 @@ __device__ __forceinline__ void fused_keep_scales(uint64_t seed, uint64_t offset
         s0[2 * i] = ((o[i] & 0xffffu) >= thr) ? inv : 0.f;      s0[2 * i + 1] = ((o[i] >> 16) >= thr) ? inv : 0.f;
         s1[2 * i] = ((o[2 + i] & 0xffffu) >= thr) ? inv : 0.f;  s1[2 * i + 1] = ((o[2 + i] >> 16) >= thr) ? inv : 0.f;
     }
+}
+
+// the same keep scales from the flags the flash forward stored for this lane and tile (bit hp * 8 + 2 r + e: key r of the lane's group, head 2 hp + e)
+__device__ __forceinline__ void fused_keep_from_bits(uint32_t kb, float p, int hp, float (&s0)[4], float (&s1)[4]) {
+    const float inv = 1.0f / (1.0f - p);
+    const uint32_t w = kb >> (hp * 8);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s0[r] = (w & (1u << (2 * r))) ? inv : 0.f; s1[r] = (w & (2u << (2 * r))) ? inv : 0.f; }
 }
 
 // Fragment record of one (b, h, 16-row tile): FULL = DSTEPS - TAIL16 steps of 32 head dims (64 lanes x 16 B) followed,
@@ -563,6 +572,14 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
             constexpr int NB = NJ / JB;
             f32x4_t acc[KT][H];
             f32x4_t acc2[(MODE >= 2) ? KT : 1][(MODE >= 2) ? H : 1];
+            // dropout masks of this macro step's tiles, when the forward stored them: requested here, ahead of the MFMA phase that hides the trip
+            uint32_t kbits[(MODE >= 2 && DROP) ? KT : 1];
+            const bool have_bits = MODE >= 2 && DROP && a.keepbits != nullptr;
+            if (have_bits) {
+#pragma unroll
+                for (int j = 0; j < KT; ++j)
+                    kbits[(MODE >= 2 && DROP) ? j : 0] = a.keepbits[(((long)b * nt + qt) * nt + min(kt_first + j, nt - 1)) * 64 + lane];
+            }
 #ifdef SPE_DBG_NOLOAD
             if (km == KM0) load_batch(0, kt_first);
 #else
@@ -849,7 +866,8 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
 #pragma unroll
                         for (int hp = 0; hp < H / 2; ++hp) {
                             float k0[4], k1[4];
-                            fused_keep_scales<H>(a.seed, a.offset, a.p_drop, b, hp, q, KB(j), N, k0, k1);
+                            if (have_bits) fused_keep_from_bits(kbits[(MODE >= 2 && DROP) ? j : 0], a.p_drop, hp, k0, k1);
+                            else fused_keep_scales<H>(a.seed, a.offset, a.p_drop, b, hp, q, KB(j), N, k0, k1);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { acc2[j][2 * hp][r] *= k0[r]; acc2[j][2 * hp + 1][r] *= k1[r]; }
                         }
@@ -922,7 +940,8 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
 #pragma unroll
                         for (int hp = 0; hp < H / 2; ++hp) {
                             float k0[4], k1[4];
-                            fused_keep_scales<H>(a.seed, a.offset, a.p_drop, b, hp, q, KB(j), N, k0, k1);
+                            if (have_bits) fused_keep_from_bits(kbits[(MODE >= 2 && DROP) ? j : 0], a.p_drop, hp, k0, k1);
+                            else fused_keep_scales<H>(a.seed, a.offset, a.p_drop, b, hp, q, KB(j), N, k0, k1);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { acc2[j][2 * hp][r] *= k0[r]; acc2[j][2 * hp + 1][r] *= k1[r]; }
                         }
@@ -1336,12 +1355,24 @@ static int dispatch_mode(const FusedArgs& a, int mode, bool drop, int nwg, hipSt
 }
 
 // C-ABI: see include/spe_hip.h (spe_talking_fused).  Returns -2 for unsupported (H, head dim).
+extern "C" int spe_talking_fused_bits(int mode, const void* Qf, const void* Kf, const void* Vf, const void* dOf,
+                                      const float* Wl, const float* bl, const float* Ww, const float* bw,
+                                      const float* M, const float* IL, const float* D, float* ws_stats, float* ws_w, void* outT, const void* keepbits,
+                                      int B, int H, int N, int dh, int nwg, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st);
 extern "C" int spe_talking_fused(int mode, const void* Qf, const void* Kf, const void* Vf, const void* dOf,
                                  const float* Wl, const float* bl, const float* Ww, const float* bw,
                                  const float* M, const float* IL, const float* D, float* ws_stats, float* ws_w, void* outT,
                                  int B, int H, int N, int dh, int nwg, float p_drop, uint64_t seed, uint64_t offset,
                                  hipStream_t st) {
+    return spe_talking_fused_bits(mode, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, ws_stats, ws_w, outT, nullptr, B, H, N, dh, nwg, p_drop, seed, offset, st);
+}
+// C-ABI: see include/spe_hip.h
+extern "C" int spe_talking_fused_bits(int mode, const void* Qf, const void* Kf, const void* Vf, const void* dOf,
+                                      const float* Wl, const float* bl, const float* Ww, const float* bw,
+                                      const float* M, const float* IL, const float* D, float* ws_stats, float* ws_w, void* outT, const void* keepbits,
+                                      int B, int H, int N, int dh, int nwg, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
     FusedArgs a;
+    a.keepbits = (mode >= 2 && p_drop > 0.f) ? reinterpret_cast<const unsigned*>(keepbits) : nullptr;
     a.Qf = (const u32x4_t*)Qf; a.Kf = (const u32x4_t*)Kf; a.Vf = (const u32x4_t*)Vf; a.dOf = (const u32x4_t*)dOf;
     a.Wl = Wl; a.bl = bl; a.Ww = Ww; a.bw = bw; a.M = M; a.IL = IL; a.D = D;
     a.ws_stats = ws_stats; a.ws_w = ws_w; a.outT = (unsigned short*)outT;

@@ -1161,7 +1161,12 @@ def fused_plan(B, N, mode):
     return spw.value, nwg.value
 
 
-def talking_fused(mode, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, ws_stats, ws_w, outT, B, H, N, dh, p_drop, seed, offset):
+def talking_fused(mode, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, ws_stats, ws_w, outT, B, H, N, dh, p_drop, seed, offset, keepbits=None):
+    """keepbits (modes 2, 3 with dropout): the keep flags stored by talking_flash_fwd - loaded instead of regenerated."""
+    if keepbits is not None:
+        _call("spe_talking_fused_bits", mode, _p(Qf), _p(Kf), _p(Vf), _p(dOf), _p(Wl), _p(bl), _p(Ww), _p(bw), _p(M), _p(IL), _p(D),
+              _p(ws_stats), _p(ws_w), _p(outT), _p(keepbits), B, H, N, dh, FUSED_NWG[mode], float(p_drop), seed, offset, _st())
+        return
     _call("spe_talking_fused", mode, _p(Qf), _p(Kf), _p(Vf), _p(dOf), _p(Wl), _p(bl), _p(Ww), _p(bw), _p(M), _p(IL), _p(D),
           _p(ws_stats), _p(ws_w), _p(outT), B, H, N, dh, FUSED_NWG[mode], float(p_drop), seed, offset, _st())
 
@@ -1362,8 +1367,12 @@ def _flash_ws(device, floats):
     return ent
 
 
-def talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, offset, want16=False, want16lo=False):
-    """-> O [B,N,H*dh] fp32 (+ bf16 copy, + its low part)."""
+FLASH_KEEPBITS = os.environ.get("SPE_FLASH_KEEPBITS", "1") != "0"      # developer knob (A/B)
+
+
+def talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, offset, want16=False, want16lo=False, want_bits=False):
+    """-> O [B,N,H*dh] fp32 (+ bf16 copy, + its low part; want_bits with dropout: + the keep flags [B,nt,nt,64] int32 of every tile
+    for the backward's q-major passes - appended as a 4th result)."""
     dev = Qf.device
     nmaj = flash_plan(B, N)[2]
     ws = _flash_ws(dev, B * nmaj * FLASH_SLOTS * 128 * H * 16 * ((dh + 15) // 16))
@@ -1371,8 +1380,12 @@ def talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, of
     O = torch.empty((B, N, C), device=dev, dtype=torch.float32)
     O16 = torch.empty((B * N, C), device=dev, dtype=torch.bfloat16) if want16 else None
     O16lo = torch.empty((B * N, C), device=dev, dtype=torch.bfloat16) if (want16 and want16lo) else None
+    nt = (N + 15) // 16
+    bits = torch.empty((B, nt, nt, 64), device=dev, dtype=torch.int32) if (want_bits and p_drop > 0 and FLASH_KEEPBITS) else None
     _call("spe_talking_flash_fwd", _p(Qf), _p(Kf), _p(V16), _p(Wl), _p(Ww), _p(bw), _p(c0), c0.shape[1], _p(ws), _p(O), _p(O16), _p(O16lo),
-          B, H, N, dh, FLASH_NWG, float(p_drop), seed, offset, _st())
+          _p(bits), B, H, N, dh, FLASH_NWG, float(p_drop), seed, offset, _st())
+    if want_bits:
+        return O, O16, O16lo, bits
     return O, O16, O16lo
 
 

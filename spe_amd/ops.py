@@ -460,7 +460,8 @@ class _TalkingHeadsAttentionFused(Function):
         if flash:
             # P' goes from the head mix straight into the P' V products (csrc/attn_flash.hip): the 554 MB (cfg2) P'd tensor of the
             # write pass is neither stored, streamed back nor saved - the backward recomputes it inside its dV pass
-            O, O16, O16lo = K.talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, off, want16, K.split_fwd())
+            O, O16, O16lo, bits = K.talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, off, want16, K.split_fwd(),
+                                                      want_bits=True)
             Pd = c0                                                        # what the backward needs instead of P'd
         else:
             Pd = K.score_blocks(B, H, N, qkv.device, torch.float16)          # fp16(P'd * PD_SCALE)
@@ -473,7 +474,10 @@ class _TalkingHeadsAttentionFused(Function):
             K.attach16(O, O16, O16lo)        # the output projection's operand, written by the contraction's epilogue
         ctx.meta = (B, N, C, H, dh, nt, scale, p_drop, seed, off, flash)
         ctx.wparams = (Wl, bl, Ww, bw)      # leaves: looked up in backward for their gradient buckets
-        saved = (packed[3], packed[4], packed[5], Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw) if train else ()
+        # with dropout the flash forward leaves the keep flags of every tile behind (1 bit per element): backward passes 1 and 2 load them
+        kb = bits if (flash and train and bits is not None) else None
+        ctx.has_bits = kb is not None
+        saved = (packed[3], packed[4], packed[5], Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw) + ((kb,) if kb is not None else ()) if train else ()
         return O, saved
 
     @staticmethod
@@ -485,7 +489,8 @@ class _TalkingHeadsAttentionFused(Function):
     def _bwd(ctx, saved, dO, out16):
         """-> (dqkv, dWl, dbl, dWw, dbw).  out16: dqkv comes back as the bf16 [B, N, 3C] operand of the qkv Linear's backward GEMMs
         (written by the contraction / merge epilogues); no fp32 copy exists then."""
-        Vf, K16, Q16, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw = saved
+        Vf, K16, Q16, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw = saved[:12]
+        kbits = saved[12] if ctx.has_bits else None
         B, N, C, H, dh, nt, scale, p_drop, seed, off, flash = ctx.meta
         spw, nwg = K.fused_plan(B, N, 2)
         dO = dO.contiguous()
@@ -499,10 +504,10 @@ class _TalkingHeadsAttentionFused(Function):
         nw = 2 * (H * H + H)
         ws_stats = torch.empty((B * nt * 8 * H * 32,), device=dO.device, dtype=torch.float32)
         ws_w = torch.empty((nwg, nw), device=dO.device, dtype=torch.float32)
-        K.talking_fused(2, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, None, ws_stats, ws_w, None, B, H, N, dh, p_drop, seed, off)
+        K.talking_fused(2, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, None, ws_stats, ws_w, None, B, H, N, dh, p_drop, seed, off, keepbits=kbits)
         D, _ = K.attn_merge(ws_stats, B, H, N, spw, 2)
         dS = K.score_blocks(B, H, N, dO.device)
-        K.talking_fused(3, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, None, ws_w, dS, B, H, N, dh, p_drop, seed, off)
+        K.talking_fused(3, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, None, ws_w, dS, B, H, N, dh, p_drop, seed, off, keepbits=kbits)
         # dV[key,d] = sum_q P'd[q,key] dO[q,d] - issued here, between backward pass 2 and the contractions that re-read
         # its 554 MB of dS: a streaming read right after a pass that wrote that much runs ~20 % slower (measured)
         if flash:       # Pd holds the row constants c0: P'd is recomputed tile by tile inside the dV pass

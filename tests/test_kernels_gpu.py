@@ -635,11 +635,16 @@ def test_fused_mlp_residual_matches_composite(dev):
         with torch.no_grad():
             oi = ops.mlp_gelu_residual(xn.detach(), W1.detach(), b1.detach(), W2.detach(), b2.detach(), xr.detach(), gamma.detach())
         assert torch.equal(oi, out.detach())
-        # DropPath scale present -> composite path
+        # DropPath scale present: still ONE node (round 4: the per-sample scale rides on the fc2 epilogue) with the composite's result
         ss = torch.tensor([1.25, 0.0], device=dev)
         o2 = ops.mlp_gelu_residual(xn, W1, b1, W2, b2, xr, gamma, ss)
-        assert not o2.grad_fn.name().startswith("_MlpGeluRes")
-        assert rel(o2, ops.layerscale_residual(xr, ops.mlp_gelu(xn, W1, b1, W2, b2), gamma, ss)) < 1e-6
+        assert o2.grad_fn.name().startswith("_MlpGeluRes")
+        oc = ops.layerscale_residual(xr, ops.mlp_gelu(xn, W1, b1, W2, b2), gamma, ss)
+        assert rel(o2, oc) < 1e-6
+        gf = torch.autograd.grad(o2, [xn, W1, W2, gamma], go)
+        gc = torch.autograd.grad(oc, [xn, W1, W2, gamma], go)
+        for a_, b_ in zip(gf, gc):
+            assert rel(a_, b_) < 2e-3
     finally:
         K.MLP_PRE_F16 = saved16
 
@@ -699,8 +704,15 @@ def test_fused_linear_residual_matches_composite(dev):
         assert rel(a, c) < (1e-3 if (nm == "gamma" and K.MLP_PRE_F16) else 5e-6), (nm, rel(a, c))
     with torch.no_grad():
         assert torch.equal(ops.linear_residual(xa.detach(), W.detach(), b.detach(), xr.detach(), gamma.detach()), out.detach())
+    # DropPath scale present: still one node (round 4: the per-sample scale rides on the GEMM epilogue), same result as the composite
     ss = torch.tensor([1.25, 0.0], device=dev)
-    assert not ops.linear_residual(xa, W, b, xr, gamma, ss).grad_fn.name().startswith("_LinearRes")
+    o2 = ops.linear_residual(xa, W, b, xr, gamma, ss)
+    assert o2.grad_fn.name().startswith("_LinearRes")
+    oc = ops.layerscale_residual(xr, ops.linear(xa, W, b), gamma, ss)
+    assert rel(o2, oc) < 1e-6
+    go2 = torch.randn_like(oc)
+    for a_, b_ in zip(torch.autograd.grad(o2, [xa, W, gamma], go2), torch.autograd.grad(oc, [xa, W, gamma], go2)):
+        assert rel(a_, b_) < 2e-3
 
 
 def test_layer_norm_skip_sums_both_gradients(dev):
