@@ -365,6 +365,10 @@ int spe_matcher_cost(const float* logits, const float* boxes, const int* tgt_ids
  * remaining costs are all NaN / infinite (SciPy raises ValueError there); that problem gets the identity assignment. */
 int spe_hungarian(const float* cost, const int* toff, long* srow, long* gidx, int* lidx, int* err, int L, int B, int Q,
                   spe_stream_t stream);
+/* One-to-many target jitter (reference models/conditional_detr.py:409-431): out [M][ratio][4] - for every cxcywh box up to ratio - 1 of
+ * its candidates scale[m][c][:] * box[m][:] (c < ncand, attempt order) whose IoU with the box exceeds 0.7, then the box itself for the
+ * picks that found none and for the last row.  scale [M][ncand][4]: the uniform draws (the caller's generator), 16-B aligned. */
+int spe_jitter_pick(const float* box, const float* scale, float* out, int M, int ncand, int ratio, spe_stream_t stream);
 
 /* ---- weighted sigmoid focal loss (reference models/conditional_detr.py:468-494, 504-535):
  * logits[L*rows_per_l, Kc]; tclass[row] in [0,Kc] (Kc = no object); roww[row] row weight or

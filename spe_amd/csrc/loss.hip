@@ -514,3 +514,56 @@ extern "C" int spe_nms_sorted(const float* boxes, const long* labels, const int*
     SPE_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// One-to-many target jitter (reference models/conditional_detr.py:409-431: every GT box becomes `ratio` rows - up to ratio - 1 copies
+// scaled by uniform factors in [1 - j, 1 + j], each the first of <= 1000 attempts whose IoU with the original exceeds 0.7, the original
+// last).  The host-side mirror draws the 1000 candidate scales per box with torch's generator in ONE launch; this kernel does the rest
+// (candidate boxes, IoU, the first ratio - 1 kept candidates in attempt order) instead of ~25 elementwise / scan / gather launches
+// over [M, 1000, 4] tensors per criterion call.  One wave per box; the arithmetic is written without contraction so that the
+// decisions equal the elementwise composition's.
+__global__ __launch_bounds__(64) void jitter_pick_kernel(const float* __restrict__ box, const float* __restrict__ scale, float* __restrict__ out,
+                                                         int M, int ncand, int ratio) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    if (m >= M) return;
+    const float b0 = box[m * 4], b1 = box[m * 4 + 1], b2 = box[m * 4 + 2], b3 = box[m * 4 + 3];
+    const float bx0 = __fsub_rn(b0, __fmul_rn(0.5f, b2)), by0 = __fsub_rn(b1, __fmul_rn(0.5f, b3));
+    const float bx1 = __fadd_rn(b0, __fmul_rn(0.5f, b2)), by1 = __fadd_rn(b1, __fmul_rn(0.5f, b3));
+    const float area_b = __fmul_rn(__fsub_rn(bx1, bx0), __fsub_rn(by1, by0));
+    float* o = out + (long)m * ratio * 4;
+    int found = 0;                                       // kept candidates so far (wave-uniform)
+    for (int c0 = 0; c0 < ncand && found < ratio - 1; c0 += 64) {
+        const int c = c0 + lane;
+        bool keep = false;
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+        if (c < ncand) {
+            const float4 sc = *reinterpret_cast<const float4*>(scale + ((long)m * ncand + c) * 4);
+            q0 = __fmul_rn(sc.x, b0); q1 = __fmul_rn(sc.y, b1); q2 = __fmul_rn(sc.z, b2); q3 = __fmul_rn(sc.w, b3);
+            const float ax0 = __fsub_rn(q0, __fmul_rn(0.5f, q2)), ay0 = __fsub_rn(q1, __fmul_rn(0.5f, q3));
+            const float ax1 = __fadd_rn(q0, __fmul_rn(0.5f, q2)), ay1 = __fadd_rn(q1, __fmul_rn(0.5f, q3));
+            const float w = fmaxf(__fsub_rn(fminf(ax1, bx1), fmaxf(ax0, bx0)), 0.f), h = fmaxf(__fsub_rn(fminf(ay1, by1), fmaxf(ay0, by0)), 0.f);
+            const float inter = __fmul_rn(w, h);
+            const float area_a = __fmul_rn(__fsub_rn(ax1, ax0), __fsub_rn(ay1, ay0));
+            const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_a, area_b), inter));
+            keep = iou > 0.7f;
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+            const int rank = found + __popcll(mask & ((1ull << lane) - 1ull));       // 0-based rank among the kept candidates
+            if (rank < ratio - 1) { o[rank * 4] = q0; o[rank * 4 + 1] = q1; o[rank * 4 + 2] = q2; o[rank * 4 + 3] = q3; }
+        }
+        found += __popcll(mask);
+    }
+    if (found > ratio - 1) found = ratio - 1;
+    // picks without a kept candidate, and the last row: the original box
+    for (int s = found + lane; s < ratio; s += 64) { o[s * 4] = b0; o[s * 4 + 1] = b1; o[s * 4 + 2] = b2; o[s * 4 + 3] = b3; }
+}
+
+// C-ABI: see include/spe_hip.h
+extern "C" int spe_jitter_pick(const float* box, const float* scale, float* out, int M, int ncand, int ratio, hipStream_t st) {
+    if (M <= 0) return 0;
+    if (ratio < 1 || ncand < 0 || (reinterpret_cast<uintptr_t>(scale) & 15)) return -2;
+    hipLaunchKernelGGL(jitter_pick_kernel, dim3(M), dim3(64), 0, st, box, scale, out, M, ncand, ratio);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}

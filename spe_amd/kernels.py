@@ -1419,6 +1419,15 @@ def attn_merge_rows(ws_stats, bl, B, H, N, spw):
     return M, IL, c0
 
 
+def jitter_pick(box, scale, ratio):
+    """box [M,4] cxcywh, scale [M,ncand,4] uniform factors -> [M, ratio, 4]: the first ratio - 1 candidates with IoU > 0.7, original last."""
+    _chk(box, scale)
+    M, ncand = scale.shape[0], scale.shape[1]
+    out = torch.empty((M, ratio, 4), device=box.device, dtype=torch.float32)
+    _call("spe_jitter_pick", _p(box), _p(scale), _p(out), M, ncand, int(ratio), _st())
+    return out
+
+
 def talking_wgrad_reduce(ws_w, H, params):
     """Column sums of the weight-gradient partials [nwg, 2*(H*H+H)] as (dWl [H,H], dbl [H], dWw [H,H], dbw [H]), written
     into the parameters' all-reduce bucket views when those are still unclaimed this step (params = Wl, bl, Ww, bw)."""

@@ -110,6 +110,9 @@ class _BoxLoss(Function):
         return dpred, None, None, None, None, None, None
 
 
+JITTER_KERNEL = True        # tests: False runs the elementwise composition on device tensors too
+
+
 def jitter_targets(targets, ratio, jitter):
     """One-to-many targets (conditional_detr.py:409-431): each GT box -> `ratio` rows: up to ratio-1
     multiplicatively jittered copies (first of 1000 candidates with IoU>0.7), original box last; labels
@@ -122,6 +125,11 @@ def jitter_targets(targets, ratio, jitter):
         box = torch.cat([t["boxes"] for t in out if t["boxes"].shape[0] > 0])
         M = box.shape[0]
         scale = torch.empty((M, 1000, 4), dtype=box.dtype, device=box.device).uniform_(1 - jitter, 1 + jitter)
+        if JITTER_KERNEL and box.is_cuda and box.dtype == torch.float32:
+            # candidates, IoU test and the first ratio - 1 kept ones per box in ONE launch (csrc/loss.hip: jitter_pick_kernel); same picks
+            # as the elementwise composition below, which stays for host tensors (tests of the host logic)
+            rep = K.jitter_pick(box.contiguous(), scale, ratio).reshape(M * ratio, 4)
+            return _split_jittered(out, counts, rep, ratio)
         cand = scale * box[:, None, :]
         a = box_ops.box_cxcywh_to_xyxy(cand)
         b = box_ops.box_cxcywh_to_xyxy(box)[:, None, :]
@@ -140,11 +148,17 @@ def jitter_targets(targets, ratio, jitter):
             got = cand[torch.arange(M, device=box.device)[:, None], idx]                 # [M, ratio-1, 4]
             rep[:, :ratio - 1] = torch.where(has[..., None], got, box[:, None, :])
         rep = rep.reshape(M * ratio, 4)
-        off = 0
-        for t, m in zip(out, counts):
-            if m > 0:
-                t["boxes"] = rep[off * ratio:(off + m) * ratio]
-                off += m
+        return _split_jittered(out, counts, rep, ratio)
+    return _split_jittered(out, counts, None, ratio)
+
+
+def _split_jittered(out, counts, rep, ratio):
+    """Hand the [sum(M) * ratio, 4] jittered boxes back to the per-image target dicts; labels / scores repeat `ratio` times."""
+    off = 0
+    for t, m in zip(out, counts):
+        if m > 0 and rep is not None:
+            t["boxes"] = rep[off * ratio:(off + m) * ratio]
+            off += m
     for t in out:
         t["labels"] = t["labels"].unsqueeze(1).repeat(1, ratio).reshape(-1)
         if "scores" in t:

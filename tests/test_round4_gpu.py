@@ -271,3 +271,29 @@ def test_attention_dropout_keep_flags_equal_regenerated_masks(dev):
         for a, b in zip(*res):
             assert torch.equal(a, b)
         assert res[0][1].abs().sum() > 0
+
+
+def test_jitter_pick_kernel_equals_elementwise_composition(dev):
+    """One-to-many target jitter (reference models/conditional_detr.py:409-431): the one-launch pick kernel against the elementwise
+    torch composition on the SAME uniform draws - identical boxes (the arithmetic is written without contraction), incl. boxes for which
+    fewer than ratio - 1 candidates pass the IoU test (tiny boxes: every jitter fails) and images without targets."""
+    from spe_amd.models import conditional_detr as cd
+    g = torch.Generator().manual_seed(4)
+    targets = []
+    for m in (7, 0, 23):
+        b = torch.rand(m, 4, generator=g) * 0.5 + 0.2
+        if m:
+            b[0, 2:] = 1e-6                          # degenerate size: IoU of any jittered copy is far below 0.7 or undefined
+        targets.append({"boxes": b.to(dev), "labels": torch.randint(0, 20, (m,), generator=g).to(dev), "scores": torch.rand(m, generator=g).to(dev)})
+    outs = []
+    for kern in (True, False):
+        cd.JITTER_KERNEL = kern
+        try:
+            torch.manual_seed(123)
+            outs.append(cd.jitter_targets(targets, 5, 0.1))
+        finally:
+            cd.JITTER_KERNEL = True
+    for a, b in zip(*outs):
+        assert a["boxes"].shape == b["boxes"].shape and torch.equal(a["labels"], b["labels"]) and torch.equal(a["scores"], b["scores"])
+        assert torch.equal(a["boxes"], b["boxes"])
+    assert outs[0][2]["boxes"].shape == (23 * 5, 4) and outs[0][1]["boxes"].shape[0] == 0
