@@ -611,7 +611,11 @@ def linear_res_bwd(dout2, saved, W, gamma, need_dx=True, grad_bufs=(None, None, 
     return dx, dW, db, dg
 
 
-MLP_PRE_F16 = os.environ.get("SPE_MLP_PRE_F16", "1") != "0"      # developer knob (A/B)
+# Saves that only the backward reads (the MLP's pre-activation for gelu'(.), the branch outputs for the LayerScale gamma gradients) as
+# IEEE fp16 instead of fp32: half the bytes, but from the accumulator layout a 16-bit tile leaves as 32-B row pieces - the fp32 stores are
+# faster than the fp16 ones they replaced (fc1 + GELU isolated: 74.6 vs 80.9 us; step 54.9 -> 54.4 ms in same-box A/B, round 4), and staging
+# the tile through LDS costs a workgroup per CU.  Off by default since; 1.1 GB more saved activations at cfg2.
+MLP_PRE_F16 = os.environ.get("SPE_MLP_PRE_F16", "0") != "0"      # developer knob (A/B)
 
 
 def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True, src=None, drop1=None, drop2=None, sscale=None, rps=1):
