@@ -36,6 +36,15 @@ __device__ __forceinline__ void det_reduce(const DetWs& ws, int set, int member,
         for (int c = tid; c < L; c += nthreads) store(c, partial(c));
         return;
     }
+#if defined(SPE_ABLATE) && defined(SPE_DBG_NORED)
+    // timing experiment (tools/debug/rowops_time.py): no cross-workgroup sum.  Measured, round 4: the tail below costs 5-8 us per launch
+    // (layernorm_bwd 19.8 -> 12.1 us, lsres_bwd16 15.2 -> 10.3, conversion + column sums 11.1 -> 5.5), ~1.4 ms per step over ~250
+    // launches: six dependent round trips to the memory-side coherence point for the last workgroup.  A variant that ADDS 64-bit fixed-point
+    // partials with returning atomics (exact, order-free: 3 round trips) was slower - same-address contention, 15-19 us for the conversion
+    // even with 16 accumulator copies - and is gone; what would help is deferring the sums of several launches to one kernel boundary.
+    if (member == 0) for (int c = tid; c < L; c += nthreads) store(c, partial(c));
+    return;
+#endif
     __shared__ unsigned det_ticket;
     const int ngroups = (nmembers + DET_G - 1) / DET_G, group = member / DET_G, g0 = group * DET_G;
     const int gsize = min(DET_G, nmembers - g0);

@@ -30,3 +30,12 @@ o16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16); cs = torch.zeros(N, d
 for name, kw in (("aux fp16 + bf16 out + colsum (shipped)", dict(out16=o16, colsum=cs, aux=pre16, act=2)), ("aux fp16 + bf16 out", dict(out16=o16, aux=pre16, act=2)),
                  ("bf16 out + colsum", dict(out16=o16, colsum=cs)), ("bf16 out", dict(out16=o16))):
     print("dh single  %-36s %6.1f us" % (name, timeit(lambda: K.gemm16_ex(xh, Wh, M, N, Kd, Kd, Kd, **kw))))
+# proj / fc2 forward (split, residual epilogue): what the saved branch output y (C2) costs
+for nm, (N2, K2) in (("proj", (384, 384)), ("fc2", (384, 1536))):
+    x2 = torch.randn(M, K2, generator=g).to(dev); W2 = (torch.randn(N2, K2, generator=g) / K2 ** 0.5).to(dev); b2 = torch.randn(N2, generator=g).to(dev)
+    xh2 = x2.to(torch.bfloat16); xl2 = (x2 - xh2.float()).to(torch.bfloat16); Wh2 = W2.to(torch.bfloat16); Wl2 = (W2 - Wh2.float()).to(torch.bfloat16)
+    res = torch.randn(M, N2, generator=g).to(dev); gam = torch.rand(N2, generator=g).to(dev)
+    C2_ = torch.empty(M, N2, device=dev); y32 = torch.empty(M, N2, device=dev); y16 = torch.empty(M, N2, device=dev, dtype=torch.float16)
+    for name, kw in (("res + y fp32 (shipped)", dict(C2=y32)), ("res + y fp16", dict(C2=y16)), ("res, no y", dict())):
+        print("%-4s split  %-36s %6.1f us" % (nm, name, timeit(lambda: K.gemm16_ex(xh2, Wh2, M, N2, K2, K2, K2, bias=b2, C=C2_, res=res, rgamma=gam, Alo=xl2, Blo=Wl2, **kw))))
+    print("%-4s split  %-36s %6.1f us" % (nm, "plain fp32 C", timeit(lambda: K.gemm16(xh2, Wh2, C2_, M, N2, K2, K2, K2, N2, bias=b2, Alo=xl2, Blo=Wl2))))
