@@ -45,6 +45,20 @@ int spe_abi_version(void);
  * the model path); entry points that need it return -4 when none is registered or it is too small.  All launches that use it
  * must be ordered on one stream at a time.  ws = NULL unregisters. */
 int spe_set_reduce_workspace(void* ws, size_t bytes, spe_stream_t stream);
+/* Deferred sums (round 4).  The fixed-order tree costs the last workgroup of every launch six dependent trips to the coherence point
+ * (5-8 us; ~250 launches per step).  When the destination of a sum is a parameter gradient inside the caller's all-reduce buckets, nothing
+ * reads it before the bucket is reduced / the optimiser runs: the owner of the buckets registers their address ranges
+ * (spe_reduce_defer_ranges: n <= 64 ranges, n = 0 switches deferral off) and an arena (spe_reduce_defer_arena: caller-owned device memory,
+ * 256-B aligned, a few tens of MB); entry points whose destinations ALL lie inside the ranges (spe_layernorm_bwd / _res_bwd,
+ * spe_layerscale_residual_bwd16(d), spe_cvt_bf16 with colsum, spe_gemm_bf16nt_ex(d) with colsum, spe_colsum_bf16_blocks) then only leave
+ * their per-workgroup partial rows in the arena, and spe_reduce_flush adds the rows of ALL pending launches to their destinations in ONE
+ * kernel (members in index order: bitwise reproducible), stream-ordered after them.  The caller MUST flush before anything reads those
+ * gradients (before a bucket's all-reduce, at the end of the backward); the library flushes by itself when its table or the arena is full.
+ * spe_reduce_pending: launches waiting for a flush.  -3: ranges / arena changed while sums are pending. */
+int spe_reduce_defer_ranges(const void* const* ptrs, const size_t* bytes, int n);
+int spe_reduce_defer_arena(void* arena, size_t bytes);
+int spe_reduce_flush(spe_stream_t stream);
+int spe_reduce_pending(void);
 
 /* ---- contraction ----------------------------------------------------------------------
  * C[z] = act(alpha * opA(A[z]) @ opB(B[z]) + bias) for z = (z0, z1) in batch0 x batch1, each

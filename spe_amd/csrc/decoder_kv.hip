@@ -216,9 +216,13 @@ extern "C" int spe_colsum_bf16_blocks(const void* x, long ld, long R, int nblk, 
         static const int ry_max = getenv("SPE_COLSUM_RY") ? atoi(getenv("SPE_COLSUM_RY")) : 96;       // developer knob (tuning)
         long ry = (R + 63) / 64; if (ry > ry_max) ry = ry_max; if (ry < 1) ry = 1;
         while (gx * ry > 1024 && ry > 16) ry /= 2;            // a few workgroups per CU are enough; the slabs cost a reduction each
-        const DetWs ws = spe_detws();
-        DET_CHECK(ws, gx, ry, 256);
+        DetWs ws = spe_detws();
+        DetDeferSeg sg[KV_MAXBLK];
+        for (int i = 0; i < nblk; ++i) sg[i] = DetDeferSeg{outs[i], blkC};
+        float* region = det_defer_try(gx, ry, 256, nblk, sg, st);         // deferred: the block sums land at the next flush
+        if (region) ws.defer = region; else DET_CHECK(ws, gx, ry, 256);
         hipLaunchKernelGGL(colsum_bf16_blocks_v8_kernel, dim3(gx, (unsigned)ry), dim3(256), 0, st, a, ws);
+        if (region) det_defer_commit(region, gx, ry, 256, nblk, sg, accumulate);
         SPE_CHECK_LAUNCH();
         return 0;
     }

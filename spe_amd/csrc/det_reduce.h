@@ -17,10 +17,28 @@ struct DetWs {
     unsigned* tickets;      // ntickets counters, zero when no launch is in flight
     long slab_floats;
     int ntickets;
+    float* defer;           // != NULL: DEFERRED reduction - every member only leaves its partial at defer[(set * nmembers + member) * L + c]
+                            // (plain stores); the sums are taken later, for many launches at once, by spe_reduce_flush (misc.hip)
 };
 #define DET_G 16
 // host side (misc.hip): the registered workspace, or {nullptr, ...}
 DetWs spe_detws();
+// ---- deferred reductions (round 4).  The tree of det_reduce costs the LAST workgroup of a launch six dependent round trips to the
+// memory-side coherence point: 5-8 us at the end of every LayerNorm / LayerScale backward, conversion with column sums and GEMM epilogue
+// with a bias gradient - ~250 launches, ~1.4 ms per step (tools/debug/rowops_time.py).  The destinations of those sums are PARAMETER
+// gradients inside the all-reduce buckets: nothing reads them before the bucket is reduced / the optimiser runs.  The owner of those
+// buckets registers their address ranges (spe_reduce_defer_ranges) and an arena; a launcher whose destinations ALL lie inside the ranges
+// hands its kernel a region of the arena for the partial rows (plain stores, no tickets) and records where the totals belong;
+// spe_reduce_flush sums the rows of ALL recorded launches in one kernel - members in index order, so the result is as reproducible as
+// the tree's - ordered after the producers by the stream.  Destinations outside the ranges (loss sums, temporaries) keep the tree.
+#define DET_DEFER_MAXSEG 40
+struct DetDeferSeg { float* dst; int len; };
+// host side (misc.hip).  det_defer_try: region for sets * members rows of L floats when deferral applies to these destinations and
+// everything fits (flushing first if the table or the arena is full), else nullptr; det_defer_commit: totals o = set * L + c,
+// o < sum(len), go to the segments in order (dst += or =).
+float* det_defer_try(long sets, long members, long L, int nseg, const DetDeferSeg* segs, hipStream_t st);
+void det_defer_commit(float* region, long sets, long members, long L, int nseg, const DetDeferSeg* segs, int accumulate);
+
 // floats / tickets one launch needs: `sets` reductions of `members` partial vectors of L values each
 static inline long det_slab_floats(long sets, long members, long L) { return members <= 1 ? 0 : sets * (members + (members + DET_G - 1) / DET_G) * L; }
 static inline long det_tickets(long sets, long members) { return members <= 1 ? 0 : sets * ((members + DET_G - 1) / DET_G + 1); }
@@ -36,12 +54,17 @@ __device__ __forceinline__ void det_reduce(const DetWs& ws, int set, int member,
         for (int c = tid; c < L; c += nthreads) store(c, partial(c));
         return;
     }
+    if (ws.defer) {         // deferred: the partial row only (see above)
+        float* row = ws.defer + ((long)set * nmembers + member) * L;
+        for (int c = tid; c < L; c += nthreads) row[c] = partial(c);
+        return;
+    }
 #if defined(SPE_ABLATE) && defined(SPE_DBG_NORED)
     // timing experiment (tools/debug/rowops_time.py): no cross-workgroup sum.  Measured, round 4: the tail below costs 5-8 us per launch
     // (layernorm_bwd 19.8 -> 12.1 us, lsres_bwd16 15.2 -> 10.3, conversion + column sums 11.1 -> 5.5), ~1.4 ms per step over ~250
     // launches: six dependent round trips to the memory-side coherence point for the last workgroup.  A variant that ADDS 64-bit fixed-point
     // partials with returning atomics (exact, order-free: 3 round trips) was slower - same-address contention, 15-19 us for the conversion
-    // even with 16 accumulator copies - and is gone; what would help is deferring the sums of several launches to one kernel boundary.
+    // even with 16 accumulator copies - and is gone; the sums into the gradient buckets are deferred to one flush kernel instead (above).
     if (member == 0) for (int c = tid; c < L; c += nthreads) store(c, partial(c));
     return;
 #endif

@@ -620,11 +620,15 @@ extern "C" int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, v
     // the grid covers the padded row range of the transpose so that its zero columns are written too
     const long rows = outT ? ((ldt > R) ? ldt : R) : R;
     dim3 grid((C + 63) / 64, (unsigned)((rows + 63) / 64));
-    const DetWs ws = spe_detws();
-    if (colsum) DET_CHECK(ws, (C + 63) / 64, (R + 63) / 64, 64);
+    DetWs ws = spe_detws();
+    const DetDeferSeg sg[1] = {{colsum, C}};
+    float* region = colsum ? det_defer_try((C + 63) / 64, (R + 63) / 64, 64, 1, sg, stream) : nullptr;  // deferred: colsum += totals at the next flush
+    if (region) ws.defer = region;
+    else if (colsum) DET_CHECK(ws, (C + 63) / 64, (R + 63) / 64, 64);
     hipLaunchKernelGGL(cvt_bf16_kernel, grid, dim3(256), 0, stream, x, ldx, R, C, reinterpret_cast<unsigned short*>(out),
                        reinterpret_cast<unsigned short*>(out_lo), ldo,
                        reinterpret_cast<unsigned short*>(outT), ldt, colsum, aux, act, ws);
+    if (region) det_defer_commit(region, (C + 63) / 64, (R + 63) / 64, 64, 1, sg, 1);
     SPE_CHECK_LAUNCH();
     return 0;
 }

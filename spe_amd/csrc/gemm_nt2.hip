@@ -196,7 +196,12 @@ static int launch_nt2(const Gemm16Args& p, hipStream_t stream, int mpan = 0) {
     int tiles = tiles_m * tiles_n;
     if (q.xcd_bind == 1) tiles = 8 * ((tiles_m + 7) / 8) * tiles_n;
     if (q.xcd_bind == 2) tiles = 8 * ((tiles_n + 7) / 8) * tiles_m;
+    // column sums of the extended epilogue (a bias gradient): deferred when the caller said so - sets = column tiles, members = row tiles
+    const DetDeferSeg sg[1] = {{q.colsum, q.N}};
+    float* region = (EX && q.colsum && mpan == 0) ? det_defer_try(tiles_n, tiles_m, BN, 1, sg, stream) : nullptr;
+    if (region) q.ws.defer = region;
     hipLaunchKernelGGL((gemm_nt2_kernel<BM, BN, BK, NST, SPLIT, EX, F16>), dim3(tiles), dim3(256), smem, stream, q);
+    if (region) det_defer_commit(region, tiles_n, tiles_m, BN, 1, sg, 1);
     SPE_CHECK_LAUNCH();
     return 0;
 }

@@ -177,11 +177,11 @@ extern "C" int spe_occupy(int nwg, long micros, float* buf, long buf_floats, hip
 }
 
 // ---- reduction workspace of the deterministic cross-workgroup sums (det_reduce.h) -------------------------------------
-static DetWs g_detws = {nullptr, nullptr, 0, 0};
+static DetWs g_detws = {nullptr, nullptr, 0, 0, nullptr};
 DetWs spe_detws() { return g_detws; }
 // C-ABI: see include/spe_hip.h.  The first 64 KiB hold the tickets (zeroed here, on `st`), the rest the partial-sum slabs.
 extern "C" int spe_set_reduce_workspace(void* ws, size_t bytes, hipStream_t st) {
-    if (!ws) { g_detws = DetWs{nullptr, nullptr, 0, 0}; return 0; }
+    if (!ws) { g_detws = DetWs{nullptr, nullptr, 0, 0, nullptr}; return 0; }
     const size_t tbytes = 64 * 1024;
     if ((reinterpret_cast<uintptr_t>(ws) & 255) || bytes < tbytes + (1u << 20)) return -2;
     hipError_t e = hipMemsetAsync(ws, 0, tbytes, st);
@@ -192,6 +192,89 @@ extern "C" int spe_set_reduce_workspace(void* ws, size_t bytes, hipStream_t st) 
     g_detws.slab_floats = (long)((bytes - tbytes) / sizeof(float));
     return 0;
 }
+
+// ---- deferred reductions (det_reduce.h): arena, pending table, flush kernel ------------------------------------------------
+#define DEFER_MAXENT 24
+struct DeferEntry { const float* src; int members, L, sets, seg0, nseg, accumulate; };
+struct DeferTable { DeferEntry e[DEFER_MAXENT]; DetDeferSeg seg[DET_DEFER_MAXSEG]; int n; };
+static DeferTable g_dt = {};
+static int g_dt_nseg = 0;
+static float* g_arena = nullptr; static long g_arena_floats = 0, g_arena_cur = 0;
+#define DEFER_MAXRANGE 64
+static const char* g_rng_lo[DEFER_MAXRANGE]; static const char* g_rng_hi[DEFER_MAXRANGE]; static int g_nrange = 0;
+
+// entry blockIdx.y: output o = blockIdx.x * 16 + (threadIdx.x >> 4); its 16 lanes take members lane, lane + 16, .. (all loads in flight),
+// the lanes are added in lane order: a fixed order, whatever the schedule
+__global__ __launch_bounds__(256) void reduce_flush_kernel(DeferTable t) {
+    const DeferEntry e = t.e[blockIdx.y];
+    const long total = (long)e.sets * e.L;
+    const long o = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (o >= total) return;                     // whole 16-lane groups leave together
+    const int ml = threadIdx.x & 15;
+    const int set = (int)(o / e.L), c = (int)(o - (long)set * e.L);
+    const float* p = e.src + ((long)set * e.members) * e.L + c;
+    float s = 0.f;
+    for (int m = ml; m < e.members; m += 16) s += p[(long)m * e.L];
+    // lanes 0..15 in order
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += __shfl(s, (threadIdx.x & 48) + k, 64);
+    if (ml != 0) return;
+    long off = o;
+    for (int k = 0; k < e.nseg; ++k) {
+        const DetDeferSeg sg = t.seg[e.seg0 + k];
+        if (off < sg.len) { if (sg.dst) sg.dst[off] = e.accumulate ? sg.dst[off] + tot : tot; return; }
+        off -= sg.len;
+    }
+}
+
+static int defer_flush(hipStream_t st) {
+    if (g_dt.n == 0) { g_arena_cur = 0; g_dt_nseg = 0; return 0; }
+    long maxo = 0;
+    for (int i = 0; i < g_dt.n; ++i) { const long o = (long)g_dt.e[i].sets * g_dt.e[i].L; if (o > maxo) maxo = o; }
+    hipLaunchKernelGGL(reduce_flush_kernel, dim3((unsigned)((maxo + 15) / 16), (unsigned)g_dt.n), dim3(256), 0, st, g_dt);
+    g_dt.n = 0; g_dt_nseg = 0; g_arena_cur = 0;
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+float* det_defer_try(long sets, long members, long L, int nseg, const DetDeferSeg* segs, hipStream_t st) {
+    if (!g_nrange || !g_arena || members <= 1 || nseg > DET_DEFER_MAXSEG) return nullptr;
+    for (int k = 0; k < nseg; ++k) {              // every destination inside a registered range (NULL: not wanted, nothing to write)
+        const char* d = reinterpret_cast<const char*>(segs[k].dst);
+        if (!d) continue;
+        bool in = false;
+        for (int r = 0; r < g_nrange && !in; ++r) in = d >= g_rng_lo[r] && d + (long)segs[k].len * 4 <= g_rng_hi[r];
+        if (!in) return nullptr;
+    }
+    const long need = (sets * members * L + 63) & ~63L;
+    if (need > g_arena_floats) return nullptr;
+    if (g_dt.n >= DEFER_MAXENT || g_dt_nseg + nseg > DET_DEFER_MAXSEG || g_arena_cur + need > g_arena_floats) {
+        if (defer_flush(st) != 0) return nullptr;      // stream-ordered before this launch reuses the arena
+    }
+    return g_arena + g_arena_cur;
+}
+void det_defer_commit(float* region, long sets, long members, long L, int nseg, const DetDeferSeg* segs, int accumulate) {
+    DeferEntry& e = g_dt.e[g_dt.n++];
+    e.src = region; e.members = (int)members; e.L = (int)L; e.sets = (int)sets; e.seg0 = g_dt_nseg; e.nseg = nseg; e.accumulate = accumulate;
+    for (int k = 0; k < nseg; ++k) g_dt.seg[g_dt_nseg++] = segs[k];
+    g_arena_cur += (sets * members * L + 63) & ~63L;
+}
+// C-ABI: see include/spe_hip.h
+extern "C" int spe_reduce_defer_arena(void* arena, size_t bytes) {
+    if (g_dt.n) return -3;                      // pending sums: flush first
+    g_arena = reinterpret_cast<float*>(arena); g_arena_floats = arena ? (long)(bytes / sizeof(float)) : 0; g_arena_cur = 0;
+    if (arena && (reinterpret_cast<uintptr_t>(arena) & 255)) { g_arena = nullptr; g_arena_floats = 0; return -2; }
+    return 0;
+}
+extern "C" int spe_reduce_defer_ranges(const void* const* ptrs, const size_t* bytes, int n) {
+    if (g_dt.n) return -3;
+    if (n < 0 || n > DEFER_MAXRANGE) return -2;
+    for (int i = 0; i < n; ++i) { g_rng_lo[i] = reinterpret_cast<const char*>(ptrs[i]); g_rng_hi[i] = g_rng_lo[i] + bytes[i]; }
+    g_nrange = n;
+    return 0;
+}
+extern "C" int spe_reduce_flush(hipStream_t st) { return defer_flush(st); }
+extern "C" int spe_reduce_pending(void) { return g_dt.n; }
 
 extern "C" int spe_abi_version(void) { return 5; }    // 2: round 2 (signatures of spe_hungarian, spe_adamw_flat, spe_layernorm_fwd, spe_attn_contract, spe_talking_fused_plan changed; new entry points)
 

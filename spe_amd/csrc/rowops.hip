@@ -341,10 +341,14 @@ static int ln_bwd_launch(const float* dy, const float* x, const float* gamma, co
         attr = true;
     }
     long nb = (R + NW - 1) / NW; if (nb > 256) nb = 256;
-    const DetWs ws = spe_detws();
-    DET_CHECK(ws, 1, nb, 2 * C);
+    DetWs ws = spe_detws();
+    // deferred (destinations inside the registered bucket ranges): the workgroups leave their 2 C partials behind, dgamma / dbeta += totals at the next flush
+    const DetDeferSeg sg[2] = {{dgamma, C}, {dbeta, C}};
+    float* region = det_defer_try(1, nb, 2 * C, 2, sg, st);
+    if (region) ws.defer = region; else DET_CHECK(ws, 1, nb, 2 * C);
     hipLaunchKernelGGL(ln_bwd_kernel<NW>, dim3((unsigned)nb), dim3(NW * 64), 2 * NW * (C + 4) * (int)sizeof(float), st, dy, x, gamma, mean,
                        rstd, dx, dgamma, dbeta, R, C, add, dz, p, seed, offset, ws);
+    if (region) det_defer_commit(region, 1, nb, 2 * C, 2, sg, 1);
     SPE_CHECK_LAUNCH();
     return 0;
 }
@@ -748,11 +752,14 @@ static int lsres_bwd16_launch(const float* dout, const void* y, int y_f16, const
         attr = true;
     }
     long nb = (ldt + 63) / 64; if (nb > 256) nb = 256;
-    const DetWs ws = spe_detws();
-    DET_CHECK(ws, 1, nb, 2 * C);
+    DetWs ws = spe_detws();
+    const DetDeferSeg sg[2] = {{dgamma, C}, {db, C}};
+    float* region = det_defer_try(1, nb, 2 * C, 2, sg, st);        // deferred: dgamma / db += totals at the next flush
+    if (region) ws.defer = region; else DET_CHECK(ws, 1, nb, 2 * C);
     hipLaunchKernelGGL(lsres_bwd16_kernel, dim3((unsigned)nb), dim3(1024), smem, st, dout, reinterpret_cast<const float*>(y), gamma,
                        reinterpret_cast<unsigned short*>(dy16), reinterpret_cast<unsigned short*>(dy16T), ldt, db, dgamma, R, C, ws, y_f16,
                        p_drop, seed, offset, sscale, rps);
+    if (region) det_defer_commit(region, 1, nb, 2 * C, 2, sg, 1);
     SPE_CHECK_LAUNCH();
     return 0;
 }

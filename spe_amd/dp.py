@@ -95,6 +95,15 @@ class GradAllReducer:
                 for t in buffers:
                     bc(t)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        # bias / LayerNorm / LayerScale gradients are sums over workgroups: with the buckets registered their kernels only leave partial
+        # rows and ONE launch adds them for many producers (kernels.defer_reductions); flushed before a bucket goes out, in finish() and
+        # - by kernels.backward_scope - at the end of every backward pass
+        # A parameter used by SEVERAL nodes of one graph (the decoder's final LayerNorm, applied to every layer's output) must not
+        # take part: autograd adds the nodes' gradients itself and would read the bucket view before the deferred part has landed.
+        # Such parameters are learned in the first step (deferral still off; static graph, like the unused ones): they never get a
+        # bucket view again (_spe_shared), and the buckets are registered at the end of the first finish().
+        self._defer = False
+        self._defer_wanted = bool(self.params) and self.params[0].is_cuda and len(self.buckets) <= 64
         # Parameters that received no gradient in the first step (e.g. `backbone.0.body.head.*`) are treated as
         # statically unused afterwards (cf. DDP static_graph): their bucket no longer waits for them, so it - and,
         # because collectives go out strictly in bucket order, every later bucket - can start during backward
@@ -160,11 +169,20 @@ class GradAllReducer:
                 p._spe_grad_fresh = True
         self._next = 0
         self._fired = set()
+        if self._defer:
+            from . import kernels as _K
+            _K._FLUSH_QUEUED[0] = False        # (a backward that raised may have left its end-of-pass flush queued and never run)
+
+    def _flush_deferred(self):
+        if self._defer:
+            from . import kernels as _K
+            _K.reduce_flush()
 
     def zero_grad(self):
         self.reset()
 
     def _launch(self, b):
+        self._flush_deferred()                 # the bucket's deferred sums land before it is reduced / handed to the optimiser
         if self.collective:
             buf = b["flat"]
             if self.wire_dtype is not None:
@@ -190,6 +208,14 @@ class GradAllReducer:
         if p.grad.data_ptr() != view.data_ptr():
             # the gradient was produced outside the bucket (torch op, or a parameter used twice whose contributions
             # autograd summed into a temporary): AccumulateGrad runs once per backward with the TOTAL, so copy it in
+            if not getattr(p, "_spe_grad_fresh", True) and not getattr(p, "_spe_shared", False):
+                # its bucket view HAD been handed to a kernel: the parameter is used by more than one node
+                p._spe_shared = True
+                if self._defer:
+                    import warnings
+                    warnings.warn("GradAllReducer: a parameter turned out to be shared between graph nodes after the first step; "
+                                  "its gradient of this step may miss a deferred bias / LayerNorm sum (construct the reducer "
+                                  "before the first backward of the final graph, or set SPE_DEFER_REDUCE=0)")
             view.copy_(p.grad)
             p._spe_grad_fresh = False
             p.grad = view
@@ -205,6 +231,7 @@ class GradAllReducer:
 
     def finish(self):
         """Reduce buckets that never filled (unused parameters), wait for every collective, average."""
+        self._flush_deferred()
         if self._static_unused is not None:
             # a LARGE parameter that fired in the first step but not in this one still holds the previous step's gradient (its
             # view is not zeroed by reset()): zero it before its bucket goes out.  Such a bucket cannot have been launched yet -
@@ -218,6 +245,11 @@ class GradAllReducer:
             self._next += 1
         if self.learn_unused and self._static_unused is None:
             self._static_unused = frozenset(p for p in self.params if p not in self._fired)
+        if self._defer_wanted and not self._defer:          # end of the first step: shared parameters are known now
+            from . import kernels as _K
+            _K.defer_reductions([b["flat"] for b in self.buckets])
+            self._defer = _K._DEFER_FLATS is not None
+            self._defer_wanted = False
         ev = None
         if self.measure and self.collective:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -253,6 +285,11 @@ class GradAllReducer:
     def remove(self):
         for h in self._hooks:
             h.remove()
+        if self._defer:
+            from . import kernels as _K
+            if _K._DEFER_FLATS is not None and _K._DEFER_FLATS and _K._DEFER_FLATS[0] is self.buckets[0]["flat"]:
+                _K.defer_reductions(None)
+            self._defer = False
         if self._cu_reserve_prev is not None:
             from . import kernels as _K
             _K.set_cu_reserve(self._cu_reserve_prev)

@@ -33,11 +33,28 @@ def backward_scope(fn):
     @_functools.wraps(fn)
     def wrapped(ctx, *grads):
         prev, _TLS.in_bwd = _in_bwd(), True
+        if _DEFER_FLATS is not None and not _FLUSH_QUEUED[0]:
+            # deferred sums (defer_reductions) of this backward pass land when the engine is done with it - before backward() /
+            # autograd.grad() return to whoever reads the gradients
+            _FLUSH_QUEUED[0] = True
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_flush_after_backward)
+            except RuntimeError:               # not inside an engine run (a backward called by hand)
+                _FLUSH_QUEUED[0] = False
         try:
             return fn(ctx, *grads)
         finally:
             _TLS.in_bwd = prev
     return wrapped
+
+
+_FLUSH_QUEUED = [False]
+_DEFER_FLATS = None        # strong references: a registered address range must not be freed and handed to another tensor
+
+
+def _flush_after_backward():
+    _FLUSH_QUEUED[0] = False
+    reduce_flush()
 
 
 def forward_scope(fn):
@@ -146,6 +163,39 @@ def _guard_reduce_ws(cur, st):
     _RWS_STREAM, _RWS_DEVIDX = st, cur
 
 
+# ---- deferred cross-workgroup sums (include/spe_hip.h: spe_reduce_defer_*; csrc/det_reduce.h) ------------------------------------
+# Sums whose destination is a parameter gradient inside the registered all-reduce buckets are left as per-workgroup partial rows and
+# added by ONE flush launch for many producers (the fixed-order tree costs every producer 5-8 us).  The reducer registers its buckets
+# and flushes before a bucket goes out / at the end of the backward.
+DEFER_REDUCE = os.environ.get("SPE_DEFER_REDUCE", "1") != "0"      # developer knob (A/B)
+_DEFER_ARENA = None
+
+
+def defer_reductions(flats, arena_bytes=48 << 20):
+    """flats: the flat gradient buffers (fp32 CUDA tensors) whose views may receive deferred sums; None / empty: deferral off."""
+    global _DEFER_ARENA, _DEFER_FLATS
+    if _DEFER_FLATS is not None:
+        lib.call("spe_reduce_flush", _st())
+    if not flats or not DEFER_REDUCE or not flats[0].is_cuda or flats[0].dtype != torch.float32:
+        lib.call("spe_reduce_defer_ranges", None, None, 0)
+        _DEFER_FLATS = None
+        return
+    if _DEFER_ARENA is None or _DEFER_ARENA.device != flats[0].device:
+        _DEFER_ARENA = torch.empty((arena_bytes,), device=flats[0].device, dtype=torch.uint8)
+        lib.call("spe_reduce_defer_arena", _DEFER_ARENA.data_ptr(), arena_bytes)
+    n = len(flats)
+    ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in flats])
+    sizes = (ctypes.c_size_t * n)(*[f.numel() * 4 for f in flats])
+    lib.call("spe_reduce_defer_ranges", ptrs, sizes, n)
+    _DEFER_FLATS = list(flats)
+
+
+def reduce_flush():
+    """Add every pending deferred sum to its destination (one launch on the current stream; nothing pending: no launch)."""
+    if _DEFER_FLATS is not None:
+        lib.call("spe_reduce_flush", _st())
+
+
 def _call(name, *args):
     if _RWS is None:
         _register_reduce_ws()
@@ -193,8 +243,8 @@ def grad_buffer(param):
     that writes its parameter gradient straight into this view - and returns it - makes autograd's AccumulateGrad
     adopt the tensor as `.grad` without a copy or an add (one elementwise launch per parameter otherwise).  Handed
     out once per step: a parameter used twice gets an ordinary temporary the second time and autograd adds it."""
-    if param is None or not getattr(param, "_spe_grad_fresh", False):
-        return None
+    if param is None or not getattr(param, "_spe_grad_fresh", False) or getattr(param, "_spe_shared", False):
+        return None             # (_spe_shared: used by several nodes of the graph - autograd sums their gradients itself, see dp._on_grad)
     param._spe_grad_fresh = False
     buf = param._spe_grad_buf
     return buf.view_as(buf)            # fresh alias: AccumulateGrad only steals a tensor nobody else references

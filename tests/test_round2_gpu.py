@@ -552,7 +552,14 @@ def _dp2_worker(rank, world, port, out):
             red.finish()
             got = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).flatten() for p_ in ps_]) * red.grad_scale()
             err = float((got - flat).norm() / flat.norm())
-            assert err < 1e-5, ("bucket gradients != mean of the ranks' gradients", rank, it, err)
+            if err >= 1e-5:                                  # name the worst parameters
+                offs, worst = 0, []
+                for n_, p_ in named:
+                    k = p_.numel()
+                    worst.append((float((got[offs:offs + k] - flat[offs:offs + k]).norm()), n_, float(flat[offs:offs + k].norm())))
+                    offs += k
+                worst.sort(reverse=True)
+                raise AssertionError(("bucket gradients != mean of the ranks' gradients", rank, it, err, worst[:4]))
             opt.step()
             mine = torch.cat([p_.detach().flatten() for p_ in ps_])
             both = [torch.zeros_like(mine) for _ in range(world)]

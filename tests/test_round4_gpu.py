@@ -297,3 +297,69 @@ def test_jitter_pick_kernel_equals_elementwise_composition(dev):
         assert a["boxes"].shape == b["boxes"].shape and torch.equal(a["labels"], b["labels"]) and torch.equal(a["scores"], b["scores"])
         assert torch.equal(a["boxes"], b["boxes"])
     assert outs[0][2]["boxes"].shape == (23 * 5, 4) and outs[0][1]["boxes"].shape[0] == 0
+
+
+def test_deferred_reductions_match_tree_sums_and_handle_shared_parameters(dev):
+    """Bias / LayerNorm / LayerScale gradients whose destination is a registered all-reduce bucket are summed by ONE flush launch for
+    many producers (spe_reduce_defer_* / csrc/det_reduce.h) instead of by a cross-workgroup tree at the end of every producer: same values
+    as the tree up to the order of the fp32 additions, bitwise reproducible, available right after backward() (and autograd.grad()).
+    A parameter used by two nodes of the graph (as the decoder's final LayerNorm is) is learned in the first step and keeps out of it.
+    Reference: the autograd of nn.LayerNorm / nn.Linear biases under DDP (main.py:172)."""
+    import torch.nn as nn
+    from spe_amd import kernels as K, ops
+    from spe_amd.dp import GradAllReducer
+    from spe_amd.models.cait import LayerScale_Block
+    from spe_amd.models.layers import LayerNorm
+    K.set_precision("bf16s")
+    torch.manual_seed(2)
+    C, H, B, N = 384, 8, 2, 1100
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = nn.ModuleList([LayerScale_Block(C, H, init_values=0.3) for _ in range(2)])
+            self.norm = LayerNorm(C)                       # applied twice: a shared parameter
+        def forward(self, x):
+            outs = []
+            for b in self.blocks:
+                x = b(x)
+                outs.append(self.norm(x))
+            return outs[0] + outs[1]
+
+    net = Net().to(dev).train()
+    x = torch.randn(B, N, C, device=dev)
+    w = torch.randn(B, N, C, device=dev)
+    params = [p for p in net.parameters() if p.requires_grad]
+    names = [n for n, p in net.named_parameters() if p.requires_grad]
+
+    def grads(defer, steps):
+        old = K.DEFER_REDUCE
+        K.DEFER_REDUCE = defer
+        try:
+            red = GradAllReducer(params, flatten_params=False)
+            out = []
+            for _ in range(steps):
+                red.reset()
+                (net(x) * w).sum().backward()
+                pending_after_backward = K.lib.load().spe_reduce_pending()      # raw call: the return value is the count
+                snap = [p.grad.clone() for p in params]      # read BEFORE finish(): the end-of-backward flush has run
+                red.finish()
+                out.append((snap, [p.grad.clone() for p in params], pending_after_backward))
+            deferring = red._defer
+            red.remove()
+            return out, deferring
+        finally:
+            K.DEFER_REDUCE = old
+
+    ref, d0 = grads(False, 2)
+    got, d1 = grads(True, 3)
+    assert not d0 and d1
+    assert getattr(net.norm.weight, "_spe_shared", False) and getattr(net.norm.bias, "_spe_shared", False)
+    for step in (1, 2):                                      # steps with deferral active
+        snap, fin, pend = got[step]
+        assert pend == 0
+        for n, a, b, r in zip(names, snap, fin, ref[1][1]):
+            assert torch.equal(a, b), n                      # nothing changed between the end of backward and finish()
+            assert (a - r).norm() <= 2e-6 * r.norm() + 1e-7, (n, float((a - r).norm() / (r.norm() + 1e-30)))
+    for a, b in zip(got[1][1], got[2][1]):
+        assert torch.equal(a, b)                             # same inputs, same weights: bitwise the same sums
