@@ -152,6 +152,7 @@ class GradAllReducer:
         First step: the whole buckets are zeroed (330 MB at cfg2).  From the second step on only the views that need it are:
         small accumulate-into gradients and statically unused parameters (< 1 % of the bytes, one multi-tensor launch); a large
         parameter that unexpectedly received no gradient is zeroed in finish()."""
+        self._flush_deferred()      # sums a failed backward left pending land in the OLD gradients, not on top of the new ones
         skip = self._static_unused or ()
         if self._static_unused is None:
             for b in self.buckets:
