@@ -32,7 +32,7 @@ typedef struct ihipStream_t* spe_stream_t; /* == hipStream_t */
  * takes `fmt`, spe_attn_pack_multi kinds carry an element-format bit, spe_talking_fused expects fp16 Q / K fragments and writes
  * fp16 P'd blocks; split-operand GEMM entry points); 4: deterministic reductions - spe_set_reduce_workspace is new and required
  * before any entry point that sums across workgroups, spe_box_loss takes L, spe_linear_small_fwd / _bwd are new; 5 (round 4):
- * the flash-style talking-heads entry points spe_talking_flash_* are new */
+ * the flash-style talking-heads entry points spe_talking_flash_* are new; 6 (round 5): spe_talking_bwdq_* are new */
 int spe_abi_version(void);
 
 /* ---- reduction workspace --------------------------------------------------------------------
@@ -284,6 +284,30 @@ int spe_talking_flash_fwd(const void* Qf, const void* Kf, const void* V16, const
 int spe_talking_flash_dv(const void* Qf, const void* Kf, const void* dO16, const float* Wl, const float* Ww, const float* bw,
                          const float* c0, int Np, float* ws, float* dv, void* dv16, long ob, long on, long oh, int B, int H, int N, int dh,
                          int nwg, float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
+
+/* ---- query-major backward passes of the talking-heads attention on the flash skeleton (round 5; reference: the autograd of
+ * models/cait.py:377-389 - proj_l, softmax, proj_w, attn_drop - i.e. what spe_talking_fused modes 2 / 3 and the dQ contraction of
+ * spe_attn_contract compute, csrc/attn_flash_bwd.hip).  A workgroup of 4 waves (one per SIMD, 512 registers each) keeps 4 q-tiles'
+ * Q / dO fragment records in registers and streams the key-side tiles through LDS.
+ * spe_talking_bwdq_plan: the work split for an `nwg` workgroup budget - steps per workgroup, workgroups launched, major (4 q-tile) groups per
+ *   image.  Workspaces: ws_d B * nmajor * 8 * 4 * H * 16 floats, ws_q B * nmajor * 8 * 4 * H * ceil(dh / 16) * 256 floats, ws_w
+ *   (nwg_used * 4) rows of 2 * (H * H + H) floats - row layout [dWl | dbl | dWw | dbw], pass 2 fills the first half, pass 1 the second;
+ *   spe_talking_wgrad_reduce(ws_w, 4 * nwg_used, ...) sums them.
+ * spe_talking_bwdq_pass1: Drows[b][q][h'] = sum_key dP[h'] P[h'] ([B][Np][H], rows >= N zero), dWw / dbw partials.  Qf, Kf fp16 fragment
+ *   records (the forward's), dOf, Vf bf16 fragment records (spe_attn_pack_multi kind 0), c0 [B][Np][H] of spe_attn_merge_rows.
+ * spe_talking_bwdq_pass2: dS = proj_l^T (P (dP - D)) as bf16 16 x 16 blocks (the layout of spe_talking_fused mode 3: the dK contraction
+ *   reads them), dWl / dbl partials, and dq[b, q, h, :] = scale * sum_key dS[b,h][q,key] k[b, key, h, :] accumulated in registers (element
+ *   strides ob, on, oh; dq fp32 and / or dq16 bf16 with the same addressing, either may be NULL).  K16 = bf16 k in the 16-wide layout
+ *   (spe_attn_pack_multi kind 1).
+ * keepbits: the dropout keep flags of spe_talking_flash_fwd, required when p_drop > 0.  Supported: H in {4, 8}, head dim <= 64; -2 otherwise. */
+int spe_talking_bwdq_plan(int B, int N, int nwg, int* steps_per_wg, int* nwg_used, int* nmajor);
+int spe_talking_bwdq_pass1(const void* Qf, const void* dOf, const void* Kf, const void* Vf, const float* Wl, const float* Ww,
+                           const float* c0, int Np, float* ws_d, float* ws_w, float* Drows, const void* keepbits, int B, int H, int N, int dh,
+                           int nwg, float p_drop, spe_stream_t stream);
+int spe_talking_bwdq_pass2(const void* Qf, const void* dOf, const void* Kf, const void* Vf, const void* K16, const float* Wl, const float* Ww,
+                           const float* c0, const float* Drows, int Np, float* ws_q, float* ws_w, void* dS, float* dq, void* dq16,
+                           long ob, long on, long oh, float scale, const void* keepbits, int B, int H, int N, int dh, int nwg, float p_drop,
+                           spe_stream_t stream);
 
 /* ---- streaming contractions of a blocked 16-bit score tensor T (written by spe_talking_fused modes 1/3):
  *   trans = 0: out[b, q, h, :]   = alpha * sum_key T[b,h][q,key] x[b, key, h, :]   (`attn @ v`, cait.py:388; dQ)

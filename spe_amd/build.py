@@ -16,6 +16,13 @@ LIB = os.path.join(HERE, "libspe_hip.so")
 COMM_LIB = os.path.join(HERE, "libspe_comm.so")      # RCCL collectives behind include/spe_comm.h (csrc/comm/)
 STAMP = os.path.join(HERE, "libspe_hip.srchash")     # content hash of the sources the library was built from
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# per-file flags.  attn_flash_bwd.hip runs one wave per SIMD with its big operands / accumulators in AccVGPRs through inline assembly; the
+# builtin matrix instructions around them must keep their results in ordinary VGPRs (see the file header)
+EXTRA_FLAGS = {"attn_flash_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
+def flags_for(src):
+    return FLAGS + EXTRA_FLAGS.get(os.path.basename(src), [])
 
 
 def sources():
@@ -55,10 +62,10 @@ def needs_build():
 def _compile(src, hipcc, verbose):
     name = os.path.splitext(os.path.basename(src))[0]
     obj, tag = os.path.join(OBJ, name + ".o"), os.path.join(OBJ, name + ".hash")
-    want = _hash([src] + _headers(), " ".join(FLAGS).encode())
+    want = _hash([src] + _headers(), " ".join(flags_for(src)).encode())
     if os.path.exists(obj) and os.path.exists(tag) and open(tag).read().strip() == want:
         return obj
-    cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj + ".tmp"]
+    cmd = [hipcc] + flags_for(src) + ["-c", src, "-o", obj + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr, flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)

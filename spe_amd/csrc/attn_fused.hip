@@ -181,6 +181,11 @@ __device__ __forceinline__ void mixA_build(const float* __restrict__ W, int lane
 // F16: x and A in fp16 (the forward mix P' = Ww P + bw; x arrives scaled by SPE_PD_SCALE, so does init), else bf16
 template <int H, bool F16 = false>
 __device__ __forceinline__ void mix_mfma_key(const float (&x)[H], const s16x4m_t (&A)[H / 4][H / 4], const float* init, f32x4_t (&out)[H / 4]) {
+#ifdef SPE_DBG_NOMM
+#pragma unroll
+    for (int gh = 0; gh < H / 4; ++gh) out[gh] = (f32x4_t){x[4 * gh], x[4 * gh + 1], x[4 * gh + 2], x[4 * gh + 3]};
+    return;
+#endif
     s16x4m_t bv[H / 4];
 #pragma unroll
     for (int hh = 0; hh < H / 4; ++hh) bv[hh] = pack4<F16>(x[4 * hh], x[4 * hh + 1], x[4 * hh + 2], x[4 * hh + 3]);
@@ -224,6 +229,13 @@ __device__ __forceinline__ void mix_keys_f32(const f32x4_t (&s)[H], const float 
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int gh = 0; gh < H / 4; ++gh) out[r][gh] = (f32x4_t){c[4 * gh], c[4 * gh + 1], c[4 * gh + 2], c[4 * gh + 3]};
+#ifdef SPE_DBG_NOMIX4
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < H; ++g) out[r][g >> 2][g & 3] += s[g][r];
+    return;
+#endif
 #pragma unroll
     for (int h = 0; h < H; ++h)
 #pragma unroll
@@ -363,7 +375,13 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
 #define SPE_FUSED_GWMFMA3 1
 #endif
     // weight-gradient outer products on the matrix pipe (below): backward pass 1 (dWw, dbw) and backward pass 2 (dWl, dbl)
+#ifdef SPE_DBG_NOGWM
     constexpr bool GWM = SPE_FUSED_GWMFMA && (H % 4 == 0) && (MODE == 2 || (MODE == 3 && SPE_FUSED_GWMFMA3));
+#define SPE_GWM_BODY 0
+#else
+    constexpr bool GWM = SPE_FUSED_GWMFMA && (H % 4 == 0) && (MODE == 2 || (MODE == 3 && SPE_FUSED_GWMFMA3));
+#define SPE_GWM_BODY 1
+#endif
     // backward pass 1 with the outer products on the matrix pipe has ~36 registers to spare: 8 heads per fragment batch there too
 #ifndef SPE_FUSED_JB3
 #define SPE_FUSED_JB3 8
@@ -872,7 +890,7 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                             for (int r = 0; r < 4; ++r) { acc2[j][2 * hp][r] *= k0[r]; acc2[j][2 * hp + 1][r] *= k1[r]; }
                         }
                     }
-                    if constexpr (GWM) {
+                    if constexpr (GWM && SPE_GWM_BODY) {
                         // dWw += dP' P^T, dbw += dP' over this tile's 256 positions: transpose through the wave's LDS tile, 16 MFMAs
 #pragma unroll
                         for (int g = 0; g < H; ++g) {
@@ -1008,7 +1026,7 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                             for (int gp = 0; gp < H / 2; ++gp) if (!kv) d2[r][gp] = splat2(0.f);
                         }
                     }
-                    if constexpr (GWM) {
+                    if constexpr (GWM && SPE_GWM_BODY) {
                         // dWl += dS' S^T over this tile's 256 positions on the matrix pipe (see backward pass 1).  dbl stays an fp32 sum
                         // on the vector pipe: its exact value is 0 (softmax is shift invariant), and the bf16 rounding of dS' in the
                         // MFMA operand would leave 2^-9-grade noise where the fp32 sum leaves 1e-7
@@ -1034,7 +1052,7 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                                                                                                  __builtin_bit_cast(s16x4m_t, (u32x2w_t){yb[2], yb[3]}), gwacc[(2 * c + 1) & 3], 0, 0, 0);
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    } else {
+                    } else if constexpr (!GWM) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -1073,7 +1091,11 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                             }
                         }
                     }
+#ifdef SPE_DBG_NOST3
+                    if (TV(j) && a.N < 0) {
+#else
                     if (TV(j)) {
+#endif
 #pragma unroll
                         for (int h = 0; h < H; ++h) {
                             bf16x4_t o;

@@ -16,6 +16,10 @@
 #undef SPE_DBG_NOSTAGE
 #undef SPE_DBG_NOLOAD
 #undef SPE_DBG_NOGW
+#undef SPE_DBG_NOMIX4
+#undef SPE_DBG_NOMM
+#undef SPE_DBG_NOGWM
+#undef SPE_DBG_NOST3
 #undef SPE_DBG_LN_NOATOMIC
 #undef SPE_ABL_NOSTORE
 #undef SPE_ABL_NOLOOP

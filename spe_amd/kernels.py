@@ -1456,6 +1456,43 @@ def talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, c0, dv4, p_drop, seed, offset, dv
     return ref
 
 
+# ---- query-major backward passes on the flash skeleton (csrc/attn_flash_bwd.hip): 4-wave workgroups, one wave per SIMD, one per CU
+def bwdq_supported(H, dh):
+    DT = (dh + 15) // 16
+    return H in (4, 8) and dh <= 64 and 6 * H * DT * 512 + 256 + 4096 * H <= 160 * 1024
+
+
+def bwdq_plan(B, N):
+    """(steps per workgroup, workgroups, major (4 q-tile) groups per image) of the q-major backward passes."""
+    spw, nwg, nmaj = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    lib.call("spe_talking_bwdq_plan", B, N, max(8, FLASH_NWG - _CU_RESERVE), ctypes.byref(spw), ctypes.byref(nwg), ctypes.byref(nmaj))
+    return spw.value, nwg.value, nmaj.value
+
+
+def talking_bwdq_pass1(Qf, dOf, Kf, Vf, Wl, Ww, c0, keepbits, B, H, N, dh, p_drop):
+    """-> (Drows [B, Np, H]: D = sum_key dP P, query-major; ws_w [4 nwg, 2 (H H + H)]: its dWw / dbw half filled)."""
+    dev = Qf.device
+    _, nwg, nmaj = bwdq_plan(B, N)
+    ws_d = _flash_ws(dev, B * nmaj * FLASH_SLOTS * 4 * H * 16)
+    ws_w = torch.empty((4 * nwg, 2 * (H * H + H)), device=dev, dtype=torch.float32)
+    Drows = torch.empty((B, c0.shape[1], H), device=dev, dtype=torch.float32)
+    _call("spe_talking_bwdq_pass1", _p(Qf), _p(dOf), _p(Kf), _p(Vf), _p(Wl), _p(Ww), _p(c0), c0.shape[1], _p(ws_d), _p(ws_w), _p(Drows),
+          _p(keepbits), B, H, N, dh, max(8, FLASH_NWG - _CU_RESERVE), float(p_drop), _st())
+    return Drows, ws_w
+
+
+def talking_bwdq_pass2(Qf, dOf, Kf, Vf, K16, Wl, Ww, c0, Drows, ws_w, dS, dq4, dq16, scale, keepbits, B, H, N, dh, p_drop):
+    """dS (bf16 blocks) and dq = scale dS k (dq4 fp32 view [B,N,H,dh] and / or dq16 bf16 view with the same strides); fills the dWl / dbl half
+    of ws_w."""
+    ref = dq4 if dq4 is not None else dq16
+    assert ref.stride(3) == 1 and (dq4 is None or dq16 is None or dq4.stride() == dq16.stride())
+    nmaj = bwdq_plan(B, N)[2]
+    ws_q = _flash_ws(ref.device, B * nmaj * FLASH_SLOTS * 4 * H * 256 * ((dh + 15) // 16))
+    _call("spe_talking_bwdq_pass2", _p(Qf), _p(dOf), _p(Kf), _p(Vf), _p(K16), _p(Wl), _p(Ww), _p(c0), _p(Drows), c0.shape[1], _p(ws_q), _p(ws_w),
+          _p(dS), _p(dq4), _p(dq16), ref.stride(0), ref.stride(1), ref.stride(2), float(scale), _p(keepbits), B, H, N, dh,
+          max(8, FLASH_NWG - _CU_RESERVE), float(p_drop), _st())
+
+
 def attn_merge(ws_stats, B, H, N, spw, mode):
     out0 = torch.empty((B, H, N), device=ws_stats.device, dtype=torch.float32)
     out1 = torch.empty_like(out0) if mode == 0 else None

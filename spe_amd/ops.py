@@ -411,6 +411,9 @@ class _TalkingHeadsAttention(Function):
         return dqkv, dWl, dbl, dWw, dbw, None, None, None
 
 
+BWDQ = os.environ.get("SPE_BWDQ", "1") != "0"       # developer knob (A/B): the q-major flash-skeleton backward passes
+
+
 class _TalkingHeadsAttentionFused(Function):
     """Same operator on the fused score kernels (csrc/attn_fused.hip): no fp32 N x N tensor in HBM.
     forward : pack q*scale*log2e, k, v (fp16) -> statistics pass -> write pass (P'd * 2^8, blocked fp16) -> O = P'd V (streaming contraction)
@@ -502,12 +505,19 @@ class _TalkingHeadsAttentionFused(Function):
         dO4 = dO.view(B, N, H, dh)
         dOf, dO16 = K.attn_pack_multi([(dO4, 1.0, 32), (dO4, 1.0, 16)])
         nw = 2 * (H * H + H)
-        ws_stats = torch.empty((B * nt * 8 * H * 32,), device=dO.device, dtype=torch.float32)
-        ws_w = torch.empty((nwg, nw), device=dO.device, dtype=torch.float32)
-        K.talking_fused(2, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, None, ws_stats, ws_w, None, B, H, N, dh, p_drop, seed, off, keepbits=kbits)
-        D, _ = K.attn_merge(ws_stats, B, H, N, spw, 2)
         dS = K.score_blocks(B, H, N, dO.device)
-        K.talking_fused(3, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, None, ws_w, dS, B, H, N, dh, p_drop, seed, off, keepbits=kbits)
+        # q-major passes on the flash skeleton (csrc/attn_flash_bwd.hip): pass 2 also accumulates dQ in registers - the streaming dQ
+        # contraction and one of the two reads of dS are gone
+        bwdq = flash and BWDQ and K.bwdq_supported(H, dh) and (p_drop <= 0 or kbits is not None)
+        if bwdq:
+            Drows, ws_w = K.talking_bwdq_pass1(Qf, dOf, Kf, Vf, Wl, Ww, Pd, kbits, B, H, N, dh, p_drop)
+            K.talking_bwdq_pass2(Qf, dOf, Kf, Vf, K16, Wl, Ww, Pd, Drows, ws_w, dS, f32(dq), b16(dq), scale, kbits, B, H, N, dh, p_drop)
+        else:
+            ws_stats = torch.empty((B * nt * 8 * H * 32,), device=dO.device, dtype=torch.float32)
+            ws_w = torch.empty((nwg, nw), device=dO.device, dtype=torch.float32)
+            K.talking_fused(2, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, None, ws_stats, ws_w, None, B, H, N, dh, p_drop, seed, off, keepbits=kbits)
+            D, _ = K.attn_merge(ws_stats, B, H, N, spw, 2)
+            K.talking_fused(3, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, None, ws_w, dS, B, H, N, dh, p_drop, seed, off, keepbits=kbits)
         # dV[key,d] = sum_q P'd[q,key] dO[q,d] - issued here, between backward pass 2 and the contractions that re-read
         # its 554 MB of dS: a streaming read right after a pass that wrote that much runs ~20 % slower (measured)
         if flash:       # Pd holds the row constants c0: P'd is recomputed tile by tile inside the dV pass
@@ -516,7 +526,8 @@ class _TalkingHeadsAttentionFused(Function):
             K.attn_contract(Pd, dO16, f32(dv), True, alpha=1.0 / K.PD_SCALE, out16=b16(dv))
         dWl, dbl, dWw, dbw = K.talking_wgrad_reduce(ws_w, H, ctx.wparams)
         # dQ[q,d] = scale * sum_key dS[q,key] K[key,d] ; dK[key,d] = scale * sum_q dS[q,key] Q[q,d]
-        K.attn_contract(dS, K16, f32(dq), False, alpha=scale, out16=b16(dq))
+        if not bwdq:
+            K.attn_contract(dS, K16, f32(dq), False, alpha=scale, out16=b16(dq))
         K.attn_contract(dS, Q16, f32(dk), True, alpha=scale, out16=b16(dk))
         return dqkv, dWl, dbl, dWw, dbw
 

@@ -20,7 +20,7 @@ def test_library_exports_every_header_symbol():
     for name, sig in protos.items():
         fn = getattr(l, name)            # AttributeError == missing export
         assert fn.restype is ctypes.c_int and len(fn.argtypes) == len(sig)
-    assert l.spe_abi_version() == 5
+    assert l.spe_abi_version() == 6
 
 
 def test_comm_library_exports_every_header_symbol():

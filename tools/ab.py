@@ -13,13 +13,26 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from spe_amd.build import CSRC, sources  # noqa: E402
+from spe_amd.build import CSRC, OBJ, sources, flags_for  # noqa: E402
+
+# a variant only recompiles the sources its flags can reach (ONLY=file1.hip,file2.hip in the environment) and links the product build's
+# objects for everything else
+ONLY = [f for f in os.environ.get("ONLY", "").split(",") if f]
 
 
 def one(name, flags):
     out = os.path.join(ROOT, "build_ab", name + ".so")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DSPE_ABLATE", "-o", out] + flags.split() + sources()
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    objs = []
+    for src in sources():
+        base = os.path.splitext(os.path.basename(src))[0]
+        prod = os.path.join(OBJ, base + ".o")
+        if ONLY and os.path.basename(src) not in ONLY and os.path.exists(prod):
+            objs.append(prod)
+            continue
+        obj = os.path.join(ROOT, "build_ab", name + "." + base + ".o")
+        subprocess.run(["/opt/rocm/bin/hipcc"] + flags_for(src) + ["-DSPE_ABLATE"] + flags.split() + ["-c", src, "-o", obj], check=True, cwd=CSRC)
+        objs.append(obj)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, check=True, cwd=CSRC)
     return out
 
 
