@@ -33,6 +33,29 @@
 #ifndef FLB_PHASEFENCE
 #define FLB_PHASEFENCE 1
 #endif
+#define FLB_GWR 144                      // row pitch of the weight-gradient transpose tiles (bytes)
+#ifndef FLB_NK16
+#define FLB_NK16 3                       // slots of the 16-wide K tiles (pass 2): tile i is read by the back half of step i, one step after its K / V stage
+#endif
+#ifndef FLB_SGB
+#define FLB_SGB 0                        // 1: sched_group_barrier interleave request (FLB_SGB_N x {FLB_SGB_M matrix, FLB_SGB_V vector instructions})
+#endif
+#ifndef FLB_SGB_N
+#define FLB_SGB_N 120
+#endif
+#ifndef FLB_SGB_M
+#define FLB_SGB_M 1
+#endif
+#ifndef FLB_SGB_V
+#define FLB_SGB_V 2
+#endif
+#ifndef FLB_DQAHEAD
+#define FLB_DQAHEAD 2                    // heads the 16-wide K operand loads of the dQ products run ahead of their matrix instructions
+#endif
+#define FLB_SB_NOMEM 0x00F               // sched_barrier mask: ALU / VALU / SALU / MFMA may cross, memory instructions (LDS reads) may not
+#ifndef FLB_PIPE
+#define FLB_PIPE 1                       // source order inside a pipelined step: 1 = front(i + 1) first, 0 = back(i) first
+#endif
 #if FLB_PHASEFENCE
 #define FLB_PHASE() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -67,17 +90,34 @@ struct FlashBwdArgs {
 // ---- score products with the B operand in AccVGPRs.  One statement per head: FULL chained 32-deep steps into c, the 16-deep tail step into
 // its OWN accumulator t (an accumulate chain never mixes two MFMA shapes: attn_fused.hip).  No wait states inside: the results are only
 // read behind flb_fence*, which follows the whole batch.
+// One statement per chunk of 4 heads: the FULL 32-deep steps of all four heads first, then (TAIL16) their 16-deep tail steps accumulating
+// onto the same registers - a head's two shapes are then three instructions apart, the first has long left the pipe when the second reads
+// its result (back to back, hipcc's placement in attn_fused.hip, the mixed-shape chain gave run-to-run different sums).  No wait states
+// inside: the results are only read behind flb_fence4, which follows the statement.
 #define FLB_SCORE_ASM(NAME, M32, M16)                                                                                                      \
     template <int FULL, bool TAIL16>                                                                                                       \
-    __device__ __forceinline__ void NAME(const flu32x4_t* k32, flu32x2_t k16, const flu32x4_t* q32, flu32x2_t q16, f32x4_t& c, f32x4_t& t) { \
+    __device__ __forceinline__ void NAME(const flu32x4_t (*k32)[FULL ? FULL : 1], const flu32x2_t* k16, const flu32x4_t (*q32)[FULL ? FULL : 1], \
+                                         const flu32x2_t* q16, f32x4_t* c) {                                                               \
         if constexpr (FULL == 1 && TAIL16)                                                                                                 \
-            asm volatile(M32 " %0, %2, %4, 0\n\t" M16 " %1, %3, %5, 0" : "=&v"(c), "=&v"(t) : "v"(k32[0]), "v"(k16), "a"(q32[0]), "a"(q16));    \
+            asm(M32 " %0, %4, %12, 0\n\t" M32 " %1, %5, %13, 0\n\t" M32 " %2, %6, %14, 0\n\t" M32 " %3, %7, %15, 0\n\t"                 \
+                M16 " %0, %8, %16, %0\n\t" M16 " %1, %9, %17, %1\n\t" M16 " %2, %10, %18, %2\n\t" M16 " %3, %11, %19, %3"                 \
+                : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])                                                                       \
+                : "v"(k32[0][0]), "v"(k32[1][0]), "v"(k32[2][0]), "v"(k32[3][0]), "v"(k16[0]), "v"(k16[1]), "v"(k16[2]), "v"(k16[3]),      \
+                  "a"(q32[0][0]), "a"(q32[1][0]), "a"(q32[2][0]), "a"(q32[3][0]), "a"(q16[0]), "a"(q16[1]), "a"(q16[2]), "a"(q16[3]));     \
         else if constexpr (FULL == 2 && !TAIL16)                                                                                           \
-            asm volatile(M32 " %0, %1, %3, 0\n\t" M32 " %0, %2, %4, %0" : "=&v"(c) : "v"(k32[0]), "v"(k32[1]), "a"(q32[0]), "a"(q32[1]));      \
+            asm(M32 " %0, %4, %12, 0\n\t" M32 " %1, %5, %13, 0\n\t" M32 " %2, %6, %14, 0\n\t" M32 " %3, %7, %15, 0\n\t"                 \
+                M32 " %0, %8, %16, %0\n\t" M32 " %1, %9, %17, %1\n\t" M32 " %2, %10, %18, %2\n\t" M32 " %3, %11, %19, %3"                 \
+                : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])                                                                       \
+                : "v"(k32[0][0]), "v"(k32[1][0]), "v"(k32[2][0]), "v"(k32[3][0]), "v"(k32[0][1]), "v"(k32[1][1]), "v"(k32[2][1]), "v"(k32[3][1]), \
+                  "a"(q32[0][0]), "a"(q32[1][0]), "a"(q32[2][0]), "a"(q32[3][0]), "a"(q32[0][1]), "a"(q32[1][1]), "a"(q32[2][1]), "a"(q32[3][1])); \
         else if constexpr (FULL == 1 && !TAIL16)                                                                                           \
-            asm volatile(M32 " %0, %1, %2, 0" : "=&v"(c) : "v"(k32[0]), "a"(q32[0]));                                                      \
+            asm(M32 " %0, %4, %8, 0\n\t" M32 " %1, %5, %9, 0\n\t" M32 " %2, %6, %10, 0\n\t" M32 " %3, %7, %11, 0"                        \
+                : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])                                                                       \
+                : "v"(k32[0][0]), "v"(k32[1][0]), "v"(k32[2][0]), "v"(k32[3][0]), "a"(q32[0][0]), "a"(q32[1][0]), "a"(q32[2][0]), "a"(q32[3][0])); \
         else                                                                                                                               \
-            asm volatile(M16 " %0, %1, %2, 0" : "=&v"(t) : "v"(k16), "a"(q16));                                                            \
+            asm(M16 " %0, %4, %8, 0\n\t" M16 " %1, %5, %9, 0\n\t" M16 " %2, %6, %10, 0\n\t" M16 " %3, %7, %11, 0"                        \
+                : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])                                                                       \
+                : "v"(k16[0]), "v"(k16[1]), "v"(k16[2]), "v"(k16[3]), "a"(q16[0]), "a"(q16[1]), "a"(q16[2]), "a"(q16[3]));                 \
     }
 FLB_SCORE_ASM(flb_score_f16, "v_mfma_f32_16x16x32_f16", "v_mfma_f32_16x16x16_f16")
 FLB_SCORE_ASM(flb_score_bf16, "v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x16_bf16")
@@ -85,7 +125,7 @@ FLB_SCORE_ASM(flb_score_bf16, "v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x16_b
 // results of the matrix instructions issued above become readable: 13 wait states behind the last one (8-pass instruction -> any reader),
 // tied to the registers so that no consumer is scheduled in front of it
 __device__ __forceinline__ void flb_fence4(f32x4_t& a, f32x4_t& b, f32x4_t& c, f32x4_t& d) {
-    asm volatile("s_nop 7\n\ts_nop 4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    asm("s_nop 7\n\ts_nop 4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
 // dQ^T[d][q] += K^T[d][key] dS^T[key][q] for one head: DT accumulate instructions on AccVGPR accumulators; s_nop 1: pk was just written
@@ -93,15 +133,15 @@ __device__ __forceinline__ void flb_fence4(f32x4_t& a, f32x4_t& b, f32x4_t& c, f
 template <int DT>
 __device__ __forceinline__ void flb_dq_mfma(f32x4_t* acc, const fls16x4_t* ka, fls16x4_t pk) {
     if constexpr (DT == 1)
-        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+a"(acc[0]) : "v"(ka[0]), "v"(pk));
+        asm("s_nop 1\n\tv_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+a"(acc[0]) : "v"(ka[0]), "v"(pk));
     else if constexpr (DT == 2)
-        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_16x16x16_bf16 %1, %3, %4, %1"
+        asm("s_nop 1\n\tv_mfma_f32_16x16x16_bf16 %0, %2, %4, %0\n\tv_mfma_f32_16x16x16_bf16 %1, %3, %4, %1"
                      : "+a"(acc[0]), "+a"(acc[1]) : "v"(ka[0]), "v"(ka[1]), "v"(pk));
     else if constexpr (DT == 3)
-        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x16_bf16 %0, %3, %6, %0\n\tv_mfma_f32_16x16x16_bf16 %1, %4, %6, %1\n\tv_mfma_f32_16x16x16_bf16 %2, %5, %6, %2"
+        asm("s_nop 1\n\tv_mfma_f32_16x16x16_bf16 %0, %3, %6, %0\n\tv_mfma_f32_16x16x16_bf16 %1, %4, %6, %1\n\tv_mfma_f32_16x16x16_bf16 %2, %5, %6, %2"
                      : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]) : "v"(ka[0]), "v"(ka[1]), "v"(ka[2]), "v"(pk));
     else
-        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x16_bf16 %0, %4, %8, %0\n\tv_mfma_f32_16x16x16_bf16 %1, %5, %8, %1\n\t"
+        asm("s_nop 1\n\tv_mfma_f32_16x16x16_bf16 %0, %4, %8, %0\n\tv_mfma_f32_16x16x16_bf16 %1, %5, %8, %1\n\t"
                      "v_mfma_f32_16x16x16_bf16 %2, %6, %8, %2\n\tv_mfma_f32_16x16x16_bf16 %3, %7, %8, %3"
                      : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]) : "v"(ka[0]), "v"(ka[1]), "v"(ka[2]), "v"(ka[3]), "v"(pk));
 }
@@ -113,10 +153,11 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
     constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
     constexpr int NW = FLB_NW, HB = (H >= FLB_HB) ? FLB_HB : H;
     constexpr int TILEB = H * REC;                  // one operand, one 16-row tile, all heads
-    constexpr int NOP = (PASS == 2) ? 3 : 2;        // streamed operands per step: K fragments, V fragments, (pass 2) K in the 16-wide layout
-    constexpr int STAGEB = NOP * TILEB;
+    constexpr int KVB = 2 * TILEB;                  // a K / V stage: K fragments, V fragments
+    constexpr int NK16 = (PASS == 2) ? FLB_NK16 : 0;
     constexpr int F1 = FULL ? FULL : 1;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [stage 0][stage 1][zeros 128 B][ones 128 B][NW transpose tiles of 1024 * H B]
+    // LDS: [K / V stage 0][K / V stage 1][pass 2: FLB_NK16 slots of K in the 16-wide layout][constants 512 B][NW x 3 transpose tiles]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
     const int nt = a.nt, N = a.N;
@@ -130,14 +171,20 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
     if constexpr (PASS == 2) fl_mixA_16<H, true, false>(a.Wl, lane, 1.0f, Alt);
 
     // ---- weight-gradient outer products on the matrix pipe through a wave-private LDS transpose (see attn_fused.hip, GWM):
-    // pass 1: X = dP', Y = P -> dWw (+ dbw from the ones column) ; pass 2: X = dS', Y = S -> dWl (dbl stays an fp32 vector sum)
-    unsigned char* gconst = smem + 2 * STAGEB;
-    unsigned char* sgw = gconst + 256 + wave * (1024 * H);
-    if (threadIdx.x < 32) reinterpret_cast<uint2*>(gconst)[threadIdx.x] = (threadIdx.x < 16) ? make_uint2(0u, 0u) : make_uint2(0x3F803F80u, 0x3F803F80u);
+    // pass 1: X = dP', Y = P -> dWw (+ dbw from the ones column) ; pass 2: X = dS', Y = S -> dWl (dbl stays an fp32 vector sum).
+    // Transpose tile: rows [key group 4][head H] of 16 packets (queries) x 8 B, row pitch FLB_GWR = 144 B - with the natural 128 B the 16-B
+    // reads of 8 heads fall on 2 bank groups (4-way conflicts: SQ_LDS_BANK_CONFLICT was half of the LDS cycles of the round-3 passes); 144 B
+    // spreads the 8 rows of a lane group over distinct banks, and the constant blocks sit on banks no row uses.  The operand the FRONT half
+    // of a tile writes (pass 1: X, pass 2: Y) is double-buffered by tile parity: the front half of tile j + 1 runs beside the back half of tile j.
+    constexpr int GWR = FLB_GWR, GWT = 4 * H * GWR;
+    unsigned char* gconst = smem + 2 * KVB + NK16 * TILEB;                  // 512 B: zeros at + 48 (128 B), bf16 ones at + 208 (128 B)
+    unsigned char* sgw = gconst + 512 + wave * (3 * GWT);                   // [front operand, parity 0][front operand, parity 1][back operand]
+    if (threadIdx.x < 64) reinterpret_cast<uint2*>(gconst)[threadIdx.x] = (threadIdx.x >= 26 && threadIdx.x < 42) ? make_uint2(0x3F803F80u, 0x3F803F80u) : make_uint2(0u, 0u);
     const int gm = lane & 15, gk = lane >> 4;
-    unsigned char* gw_wr = sgw + ((gk * H) * 16 + gm) * 8;                                  // + h * 128: packet of head h, query gm, key group gk
-    const unsigned char* gw_xrd = (gm < H) ? sgw + ((gk * H + gm) * 16) * 8 : gconst;       // 16 packets (queries 0..15) of head gm
-    const unsigned char* gw_yrd = (gm < H) ? sgw + 512 * H + ((gk * H + gm) * 16) * 8 : ((gm == H) ? gconst + 128 : gconst);
+    unsigned char* gw_wr = sgw + (gk * H) * GWR + gm * 8;                   // + tile * GWT + h * GWR: packet of head h, query gm, key group gk
+    const unsigned gw_rd = (unsigned)((gk * H + gm) * GWR);                 // + tile * GWT: 16 packets (queries 0..15) of head gm
+    const unsigned char* gw_zero = gconst + 48;
+    const unsigned char* gw_ones = gconst + 208;
     f32x4_t gwacc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) gwacc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -184,11 +231,11 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
             } else { qta[h] = (flu32x2_t){0u, 0u}; dta[h] = (flu32x2_t){0u, 0u}; }
         }
         // ---- row constants of this lane's query
-        f32x4_t c0v[H / 4], Dv[(PASS == 2) ? H / 4 : 1];
+        f32x4_t c0v[H / 4], Dn[(PASS == 2) ? H / 4 : 1];           // Dn = -D
 #pragma unroll
         for (int gh = 0; gh < H / 4; ++gh) {
             c0v[gh] = *reinterpret_cast<const f32x4_t*>(a.c0 + ((long)b * a.Np + q) * H + 4 * gh);
-            if constexpr (PASS == 2) Dv[gh] = *reinterpret_cast<const f32x4_t*>(a.Drows + ((long)b * a.Np + q) * H + 4 * gh);
+            if constexpr (PASS == 2) Dn[gh] = -*reinterpret_cast<const f32x4_t*>(a.Drows + ((long)b * a.Np + q) * H + 4 * gh);
         }
         float rD[(PASS == 1) ? H : 1];
 #pragma unroll
@@ -199,87 +246,137 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
 #pragma unroll
             for (int dt = 0; dt < ((PASS == 2) ? DT : 1); ++dt) dQ[g][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-        // the streamed operand tiles of key tile kt -> stage st: NOP * TILEB / 1024 pieces shared by the waves
-        auto issue_tiles = [&](int kt, int st) {
+        // the streamed operand tiles of key tile kt (local index i): K, V fragments -> K / V stage i & 1, (pass 2) 16-wide K -> slot i % NK16
+        auto issue_tiles = [&](int i) {
 #ifdef FLB_DBG_NODMA
-            if (kt != kt0) return;
+            if (i != 0) return;
 #endif
+            const int kt = kt0 + i;
 #pragma unroll
-            for (int op = 0; op < NOP; ++op) {
+            for (int op = 0; op < ((PASS == 2) ? 3 : 2); ++op) {
                 const unsigned char* base = (op == 0) ? a.Kf : ((op == 1) ? a.Vf : a.K16);
                 const unsigned char* tb = base + ((long)b * H * nt + kt) * REC;
+                const unsigned dst = (op < 2) ? lds0 + (i & 1) * KVB + op * TILEB : lds0 + 2 * KVB + (i % (NK16 ? NK16 : 1)) * TILEB;
 #pragma unroll
-                for (int i = 0; i < NPW; ++i) {
-                    const int p = i * NW + wave;
+                for (int ii = 0; ii < NPW; ++ii) {
+                    const int p = ii * NW + wave;
                     if (NP % NW != 0 && p >= NP) break;
-                    fl_glds16_s(tb, voff[i], lds0 + st * STAGEB + op * TILEB + p * 1024);
+                    fl_glds16_s(tb, voff[ii], dst + p * 1024);
                 }
             }
         };
 
-        // ---- one key tile.  MASK: the ragged last tile (keys >= N get P = 0)
-        auto tile = [&](int i, auto mask_c) {
+        // ---- FRONT half of key tile i (matrix-heavy), in chunks of FLB_HB heads:
+        //   front_k: S^T = K Q^T (lane = (query l & 15, keys 4 (l >> 4) + r)) of the chunk's heads, S' += Wl S on the fly (head-outer,
+        //            attn_flash.hip FLF_MIXH) -> sp (the exponent of P; initialised with the row constants: MASK - the ragged last tile -
+        //            gives keys >= N the exponent -inf, i.e. P = 0)
+        //   front_v: dP'^T = V dO^T (bf16) of the chunk's heads, dropout, dP += Ww^T dP' -> dp
+        // operand fragments of a chunk: LDS -> registers (issued a whole chunk ahead of their use in the pipelined step: a single wave per SIMD
+        // has nobody to cover an exposed s_waitcnt)
+        struct Frags { flu32x4_t f[HB][F1]; flu32x2_t t[HB]; };
+        auto load_frags = [&](const unsigned char* tile, int h0, Frags& o) {
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                const unsigned char* r = tile + (h0 + hb) * REC;
+#pragma unroll
+                for (int st = 0; st < FULL; ++st) o.f[hb][st] = *reinterpret_cast<const flu32x4_t*>(r + st * 1024 + lane * 16);
+                if constexpr (TAIL16) o.t[hb] = *reinterpret_cast<const flu32x2_t*>(r + FULL * 1024 + lane * 8);
+                else o.t[hb] = (flu32x2_t){0u, 0u};
+            }
+        };
+        auto load_k = [&](int i, int h0, Frags& o) { load_frags(smem + (i & 1) * KVB, h0, o); };
+        auto load_v = [&](int i, int g0, Frags& o) { load_frags(smem + (i & 1) * KVB + TILEB, g0, o); };
+        auto front_k = [&](int i, auto h0_c, const Frags& kfr, f32x4_t (&sp)[4][H / 4], auto mask_c) {
             constexpr bool MASK = decltype(mask_c)::value;
-            const int kt = kt0 + i;
-            const unsigned char* sK = smem + (i & 1) * STAGEB;
-            const unsigned char* sV = sK + TILEB;
-            const unsigned char* sK16 = sV + TILEB;
-            const int key0 = kt * 16 + 4 * (lane >> 4);
-            uint32_t kb = 0u;
-            if constexpr (DROP) kb = a.keepbits[(((long)b * nt + qt) * nt + kt) * 64 + lane];
-
-            // ---- S^T = K Q^T (lane = (query l & 15, keys 4 (l >> 4) + r)), S' = Wl S + c0 on the fly, head-outer (attn_flash.hip, FLF_MIXH)
-            f32x4_t sp[4][H / 4];
+            constexpr int h0 = decltype(h0_c)::value;
+            unsigned char* gwf = gw_wr + (i & 1) * GWT;         // this tile's front operand of the outer product
+            if constexpr (h0 == 0) {
+                const int key0 = (kt0 + i) * 16 + 4 * (lane >> 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int gh = 0; gh < H / 4; ++gh) {
-                    if constexpr (MASK) {
-                        const bool kv = key0 + r < N;
+                    for (int gh = 0; gh < H / 4; ++gh) {
+                        if constexpr (MASK) {
+                            const bool kv = key0 + r < N;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) sp[r][gh][k] = kv ? c0v[gh][k] : -INFINITY;
-                    } else sp[r][gh] = c0v[gh];
-                }
+                            for (int k = 0; k < 4; ++k) sp[r][gh][k] = kv ? c0v[gh][k] : -INFINITY;
+                        } else sp[r][gh] = c0v[gh];
+                    }
+            }
+            f32x4_t c[HB];
+            static_assert(HB == 4, "chunk of 4 heads");
+            flb_score_f16<FULL, TAIL16>(kfr.f, kfr.t, &qa[h0], &qta[h0], c);
+            flb_fence4(c[0], c[1], c[2], c[3]);
 #pragma unroll
-            for (int h0 = 0; h0 < H; h0 += HB) {
-                flu32x4_t kf[HB][F1]; flu32x2_t kt16[HB];
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb) {
-                    const unsigned char* kr = sK + (h0 + hb) * REC;
-#pragma unroll
-                    for (int st = 0; st < FULL; ++st) kf[hb][st] = *reinterpret_cast<const flu32x4_t*>(kr + st * 1024 + lane * 16);
-                    if constexpr (TAIL16) kt16[hb] = *reinterpret_cast<const flu32x2_t*>(kr + FULL * 1024 + lane * 8);
-                    else kt16[hb] = (flu32x2_t){0u, 0u};
-                }
-                f32x4_t c[HB], t[HB];
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb) flb_score_f16<FULL, TAIL16>(kf[hb], kt16[hb], qa[h0 + hb], qta[h0 + hb], c[hb], t[hb]);
-                if constexpr (FULL > 0) { static_assert(HB == 4, "fence arity"); flb_fence4(c[0], c[1], c[2], c[3]); }
-                if constexpr (TAIL16) flb_fence4(t[0], t[1], t[2], t[3]);
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb) {
-                    f32x4_t cs;
-                    if constexpr (FULL > 0 && TAIL16) cs = c[hb] + t[hb];
-                    else if constexpr (FULL > 0) cs = c[hb];
-                    else cs = t[hb];
+            for (int hb = 0; hb < HB; ++hb) {
+                const f32x4_t cs = c[hb];
 #ifndef FLB_DBG_NOGWM
-                    // pass 2: bf16(S) of this head is the Y operand of the dWl outer product - straight into the wave's transpose tile (its
-                    // previous contents were read by this wave's own, older LDS instructions)
-                    if constexpr (PASS == 2) *reinterpret_cast<fls16x4_t*>(gw_wr + 512 * H + (h0 + hb) * 128) = fl_pack4<false>(cs[0], cs[1], cs[2], cs[3]);
+                // pass 2: bf16(S) of this head is the Y operand of the dWl outer product - straight into the wave's transpose tile
+                if constexpr (PASS == 2) *reinterpret_cast<fls16x4_t*>(gwf + (h0 + hb) * GWR) = fl_pack4<false>(cs[0], cs[1], cs[2], cs[3]);
 #endif
 #ifndef FLB_DBG_NOMIX1
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = __builtin_amdgcn_mfma_f32_4x4x1f32(Al4[gh][h0 + hb], cs[r], sp[r][gh], 0, 0, 0);
+                    for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = __builtin_amdgcn_mfma_f32_4x4x1f32(Al4[gh][h0 + hb], cs[r], sp[r][gh], 0, 0, 0);
 #else
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sp[r][(h0 + hb) >> 2][(h0 + hb) & 3] += cs[r];
+                for (int r = 0; r < 4; ++r) sp[r][(h0 + hb) >> 2][(h0 + hb) & 3] += cs[r];
+#endif
+            }
+        };
+        auto front_v = [&](int i, auto g0_c, const Frags& vfr, f32x4_t (&dp)[4][H / 4], uint32_t kb) {
+            constexpr int g0 = decltype(g0_c)::value;
+            unsigned char* gwf = gw_wr + (i & 1) * GWT;
+            if constexpr (g0 == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int gh = 0; gh < H / 4; ++gh) {         // pass 2: the mix starts from -D, its result is dP - D
+                        if constexpr (PASS == 2) dp[r][gh] = Dn[gh];
+                        else dp[r][gh] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    }
+            }
+            f32x4_t es[HB];
+            flb_score_bf16<FULL, TAIL16>(vfr.f, vfr.t, &da[g0], &dta[g0], es);
+            flb_fence4(es[0], es[1], es[2], es[3]);
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                if constexpr (DROP) {       // bit hp * 8 + 2 r + e: key r of the lane's group, head 2 hp + e
+                    const int g = g0 + hb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) es[hb][r] *= ((kb >> ((g >> 1) * 8 + 2 * r + (g & 1))) & 1u) ? keep_inv : 0.f;
+                }
+#ifndef FLB_DBG_NOGWM
+                // pass 1: bf16(dP') of this head is the X operand of the dWw outer product
+                if constexpr (PASS == 1) *reinterpret_cast<fls16x4_t*>(gwf + (g0 + hb) * GWR) = fl_pack4<false>(es[hb][0], es[hb][1], es[hb][2], es[hb][3]);
+#endif
+            }
+#pragma unroll
+            for (int hq = 0; hq < HB / 4; ++hq)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#ifndef FLB_DBG_NOMIX16
+                    const fls16x4_t bv = fl_pack4<false>(es[4 * hq][r], es[4 * hq + 1][r], es[4 * hq + 2][r], es[4 * hq + 3][r]);
+#pragma unroll
+                    for (int gh = 0; gh < H / 4; ++gh) dp[r][gh] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(Awt[gh][g0 / 4 + hq], bv, dp[r][gh], 0, 0, 0);
+#else
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dp[r][g0 / 4 + hq][k] += es[4 * hq + k][r];
 #endif
                 }
-            }
-            FLB_PHASE();
-            // ---- P = exp2(S' + c0)   (sp[r][gh][i]: head 4 gh + i at key r)
+        };
+        auto load_kb = [&](int i) -> uint32_t {
+            if constexpr (DROP) return a.keepbits[(((long)b * nt + qt) * nt + (kt0 + i)) * 64 + lane];
+            else return 0u;
+        };
+
+        // ---- BACK half of key tile i (vector-heavy), in four chunks:
+        //   back_exp: P = exp2(sp)
+        //   back_ds : pass 1: D += dP . P, bf16(P) -> transpose tile ; pass 2: dS' = P (dP - D), dbl, bf16(dS') -> transpose tile
+        //   back_gw : the outer product (dWw / dbw resp. dWl) from the transpose tiles ; pass 2: dS = Wl^T dS' -> ds
+        //   back_dq : pass 2: bf16 block of dS -> HBM, dQ^T += K^T dS^T
+        auto back_exp = [&](f32x4_t (&sp)[4][H / 4]) {
 #ifndef FLB_DBG_NOEXP
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -288,93 +385,38 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
 #pragma unroll
                     for (int k = 0; k < 4; ++k) sp[r][gh][k] = fl_exp2(sp[r][gh][k]);
 #endif
-
-            FLB_PHASE();
-            // ---- dP'^T = V dO^T (bf16 operands), dropout, dP = Ww^T dP' head group by head group
-            f32x4_t dp[4][H / 4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int gh = 0; gh < H / 4; ++gh) dp[r][gh] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int g0 = 0; g0 < H; g0 += HB) {
-                flu32x4_t vf[HB][F1]; flu32x2_t vt16[HB];
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb) {
-                    const unsigned char* vr = sV + (g0 + hb) * REC;
-#pragma unroll
-                    for (int st = 0; st < FULL; ++st) vf[hb][st] = *reinterpret_cast<const flu32x4_t*>(vr + st * 1024 + lane * 16);
-                    if constexpr (TAIL16) vt16[hb] = *reinterpret_cast<const flu32x2_t*>(vr + FULL * 1024 + lane * 8);
-                    else vt16[hb] = (flu32x2_t){0u, 0u};
-                }
-                f32x4_t e[HB], u[HB];
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb) flb_score_bf16<FULL, TAIL16>(vf[hb], vt16[hb], da[g0 + hb], dta[g0 + hb], e[hb], u[hb]);
-                if constexpr (FULL > 0) flb_fence4(e[0], e[1], e[2], e[3]);
-                if constexpr (TAIL16) flb_fence4(u[0], u[1], u[2], u[3]);
-                f32x4_t es[HB];
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb) {
-                    if constexpr (FULL > 0 && TAIL16) es[hb] = e[hb] + u[hb];
-                    else if constexpr (FULL > 0) es[hb] = e[hb];
-                    else es[hb] = u[hb];
-                    if constexpr (DROP) {       // bit hp * 8 + 2 r + e: key r of the lane's group, head 2 hp + e
-                        const int g = g0 + hb;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) es[hb][r] *= ((kb >> ((g >> 1) * 8 + 2 * r + (g & 1))) & 1u) ? keep_inv : 0.f;
-                    }
-#ifndef FLB_DBG_NOGWM
-                    // pass 1: bf16(dP') of this head is the X operand of the dWw outer product
-                    if constexpr (PASS == 1) *reinterpret_cast<fls16x4_t*>(gw_wr + (g0 + hb) * 128) = fl_pack4<false>(es[hb][0], es[hb][1], es[hb][2], es[hb][3]);
-#endif
-                }
-#pragma unroll
-                for (int hq = 0; hq < HB / 4; ++hq)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-#ifndef FLB_DBG_NOMIX16
-                        const fls16x4_t bv = fl_pack4<false>(es[4 * hq][r], es[4 * hq + 1][r], es[4 * hq + 2][r], es[4 * hq + 3][r]);
-#pragma unroll
-                        for (int gh = 0; gh < H / 4; ++gh) dp[r][gh] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(Awt[gh][g0 / 4 + hq], bv, dp[r][gh], 0, 0, 0);
-#else
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) dp[r][g0 / 4 + hq][k] += es[4 * hq + k][r];
-#endif
-                    }
-            }
-
-            FLB_PHASE();
+        };
+        auto back_ds = [&](f32x4_t (&sp)[4][H / 4], f32x4_t (&dp)[4][H / 4]) {
+            unsigned char* gwb = gw_wr + 2 * GWT;               // the back operand of the outer product
             if constexpr (PASS == 1) {
-                // ---- D += dP . P over this lane's keys ; dWw += dP' P^T, dbw += dP' over the tile's 256 positions
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int g = 0; g < H; ++g) rD[g] = fmaf(dp[r][g >> 2][g & 3], sp[r][g >> 2][g & 3], rD[g]);
-#ifndef FLB_DBG_NOGWM
-#pragma unroll
-                for (int g = 0; g < H; ++g)
-                    *reinterpret_cast<fls16x4_t*>(gw_wr + 512 * H + g * 128) =
-                        fl_pack4<false>(sp[0][g >> 2][g & 3], sp[1][g >> 2][g & 3], sp[2][g >> 2][g & 3], sp[3][g >> 2][g & 3]);
-#endif
             } else {
-                // ---- dS' = P (dP - D) (zero for keys >= N: P = 0 there) ; dbl ; dWl += dS' S^T
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = sp[r][gh] * (dp[r][gh] - Dv[gh]);
+                    for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = sp[r][gh] * dp[r][gh];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int g = 0; g < H; ++g) gb[g] += sp[r][g >> 2][g & 3];
-#ifndef FLB_DBG_NOGWM
-#pragma unroll
-                for (int g = 0; g < H; ++g)
-                    *reinterpret_cast<fls16x4_t*>(gw_wr + g * 128) =
-                        fl_pack4<false>(sp[0][g >> 2][g & 3], sp[1][g >> 2][g & 3], sp[2][g >> 2][g & 3], sp[3][g >> 2][g & 3]);
-#endif
             }
 #ifndef FLB_DBG_NOGWM
+#pragma unroll
+            for (int g = 0; g < H; ++g)
+                *reinterpret_cast<fls16x4_t*>(gwb + g * GWR) =
+                    fl_pack4<false>(sp[0][g >> 2][g & 3], sp[1][g >> 2][g & 3], sp[2][g >> 2][g & 3], sp[3][g >> 2][g & 3]);
+#endif
+        };
+        auto back_gw = [&](int i, f32x4_t (&sp)[4][H / 4], f32x4_t (&ds)[4][H / 4]) {
+#ifndef FLB_DBG_NOGWM
             {
+                const unsigned rdf = gw_rd + (i & 1) * GWT, rdb = gw_rd + 2 * GWT;
+                // lanes >= H of a 16-lane group read zeros (X, Y) or ones (Y, lane H: the bias column)
+                const unsigned char* gw_xrd = (gm < H) ? sgw + ((PASS == 1) ? rdf : rdb) : gw_zero;
+                const unsigned char* gw_yrd = (gm < H) ? sgw + ((PASS == 1) ? rdb : rdf) : ((gm == H) ? gw_ones : gw_zero);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // wave-private tile: the other lanes' packets are read next
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
@@ -386,13 +428,10 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
                     gwacc[(2 * c + 1) & 3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(fls16x4_t, (flu32x2_t){xa[2], xa[3]}),
                                                                                          __builtin_bit_cast(fls16x4_t, (flu32x2_t){yb[2], yb[3]}), gwacc[(2 * c + 1) & 3], 0, 0, 0);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the tile is rewritten by the next key tile
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the back tile is rewritten by the next key tile
             }
 #endif
-            FLB_PHASE();
             if constexpr (PASS == 2) {
-                // ---- dS = Wl^T dS' (bf16 operands, fp32 accumulate) -> bf16 ; store the block ; dQ^T += K^T dS^T
-                f32x4_t ds[4][H / 4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
 #ifndef FLB_DBG_NOMIX16
@@ -405,45 +444,136 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
                     for (int gh = 0; gh < H / 4; ++gh) ds[r][gh] = sp[r][gh];
 #endif
                 }
+            }
+        };
+        auto back_dq = [&](int i, f32x4_t (&ds)[4][H / 4]) {
+            if constexpr (PASS == 2) {
+                const int kt = kt0 + i;
+                const unsigned char* sK16 = smem + 2 * KVB + (i % (NK16 ? NK16 : 1)) * TILEB;
+                fls16x4_t ka[H][DT];                // requested FLB_DQAHEAD heads ahead of the matrix instructions that consume them
+#pragma unroll
+                for (int h = 0; h < ((FLB_DQAHEAD < H) ? FLB_DQAHEAD : H); ++h)
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) ka[h][dt] = *reinterpret_cast<const fls16x4_t*>(sK16 + h * REC + dt * 512 + lane * 8);
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
+                    if (h + FLB_DQAHEAD < H) {
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) ka[h + FLB_DQAHEAD][dt] = *reinterpret_cast<const fls16x4_t*>(sK16 + (h + FLB_DQAHEAD) * REC + dt * 512 + lane * 8);
+                        __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);        // the loads stay ahead: only register-only instructions may cross
+                    }
                     const fls16x4_t pk = fl_pack4<false>(ds[0][h >> 2][h & 3], ds[1][h >> 2][h & 3], ds[2][h >> 2][h & 3], ds[3][h >> 2][h & 3]);
 #ifndef FLB_DBG_NOST
                     __builtin_nontemporal_store(__builtin_bit_cast(flu32x2_t, pk),
                                                 reinterpret_cast<flu32x2_t*>(a.dS + (((((long)b * H + h) * nt + qt) * nt + kt) * 64 + lane) * 4));
 #endif
 #ifndef FLB_DBG_NODQ
-                    fls16x4_t ka[DT];
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) ka[dt] = *reinterpret_cast<const fls16x4_t*>(sK16 + h * REC + dt * 512 + lane * 8);
-                    flb_dq_mfma<DT>(dQ[h], ka, pk);
+                    flb_dq_mfma<DT>(dQ[h], ka[h], pk);
 #else
-                    dQ[h][0][0] += __builtin_bit_cast(float, (unsigned)pk[0] << 16);
+                    dQ[h][0][0] += __builtin_bit_cast(float, (unsigned)pk[0] << 16) + __builtin_bit_cast(float, (unsigned)ka[h][0][0] << 16);
 #endif
                 }
             }
         };
-
-        issue_tiles(kt0, 0);
-        // the ragged last key tile of an image (keys >= N) runs the masked instance of the tile code AFTER the loop over the full tiles: one
-        // instance per loop keeps the accumulators in place (with both instances inside one loop hipcc copied all 96 of them around
-        // every step)
-        const int nfull = ((N & 15) != 0 && kt0 + seg == nt) ? seg - 1 : seg;
-        auto admit = [&](int i) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of step i have landed (and its stores of step i - 1 are out)
-            __builtin_amdgcn_s_barrier();                          // everybody's have, and everybody is done with the stage refilled next
-            asm volatile("" ::: "memory");
-            if (i + 1 < seg) issue_tiles(kt0 + i + 1, (i + 1) & 1);
+        // the halves as a whole (pipeline prologue / epilogue, the ragged tile)
+        auto front = [&](int i, f32x4_t (&sp)[4][H / 4], f32x4_t (&dp)[4][H / 4], auto mask_c) {
+            const uint32_t kb = load_kb(i);
+            Frags fa, fb;
+            load_k(i, 0, fa);
+            if constexpr (H > HB) load_k(i, HB, fb);
+            front_k(i, std::integral_constant<int, 0>{}, fa, sp, mask_c);
+            load_v(i, 0, fa);
+            if constexpr (H > HB) front_k(i, std::integral_constant<int, HB>{}, fb, sp, mask_c);
+            if constexpr (H > HB) load_v(i, HB, fb);
+            front_v(i, std::integral_constant<int, 0>{}, fa, dp, kb);
+            if constexpr (H > HB) front_v(i, std::integral_constant<int, HB>{}, fb, dp, kb);
         };
-        for (int i = 0; i < nfull; ++i) {
-            admit(i);
-            if (wvalid) tile(i, std::false_type{});
+        auto back = [&](int i, f32x4_t (&sp)[4][H / 4], f32x4_t (&dp)[4][H / 4]) {
+            f32x4_t ds[4][H / 4];
+            back_exp(sp);
+            back_ds(sp, dp);
+            back_gw(i, sp, ds);
+            back_dq(i, ds);
+        };
+        // One pipelined step: the front half of tile i + 1 beside the back half of tile i, chunk by chunk - every scheduling region holds one
+        // matrix-heavy and one vector-heavy chunk of INDEPENDENT work, which the scheduler interleaves (a single wave per SIMD has no partner
+        // wave to fill its stalls).  The LDS operands of a chunk are requested at the top of the PREVIOUS region (fr0 / fr1 alternate) and
+        // pinned there by a scheduling barrier only register-only instructions may cross; the full barriers bound the live ranges.
+        // fr0 arrives holding the K fragments of tile i + 1's first chunk (requested by the previous step or the prologue).
+        auto step = [&](int i, f32x4_t (&sp)[4][H / 4], f32x4_t (&dp)[4][H / 4], f32x4_t (&spn)[4][H / 4], f32x4_t (&dpn)[4][H / 4], Frags& fr0, Frags& fr1,
+                        bool more) {
+            f32x4_t ds[4][H / 4];
+            const uint32_t kb = load_kb(i + 1);
+            if constexpr (H > HB) load_k(i + 1, HB, fr1); else load_v(i + 1, 0, fr1);
+            __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
+            front_k(i + 1, std::integral_constant<int, 0>{}, fr0, spn, std::false_type{});
+            back_exp(sp);
+            FLB_PHASE();
+            if constexpr (H > HB) {
+                load_v(i + 1, 0, fr0);
+                __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
+                front_k(i + 1, std::integral_constant<int, HB>{}, fr1, spn, std::false_type{});
+            }
+            back_ds(sp, dp);
+            FLB_PHASE();
+            if constexpr (H > HB) {
+                load_v(i + 1, HB, fr1);
+                __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
+                front_v(i + 1, std::integral_constant<int, 0>{}, fr0, dpn, kb);
+            } else front_v(i + 1, std::integral_constant<int, 0>{}, fr1, dpn, kb);
+            back_gw(i, sp, ds);
+            FLB_PHASE();
+            if constexpr (H > HB) front_v(i + 1, std::integral_constant<int, HB>{}, fr1, dpn, kb);
+            back_dq(i, ds);
+            (void)more;
+        };
+
+        // step i + 1 is admitted: this wave's pieces have landed, a barrier (everybody's have, and everybody is done with the buffers refilled
+        // next), then the tiles of step i + 2 go out with a whole step to land
+        auto admit = [&](int nxt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (nxt + 1 < seg) issue_tiles(nxt + 1);
+        };
+
+        // Software pipeline over the segment's key tiles: the matrix-heavy front half of tile i + 1 runs in ONE scheduling region with the
+        // vector-heavy back half of tile i - a single wave per SIMD has no partner wave to fill its stalls, so the two independent instruction
+        // streams are interleaved inside the wave.  The ragged last key tile of an image runs the masked front instance after the loop: one
+        // instance per loop keeps the accumulators in place (with both instances inside one loop hipcc copied all 96 around every step).
+        const int nfull = ((N & 15) != 0 && kt0 + seg == nt) ? seg - 1 : seg;
+        f32x4_t spA[4][H / 4], dpA[4][H / 4], spB[4][H / 4], dpB[4][H / 4];
+        Frags frA, frB;
+        issue_tiles(0);
+        admit(0);
+        if (nfull > 0) {
+            if (wvalid) front(0, spA, dpA, std::false_type{});
+            for (int i = 0; i + 1 < nfull; ++i) {
+                admit(i + 1);
+                if (wvalid) {
+                    load_k(i + 1, 0, frA);       // (the stage was admitted above)
+                    step(i, spA, dpA, spB, dpB, frA, frB, false);
+#if FLB_SGB
+                    // interleave request for the step's region: FLB_SGB_M matrix instructions, then FLB_SGB_V vector instructions, repeated
+#pragma unroll
+                    for (int k = 0; k < FLB_SGB_N; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x8, FLB_SGB_M, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x2, FLB_SGB_V, 0);
+                    }
+#endif
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int gh = 0; gh < H / 4; ++gh) { spA[r][gh] = spB[r][gh]; dpA[r][gh] = dpB[r][gh]; }
+                }
+            }
+            if (nfull < seg) admit(nfull);
+            if (wvalid) back(nfull - 1, spA, dpA);
         }
         if (nfull < seg) {
-            admit(nfull);
-            if (wvalid) tile(nfull, std::true_type{});
+            if (wvalid) { front(nfull, spA, dpA, std::true_type{}); back(nfull, spA, dpA); }
         }
-        __builtin_amdgcn_s_barrier();              // the last stage has been read by everybody: the next segment may refill it
+        __builtin_amdgcn_s_barrier();              // the last buffers have been read by everybody: the next segment may refill them
 
         // ---- partial results of this segment -> the major's slot
         const int first_wg = (int)(((long)bm * nt) / a.spw);
@@ -561,7 +691,7 @@ static inline int flb_dsteps(int dh, int* tail) {
 template <int H, int DSTEPS, bool TAIL16, int PASS>
 static int launch_bwdq(const FlashBwdArgs& a, int nwg, bool drop, hipStream_t st) {
     constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
-    constexpr int smem = 2 * ((PASS == 2) ? 3 : 2) * H * REC + 256 + FLB_NW * 1024 * H;
+    constexpr int smem = 4 * H * REC + ((PASS == 2) ? FLB_NK16 : 0) * H * REC + 512 + FLB_NW * 3 * 4 * H * FLB_GWR;
     if (smem > 160 * 1024) return -2;
     static bool attr_set[2] = {false, false};
     const void* fn = drop ? reinterpret_cast<const void*>(&talking_bwdq_kernel<H, DSTEPS, TAIL16, true, PASS>)

@@ -1459,7 +1459,7 @@ def talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, c0, dv4, p_drop, seed, offset, dv
 # ---- query-major backward passes on the flash skeleton (csrc/attn_flash_bwd.hip): 4-wave workgroups, one wave per SIMD, one per CU
 def bwdq_supported(H, dh):
     DT = (dh + 15) // 16
-    return H in (4, 8) and dh <= 64 and 6 * H * DT * 512 + 256 + 4096 * H <= 160 * 1024
+    return H in (4, 8) and dh <= 64 and 7 * H * DT * 512 + 512 + 4 * 3 * 4 * H * 144 <= 160 * 1024
 
 
 def bwdq_plan(B, N):
@@ -1528,6 +1528,21 @@ def talking_wgrad_reduce(ws_w, H, params):
         buf = grad_buffer(prm)
         outs.append(buf.view(shp) if buf is not None else torch.empty(shp, device=ws_w.device, dtype=torch.float32))
     _call("spe_talking_wgrad_reduce", _p(ws_w), ws_w.shape[0], H, _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), _st())
+    return outs
+
+
+def talking_wgrad_reduce2(ws_l, ws_w, H, params):
+    """The same with the two halves of the partial rows in different workspaces: (dWl, dbl) from ws_l's first half, (dWw, dbw) from ws_w's
+    second half (pass 2 and pass 1 run on kernels with different grids)."""
+    shapes = ((H, H), (H,), (H, H), (H,))
+    outs = []
+    for prm, shp in zip(params, shapes):
+        buf = grad_buffer(prm)
+        outs.append(buf.view(shp) if buf is not None else torch.empty(shp, device=ws_l.device, dtype=torch.float32))
+    scratch = torch.empty((2 * (H * H + H),), device=ws_l.device, dtype=torch.float32)
+    hh = H * H
+    _call("spe_talking_wgrad_reduce", _p(ws_l), ws_l.shape[0], H, _p(outs[0]), _p(outs[1]), _p(scratch), _p(scratch[hh:]), _st())
+    _call("spe_talking_wgrad_reduce", _p(ws_w), ws_w.shape[0], H, _p(scratch), _p(scratch[hh:]), _p(outs[2]), _p(outs[3]), _st())
     return outs
 
 

@@ -411,7 +411,11 @@ class _TalkingHeadsAttention(Function):
         return dqkv, dWl, dbl, dWw, dbw, None, None, None
 
 
-BWDQ = os.environ.get("SPE_BWDQ", "1") != "0"       # developer knob (A/B): the q-major flash-skeleton backward passes
+# developer knob (A/B): 0 = round-3 backward passes 1 / 2 + the streaming dQ contraction ; 1 = both passes on the flash skeleton
+# (csrc/attn_flash_bwd.hip) ; 2 (default) = pass 1 on the round-3 kernel (two waves per SIMD: faster for the pass without dQ accumulators),
+# pass 2 + dQ on the flash skeleton.  Measured in the cfg2 step, same box: 53.4 / 53.5 ms (0), 52.6 (1), 52.0 / 52.9 (2).
+BWDQ_MODE = int(os.environ.get("SPE_BWDQ", "2"))
+BWDQ = BWDQ_MODE != 0
 
 
 class _TalkingHeadsAttentionFused(Function):
@@ -509,7 +513,16 @@ class _TalkingHeadsAttentionFused(Function):
         # q-major passes on the flash skeleton (csrc/attn_flash_bwd.hip): pass 2 also accumulates dQ in registers - the streaming dQ
         # contraction and one of the two reads of dS are gone
         bwdq = flash and BWDQ and K.bwdq_supported(H, dh) and (p_drop <= 0 or kbits is not None)
-        if bwdq:
+        if bwdq and BWDQ_MODE == 2:
+            # pass 1 on the round-3 kernel (two waves per SIMD: faster for the pass that has no dQ accumulators), pass 2 + dQ on the flash skeleton
+            ws_stats = torch.empty((B * nt * 8 * H * 32,), device=dO.device, dtype=torch.float32)
+            ws_w1 = torch.empty((nwg, nw), device=dO.device, dtype=torch.float32)
+            K.talking_fused(2, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, None, ws_stats, ws_w1, None, B, H, N, dh, p_drop, seed, off, keepbits=kbits)
+            D, _ = K.attn_merge(ws_stats, B, H, N, spw, 2)
+            Drows = K.flash_rows(D, None, None, B, H, N, 1)
+            ws_w = torch.empty((4 * K.bwdq_plan(B, N)[1], nw), device=dO.device, dtype=torch.float32)
+            K.talking_bwdq_pass2(Qf, dOf, Kf, Vf, K16, Wl, Ww, Pd, Drows, ws_w, dS, f32(dq), b16(dq), scale, kbits, B, H, N, dh, p_drop)
+        elif bwdq:
             Drows, ws_w = K.talking_bwdq_pass1(Qf, dOf, Kf, Vf, Wl, Ww, Pd, kbits, B, H, N, dh, p_drop)
             K.talking_bwdq_pass2(Qf, dOf, Kf, Vf, K16, Wl, Ww, Pd, Drows, ws_w, dS, f32(dq), b16(dq), scale, kbits, B, H, N, dh, p_drop)
         else:
@@ -524,7 +537,10 @@ class _TalkingHeadsAttentionFused(Function):
             K.talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, Pd, f32(dv), p_drop, seed, off, dv16=b16(dv))
         else:
             K.attn_contract(Pd, dO16, f32(dv), True, alpha=1.0 / K.PD_SCALE, out16=b16(dv))
-        dWl, dbl, dWw, dbw = K.talking_wgrad_reduce(ws_w, H, ctx.wparams)
+        if bwdq and BWDQ_MODE == 2:
+            dWl, dbl, dWw, dbw = K.talking_wgrad_reduce2(ws_w, ws_w1, H, ctx.wparams)
+        else:
+            dWl, dbl, dWw, dbw = K.talking_wgrad_reduce(ws_w, H, ctx.wparams)
         # dQ[q,d] = scale * sum_key dS[q,key] K[key,d] ; dK[key,d] = scale * sum_q dS[q,key] Q[q,d]
         if not bwdq:
             K.attn_contract(dS, K16, f32(dq), False, alpha=scale, out16=b16(dq))

@@ -100,7 +100,7 @@ if __name__ == "__main__":
     run(1, 8, 100, 48, 0.0)
     run(2, 4, 196, 48, 0.0)
     run(2, 8, 1100, 48, 0.1)
-    run(1, 8, 520, 64, 0.0)
+    run(1, 8, 520, 64, 0.0) if K.bwdq_supported(8, 64) else None
     run(1, 4, 300, 32, 0.05)
     run(2, 8, 400, 16, 0.0)
     run(2, 8, 4150, 48, 0.0, time_it=True)
