@@ -38,6 +38,7 @@
 // the q-tile) and are merged by spe_attn_merge.
 #include "common.h"
 #include "attn_pack.h"
+#include "attn_flash_common.h"
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
@@ -444,8 +445,10 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
     s16x4m_t Aw[(MM && MODE >= 1) ? H / 4 : 1][(MM && MODE >= 1) ? H / 4 : 1];       // mode 1: Ww ; modes 2, 3: Ww^T
     s16x4m_t Al[(MM && MODE == 3) ? H / 4 : 1][(MM && MODE == 3) ? H / 4 : 1];       // mode 3: Wl^T
     if constexpr (MM && MODE == 1) mixA_build<H, false, true>(a.Ww, lane, Aw);          // forward mix: fp16 operands
-    if constexpr (MM && MODE >= 2) mixA_build<H, true>(a.Ww, lane, Aw);
-    if constexpr (MM && MODE == 3) mixA_build<H, true>(a.Wl, lane, Al);
+    // round 5: the backward's two 16-bit mixes as 4-lane-block matrix instructions (v_mfma_f32_4x4x4_16b_bf16, 11 cycles each - the form the
+    // flash kernels use, attn_flash_common.h) instead of block-diagonal 16x16x16 ones (18 cycles each)
+    if constexpr (MM && MODE >= 2) fl_mixA_16<H, true, false>(a.Ww, lane, 1.0f, Aw);
+    if constexpr (MM && MODE == 3) fl_mixA_16<H, true, false>(a.Wl, lane, 1.0f, Al);
     constexpr bool M4 = SPE_FUSED_MIX4 && (H % 4 == 0);
     float Al4[M4 ? H / 4 : 1][M4 ? H : 1];                 // f32 operand of the S' mix (see mix_keys_f32)
     if constexpr (M4) mixA4_build<H, false>(a.Wl, lane, Al4);
@@ -459,16 +462,19 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
     // - the vector pipe, not the matrix pipe, bounds these passes; packed fp32 FMAs next to MFMAs are an
     // anti-lever on this chip (MI355X_MICROARCH.md, price of a filler beside MFMAs).
     constexpr int GW_RED = 4 * (H * 16 * 2 > (H * H + H) ? H * 16 * 2 : (H * H + H));        // floats of sred
-    unsigned char* gconst = reinterpret_cast<unsigned char*>(sred + GW_RED);                  // [zeros 128 B][ones 128 B]
-    unsigned char* sgw = gconst + 256 + wave * (1024 * H);                                    // this wave's [X | Y] tiles, 512*H bytes each
+    // round 5: row pitch 144 B instead of 128 (the 16-B reads of 8 heads then fall on distinct bank groups - SQ_LDS_BANK_CONFLICT was half of
+    // this kernel's LDS cycles: profiles/r05_fused_pmc.txt), constant blocks on banks no row uses (see attn_flash_bwd.hip)
+    constexpr int GWR = 144, GWT = 4 * H * GWR;
+    unsigned char* gconst = reinterpret_cast<unsigned char*>(sred + GW_RED);                  // 512 B: zeros at + 48 (128 B), bf16 ones at + 208 (128 B)
+    unsigned char* sgw = gconst + 512 + wave * (2 * GWT);                                     // this wave's [X | Y] tiles
     f32x4_t gwacc[GWM ? 4 : 1];
     const unsigned char* gw_xrd = nullptr; const unsigned char* gw_yrd = nullptr; unsigned char* gw_wr = nullptr;
     if constexpr (GWM) {
-        if (threadIdx.x < 32) reinterpret_cast<uint2*>(gconst)[threadIdx.x] = (threadIdx.x < 16) ? make_uint2(0u, 0u) : make_uint2(0x3F803F80u, 0x3F803F80u);
+        if (threadIdx.x < 64) reinterpret_cast<uint2*>(gconst)[threadIdx.x] = (threadIdx.x >= 26 && threadIdx.x < 42) ? make_uint2(0x3F803F80u, 0x3F803F80u) : make_uint2(0u, 0u);
         const int gm = lane & 15, gk = lane >> 4;
-        gw_wr = sgw + ((gk * H) * 16 + gm) * 8;                                 // + h * 128: packet of head h, query gm, key group gk
-        gw_xrd = (gm < H) ? sgw + ((gk * H + gm) * 16) * 8 : gconst;            // 16 packets (queries 0..15) of head gm
-        gw_yrd = (gm < H) ? sgw + 512 * H + ((gk * H + gm) * 16) * 8 : ((gm == H) ? gconst + 128 : gconst);
+        gw_wr = sgw + (gk * H) * GWR + gm * 8;                                  // + h * GWR: packet of head h, query gm, key group gk
+        gw_xrd = (gm < H) ? sgw + (gk * H + gm) * GWR : gconst + 48;            // 16 packets (queries 0..15) of head gm
+        gw_yrd = (gm < H) ? sgw + GWT + (gk * H + gm) * GWR : ((gm == H) ? gconst + 208 : gconst + 48);
 #pragma unroll
         for (int i = 0; i < 4; ++i) gwacc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
@@ -894,8 +900,8 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                         // dWw += dP' P^T, dbw += dP' over this tile's 256 positions: transpose through the wave's LDS tile, 16 MFMAs
 #pragma unroll
                         for (int g = 0; g < H; ++g) {
-                            *reinterpret_cast<s16x4m_t*>(gw_wr + g * 128) = pack4<false>(acc2[j][g][0], acc2[j][g][1], acc2[j][g][2], acc2[j][g][3]);
-                            *reinterpret_cast<s16x4m_t*>(gw_wr + 512 * H + g * 128) =
+                            *reinterpret_cast<s16x4m_t*>(gw_wr + g * GWR) = pack4<false>(acc2[j][g][0], acc2[j][g][1], acc2[j][g][2], acc2[j][g][3]);
+                            *reinterpret_cast<s16x4m_t*>(gw_wr + GWT + g * GWR) =
                                 pack4<false>(PT[j][0][g / 2][g & 1], PT[j][1][g / 2][g & 1], PT[j][2][g / 2][g & 1], PT[j][3][g / 2][g & 1]);
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // wave-private tile: the other lanes' packets are read next
@@ -920,7 +926,7 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
 #pragma unroll
                             for (int g = 0; g < H; ++g) x[g] = acc2[j][g][r];
                             f32x4_t m4[H / 4];
-                            mix_mfma_key<H>(x, Aw, nullptr, m4);               // dP = Ww^T dP' of this key
+                            fl_mix_16<H, false>(x, Aw, nullptr, m4);               // dP = Ww^T dP' of this key
 #pragma unroll
                             for (int hp = 0; hp < H / 2; ++hp) mt[hp] = (f32x2_t){m4[hp >> 1][2 * (hp & 1)], m4[hp >> 1][2 * (hp & 1) + 1]};
                         } else {
@@ -972,7 +978,7 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
 #pragma unroll
                             for (int g = 0; g < H; ++g) x[g] = acc2[j][g][r];
                             f32x4_t m4[H / 4];
-                            mix_mfma_key<H>(x, Aw, nullptr, m4);
+                            fl_mix_16<H, false>(x, Aw, nullptr, m4);
 #pragma unroll
                             for (int hp = 0; hp < H / 2; ++hp) mt[hp] = (f32x2_t){m4[hp >> 1][2 * (hp & 1)], m4[hp >> 1][2 * (hp & 1) + 1]};
                         } else {
@@ -1036,8 +1042,8 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
                             for (int gp = 0; gp < H / 2; ++gp) gb2[(MODE == 3) ? gp : 0] += d2[r][gp];
 #pragma unroll
                         for (int g = 0; g < H; ++g) {
-                            *reinterpret_cast<s16x4m_t*>(gw_wr + g * 128) = pack4<false>(d2[0][g / 2][g & 1], d2[1][g / 2][g & 1], d2[2][g / 2][g & 1], d2[3][g / 2][g & 1]);
-                            *reinterpret_cast<s16x4m_t*>(gw_wr + 512 * H + g * 128) = pack4<false>(acc[j][g][0], acc[j][g][1], acc[j][g][2], acc[j][g][3]);
+                            *reinterpret_cast<s16x4m_t*>(gw_wr + g * GWR) = pack4<false>(d2[0][g / 2][g & 1], d2[1][g / 2][g & 1], d2[2][g / 2][g & 1], d2[3][g / 2][g & 1]);
+                            *reinterpret_cast<s16x4m_t*>(gw_wr + GWT + g * GWR) = pack4<false>(acc[j][g][0], acc[j][g][1], acc[j][g][2], acc[j][g][3]);
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1077,7 +1083,7 @@ __global__ __launch_bounds__(256, (MODE <= 1) ? SPE_FUSED_MINW01 : SPE_FUSED_MIN
 #pragma unroll
                             for (int g = 0; g < H; ++g) x[g] = d2[r][g / 2][g & 1];
                             f32x4_t m4[H / 4];
-                            mix_mfma_key<H>(x, Al, nullptr, m4);               // dS = Wl^T dS' of this key
+                            fl_mix_16<H, false>(x, Al, nullptr, m4);               // dS = Wl^T dS' of this key
 #pragma unroll
                             for (int hp = 0; hp < H / 2; ++hp) ds[r][hp] = (f32x2_t){m4[hp >> 1][2 * (hp & 1)], m4[hp >> 1][2 * (hp & 1) + 1]};
                         } else {
@@ -1342,7 +1348,7 @@ template <int H, int DSTEPS, bool TAIL16, int MODE, bool DROP, int KT>
 static int launch_fused(const FusedArgs& a, int nwg, hipStream_t st) {
     constexpr int NFR = H * DSTEPS;
     constexpr int smem = ((MODE <= 1) ? SPE_FUSED_QP : 1) * NFR * 64 * 16 * ((MODE >= 2) ? 2 : 1) + 4 * (H * 16 * 2 > (H * H + H) ? H * 16 * 2 : (H * H + H)) * 4
-                         + (((MODE == 2 || (MODE == 3 && SPE_FUSED_GWMFMA3)) && SPE_FUSED_GWMFMA && H % 4 == 0) ? 256 + 4 * 1024 * H : 0);      // GWM: constants + the 4 waves' transpose tiles
+                         + (((MODE == 2 || (MODE == 3 && SPE_FUSED_GWMFMA3)) && SPE_FUSED_GWMFMA && H % 4 == 0) ? 512 + 4 * 2 * 4 * H * 144 : 0);      // GWM: constants + the 4 waves' transpose tiles
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&talking_fused_kernel<H, DSTEPS, TAIL16, MODE, DROP, KT>),
