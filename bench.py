@@ -205,8 +205,8 @@ def roofline_inputs():
 
 def parity_record():
     """Measured errors of the benchmarked precision mode against the REFERENCE at cfg2's token count
-    (tests/test_config_golden.py on the GPU box -> profiles/parity_r04.json)."""
-    obj, prov = _load_profile("parity_r04.json")
+    (tests/test_config_golden.py on the GPU box -> profiles/parity_r05.json)."""
+    obj, prov = _load_profile("parity_r05.json")
     if not obj:
         obj, prov = _load_profile("parity_r03.json")
     return obj, prov
@@ -320,13 +320,14 @@ def main():
     # memory-side projections ca_kcontent / ca_v / ca_kpos of reference models/transformer.py:389-419:
     # [B*S, d] x [d, d] = [8300 x 384] x [384 x 384] at cfg2)
     DOM, HBMK = "spe_talking_fused", "spe_attn_contract"
+    DOMQ = "spe_talking_bwdq_pass2"       # round 5: backward pass 2 + dQ on the flash skeleton (the default; spe_talking_fused mode 3 when SPE_BWDQ=0)
     FLF, FLV = "spe_talking_flash_fwd", "spe_talking_flash_dv"
     body = model.backbone[0].body
     S_rows, d_model = a.batch * (a.height // 16) * (a.width // 16), body.embed_dim
     n_dec = args.dec_layers
     CAG_N = 2 * n_dec * d_model          # ca_kcontent + ca_v of all decoder layers in one launch (ops.multi_linear)
     CAG = f"spe_gemm_bf16nt:{S_rows},{CAG_N},{d_model}"
-    K.enable_timing([DOM, HBMK, CAG, FLF, FLV])
+    K.enable_timing([DOM, DOMQ, HBMK, CAG, FLF, FLV])
     reducer.measure = True
     sync()
     t0 = time.perf_counter()
@@ -372,18 +373,26 @@ def main():
         imgs = a.batch * world * a.steps
         N = (a.height // 16) * (a.width // 16)
         Hh, dh_ = body.num_heads, body.embed_dim // body.num_heads
+        default_backbone = a.backbone == "TSCAM_cait_S24" and a.height == 800 and a.width == 1333
+        default_cfg = default_backbone and a.queries == 100 and a.batch == 2
         rin, rin_prov = roofline_inputs()
         par_all, par_prov = parity_record()
         kin = rin.get("kernels", {})
         pk = rin.get("peaks_measured", {})
         # K.timing_results() keys fused launches by mode: "spe_talking_fused:3" = backward pass 2
         launches, mean_ms = K_res.get(DOM + ":3", (0, 0.0))
-        # MFMA work of one launch: S = QK^T (a recomputation: SURVEY 8(d) does not count it) and dP' = dO V^T (algorithmic)
-        # for all heads, 2*N*N*dh FLOP each.  `achieved` counts both (what the matrix pipe executes); `achieved_algorithmic`
-        # only dP'.
+        lq, mq = K_res.get(DOMQ, (0, 0.0))
+        dom_q = lq > 0                   # the flash-skeleton pass 2 ran: it also accumulates dQ = dS K (the streaming dQ contraction is gone)
+        if dom_q:
+            launches, mean_ms = lq, mq
+        # MFMA work of one launch: S = QK^T (a recomputation: SURVEY 8(d) does not count it), dP' = dO V^T (algorithmic) and - flash-skeleton
+        # pass 2 - dQ = dS K (algorithmic) for all heads, 2*N*N*dh FLOP each.  `achieved` = the algorithmic products, `executed` adds the recomputed S.
         mf = (2.0 * N * N * dh_) * Hh * a.batch
-        ach = 2 * mf / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
-        ach_alg = mf / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
+        n_alg = 2 if dom_q else 1
+        ach = (n_alg + 1) * mf / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
+        ach_alg = n_alg * mf / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
+        # the PATH's algorithmic FLOPs per image (forward 1.16 TF at enc_layers 0 + 0.044 TF per encoder layer, x3 for fwd + bwd) x images / s
+        path_tf_per_img = 3.0 * (1.16 + 0.0444 * a.enc_layers) if default_backbone else None
         # vector-pipe work that is left in this pass: the dWl outer product (2*H FLOP per score and head; the three head
         # mixes run on the matrix pipe since round 2 - S' = Wl S in fp32 on v_mfma_f32_4x4x1, dP and dS in bf16), reported
         # against the 157.3 TFLOP/s vector peak; exp2 (quarter rate) and the bf16 packing are not counted as FLOP
@@ -429,16 +438,26 @@ def main():
             "dist": dist_info,
             "hbm_peak_allocated_gb": round(peak_mem / 1e9, 2),           # torch allocator high-water mark through the timed steps (of 288 GB)
             "allreduce_exposed_ms_per_step": max(exposed), "allreduce_exposed_ms_per_rank": exposed,
-            "roofline": {"bound": "mfma", "kernel": "talking_fused_kernel<8,2,3> (attention backward pass 2)", "launches": launches,
-                         # algorithmic work only (dP' = dO V^T); the recomputed S = Q K^T is reported as `executed`
+            "roofline": {"bound": "mfma",
+                         "kernel": ("talking_bwdq_kernel<8,2,tail,PASS 2> + its dQ merge (attention backward pass 2 with dQ = dS K accumulated in registers)" if dom_q
+                                    else "talking_fused_kernel<8,2,3> (attention backward pass 2)"), "launches": launches,
+                         # algorithmic work only (dP' = dO V^T, and dQ = dS K when the flash-skeleton pass ran); the recomputed S = Q K^T is `executed`
                          "avg_ms": mean_ms, "achieved": ach_alg, "executed": ach, "peak": 2500.0,
-                         "peak_measured": pk.get("mfma_bf16_tflops"), "unit": "TFLOP/s", "frac": ach_alg / 2500.0,
+                         "peak_measured": pk.get("mfma_f16_16x16x32_tflops", pk.get("mfma_bf16_tflops")), "unit": "TFLOP/s", "frac": ach_alg / 2500.0,
                          "frac_executed": ach / 2500.0,
-                         "traffic": kin.get("talking_fused_mode3", {}).get("traffic_bytes"),   # bytes/launch, PMC (profiles/roofline_inputs.json)
+                         # the whole PATH against the same peak (algorithmic FLOPs per image x images / s / peak)
+                         "path_tflop_per_image": path_tf_per_img,
+                         "path_achieved": (path_tf_per_img * imgs / dt / world) if path_tf_per_img else None,
+                         "path_frac": (path_tf_per_img * imgs / dt / world / 2500.0) if path_tf_per_img else None,
+                         "traffic": kin.get("talking_bwdq_pass2" if dom_q else "talking_fused_mode3", {}).get("traffic_bytes"),   # bytes/launch, PMC (profiles/roofline_inputs.json)
                          "traffic_provenance": rin_prov,
-                         "note": "not MFMA-bound: per 16x16 tile and wave the matrix pipe is busy ~1150 cycles (QK^T, dO V^T and the three head mixes) and the "
-                                 "vector pipe ~1700 (dWl outer product, exp2, bf16 packing) of ~5900 elapsed - operand-fragment round trips and "
-                                 "MFMA->VALU dependencies are exposed at the 2 waves/SIMD that 256 registers allow (DESIGN.md 4.1)",
+                         "limiter": "instruction issue + exposed waits of ONE wave per SIMD" if dom_q else "latency at two waves per SIMD",
+                         "note": ("priced against the MFMA roofline (its arithmetic is matrix work), bound by something else: one wave per SIMD (512 registers: Q / dO "
+                                  "fragments and the 96 dQ accumulators in AccVGPRs) issues <= 1 instruction per ~4.6 cycles; per 16x16 tile ~620 instructions, "
+                                  "matrix pipe busy ~1900 of ~6100 cycles, the wave issuing 46 %, issue-stalled 30 %, waiting 23 % (profiles/r05_fused_pmc.txt, DESIGN.md 4.1)"
+                                  if dom_q else
+                                  "priced against the MFMA roofline, bound by latency: operand-fragment round trips and MFMA->VALU dependencies are exposed at the 2 waves/SIMD "
+                                  "that 256 registers allow (waves 30 % issuing / 30 % issue-stalled / 40 % waiting: profiles/r05_fused_pmc.txt)"),
                          "valu_achieved": valu, "valu_peak": 157.3,
                          "valu_frac": valu / 157.3,
                          "hbm_kernel": {"bound": "hbm", "kernel": "attn_contract_kernel<3,*> (PV / dV / dQ / dK over blocked bf16 scores)",
@@ -469,7 +488,6 @@ def main():
             "kernel_set": dict(sorted(kernel_set.items())),
             "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("SPE_")},
         }
-        default_cfg = (a.backbone == "TSCAM_cait_S24" and a.height == 800 and a.width == 1333 and a.queries == 100 and a.batch == 2)
         if world == 1 and not a.no_cpu_baseline and default_cfg:
             def gpu_eval(img1, mask1, tg1):
                 model.eval(); crit.eval(); crit_r.eval()

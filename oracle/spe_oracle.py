@@ -33,7 +33,7 @@ def make_cfg(**kw):
     c = dict(embed_dim=192, depth=24, num_heads=4, patch_size=16, num_cls_tokens=20, layer_to_det=23,
              two_branch=False, pos_grid=(50, 84), ln_eps=1e-6,
              nheads=8, enc_layers=0, dec_layers=1, dim_feedforward=2048, num_queries=10, num_refines=1,
-             num_det_classes=21, aux_loss=True)
+             num_det_classes=21, aux_loss=True, focal_gamma=2.0)       # focal_gamma: main.py --focal_gamma (scripts/run_voc0712.py: 0.5)
     c.update(kw)
     return SimpleNamespace(**c)
 
@@ -552,7 +552,8 @@ def total_loss(sd, cfg, img, mask, targets, targets_refine_scores=None, pseudo=N
     pseudo labels of stage 0.  Eval-mode criterion (no jitter).  `pseudo`: stage-1 targets given by the caller
     (they are detached inputs of criterion_refine, engine.py:122-130) instead of this function's own."""
     out = model_forward(sd, cfg, img, mask)
-    l0 = set_criterion(out[0], targets, refine=False)
+    fg = float(getattr(cfg, "focal_gamma", 2.0))
+    l0 = set_criterion(out[0], targets, refine=False, gamma=fg)
     if pseudo is None:
         with torch.no_grad():
             pseudo = postprocess_refine(out[0], targets)
@@ -560,7 +561,7 @@ def total_loss(sd, cfg, img, mask, targets, targets_refine_scores=None, pseudo=N
         pseudo = [dict(p_) for p_ in pseudo]
     for p_, t_ in zip(pseudo, targets):
         p_["img_label"] = t_["img_label"]
-    l1 = set_criterion(out[1], pseudo, refine=True)
+    l1 = set_criterion(out[1], pseudo, refine=True, gamma=fg)
     wd = weight_dict(cfg)
     tot = sum(l0[k] * wd[k] for k in l0 if k in wd) + sum(l1[k] * wd[k] for k in l1 if k in wd)
     return tot, out, l0, l1

@@ -248,6 +248,20 @@ float* det_defer_try(long sets, long members, long L, int nseg, const DetDeferSe
     }
     const long need = (sets * members * L + 63) & ~63L;
     if (need > g_arena_floats) return nullptr;
+    // one producer per destination and flush: the flush kernel adds every pending entry onto its destination with a plain read-modify-write,
+    // one entry per blockIdx.y - a new entry whose destination overlaps a pending one (two launches into the same gradient, or an
+    // accumulate = 0 entry mixed with an accumulate = 1 one) would race with it, so the pending ones are flushed first (stream-ordered)
+    bool overlap = false;
+    for (int k = 0; k < nseg && !overlap; ++k) {
+        const char* lo = reinterpret_cast<const char*>(segs[k].dst);
+        if (!lo) continue;
+        const char* hi = lo + (long)segs[k].len * 4;
+        for (int j = 0; j < g_dt_nseg && !overlap; ++j) {
+            const char* plo = reinterpret_cast<const char*>(g_dt.seg[j].dst);
+            if (plo && lo < plo + (long)g_dt.seg[j].len * 4 && plo < hi) overlap = true;
+        }
+    }
+    if (overlap && defer_flush(st) != 0) return nullptr;
     if (g_dt.n >= DEFER_MAXENT || g_dt_nseg + nseg > DET_DEFER_MAXSEG || g_arena_cur + need > g_arena_floats) {
         if (defer_flush(st) != 0) return nullptr;      // stream-ordered before this launch reuses the arena
     }

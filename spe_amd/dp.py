@@ -168,6 +168,7 @@ class GradAllReducer:
             for p in b["params"]:
                 p.grad = None
                 p._spe_grad_fresh = True
+                p._spe_handed = False
         self._next = 0
         self._fired = set()
         if self._defer:
@@ -209,7 +210,7 @@ class GradAllReducer:
         if p.grad.data_ptr() != view.data_ptr():
             # the gradient was produced outside the bucket (torch op, or a parameter used twice whose contributions
             # autograd summed into a temporary): AccumulateGrad runs once per backward with the TOTAL, so copy it in
-            if not getattr(p, "_spe_grad_fresh", True) and not getattr(p, "_spe_shared", False):
+            if getattr(p, "_spe_handed", False) and not getattr(p, "_spe_shared", False):
                 # its bucket view HAD been handed to a kernel: the parameter is used by more than one node
                 p._spe_shared = True
                 if self._defer:
@@ -286,6 +287,10 @@ class GradAllReducer:
     def remove(self):
         for h in self._hooks:
             h.remove()
+        for p in self.params:           # per-parameter marks of THIS reducer do not survive into the next one
+            for a in ("_spe_shared", "_spe_handed", "_spe_grad_fresh", "_spe_grad_buf"):
+                if hasattr(p, a):
+                    delattr(p, a)
         if self._defer:
             from . import kernels as _K
             if _K._DEFER_FLATS is not None and _K._DEFER_FLATS and _K._DEFER_FLATS[0] is self.buckets[0]["flat"]:

@@ -246,6 +246,7 @@ def grad_buffer(param):
     if param is None or not getattr(param, "_spe_grad_fresh", False) or getattr(param, "_spe_shared", False):
         return None             # (_spe_shared: used by several nodes of the graph - autograd sums their gradients itself, see dp._on_grad)
     param._spe_grad_fresh = False
+    param._spe_handed = True          # explicit per-step flag (re-armed by the reducer's reset()): the view went to a kernel THIS step
     buf = param._spe_grad_buf
     return buf.view_as(buf)            # fresh alias: AccumulateGrad only steals a tensor nobody else references
 

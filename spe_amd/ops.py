@@ -933,7 +933,9 @@ class _MemorySideKV(Function):
         m2, p2 = memory.reshape(B * S, d), pos.reshape(B * S, d)
         m2 = m2 if m2.is_contiguous() else m2.contiguous()
         p2 = p2 if p2.is_contiguous() else p2.contiguous()
-        train = any(ctx.needs_input_grad)
+        # the bf16 backward fragments follow whether ANY backward can happen (holder.want_bwd: grad mode at the call site): with the memory-side
+        # projections frozen and the query side trainable, the cross-attention nodes still need K16 / Vf for dq
+        train = any(ctx.needs_input_grad) or bool(getattr(holder, "want_bwd", False))
         Wmh, bmc = K.weightcat_f16(Wm, bm)
         Wph, bpc = K.weightcat_f16(Wp, bp)
         ym = torch.empty((B * S, 2 * L * d), device=memory.device, dtype=torch.float16)
@@ -945,7 +947,7 @@ class _MemorySideKV(Function):
         holder.ztok = torch.zeros((1,), device=memory.device, dtype=torch.float32)
         ctx.holder = holder
         ctx.params = (Wm, Wp, bm, bp)
-        if train:
+        if any(ctx.needs_input_grad):
             # the backward runs on single bf16 operands like every other Linear backward: bf16 copies of the inputs (shared with the
             # other consumers of `memory` / `pos`) and the transposed bf16 weight stack for the input gradient
             m16, _, _ = K.act16(m2, False, memory)
@@ -1031,10 +1033,17 @@ class _CrossAttentionKV(Function):
         dOf, dO16 = K.attn_pack_multi([(dO4, 1.0, 322), (dO4, 1.0, 16)])
         dq, dk_, dv_ = K.mha_bwd(Qf, h.Kf[layer], h.Vf[layer], dOf, h.K16[layer], Q16, dO16, mask_u8, lse, D, keep, B, H, Lq, S, dk, dh, nch,
                                  scale, p_drop)
+        if not ctx.needs_input_grad[1]:                 # the memory side takes no gradient (frozen projections, detached memory): nothing to scatter
+            return dq, None, None, None, None, None, None
         if h.dYm is None:
             h.dYm = torch.empty((B * S, 2 * L * d), device=dO.device, dtype=torch.bfloat16)
             h.dYp = torch.empty((B * S, L * d), device=dO.device, dtype=torch.bfloat16)
             h.written = set()
+        if layer in h.written:
+            # spe_kv_grad_scatter stores (it does not accumulate): a second cross-attention node on the same (holder, layer) in one graph - a
+            # mem_cache reused across decoder passes - would silently drop the first node's key / value gradients
+            raise RuntimeError(f"MemoryKV: the key / value gradients of decoder layer {layer} were already written in this backward pass; a "
+                               "(holder, layer) pair feeds ONE cross-attention node per graph (do not reuse a mem_cache that holds MemoryKV entries)")
         K.kv_grad_scatter(dk_, dv_, h.dYm, h.dYp, layer, B, S, H, dh)
         h.written.add(layer)
         return dq, h.ztok, None, None, None, None, None
@@ -1051,6 +1060,7 @@ def memory_side_kv_ok(memory, Wm, Wp, H):
 def memory_side_kv(memory, pos, H, Wm, Wp, bm, bp):
     """-> (holder, tokens): see _MemorySideKV.  Wm = [kcontent_0, v_0, kcontent_1, v_1, ...], Wp = [kpos_0, ...]."""
     holder = MemoryKV()
+    holder.want_bwd = torch.is_grad_enabled()
     toks = _MemorySideKV.apply(holder, memory, pos, H, *Wm, *Wp, *bm, *bp)
     return holder, toks
 

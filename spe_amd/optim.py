@@ -41,6 +41,9 @@ class FlatAdamW(torch.optim.Optimizer):
             for p in grp["params"]:
                 gid[p] = gi
         self._step = 0
+        # ONE 0-dim step tensor shared by every parameter's state entry (torch.optim.AdamW semantics: optimizer.state[p]["step"] is always
+        # current) and bumped by a single host op per step() - not 717 tensor increments
+        self._step_t = torch.zeros((), dtype=torch.float32)
         self._buckets = []
         for b in reducer.buckets:
             n = b["flat"].numel()
@@ -57,7 +60,7 @@ class FlatAdamW(torch.optim.Optimizer):
                 else:
                     ends.append(end); groups.append(gid[p])
                 st = self.state[p]
-                st["step"] = torch.zeros((), dtype=torch.float32)
+                st["step"] = self._step_t
                 st["exp_avg"] = m[off:off + p.numel()].view_as(p)
                 st["exp_avg_sq"] = v[off:off + p.numel()].view_as(p)
             if len(ends) > 64:
@@ -74,6 +77,7 @@ class FlatAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         self._step += 1
+        self._step_t += 1
         b1, b2 = self.param_groups[0]["betas"]
         eps = self.param_groups[0]["eps"]
         bc1, bc2 = 1.0 - b1 ** self._step, 1.0 - b2 ** self._step
@@ -95,11 +99,7 @@ class FlatAdamW(torch.optim.Optimizer):
         return loss
 
     def state_dict(self):
-        """torch's format carries a per-parameter `step` tensor: written here from the optimiser's own counter instead of
-        717 host-side tensor increments in every step."""
-        for grp in self.param_groups:
-            for p in grp["params"]:
-                self.state[p]["step"].fill_(float(self._step))
+        """torch's format (a per-parameter `step` entry: here every parameter's entry is the one shared, always current step tensor)."""
         return super().state_dict()
 
     def zero_grad(self, set_to_none=True):
@@ -123,3 +123,7 @@ class FlatAdamW(torch.optim.Optimizer):
                     steps.append(int(st["step"]))
         if steps:
             self._step = max(steps)
+        self._step_t.fill_(float(self._step))
+        for g in self.param_groups:                 # re-share the step tensor (load_state_dict gave every parameter its own copy)
+            for p in g["params"]:
+                self.state[p]["step"] = self._step_t

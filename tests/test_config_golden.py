@@ -95,7 +95,7 @@ def compare_grads(named_grads, blob, norm_errs=None):
 
 
 # -------------------------------------------------------------------------------------------------- CPU: oracle
-@pytest.mark.parametrize("name", ["cfg1", "cfg2_enc3_small", "cfg2_depth2"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2_enc3_small", "cfg2_depth2", "script_voc"])
 def test_oracle_matches_reference_at_config_dims(name):
     from oracle import spe_oracle as O
     blob = torch.load(os.path.join(GOLD, f"cfg_{name}.pt"), weights_only=False)
@@ -213,19 +213,14 @@ def _to_dev(x, dev):
 TRAJ_TOL = {"bf16x3": (1e-3, 1e-3, 4e-2), "bf16s": (1e-3, 1e-2, 1.5e-1)}
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("name,prec", [(n, p) for n in ("cfg1", "cfg2_depth2") for p in ("bf16s", "bf16x3")])
-def test_training_trajectory_matches_reference(dev, name, prec):
-    """FIVE optimizer steps of the reference's loop (engine.py:88-165: train-mode criteria with the 5x one-to-many jitter,
-    clip_grad_norm_ 0.1, AdamW with main.py:177-187's three LR groups) recorded in the build container by
-    tools/gen_traj_golden.py, replayed by the product: GradAllReducer + FlatAdamW on the flat buckets, the jittered targets_cp of
-    both criteria injected from the fixture.  Asserted: every step's total loss and pre-clip gradient norm, and the norm-relative
-    error of every parameter's 5-step UPDATE (median over parameters)."""
+def _replay_trajectory(dev, name, prec, blob, tag="traj"):
+    """Replay the recorded optimizer steps of a trajectory fixture on the product (GradAllReducer + FlatAdamW on the flat buckets, the
+    jittered targets_cp of both criteria injected from the fixture) -> record with the per-step loss / gradient-norm errors and the
+    parameter-update errors; asserts every weighted loss key at step 0 (identical weights) at north_star's 1e-3."""
     from spe_amd import kernels as K
     from spe_amd.dp import GradAllReducer
     from spe_amd.optim import FlatAdamW
     from spe_amd.util.misc import NestedTensor
-    blob = torch.load(os.path.join(GOLD, f"traj_{name}.pt"), weights_only=False)
     hy = blob["hyper"]
     args, (model, crit, crit_r, pp, rpp), tensors, mask, targets = cc.build_case(name)
     chk = float(sum(v.detach().double().abs().sum() for v in model.state_dict().values() if v.is_floating_point()))
@@ -245,7 +240,7 @@ def test_training_trajectory_matches_reference(dev, name, prec):
         wd = blob["weight_dict"]
         tg = _to_dev(targets, dev)
         samples = NestedTensor(tensors.to(dev), mask.to(dev))
-        errs, gerrs = [], []
+        errs, gerrs, losses = [], [], []
         for s, st in enumerate(blob["steps"]):
             opt.zero_grad()
             out = model(samples)
@@ -256,7 +251,8 @@ def test_training_trajectory_matches_reference(dev, name, prec):
             red.finish()
             gn = float(torch.sqrt(sum((b["flat"].double() ** 2).sum() for b in red.buckets)))
             opt.step()
-            errs.append(abs(float(total.detach()) - st["total"]) / abs(st["total"]))
+            losses.append(float(total.detach()))
+            errs.append(abs(losses[-1] - st["total"]) / abs(st["total"]))
             gerrs.append(abs(gn - st["grad_norm"]) / st["grad_norm"])
             if s == 0:          # identical weights: every loss key of both criteria within north_star's bound
                 for ld, ref in ((l0, st["loss0"]), (l1, st["loss1"])):
@@ -271,20 +267,51 @@ def test_training_trajectory_matches_reference(dev, name, prec):
         us = sorted(ue.values())
         rec = {"case": name, "precision": prec, "loss_rel_err_per_step": errs, "grad_norm_rel_err_per_step": gerrs,
                "update_err_median": us[len(us) // 2], "update_err_p90": us[(9 * len(us)) // 10], "update_err_worst": max(ue.items(), key=lambda kv: kv[1]),
-               "reference_losses": [st["total"] for st in blob["steps"]]}
-        print(f"[traj {name} {prec}] " + json.dumps(rec))
+               "reference_losses": [st["total"] for st in blob["steps"]], "product_losses": losses, "updates_compared": len(us)}
+        print(f"[{tag} {name} {prec}] " + json.dumps(rec))
         od = os.path.join(os.path.dirname(HERE), "gpurun_out")
         if os.path.isdir(od):
-            with open(os.path.join(od, f"traj_{name}_{prec}.json"), "w") as fh:
+            with open(os.path.join(od, f"{tag}_{name}_{prec}.json"), "w") as fh:
                 json.dump(rec, fh)
-        t0, t1, tu = TRAJ_TOL[prec]
-        assert errs[0] < t0, errs
-        assert max(errs[1:]) < t1, errs
-        assert us[len(us) // 2] < tu and len(us) > 100, (us[len(us) // 2], len(us))
+        return rec
     finally:
         if red is not None:
             red.remove()
         K.set_precision("bf16s")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,prec", [(n, p) for n in ("cfg1", "cfg2_depth2") for p in ("bf16s", "bf16x3")])
+def test_training_trajectory_matches_reference(dev, name, prec):
+    """FIVE optimizer steps of the reference's loop (engine.py:88-165: train-mode criteria with the 5x one-to-many jitter,
+    clip_grad_norm_ 0.1, AdamW with main.py:177-187's three LR groups) recorded in the build container by
+    tools/gen_traj_golden.py, replayed by the product: GradAllReducer + FlatAdamW on the flat buckets, the jittered targets_cp of
+    both criteria injected from the fixture.  Asserted: every step's total loss and pre-clip gradient norm, and the norm-relative
+    error of every parameter's 5-step UPDATE (median over parameters)."""
+    blob = torch.load(os.path.join(GOLD, f"traj_{name}.pt"), weights_only=False)
+    rec = _replay_trajectory(dev, name, prec, blob)
+    errs = rec["loss_rel_err_per_step"]
+    t0, t1, tu = TRAJ_TOL[prec]
+    assert errs[0] < t0, errs
+    assert max(errs[1:]) < t1, errs
+    assert rec["update_err_median"] < tu and rec["updates_compared"] > 100, (rec["update_err_median"], rec["updates_compared"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["bf16s", "bf16x3"])
+def test_long_training_trajectory_stays_near_reference(dev, prec):
+    """THIRTY optimizer steps of the reference's loop at cfg2_depth2 (N = 4150 tokens; tests/golden/traj30_cfg2_depth2.pt, tools/gen_traj_golden.py
+    cfg2_depth2:30), replayed by the product with the recorded one-to-many targets: the benchmark mode's single-bf16 backward feeds AdamW
+    for 30 steps, so this bounds how far its loss curve drifts from the reference's - every step within 2 % (bf16s; round 4 only showed 5
+    steps, with the error growing to 3.9e-3 at the fifth) resp. 5e-3 (bf16x3, the 3-term parity mode)."""
+    path = os.path.join(GOLD, "traj30_cfg2_depth2.pt")
+    blob = torch.load(path, weights_only=False)
+    assert len(blob["steps"]) == 30
+    rec = _replay_trajectory(dev, "cfg2_depth2", prec, blob, tag="traj30")
+    errs = rec["loss_rel_err_per_step"]
+    assert errs[0] < 1e-3, errs
+    bound = 2e-2 if prec == "bf16s" else 5e-3
+    assert max(errs) < bound, (max(errs), errs.index(max(errs)), errs)
 
 
 @pytest.mark.gpu

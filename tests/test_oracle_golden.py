@@ -202,3 +202,21 @@ def test_jitter_targets_shape_and_order():
     assert (iou > 0.7).all() and not torch.equal(o[0]["boxes"][0], t[0]["boxes"][0])
     assert o[0]["scores"].tolist() == pytest.approx([0.9] * 5 + [0.4] * 5)
     assert o[1]["labels"].numel() == 0
+
+
+def test_oracle_flip_merge_vs_reference_golden():
+    """oracle.decouple_output against the reference's own engine_loc.decouple_output (engine_loc.py:99-124) run on seeded tensors by
+    tools/gen_infer_golden.py: every key, recursively through aux_outputs, bit for bit (the merge is copies, 1 - x and maximum)."""
+    import copy
+    from oracle import spe_oracle as O
+    blob = torch.load(os.path.join(GOLD, "infer.pt"), weights_only=False)
+    for case in blob["decouple_output"]:
+        got = O.decouple_output(copy.deepcopy(case["input"]), case["bs"])
+        ref = case["output"]
+        assert set(got) == set(ref)
+        for k, v in ref.items():
+            if k == "aux_outputs":
+                for a, b in zip(got[k], v):
+                    assert set(a) == set(b) and all(torch.equal(a[kk], b[kk]) for kk in b)
+            else:
+                assert torch.equal(got[k], v), k

@@ -132,3 +132,241 @@ def test_flash_skeleton_backward_in_the_attention_node(dev):
         assert torch.equal(res[mode][0], res[0][0])
         for a, b in zip(res[mode][1:], res[0][1:]):
             assert (a - b).norm() <= 1e-3 * b.norm(), (mode, float((a - b).norm() / b.norm()))
+
+
+# ------------------------------------------------------------------------------------------------ SURVEY 8(f) rows 1, 3, 4
+def test_flip_merge_vs_reference_golden(dev):
+    """spe_amd.infer.decouple_output against the REFERENCE's engine_loc.decouple_output (engine_loc.py:99-124), run on seeded tensors by
+    tools/gen_infer_golden.py (tests/golden/infer.pt): bit for bit, every key, through aux_outputs."""
+    import copy
+    import os
+    from spe_amd import infer
+    blob = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "infer.pt"), weights_only=False)
+
+    def to_dev(d):
+        return {k: ([to_dev(a) for a in v] if k == "aux_outputs" else v.to(dev)) for k, v in d.items()}
+    for case in blob["decouple_output"]:
+        got = infer.decouple_output(to_dev(copy.deepcopy(case["input"])), case["bs"])
+        ref = case["output"]
+        assert set(got) == set(ref)
+        for k, v in ref.items():
+            if k == "aux_outputs":
+                for a, b in zip(got[k], v):
+                    assert set(a) == set(b) and all(torch.equal(a[kk].cpu(), b[kk]) for kk in b)
+            else:
+                assert torch.equal(got[k].cpu(), v), k
+
+
+def _greedy_nms_bruteforce(boxes, scores, thr):
+    """Textbook greedy NMS (what torchvision.ops.nms implements, engine_loc.py:160): visit boxes by descending score, keep a box unless its IoU
+    with an already kept box exceeds thr.  Pure Python over lists - shares no code with oracle/ or the kernel."""
+    b = boxes.double().tolist()
+    order = sorted(range(len(b)), key=lambda i: (-float(scores[i]), i))
+    keep = []
+    for i in order:
+        x0, y0, x1, y1 = b[i]
+        ok = True
+        for j in keep:
+            u0, v0, u1, v1 = b[j]
+            iw, ih = min(x1, u1) - max(x0, u0), min(y1, v1) - max(y0, v0)
+            inter = max(iw, 0.0) * max(ih, 0.0)
+            union = (x1 - x0) * (y1 - y0) + (u1 - u0) * (v1 - v0) - inter
+            if inter / union > thr:
+                ok = False
+                break
+        if ok:
+            keep.append(i)
+    return keep
+
+
+def test_per_class_nms_vs_bruteforce(dev):
+    """spe_amd.infer.per_class_nms (one sort + one HIP launch per batch) against a brute-force O(n^2) greedy NMS run class by class the way
+    engine_loc.py:154-174 does (classes ascending - `labels.unique()` - survivors in descending score order), on boxes with clusters of
+    near-duplicates, exact duplicates, IoU pairs straddling the 0.5 threshold and a class with a single box."""
+    from spe_amd import infer
+    g = torch.Generator().manual_seed(77)
+    results = []
+    for i in range(3):
+        n = 200
+        c = torch.rand(n, 2, generator=g) * 500 + 100
+        wh = torch.rand(n, 2, generator=g) * 150 + 20
+        c[40:120] = c[:80].clone() + torch.randn(80, 2, generator=g) * 5
+        wh[40:120] = wh[:80].clone() * (1 + 0.05 * torch.randn(80, 2, generator=g))
+        boxes = torch.cat([c - wh / 2, c + wh / 2], 1)
+        labels = torch.randint(0, 5, (n,), generator=g)
+        labels[40:120] = labels[:80].clone()
+        boxes[150] = boxes[10]; labels[150] = labels[10]            # an exact duplicate
+        labels[199] = 17                                            # a class of its own
+        # a pair with IoU just below / just above 0.5 (same class): [0,0,100,100] vs a box shifted right by 33.2 / 33.4 (IoU 0.5015 / 0.4993)
+        boxes[160] = torch.tensor([0., 0., 100., 100.]); boxes[161] = torch.tensor([33.2, 0., 133.2, 100.]); boxes[162] = torch.tensor([300., 0., 400., 100.])
+        boxes[163] = torch.tensor([333.4, 0., 433.4, 100.]); labels[160:164] = 9
+        scores = torch.rand(n, generator=g)
+        results.append({"scores": scores, "labels": labels, "boxes": boxes})
+    got = infer.per_class_nms([{k: v.to(dev) for k, v in r.items()} for r in results], 0.5)
+    for r, o in zip(results, got):
+        eb, es, el = [], [], []
+        for pc in sorted(set(r["labels"].tolist())):
+            idx = (r["labels"] == pc).nonzero().reshape(-1)
+            keep = _greedy_nms_bruteforce(r["boxes"][idx], r["scores"][idx], 0.5)
+            eb.append(r["boxes"][idx][keep]); es.append(r["scores"][idx][keep]); el.append(r["labels"][idx][keep])
+        eb, es, el = torch.cat(eb), torch.cat(es), torch.cat(el)
+        assert 0 < es.numel() < r["scores"].numel()
+        assert torch.equal(o["labels"].cpu(), el) and torch.equal(o["scores"].cpu(), es) and torch.equal(o["boxes"].cpu(), eb)
+    # the straddling pairs: 160 / 161 overlap by more than 0.5 -> one survives ; 162 / 163 by less -> both survive
+    for r, o in zip(results, got):
+        n9 = int((o["labels"] == 9).sum())
+        assert n9 == 3
+
+
+def test_cam_boxes_of_device_images_vs_ndimage(dev):
+    """SURVEY 8(f) row 1 (reference cams_deit.py:61-96, engine.py:356-398; OpenCV itself is not installed, the oracle restates Suzuki-Abe and
+    its header says "parity unpinned"): an INDEPENDENT check of the box stage on the images the DEVICE path produces - outer borders are the
+    8-connected components, hole borders the enclosed 4-connected background regions (scipy.ndimage shares no code with the border follower)."""
+    import numpy as np
+    from scipy import ndimage
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    B, Kc, h, w, H, W = 2, 4, 11, 15, 160, 224
+    cams = torch.zeros(B * Kc, h, w)
+    for m in range(B * Kc):
+        for _ in range(3):
+            cy, cx = torch.rand(2, generator=g) * torch.tensor([h - 1.0, w - 1.0])
+            yy, xx = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+            cams[m] += torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * (0.8 + 2 * torch.rand(1, generator=g)) ** 2))
+    cams += 0.08 * torch.randn(cams.shape, generator=g)
+    imgs = K.cam_prepare(cams.to(dev), W, H, 0.2).cpu()           # (rows, cols) = the reference's (H, W) -> dsize quirk
+    nonempty = 0
+    for m in range(B * Kc):
+        img = imgs[m].numpy()
+        allb = K.cam_contour_boxes(imgs[m].contiguous(), 0.0, max_boxes=8192).tolist()
+        fg = img != 0
+        if not fg.any():
+            assert allb == [[0, 0, 1, 1]]
+            continue
+        nonempty += 1
+        lab, n = ndimage.label(fg, structure=np.ones((3, 3)))
+        comp = [[s[1].start, s[0].start, s[1].stop, s[0].stop] for s in ndimage.find_objects(lab)]
+        bg = np.pad(~fg, 1, constant_values=True)
+        labb, nb = ndimage.label(bg)                               # 4-connected background
+        outside = labb[0, 0]
+        holes = []
+        for k, s in enumerate(ndimage.find_objects(labb), start=1):
+            if k != outside:
+                holes.append([s[1].start - 2, s[0].start - 2, s[1].stop, s[0].stop])     # un-pad (-1), grown by 1 on each side
+        assert sorted(allb) == sorted(comp + holes), m
+        # the largest-area selection of the driver keeps a subset of these boxes
+        sel = K.cam_contour_boxes(imgs[m].contiguous(), 0.5, max_boxes=8192).tolist()
+        assert len(sel) >= 1 and all(b in allb for b in sel)
+    assert nonempty >= B * Kc - 1
+
+
+def test_product_from_deit_checkpoint_matches_reference(dev, tmp_path):
+    """SURVEY 8(f) row 4 (reference models/cait.py:1639-1663, models/cait_backbone.py:76, main.py:223-233): the backbone weights arrive through
+    a DeiT-style file - 'model' dict, 'module.'-prefixed keys, an ImageNet classifier head of another shape - given as args.backbone_checkpoint,
+    and the HIP path then reproduces the cfg1 reference fixture at north_star's 1e-3.  (pos_embed is stored at the checkpoint's own grid in
+    a real file and re-interpolated by finetune_det; the fixture's seeded pos_embed has the detection grid's shape, so the loader skips it -
+    shape mismatch, like the reference's - and the test copies it over together with the non-backbone weights.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cfg_cases as cc
+    import test_config_golden as tg
+    from spe_amd import kernels as K
+    from spe_amd.models import build_model
+    from spe_amd.util.misc import NestedTensor
+    name = "cfg1"
+    blob = torch.load(os.path.join(tg.GOLD, f"cfg_{name}.pt"), weights_only=False)
+    args, (seeded, *_), tensors, mask, targets = cc.build_case(name)
+    body = seeded.backbone[0].body
+    sd_body = {k: v.detach().clone() for k, v in body.state_dict().items()}
+    file_sd = {"module." + k: v for k, v in sd_body.items()}
+    file_sd["module.head.weight"] = torch.randn(1000, sd_body["head.weight"].shape[1])       # the released file's ImageNet head: other shape, skipped
+    file_sd["module.head.bias"] = torch.randn(1000)
+    path = str(tmp_path / "deit_cait_xxs24.pth")
+    torch.save({"model": file_sd}, path)
+    args2 = cc.make_args(cc.ALL_CASES[name])
+    args2.backbone_checkpoint = path
+    torch.manual_seed(999)                       # every weight that is NOT loaded would differ from the seeded model
+    model, crit, crit_r, pp, rpp = build_model(args2)
+    own = model.backbone[0].body.state_dict()
+    not_loaded = [k for k, v in sd_body.items() if not torch.equal(own[k], v)]
+    assert set(not_loaded) <= {"pos_embed", "head.weight", "head.bias"}, not_loaded
+    # what a checkpoint cannot carry here: the detection-grid pos_embed, the unused classifier head, and everything outside the backbone
+    full = seeded.state_dict()
+    cur = model.state_dict()
+    patch = {k: v for k, v in full.items() if not k.startswith("backbone.0.body.") or k.split("backbone.0.body.")[1] in not_loaded}
+    cur.update(patch)
+    model.load_state_dict(cur, strict=True)
+    K.set_precision("bf16s")
+    model.to(dev).train(); crit.to(dev).eval(); crit_r.to(dev).eval()
+    tgd = [{k: v.to(dev) for k, v in t.items()} for t in targets]
+    out = model(NestedTensor(tensors.to(dev), mask.to(dev)))
+    l0 = crit(out[0], tgd)
+    pseudo = [{k: v.to(dev) for k, v in p.items()} for p in blob["pseudo"]]
+    l1 = crit_r(out[1], pseudo)
+    wd = blob["weight_dict"]
+    total = sum(l0[k] * wd[k] for k in l0 if k in wd) + sum(l1[k] * wd[k] for k in l1 if k in wd)
+    total.backward()
+    torch.cuda.synchronize()
+    oe = tg.compare_outputs(out, blob)
+    le = tg.compare_losses(l0, l1, blob, skip_logging=False)
+    te = abs(float(total.detach()) - float(blob["total"])) / abs(float(blob["total"]))
+    assert max(oe.values()) < 1e-3, max(oe.items(), key=lambda kv: kv[1])
+    assert max(le.values()) < 1e-3 and te < 1e-3, (max(le.items(), key=lambda kv: kv[1]), te)
+    ge = tg.compare_grads([(k, p.grad) for k, p in model.named_parameters()], blob)
+    gs = sorted(ge.values())
+    assert gs[len(gs) // 2] < 1.5e-2 and len(ge) > 100
+
+
+# ------------------------------------------------------------------------------------------------ dropout statistics at the launch scripts' rates
+def test_dropout_streams_have_the_reference_semantics_at_script_rates(dev):
+    """Reference semantics of the three training rates of scripts/run_voc0712.py:15-41 (models/cait.py:387-392 attn_drop / proj_drop, timm DropPath
+    models/cait.py:404; nn.Dropout in models/transformer.py:279-287): every element is kept independently with probability 1 - p and kept values are
+    scaled by 1 / (1 - p), so the expectation is preserved.  The product draws its masks from Philox4x32-7 (csrc/common.h) - checked here
+    statistically at the scripts' own rates: the keep fraction within 4 sigma of 1 - p, dropped elements exactly 0, kept elements exactly
+    x / (1 - p), the output mean preserved, disjoint streams for consecutive draws, and no correlation between neighbouring elements."""
+    from spe_amd import kernels as K, ops
+    K.manual_seed(1234)
+    n = 1 << 22
+    x = torch.full((n,), 1.0, device=dev)
+    for p in (0.07, 0.2, 0.05):                                         # backbone_drop_rate, drop_path_rate, drop_attn_rate
+        seed, off = K.next_rng()
+        y = K.dropout(x, p, seed, off)
+        keep = (y != 0)
+        frac = float(keep.float().mean())
+        sigma = (p * (1 - p) / n) ** 0.5
+        assert abs(frac - (1 - p)) < 4 * sigma, (p, frac)
+        assert y[keep].min() == y[keep].max() and abs(float(y[keep][0]) * (1.0 - p) - 1.0) < 1e-6      # one value: x / (1 - p)
+        assert abs(float(y.double().mean()) - 1.0) < 4 * sigma / (1 - p)                    # expectation preserved
+        # lag-1 correlation of the keep flags: |rho| < 4 / sqrt(n)
+        k = keep.double()
+        rho = float(((k[1:] - k.mean()) * (k[:-1] - k.mean())).mean() / k.var())
+        assert abs(rho) < 4 / n ** 0.5, (p, rho)
+        # a second draw uses another part of the stream: the masks are independent (agreement = keep^2 + drop^2)
+        seed2, off2 = K.next_rng()
+        y2 = K.dropout(x, p, seed2, off2)
+        agree = float(((y2 != 0) == keep).float().mean())
+        expect = (1 - p) ** 2 + p ** 2
+        assert abs(agree - expect) < 4 * (expect * (1 - expect) / n) ** 0.5, (p, agree, expect)
+        # the same (seed, offset) regenerates the same mask (what every backward relies on)
+        assert torch.equal(K.dropout(x, p, seed, off), y)
+    # attention dropout: the keep flags of the flash forward (one bit per (head, query, key)) at attn_drop = 0.05
+    B, H, N, dh, p = 1, 8, 1024, 48, 0.05
+    x_ = _inputs(B, H, N, dh, p, dev)
+    bits = x_["bits"]                                                   # [B, nt, nt, 64] dwords, 32 flags each (4 keys x 8 heads of one query)
+    assert bits is not None
+    cnt = 0
+    b32 = bits.view(-1).to(torch.int64) & 0xFFFFFFFF
+    for s in range(32):
+        cnt += int(((b32 >> s) & 1).sum())
+    tot = B * H * N * N
+    frac = cnt / tot
+    assert abs(frac - (1 - p)) < 4 * (p * (1 - p) / tot) ** 0.5, frac
+    # DropPath: per-sample Bernoulli(1 - p) / (1 - p)
+    torch.manual_seed(5)
+    ss = torch.cat([ops.drop_path_scale(4096, 0.2, True, dev) for _ in range(8)])
+    vals = set(ss.unique().tolist())
+    assert len(vals) == 2 and 0.0 in vals and abs(max(vals) * 0.8 - 1.0) < 1e-6
+    fk = float((ss != 0).float().mean())
+    assert abs(fk - 0.8) < 4 * (0.2 * 0.8 / ss.numel()) ** 0.5
+    assert ops.drop_path_scale(8, 0.2, False, dev) is None and ops.drop_path_scale(8, 0.0, True, dev) is None

@@ -45,7 +45,7 @@ def param_groups(model):
             {"params": [p for n, p in named if "backbone" in n and p.requires_grad and "blocks_token_only" in n], "lr": LR_CLS_HEAD}]
 
 
-def run_case(name):
+def run_case(name, nsteps=STEPS, tag="traj"):
     from models import build_model as ref_build
     import util.misc as um
     args, (pmodel, *_), tensors, mask, targets = cc.build_case(name)
@@ -75,7 +75,7 @@ def run_case(name):
     orig = torch.stack([t["orig_size"] for t in targets])
     torch.manual_seed(cc.ALL_CASES[name]["seed"] + 77)        # the jitter stream (any seed: the draws are stored)
     steps = []
-    for s in range(STEPS):
+    for s in range(nsteps):
         captured["crit"].clear(); captured["crit_r"].clear()
         out = model(um.NestedTensor(tensors, mask))
         with torch.no_grad():
@@ -100,9 +100,9 @@ def run_case(name):
         print(name, "step", s, "total", steps[-1]["total"], "grad norm", steps[-1]["grad_norm"], flush=True)
     upd = {n: cc.sample(p.detach() - p0[n]) for n, p in model.named_parameters()}
     blob = {"case": name, "steps": steps, "updates": upd, "weight_dict": dict(wd),
-            "hyper": {"lr": LR, "lr_backbone": LR_BACKBONE, "lr_cls_head": LR_CLS_HEAD, "weight_decay": WD, "clip_max_norm": CLIP, "steps": STEPS},
+            "hyper": {"lr": LR, "lr_backbone": LR_BACKBONE, "lr_cls_head": LR_CLS_HEAD, "weight_decay": WD, "clip_max_norm": CLIP, "steps": nsteps},
             "sd_checksum": float(sum(v.double().abs().sum() for v in sd.values() if v.is_floating_point()))}
-    path = os.path.join(OUT, f"traj_{name}.pt")
+    path = os.path.join(OUT, f"{tag}_{name}.pt")
     torch.save(blob, path)
     print(name, "bytes", os.path.getsize(path))
 
@@ -158,5 +158,8 @@ if __name__ == "__main__":
     for n in (sys.argv[1:] or ["cfg1", "cfg2_depth2"]):
         if n.endswith(":train"):
             train_criterion_record(n[:-6])
+        elif ":" in n:                                     # <case>:<steps> -> tests/golden/traj<steps>_<case>.pt (round 5: 30 steps)
+            c, k = n.split(":")
+            run_case(c, int(k), f"traj{int(k)}")
         else:
             run_case(n)

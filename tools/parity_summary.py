@@ -1,4 +1,4 @@
-"""gpurun_out/parity_<case>_<precision>.json (written by tests/test_config_golden.py on the GPU box) -> profiles/parity_r04.json:
+"""gpurun_out/parity_<case>_<precision>.json (written by tests/test_config_golden.py on the GPU box) -> profiles/parity_r05.json:
 per precision mode the worst measured error over the cases at BASELINE.json's own dimensions, against the REFERENCE.
 bench.py copies the entry of the precision it runs into its JSON line ("precision_contract")."""
 import glob
@@ -30,7 +30,7 @@ tol = {"bf16s": "asserted: every output 1e-3, every loss key 1e-3, total loss 1e
 for k in out:
     out[k]["asserted_tolerances"] = tol.get(k)
 out["label"] = (sys.argv[1] if len(sys.argv) > 1 else "round 4") + ": tests/test_config_golden.py on the GPU box, product vs reference fixtures"
-path = os.path.join(ROOT, "profiles", "parity_r04.json")
+path = os.path.join(ROOT, "profiles", "parity_r05.json")
 json.dump(out, open(path, "w"), indent=1, sort_keys=True)
 for k, v in out.items():
     if isinstance(v, dict):

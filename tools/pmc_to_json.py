@@ -26,6 +26,8 @@ KERNELS = {
     "flash_fwd": "talking_flash_fwd_kernel<8, 2, true, false, false>",
     "flash_dv": "talking_flash_fwd_kernel<8, 2, true, false, true>",
     "flash_merge": "flash_merge_kernel",
+    "talking_bwdq_pass1": "talking_bwdq_kernel<8, 2, true, false, 1>",
+    "talking_bwdq_pass2": "talking_bwdq_kernel<8, 2, true, false, 2>",
 }
 
 
