@@ -322,12 +322,13 @@ def main():
     DOM, HBMK = "spe_talking_fused", "spe_attn_contract"
     DOMQ = "spe_talking_bwdq_pass2"       # round 5: backward pass 2 + dQ on the flash skeleton (the default; spe_talking_fused mode 3 when SPE_BWDQ=0)
     FLF, FLV = "spe_talking_flash_fwd", "spe_talking_flash_dv"
+    BWDK = "spe_talking_bwdk_pass1"       # round 5: KEY-major backward pass 1 + dV in one launch (the default; SPE_BWDQ=2: round-3 pass 1 + spe_talking_flash_dv)
     body = model.backbone[0].body
     S_rows, d_model = a.batch * (a.height // 16) * (a.width // 16), body.embed_dim
     n_dec = args.dec_layers
     CAG_N = 2 * n_dec * d_model          # ca_kcontent + ca_v of all decoder layers in one launch (ops.multi_linear)
     CAG = f"spe_gemm_bf16nt:{S_rows},{CAG_N},{d_model}"
-    K.enable_timing([DOM, DOMQ, HBMK, CAG, FLF, FLV])
+    K.enable_timing([DOM, DOMQ, HBMK, CAG, FLF, FLV, BWDK])
     reducer.measure = True
     sync()
     t0 = time.perf_counter()
@@ -483,7 +484,9 @@ def main():
             # the flash-style attention passes (no N x N tensor in HBM): forward O = P'd V and the backward's dV = P'd^T dO, timed live
             "flash_attention": {"forward": {"launches": K_res.get(FLF, (0, 0.0))[0], "avg_ms": K_res.get(FLF, (0, 0.0))[1]},
                                 "dv": {"launches": K_res.get(FLV, (0, 0.0))[0], "avg_ms": K_res.get(FLV, (0, 0.0))[1]},
-                                "note": "kernel + its partial-result merge per launch; P'd is neither stored nor saved for the backward"},
+                                # key-major backward pass 1 + dV in one walk (D, dWw, dbw and dV = P'd^T dO; replaces the round-3 pass 1 and the dV pass above)
+                                "bwd_pass1_dv": {"launches": K_res.get(BWDK, (0, 0.0))[0], "avg_ms": K_res.get(BWDK, (0, 0.0))[1]},
+                                "note": "kernel + its partial-result merge(s) per launch; P'd is neither stored nor saved for the backward"},
             # what ran: entry points of libspe_hip.so launched in one step, and every SPE_* developer knob that was set
             "kernel_set": dict(sorted(kernel_set.items())),
             "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("SPE_")},

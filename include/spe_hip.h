@@ -299,7 +299,16 @@ int spe_talking_flash_dv(const void* Qf, const void* Kf, const void* dO16, const
  *   reads them), dWl / dbl partials, and dq[b, q, h, :] = scale * sum_key dS[b,h][q,key] k[b, key, h, :] accumulated in registers (element
  *   strides ob, on, oh; dq fp32 and / or dq16 bf16 with the same addressing, either may be NULL).  K16 = bf16 k in the 16-wide layout
  *   (spe_attn_pack_multi kind 1).
+ * spe_talking_bwdk_pass1 (KEY-major: a wave keeps one key tile's K / V records and 96 dV accumulators in registers and streams the q-tiles):
+ *   backward pass 1 AND the dV pass of the same autograd in one walk - Drows and the dWw / dbw partials as spe_talking_bwdq_pass1, plus
+ *   dv[b, key, h, :] = sum_q P'd[b,h][q,key] dO[b, q, h, :] (P'd = dropout(proj_w(P)), recomputed; element strides ob, on, oh; dv fp32 and /
+ *   or dv16 bf16, either may be NULL): replaces spe_talking_fused mode 2 + spe_attn_merge + spe_talking_flash_rows + spe_talking_flash_dv.
+ *   dO16 = bf16 dO in the 16-wide layout (spe_attn_pack_multi kind 1).  Workspaces: ws_d B * nmajor * Np * H floats (D summed over the 4 key
+ *   tiles of a major), ws_v like ws_q, ws_w as above (the [dWw | dbw] half is filled).  Np >= 16 ceil(N / 16) + 64.
  * keepbits: the dropout keep flags of spe_talking_flash_fwd, required when p_drop > 0.  Supported: H in {4, 8}, head dim <= 64; -2 otherwise. */
+int spe_talking_bwdk_pass1(const void* Qf, const void* dOf, const void* dO16, const void* Kf, const void* Vf, const float* Wl, const float* Ww,
+                           const float* bw, const float* c0, int Np, float* ws_d, float* ws_v, float* ws_w, float* Drows, float* dv, void* dv16,
+                           long ob, long on, long oh, const void* keepbits, int B, int H, int N, int dh, int nwg, float p_drop, spe_stream_t stream);
 int spe_talking_bwdq_plan(int B, int N, int nwg, int* steps_per_wg, int* nwg_used, int* nmajor);
 int spe_talking_bwdq_pass1(const void* Qf, const void* dOf, const void* Kf, const void* Vf, const float* Wl, const float* Ww,
                            const float* c0, int Np, float* ws_d, float* ws_w, float* Drows, const void* keepbits, int B, int H, int N, int dh,
@@ -422,21 +431,6 @@ int spe_box_loss(const float* pred_boxes, const long* srow, const float* tbox, c
                  float* sums, float* g_l1, float* g_giou, long n, int L, spe_stream_t stream);
 int spe_box_loss_bwd(const long* srow, const int* lidx, const float* g_l1, const float* g_giou, const float* c1,
                      const float* c2, float* dpred, long n, spe_stream_t stream);
-
-/* ---- multi-head attention over a few rows: the decoder's query self-attention (reference models/transformer.py:368-386 through
- * models/attention.py:277-383; 100 queries per proposal stage) as ONE launch each way, the whole (batch, head) problem in the LDS of
- * one workgroup, plain fp32: softmax(scale q k^T + key_padding_mask), dropout, . v.  q / k / v: [B, L, H, d] views (element strides
- * batch, row, head; unit d stride); O [B, Lq, H*dv]; P [B, H, Lq, ld] (ld = Lk rounded up to 4): the softmax output, saved for the
- * backward; dq [B, Lq, H*dk], dk [B, Lk, H*dk], dv [B, Lk, H*dv] dense.  Dropout stream: element index ((b H + h) Lq + q) ld + key.
- * -2 when the problem does not fit 160 KB of LDS (callers keep the GEMM + softmax path). */
-int spe_mha_small_fwd(const float* q, long qb, long qn, long qh, const float* k, long kb, long kn, long kh,
-                      const float* v, long vb, long vn, long vh, const void* mask, float* O, float* P,
-                      int B, int H, int Lq, int Lk, int dk, int dv, float scale, float p_drop, uint64_t seed, uint64_t offset,
-                      spe_stream_t stream);
-int spe_mha_small_bwd(const float* q, long qb, long qn, long qh, const float* k, long kb, long kn, long kh,
-                      const float* v, long vb, long vn, long vh, const float* P, const float* dO, float* dq, float* dk_out, float* dv_out,
-                      int B, int H, int Lq, int Lk, int dk, int dv, float scale, float p_drop, uint64_t seed, uint64_t offset,
-                      spe_stream_t stream);
 
 /* ---- memory side of the decoder's conditional cross attention for ALL layers (reference models/transformer.py:389-419):
  * spe_kv_frags turns the fp16 outputs of the two stacked projection GEMMs (spe_gemm_bf16nt with act bits 8 + 9) -

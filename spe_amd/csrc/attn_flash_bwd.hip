@@ -682,6 +682,474 @@ __global__ __launch_bounds__(256) void bwdq_dq_merge_kernel(const float* __restr
     }
 }
 
+// =====================================================================================================================================
+// KEY-major pass (spe_talking_bwdk_pass1): backward pass 1 AND the dV pass in one walk.  A wave keeps one 16-KEY tile - its K (fp16) and V
+// (bf16) fragment records as AccVGPR B operands, the 96 dV accumulators in AccVGPRs - and streams the q-tiles: Q, dO fragments (the score
+// products' A operands), dO in the 16-wide layout (A operand of dV^T[d][key] += dO^T[d][q] P'd[q][key]) and the 512 B of row constants of
+// the tile, all by LDS-DMA.  The score tile is S[q][key] (lane = (key l & 15, queries 4 (l >> 4) + r)): the transpose of the q-major
+// passes', so that bf16(P'd) in the accumulator layout IS the B operand of the dV product.  Per tile:
+//   S, S' (fp32 mix), P = exp2 ; dP' = dropout (dO V^T) ; dP = Ww^T dP' ; D[q, h'] = sum_key dP P: a 16-lane row reduction (4 DPP steps)
+//   per (query row, head), summed over the workgroup's 4 key tiles through LDS one step later, one 512-B row block per (major, q-tile)
+//   -> ws_d ; dWw / dbw outer products (the same transpose tiles as pass 1) ; P' = Ww P + bw on bf16(P), dropout, dV += P'd^T dO.
+// No mask instance: a key >= N has K = V = 0 (zero-padded records), so dP' = dP = 0 there and its dV rows are dropped by the merge; a query
+// >= N has Q = dO = 0 and c0 = 0 (finite P, zero dO).  Replaces spe_talking_fused mode 2 + spe_attn_merge + spe_talking_flash_rows +
+// spe_talking_flash_dv + its merge: S, S', P are recomputed once for both results instead of twice.
+struct FlashBwdKArgs {
+    const unsigned char* Qf; const unsigned char* dOf; const unsigned char* dO16;     // streamed: fp16 q * scale * log2 e, bf16 dO (32-wide), bf16 dO (16-wide)
+    const unsigned char* Kf; const unsigned char* Vf;                                 // resident: fp16 k, bf16 v (32-wide records)
+    const float* Wl; const float* Ww; const float* bw;
+    const float* c0; int Np;             // [B][Np][H], rows >= N zero, Np >= 16 nt + 64 (whole 1-KB pieces are fetched)
+    float* ws_d;                         // D summed over a major's key tiles [B * nmaj][Np][H]
+    float* ws_v;                         // partial dV [B * nmaj][FL_MAXSLOT][FLB_NW][H][DT][64 lanes][4]
+    float* ws_w;                         // weight-gradient partials, the [dWw | dbw] half of each row
+    const unsigned* keepbits;
+    int B, N, nt, nmaj, spw; long total;
+    float p_drop;
+};
+
+// Row sums of a score tile in the key-major layout (lane = (key l & 15, queries 4 (l >> 4) + r)) for 4 heads: t[r][k] = the lane's term of
+// (query row r, head k) -> o[k] = the sum over the 16 keys (the lanes of a DPP row) for query row (l & 15) >> 2, in every lane of that
+// quad.  A reduce-scatter on the vector pipe, 32 DPP adds for 16 values (an all-reduce butterfly of every value costs 4 per value):
+//   rows {0, 1} stay in lanes 0..7 of the DPP row, rows {2, 3} in lanes 8..15 (partner: lane + 8, bank-masked writes) ; then row p in the
+//   even / odd bank of each half (partner: the mirrored lane of the other bank) ; then the quad's four lanes add up (xor 1, xor 2).
+// Every instruction reads registers written at least three instructions earlier (a DPP read needs two wait states behind a vector write);
+// the leading s_nop covers the products computed just before.
+__device__ __forceinline__ void flb_rowsum4(const f32x4_t (&t)[4], f32x4_t& o) {
+    float a0, a1, a2, a3, b0, b1, b2, b3;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %13, %13 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %14, %14 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %15, %15 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %20, %20 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %21, %21 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %22, %22 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %23, %23 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %16, %16 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %5, %17, %17 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %6, %18, %18 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %7, %19, %19 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %24, %24 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %5, %25, %25 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %6, %26, %26 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %7, %27, %27 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %9, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %10, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %11, %3, %3 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %8, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %9, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %10, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %11, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %9, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %10, %10, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %11, %11, %11 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %9, %9, %9 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %10, %10, %10 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %11, %11, %11 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3),
+          "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+        : "v"(t[0][0]), "v"(t[0][1]), "v"(t[0][2]), "v"(t[0][3]), "v"(t[1][0]), "v"(t[1][1]), "v"(t[1][2]), "v"(t[1][3]),
+          "v"(t[2][0]), "v"(t[2][1]), "v"(t[2][2]), "v"(t[2][3]), "v"(t[3][0]), "v"(t[3][1]), "v"(t[3][2]), "v"(t[3][3]));
+}
+
+template <int H, int DSTEPS, bool TAIL16, bool DROP>
+__global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKArgs a) {
+    constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
+    constexpr int NW = FLB_NW, HB = (H >= FLB_HB) ? FLB_HB : H;
+    constexpr int TILEB = H * REC;                  // one operand, one 16-row tile, all heads
+    constexpr int STG = 2 * TILEB;                  // a stage: Q fragments, dO fragments
+    constexpr int NK16 = FLB_NK16;
+    constexpr int F1 = FULL ? FULL : 1;
+    // LDS: [stage 0][stage 1][NK16 slots of dO in the 16-wide layout][c0 rows 2 x 1 KB][D exchange 2 x NW x (16 H floats)][constants 512 B][NW x 3 transpose tiles]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
+    const int nt = a.nt;
+    constexpr int C0OFF = 2 * STG + NK16 * TILEB, DXB = 16 * H * 4, DXOFF = C0OFF + 2048, GCOFF = DXOFF + 2 * NW * DXB;
+
+    float Al4[H / 4][H];                            // S' = Wl S (fp32, 4x4x1)
+    fl_mixA_f32<H, false>(a.Wl, lane, Al4);
+    fls16x4_t Awt[H / 4][H / 4];                    // dP = Ww^T dP' (bf16, 4x4x4)
+    fl_mixA_16<H, true, false>(a.Ww, lane, 1.0f, Awt);
+    fls16x4_t Awp[H / 4][H / 4];                    // P' = Ww P + bw (bf16, 4x4x4)
+    fl_mixA_16<H, false, false>(a.Ww, lane, 1.0f, Awp);
+    f32x4_t vbw[H / 4];
+#pragma unroll
+    for (int gh = 0; gh < H / 4; ++gh)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vbw[gh][i] = a.bw[4 * gh + i];
+
+    // weight-gradient outer products: X = dP' (front operand, double-buffered by tile parity), Y = P (back operand) - see talking_bwdq_kernel
+    constexpr int GWR = FLB_GWR, GWT = 4 * H * GWR;
+    unsigned char* gconst = smem + GCOFF;
+    unsigned char* sgw = gconst + 512 + wave * (3 * GWT);
+    if (threadIdx.x < 64) reinterpret_cast<uint2*>(gconst)[threadIdx.x] = (threadIdx.x >= 26 && threadIdx.x < 42) ? make_uint2(0x3F803F80u, 0x3F803F80u) : make_uint2(0u, 0u);
+    const int gm = lane & 15, gk = lane >> 4;
+    unsigned char* gw_wr = sgw + (gk * H) * GWR + gm * 8;
+    const unsigned gw_rd = (unsigned)((gk * H + gm) * GWR);
+    const unsigned char* gw_zero = gconst + 48;
+    const unsigned char* gw_ones = gconst + 208;
+    f32x4_t gwacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gwacc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NP = TILEB / 1024, NPW = (NP + NW - 1) / NW;
+    unsigned voff[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int o = (i * NW + wave) * 1024 + lane * 16;
+        voff[i] = (unsigned)((o / REC) * nt * REC + o % REC);
+    }
+    const float keep_inv = DROP ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    const int kbsh = 2 * (gm & 3);                                 // keep flag of (query row, this lane's key), head g: bit (g >> 1) * 8 + kbsh + (g & 1) ...
+    const int kbln = (gm >> 2) << 4;                               // ... of the word of lane (query row) | kbln of the (q-tile, key tile) block
+
+    const long s_begin = (long)blockIdx.x * a.spw;
+    long s_end = s_begin + a.spw; if (s_end > a.total) s_end = a.total;
+    long s = s_begin;
+    while (s < s_end) {
+        const int bm = (int)(s / nt), qt0 = (int)(s % nt);
+        int seg = nt - qt0; if (seg > s_end - s) seg = (int)(s_end - s);
+        const int b = bm / a.nmaj, mj = bm % a.nmaj;
+        const int kt = mj * NW + wave;                          // this wave's key tile (wave-uniform)
+        const bool wvalid = kt < nt;
+        const int ktc = wvalid ? kt : nt - 1;
+        const int nvw = (nt - mj * NW < NW) ? nt - mj * NW : NW;   // waves of this major that own a key tile
+
+        // ---- this wave's K and V records -> registers (AccVGPR B operands of the score products)
+        flu32x4_t ka[H][F1], va[H][F1];
+        flu32x2_t kta[H], vta[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const unsigned char* kb_ = a.Kf + (((long)b * H + h) * nt + ktc) * REC;
+            const unsigned char* vb_ = a.Vf + (((long)b * H + h) * nt + ktc) * REC;
+#pragma unroll
+            for (int st = 0; st < FULL; ++st) {
+                ka[h][st] = *reinterpret_cast<const flu32x4_t*>(kb_ + st * 1024 + lane * 16);
+                va[h][st] = *reinterpret_cast<const flu32x4_t*>(vb_ + st * 1024 + lane * 16);
+            }
+            if constexpr (TAIL16) {
+                kta[h] = *reinterpret_cast<const flu32x2_t*>(kb_ + FULL * 1024 + lane * 8);
+                vta[h] = *reinterpret_cast<const flu32x2_t*>(vb_ + FULL * 1024 + lane * 8);
+            } else { kta[h] = (flu32x2_t){0u, 0u}; vta[h] = (flu32x2_t){0u, 0u}; }
+        }
+        f32x4_t dV[H][DT];
+#pragma unroll
+        for (int g = 0; g < H; ++g)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) dV[g][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        // the streamed operand tiles of q-tile qt0 + i: Q, dO fragments -> stage i & 1, 16-wide dO -> slot i % NK16, row constants -> c0 buffer i & 1
+        auto issue_tiles = [&](int i) {
+            const int qt = qt0 + i;
+#pragma unroll
+            for (int op = 0; op < 3; ++op) {
+                const unsigned char* base = (op == 0) ? a.Qf : ((op == 1) ? a.dOf : a.dO16);
+                const unsigned char* tb = base + ((long)b * H * nt + qt) * REC;
+                const unsigned dst = (op < 2) ? lds0 + (i & 1) * STG + op * TILEB : lds0 + 2 * STG + (i % NK16) * TILEB;
+#pragma unroll
+                for (int ii = 0; ii < NPW; ++ii) {
+                    const int p = ii * NW + wave;
+                    if (NP % NW != 0 && p >= NP) break;
+                    fl_glds16_s(tb, voff[ii], dst + p * 1024);
+                }
+            }
+            if (wave == NW - 1) fl_glds16_s(a.c0 + ((long)b * a.Np + qt * 16) * H, (unsigned)(lane * 16), lds0 + C0OFF + (i & 1) * 1024);
+        };
+
+        struct Frags { flu32x4_t f[HB][F1]; flu32x2_t t[HB]; };
+        auto load_frags = [&](const unsigned char* tile, int h0, Frags& o) {
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                const unsigned char* r = tile + (h0 + hb) * REC;
+#pragma unroll
+                for (int st = 0; st < FULL; ++st) o.f[hb][st] = *reinterpret_cast<const flu32x4_t*>(r + st * 1024 + lane * 16);
+                if constexpr (TAIL16) o.t[hb] = *reinterpret_cast<const flu32x2_t*>(r + FULL * 1024 + lane * 8);
+                else o.t[hb] = (flu32x2_t){0u, 0u};
+            }
+        };
+        auto load_q = [&](int i, int h0, Frags& o) { load_frags(smem + (i & 1) * STG, h0, o); };
+        auto load_d = [&](int i, int g0, Frags& o) { load_frags(smem + (i & 1) * STG + TILEB, g0, o); };
+        // ---- FRONT half of q-tile i (matrix-heavy), chunks of FLB_HB heads
+        auto front_q = [&](int i, auto h0_c, const Frags& qfr, f32x4_t (&sp)[4][H / 4]) {
+            constexpr int h0 = decltype(h0_c)::value;
+            if constexpr (h0 == 0) {        // the exponent starts from the row constants of query 4 (l >> 4) + r: broadcast LDS reads
+                const unsigned char* cr = smem + C0OFF + (i & 1) * 1024 + (4 * gk) * H * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = *reinterpret_cast<const f32x4_t*>(cr + (r * H + 4 * gh) * 4);
+            }
+            f32x4_t c[HB];
+            static_assert(HB == 4, "chunk of 4 heads");
+            flb_score_f16<FULL, TAIL16>(qfr.f, qfr.t, &ka[h0], &kta[h0], c);
+            flb_fence4(c[0], c[1], c[2], c[3]);
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                const f32x4_t cs = c[hb];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = __builtin_amdgcn_mfma_f32_4x4x1f32(Al4[gh][h0 + hb], cs[r], sp[r][gh], 0, 0, 0);
+            }
+        };
+        auto front_d = [&](int i, auto g0_c, const Frags& dfr, f32x4_t (&dp)[4][H / 4], const uint32_t (&kb)[4]) {
+            constexpr int g0 = decltype(g0_c)::value;
+            unsigned char* gwf = gw_wr + (i & 1) * GWT;
+            if constexpr (g0 == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int gh = 0; gh < H / 4; ++gh) dp[r][gh] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            }
+            f32x4_t es[HB];
+            flb_score_bf16<FULL, TAIL16>(dfr.f, dfr.t, &va[g0], &vta[g0], es);
+            flb_fence4(es[0], es[1], es[2], es[3]);
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                if constexpr (DROP) {
+                    const int g = g0 + hb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) es[hb][r] *= ((kb[r] >> ((g >> 1) * 8 + kbsh + (g & 1))) & 1u) ? keep_inv : 0.f;
+                }
+                // bf16(dP') of this head: the X operand of the dWw outer product
+                *reinterpret_cast<fls16x4_t*>(gwf + (g0 + hb) * GWR) = fl_pack4<false>(es[hb][0], es[hb][1], es[hb][2], es[hb][3]);
+            }
+#pragma unroll
+            for (int hq = 0; hq < HB / 4; ++hq)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const fls16x4_t bv = fl_pack4<false>(es[4 * hq][r], es[4 * hq + 1][r], es[4 * hq + 2][r], es[4 * hq + 3][r]);
+#pragma unroll
+                    for (int gh = 0; gh < H / 4; ++gh) dp[r][gh] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(Awt[gh][g0 / 4 + hq], bv, dp[r][gh], 0, 0, 0);
+                }
+        };
+        auto load_kb = [&](int i, uint32_t (&kb)[4]) {
+            if constexpr (DROP) {
+                const unsigned* base = a.keepbits + (((long)b * nt + (qt0 + i)) * nt + ktc) * 64 + kbln + 4 * gk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kb[r] = base[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kb[r] = 0u;
+            }
+        };
+
+        // ---- BACK half of q-tile i (vector-heavy)
+        auto back_exp = [&](f32x4_t (&sp)[4][H / 4]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int gh = 0; gh < H / 4; ++gh)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sp[r][gh][k] = fl_exp2(sp[r][gh][k]);
+        };
+        auto back_ds = [&](int i, f32x4_t (&sp)[4][H / 4], f32x4_t (&dp)[4][H / 4]) {
+            unsigned char* gwb = gw_wr + 2 * GWT;
+            // D[q][g] = sum over this tile's 16 keys (the lanes of a DPP row) of dP P: after the reduce-scatter every quad holds the sums of query
+            // row 4 gk + (gm >> 2) -> this wave's block of the exchange buffer
+            float* dx = reinterpret_cast<float*>(smem + DXOFF + ((i & 1) * NW + wave) * DXB) + (4 * gk + (gm >> 2)) * H;
+#pragma unroll
+            for (int gh = 0; gh < H / 4; ++gh) {
+                f32x4_t t[4], o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] = dp[r][gh] * sp[r][gh];
+                flb_rowsum4(t, o);
+                if ((gm & 3) == 0) *reinterpret_cast<f32x4_t*>(dx + 4 * gh) = o;
+            }
+#pragma unroll
+            for (int g = 0; g < H; ++g)
+                *reinterpret_cast<fls16x4_t*>(gwb + g * GWR) =
+                    fl_pack4<false>(sp[0][g >> 2][g & 3], sp[1][g >> 2][g & 3], sp[2][g >> 2][g & 3], sp[3][g >> 2][g & 3]);
+        };
+        auto back_gw = [&](int i, f32x4_t (&sp)[4][H / 4], f32x4_t (&pp)[4][H / 4]) {
+            {
+                const unsigned rdf = gw_rd + (i & 1) * GWT, rdb = gw_rd + 2 * GWT;
+                const unsigned char* gw_xrd = (gm < H) ? sgw + rdf : gw_zero;
+                const unsigned char* gw_yrd = (gm < H) ? sgw + rdb : ((gm == H) ? gw_ones : gw_zero);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const flu32x4_t xa = *reinterpret_cast<const flu32x4_t*>(gw_xrd + c * 16);
+                    const flu32x4_t yb = *reinterpret_cast<const flu32x4_t*>(gw_yrd + c * 16);
+                    gwacc[(2 * c) & 3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(fls16x4_t, (flu32x2_t){xa[0], xa[1]}),
+                                                                                     __builtin_bit_cast(fls16x4_t, (flu32x2_t){yb[0], yb[1]}), gwacc[(2 * c) & 3], 0, 0, 0);
+                    gwacc[(2 * c + 1) & 3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(fls16x4_t, (flu32x2_t){xa[2], xa[3]}),
+                                                                                         __builtin_bit_cast(fls16x4_t, (flu32x2_t){yb[2], yb[3]}), gwacc[(2 * c + 1) & 3], 0, 0, 0);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+            // P' = Ww P + bw on bf16(P)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x[H];
+#pragma unroll
+                for (int g = 0; g < H; ++g) x[g] = sp[r][g >> 2][g & 3];
+                fl_mix_16<H, false>(x, Awp, vbw, pp[r]);
+            }
+        };
+        auto back_dv = [&](int i, f32x4_t (&pp)[4][H / 4], const uint32_t (&kb)[4]) {
+            const unsigned char* sD16 = smem + 2 * STG + (i % NK16) * TILEB;
+            fls16x4_t da[H][DT];                // requested FLB_DQAHEAD heads ahead of the matrix instructions that consume them
+#pragma unroll
+            for (int h = 0; h < ((FLB_DQAHEAD < H) ? FLB_DQAHEAD : H); ++h)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) da[h][dt] = *reinterpret_cast<const fls16x4_t*>(sD16 + h * REC + dt * 512 + lane * 8);
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                if (h + FLB_DQAHEAD < H) {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) da[h + FLB_DQAHEAD][dt] = *reinterpret_cast<const fls16x4_t*>(sD16 + (h + FLB_DQAHEAD) * REC + dt * 512 + lane * 8);
+                    __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
+                }
+                float p4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p4[r] = pp[r][h >> 2][h & 3];
+                    if constexpr (DROP) p4[r] *= ((kb[r] >> ((h >> 1) * 8 + kbsh + (h & 1))) & 1u) ? keep_inv : 0.f;
+                }
+                const fls16x4_t pk = fl_pack4<false>(p4[0], p4[1], p4[2], p4[3]);
+                flb_dq_mfma<DT>(dV[h], da[h], pk);
+            }
+        };
+        // D of q-tile i: the sum over the major's key tiles (fixed order) of the exchange blocks -> ws_d ; every wave adds a quarter of the 16 x H values
+        auto d_flush = [&](int i) {
+            constexpr int PER = 16 * H / NW;            // values per wave (32 at H = 8)
+            if (lane < PER) {
+                const float* src = reinterpret_cast<const float*>(smem + DXOFF + (i & 1) * NW * DXB) + wave * PER + lane;
+                float acc = src[0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) acc += (w < nvw) ? src[w * (DXB / 4)] : 0.f;
+                a.ws_d[((long)bm * a.Np + (qt0 + i) * 16) * H + wave * PER + lane] = acc;
+            }
+        };
+        auto front = [&](int i, f32x4_t (&sp)[4][H / 4], f32x4_t (&dp)[4][H / 4], uint32_t (&kb)[4]) {
+            load_kb(i, kb);
+            Frags fa, fb;
+            load_q(i, 0, fa);
+            if constexpr (H > HB) load_q(i, HB, fb);
+            front_q(i, std::integral_constant<int, 0>{}, fa, sp);
+            load_d(i, 0, fa);
+            if constexpr (H > HB) front_q(i, std::integral_constant<int, HB>{}, fb, sp);
+            if constexpr (H > HB) load_d(i, HB, fb);
+            front_d(i, std::integral_constant<int, 0>{}, fa, dp, kb);
+            if constexpr (H > HB) front_d(i, std::integral_constant<int, HB>{}, fb, dp, kb);
+        };
+        auto back = [&](int i, f32x4_t (&sp)[4][H / 4], f32x4_t (&dp)[4][H / 4], const uint32_t (&kb)[4]) {
+            f32x4_t pp[4][H / 4];
+            back_exp(sp);
+            back_ds(i, sp, dp);
+            back_gw(i, sp, pp);
+            back_dv(i, pp, kb);
+        };
+        // one pipelined step: the front half of q-tile i + 1 beside the back half of q-tile i (see talking_bwdq_kernel)
+        auto step = [&](int i, f32x4_t (&sp)[4][H / 4], f32x4_t (&dp)[4][H / 4], f32x4_t (&spn)[4][H / 4], f32x4_t (&dpn)[4][H / 4], Frags& fr0, Frags& fr1,
+                        const uint32_t (&kb)[4], uint32_t (&kbn)[4]) {
+            f32x4_t pp[4][H / 4];
+            load_kb(i + 1, kbn);
+            if constexpr (H > HB) load_q(i + 1, HB, fr1); else load_d(i + 1, 0, fr1);
+            __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
+            front_q(i + 1, std::integral_constant<int, 0>{}, fr0, spn);
+            back_exp(sp);
+            FLB_PHASE();
+            if constexpr (H > HB) {
+                load_d(i + 1, 0, fr0);
+                __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
+                front_q(i + 1, std::integral_constant<int, HB>{}, fr1, spn);
+            }
+            back_ds(i, sp, dp);
+            FLB_PHASE();
+            if constexpr (H > HB) {
+                load_d(i + 1, HB, fr1);
+                __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
+                front_d(i + 1, std::integral_constant<int, 0>{}, fr0, dpn, kbn);
+            } else front_d(i + 1, std::integral_constant<int, 0>{}, fr1, dpn, kbn);
+            back_gw(i, sp, pp);
+            FLB_PHASE();
+            if constexpr (H > HB) front_d(i + 1, std::integral_constant<int, HB>{}, fr1, dpn, kbn);
+            back_dv(i, pp, kb);
+        };
+        auto admit = [&](int nxt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (nxt + 1 < seg) issue_tiles(nxt + 1);
+        };
+
+        f32x4_t spA[4][H / 4], dpA[4][H / 4], spB[4][H / 4], dpB[4][H / 4];
+        uint32_t kbA[4], kbB[4];
+        Frags frA, frB;
+        issue_tiles(0);
+        admit(0);
+        if (wvalid) front(0, spA, dpA, kbA);
+        for (int i = 0; i + 1 < seg; ++i) {
+            admit(i + 1);
+            if (i > 0) d_flush(i - 1);           // written during step i - 1, one barrier ago
+            if (wvalid) {
+                load_q(i + 1, 0, frA);
+                step(i, spA, dpA, spB, dpB, frA, frB, kbA, kbB);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    kbA[r] = kbB[r];
+#pragma unroll
+                    for (int gh = 0; gh < H / 4; ++gh) { spA[r][gh] = spB[r][gh]; dpA[r][gh] = dpB[r][gh]; }
+                }
+            }
+        }
+        if (wvalid) back(seg - 1, spA, dpA, kbA);
+        __builtin_amdgcn_s_barrier();              // the last buffers have been read, the last D blocks written by everybody
+        if (seg > 1) d_flush(seg - 2);
+        d_flush(seg - 1);
+
+        // ---- partial dV of this segment -> the major's slot
+        const int first_wg = (int)(((long)bm * nt) / a.spw);
+        const int slot = (int)blockIdx.x - first_wg;
+#pragma unroll
+        for (int g = 0; g < H; ++g)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) flb_acc_fence(dV[g][dt]);
+        if (wvalid) {
+            float* dst = a.ws_v + (((long)bm * FL_MAXSLOT + slot) * NW + wave) * (long)(H * DT * 256);
+#pragma unroll
+            for (int g = 0; g < H; ++g)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4_t*>(dst + (g * DT + dt) * 256 + lane * 4) = dV[g][dt];
+        }
+        s += seg;
+    }
+
+    // ---- weight-gradient partials of this wave -> the [dWw | dbw] half of its row of ws_w
+    {
+        constexpr int NWG = 2 * (H * H + H);
+        float* row = a.ws_w + ((long)blockIdx.x * NW + wave) * NWG + (H * H + H);
+        const f32x4_t dsum = (gwacc[0] + gwacc[1]) + (gwacc[2] + gwacc[3]);
+        const int nn = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int g = 4 * (lane >> 4) + r;
+            if (g < H && nn < H) row[g * H + nn] = dsum[r];
+            if (g < H && nn == H) row[H * H + g] = dsum[r];
+        }
+    }
+}
+
+// D rows [B][Np][H] = sum over the majors of ws_d [B * nmaj][Np][H] ; rows >= N zero.  One thread per element, fixed order.
+__global__ __launch_bounds__(256) void bwdk_rows_merge_kernel(const float* __restrict__ ws, float* __restrict__ out, int B, int H, int N, int Np, int nmaj) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per = (long)Np * H;
+    if (i >= (long)B * per) return;
+    const long bq = i / H; const int q = (int)(bq % Np), b = (int)(bq / Np);
+    if (q >= N) { out[i] = 0.f; return; }
+    const float* src = ws + (long)b * nmaj * per + (i - (long)b * per);
+    float acc = 0.f;
+    for (int m = 0; m < nmaj; ++m) acc += src[(long)m * per];
+    out[i] = acc;
+}
+
 static inline int flb_dsteps(int dh, int* tail) {
     const int rem = dh % 32, full = dh / 32 + (rem > 16 ? 1 : 0);
     *tail = (rem > 0 && rem <= 16) ? 1 : 0;
@@ -781,6 +1249,71 @@ extern "C" int spe_talking_bwdq_pass2(const void* Qf, const void* dOf, const voi
     const long nvec = (long)B * p.nmaj * FLB_NW * H * DT * 64;
     hipLaunchKernelGGL(bwdq_dq_merge_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, ws_q, dq, reinterpret_cast<unsigned short*>(dq16),
                        ob, on, oh, B, H, N, a.nt, dh, DT, p.nmaj, p.spw, scale, nvec);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- key-major pass: launch, dispatch, C-ABI
+template <int H, int DSTEPS, bool TAIL16>
+static int launch_bwdk(const FlashBwdKArgs& a, int nwg, bool drop, hipStream_t st) {
+    constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
+    constexpr int smem = 4 * H * REC + FLB_NK16 * H * REC + 2048 + 2 * FLB_NW * 16 * H * 4 + 512 + FLB_NW * 3 * 4 * H * FLB_GWR;
+    if (smem > 160 * 1024) return -2;
+    static bool attr_set[2] = {false, false};
+    const void* fn = drop ? reinterpret_cast<const void*>(&talking_bwdk_kernel<H, DSTEPS, TAIL16, true>)
+                          : reinterpret_cast<const void*>(&talking_bwdk_kernel<H, DSTEPS, TAIL16, false>);
+    if (!attr_set[drop]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set[drop] = true;
+    }
+    if (drop) hipLaunchKernelGGL((talking_bwdk_kernel<H, DSTEPS, TAIL16, true>), dim3(nwg), dim3(64 * FLB_NW), smem, st, a);
+    else hipLaunchKernelGGL((talking_bwdk_kernel<H, DSTEPS, TAIL16, false>), dim3(nwg), dim3(64 * FLB_NW), smem, st, a);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
+static int dispatch_bwdk(const FlashBwdKArgs& a, int H, int dh, int nwg, hipStream_t st) {
+    int tail; const int ds = flb_dsteps(dh, &tail);
+    const bool drop = a.p_drop > 0.f;
+#define SPE_BWDK(HH)                                                                       \
+    if (H == HH && ds == 2 && tail) return launch_bwdk<HH, 2, true>(a, nwg, drop, st);     \
+    if (H == HH && ds == 2 && !tail) return launch_bwdk<HH, 2, false>(a, nwg, drop, st);   \
+    if (H == HH && ds == 1 && tail) return launch_bwdk<HH, 1, true>(a, nwg, drop, st);     \
+    if (H == HH && ds == 1 && !tail) return launch_bwdk<HH, 1, false>(a, nwg, drop, st);
+#ifdef FLB_ONLY_CFG2
+    if (H == 8 && ds == 2 && tail) return launch_bwdk<8, 2, true>(a, nwg, drop, st);
+#else
+    SPE_BWDK(8)
+    SPE_BWDK(4)
+#endif
+#undef SPE_BWDK
+    return -2;
+}
+
+extern "C" int spe_talking_bwdk_pass1(const void* Qf, const void* dOf, const void* dO16, const void* Kf, const void* Vf, const float* Wl, const float* Ww,
+                                      const float* bw, const float* c0, int Np, float* ws_d, float* ws_v, float* ws_w, float* Drows, float* dv, void* dv16,
+                                      long ob, long on, long oh, const void* keepbits, int B, int H, int N, int dh, int nwg, float p_drop, hipStream_t st) {
+    const int nt = (N + 15) / 16;
+    if ((long)B * nt <= 0) return 0;
+    if (dh < 1 || dh > 64 || nwg <= 0 || Np < nt * 16 + 64 || (p_drop > 0.f && !keepbits)) return -2;
+    if (!Qf || !dOf || !dO16 || !Kf || !Vf || !Wl || !Ww || !bw || !c0 || !ws_d || !ws_v || !ws_w || !Drows || (!dv && !dv16)) return -2;
+    const FlashPlan p = fl_plan(B, nt, FLB_NW, nt, nwg);
+    FlashBwdKArgs a;
+    a.Qf = (const unsigned char*)Qf; a.dOf = (const unsigned char*)dOf; a.dO16 = (const unsigned char*)dO16;
+    a.Kf = (const unsigned char*)Kf; a.Vf = (const unsigned char*)Vf; a.Wl = Wl; a.Ww = Ww; a.bw = bw; a.c0 = c0; a.Np = Np;
+    a.ws_d = ws_d; a.ws_v = ws_v; a.ws_w = ws_w;
+    a.keepbits = (p_drop > 0.f) ? reinterpret_cast<const unsigned*>(keepbits) : nullptr;
+    a.B = B; a.N = N; a.nt = nt; a.nmaj = p.nmaj; a.spw = p.spw; a.total = p.total; a.p_drop = p_drop;
+    int rc = dispatch_bwdk(a, H, dh, p.nwg, st);
+    if (rc != 0) return rc;
+    const long n = (long)B * Np * H;
+    hipLaunchKernelGGL(bwdk_rows_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws_d, Drows, B, H, N, Np, p.nmaj);
+    SPE_CHECK_LAUNCH();
+    const int DT = (dh + 15) / 16;
+    const long nvec = (long)B * p.nmaj * FLB_NW * H * DT * 64;
+    hipLaunchKernelGGL(bwdq_dq_merge_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, ws_v, dv, reinterpret_cast<unsigned short*>(dv16),
+                       ob, on, oh, B, H, N, nt, dh, DT, p.nmaj, p.spw, 1.0f, nvec);
     SPE_CHECK_LAUNCH();
     return 0;
 }

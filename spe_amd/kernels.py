@@ -295,9 +295,8 @@ def _chk(*ts):
             raise TypeError(f"expected float32, got {t.dtype}")
 
 
-_tn_small = int(os.environ.get("SPE_TN_SMALL_TILES", "1"))             # developer knob (A/B): 0 off, 1 default threshold, n threshold
-TN_SMALL_TILES = _tn_small != 0
-TN_SMALL_MAX = 256 if _tn_small <= 1 else _tn_small
+TN_SMALL_TILES = True     # 64 x 64 tiles for weight gradients with few output tiles (module attributes, not environment knobs)
+TN_SMALL_MAX = 256
 
 
 def auto_splitk(M, N, K, batch):
@@ -332,8 +331,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
 # (csrc/gemm_bf16.hip) - the same roundings spe_gemm_f32 applies while staging, so the products are identical, with
 # half the operand bytes and a deeper load pipeline.  Small GEMMs (decoder, heads) and the bf16x3 parity mode keep the
 # fp32-operand kernel.
-LINEAR16 = os.environ.get("SPE_LINEAR16", "1") != "0"
-LINEAR16_MIN_ROWS = int(os.environ.get("SPE_LINEAR16_MIN_ROWS", "128"))
+LINEAR16 = True              # module attributes (tools/error_budget.py and the tests flip them), not environment knobs
+LINEAR16_MIN_ROWS = 128
 _W16 = {}        # id(W) -> (weakref, version, data_ptr, epoch, W16 [N,K], W16T [K,N])
 _W16_EPOCH = 0   # bumped by writers that bypass autograd's version counters (spe_amd.optim.FlatAdamW)
 
@@ -346,7 +345,7 @@ def weights_changed():
 
 
 
-LINEAR_SMALL = os.environ.get("SPE_LINEAR_SMALL", "1") != "0"
+LINEAR_SMALL = True
 LINEAR_SMALL_MAX_ROWS = 2048
 
 
@@ -381,7 +380,7 @@ def cvt_bf16(x2, want=True, wantT=False, ldt=None, colsum_out=None, act_aux=None
 
 _W16_TABLE = None      # (signature, device job table, njobs, total tiles) of the last batched refresh
 _W16_REFRESHED = -1    # epoch of the last batched refresh
-_W16_BATCH = os.environ.get("SPE_W16_BATCH", "1") != "0"
+_W16_BATCH = True
 
 
 def _refresh_weights16():
@@ -399,7 +398,9 @@ def _refresh_weights16():
     _W16_REFRESHED = _W16_EPOCH
     if not live:
         return
-    sig = tuple((k, e[5] is not None) for k, _, e in live)
+    # the table is reused only while every entry still converts the same storage into the SAME output buffers: an entry re-created
+    # under an unchanged key (a later model whose flat parameter buffer landed on the address of a freed one) has new buffers
+    sig = tuple((k, e[3].data_ptr(), e[4].data_ptr(), e[5].data_ptr() if e[5] is not None else 0) for k, _, e in live)
     if _W16_TABLE is None or _W16_TABLE[0] != sig:
         rec = np.zeros(len(live), dtype=np.dtype([("x", "<u8"), ("out", "<u8"), ("outT", "<u8"), ("ldt", "<i8"), ("R", "<i4"),
                                                    ("C", "<i4"), ("tile0", "<i4"), ("tiles_c", "<i4"), ("out_lo", "<u8")]))
@@ -601,7 +602,7 @@ def mlp16_ok(R, K, Hd, N):
 
 # Weight gradients on ROW-MAJOR bf16 operands (spe_gemm_bf16tn: LDS transpose reads): no producer writes a transposed bf16
 # copy any more - not the activation conversions (x16T), not the backward conversions (dy16T), not the GEMM epilogues.
-DW_TN = os.environ.get("SPE_DW_TN", "1") != "0"
+DW_TN = True
 
 
 def layerscale_residual_bwd16(dout2, y2, gamma, Rp, db_out=None, dg_out=None, want_rowmajor=True, want_T=True, drop=None, sscale=None, rps=1):
@@ -666,7 +667,7 @@ def linear_res_bwd(dout2, saved, W, gamma, need_dx=True, grad_bufs=(None, None, 
 # IEEE fp16 instead of fp32: half the bytes, but from the accumulator layout a 16-bit tile leaves as 32-B row pieces - the fp32 stores are
 # faster than the fp16 ones they replaced (fc1 + GELU isolated: 74.6 vs 80.9 us; step 54.9 -> 54.4 ms in same-box A/B, round 4), and staging
 # the tile through LDS costs a workgroup per CU.  Off by default since; 1.1 GB more saved activations at cfg2.
-MLP_PRE_F16 = os.environ.get("SPE_MLP_PRE_F16", "0") != "0"      # developer knob (A/B)
+MLP_PRE_F16 = False      # module attribute (tests/test_kernels_gpu.py runs both settings), not an environment knob
 
 
 def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True, src=None, drop1=None, drop2=None, sscale=None, rps=1):
@@ -824,7 +825,7 @@ def linear_fwd(x2, W, b, act=0, want_pre=False, save_for_dw=True, src=None):
     return y, pre, x2
 
 
-LINEAR_GROUP = os.environ.get("SPE_LINEAR_GROUP", "1") != "0"
+LINEAR_GROUP = True
 
 
 def linear_group_ok(R, Ws, bs):
@@ -1167,8 +1168,7 @@ def box_loss_bwd(srow_i64, lidx_i32, g1, g2, c1, c2, shape):
 # workgroups per fused pass (256 CUs): every pass runs at 2 waves per SIMD (239-256 registers), i.e. 512 resident workgroups -
 # more only adds a partial second round (statistics / write pass 0.188 -> 0.180 ms at cfg2 with 512 instead of 768).  Modes 2
 # and 3 share ws_w rows, so they use the same count.
-FUSED_NWG = {0: int(os.environ.get("SPE_FUSED_NWG0", 512)), 1: int(os.environ.get("SPE_FUSED_NWG1", 512)),
-             2: int(os.environ.get("SPE_FUSED_NWG2", 512)), 3: int(os.environ.get("SPE_FUSED_NWG3", 512))}
+FUSED_NWG = {0: 512, 1: 512, 2: 512, 3: 512}
 _FUSED_NWG_SOLO = dict(FUSED_NWG)
 
 
@@ -1324,38 +1324,6 @@ def mha_bwd(Qf, Kf, Vf, dOf, K16, Q16, dO16, mask_u8, lse, D, keep, B, H, Lq, Lk
     return dq, dk_, dv_
 
 
-def mha_small_ok(Lq, Lk, dk, dv):
-    f = (Lq + Lk) * (dk + 1) + Lk * dv + Lq * dv + 2 * Lq * (Lk + 1)
-    # OFF by default: measured inside the cfg2 step (same box, interleaved) the one-launch kernel is SLOWER than the GEMM + softmax
-    # launches it replaces - 56.5 / 56.8 ms against 55.5 / 56.0 ms per step: 32 workgroups, every product read straight from LDS (two
-    # ds_read per FMA: LDS-bandwidth bound, ~14 us per contraction phase).  Kept behind SPE_MHA_SMALL=1 with its parity test.
-    return 4 * f <= 160 * 1024 and os.environ.get("SPE_MHA_SMALL", "0") == "1"
-
-
-def mha_small_fwd(q, k, v, mask_u8, scale, p_drop, seed, offset):
-    """q [B,Lq,H,dk], k [B,Lk,H,dk], v [B,Lk,H,dv] fp32 views (unit last stride) -> O [B,Lq,H*dv], P [B,H,Lq,ld]."""
-    B, Lq, H, dk = q.shape
-    Lk, dv = k.shape[1], v.shape[3]
-    O = torch.empty((B, Lq, H * dv), device=q.device, dtype=torch.float32)
-    P = torch.empty((B, H, Lq, pad4(Lk)), device=q.device, dtype=torch.float32)
-    _call("spe_mha_small_fwd", _p(q), q.stride(0), q.stride(1), q.stride(2), _p(k), k.stride(0), k.stride(1), k.stride(2),
-          _p(v), v.stride(0), v.stride(1), v.stride(2), _p(mask_u8), _p(O), _p(P), B, H, Lq, Lk, dk, dv, float(scale), float(p_drop),
-          seed, offset, _st())
-    return O, P
-
-
-def mha_small_bwd(q, k, v, P, dO, scale, p_drop, seed, offset):
-    B, Lq, H, dk = q.shape
-    Lk, dv = k.shape[1], v.shape[3]
-    dq = torch.empty((B, Lq, H, dk), device=q.device, dtype=torch.float32)
-    dk_ = torch.empty((B, Lk, H, dk), device=q.device, dtype=torch.float32)
-    dv_ = torch.empty((B, Lk, H, dv), device=q.device, dtype=torch.float32)
-    _call("spe_mha_small_bwd", _p(q), q.stride(0), q.stride(1), q.stride(2), _p(k), k.stride(0), k.stride(1), k.stride(2),
-          _p(v), v.stride(0), v.stride(1), v.stride(2), _p(P), _p(dO), _p(dq), _p(dk_), _p(dv_), B, H, Lq, Lk, dk, dv, float(scale),
-          float(p_drop), seed, offset, _st())
-    return dq, dk_, dv_
-
-
 _CONTRACT_WS = {}      # device -> (scratch floats, zeroed counters) shared by every contraction launch of the stream
 
 
@@ -1386,14 +1354,13 @@ def attn_contract(T, X16, out4, trans, alpha=1.0, out16=None, out16lo=None):
 
 # ---- flash-style talking-heads attention (csrc/attn_flash.hip): no N x N tensor in HBM -------------------------------------
 # workgroups: 8-wave workgroups (two waves per SIMD), one per CU
-FLASH_NWG = int(os.environ.get("SPE_FLASH_NWG", 256))
+FLASH_NWG = 256
 FLASH_SLOTS = 8
 
 
 def flash_supported(H, dh):
     """The flash kernels keep 8 resident tiles and 5 stage buffers (+ 3 KB of row constants) in LDS."""
-    return (H in (4, 8) and dh <= 64 and 13 * H * ((dh + 15) // 16) * 512 + 3072 <= 160 * 1024
-            and os.environ.get("SPE_FLASH", "1") != "0")
+    return H in (4, 8) and dh <= 64 and 13 * H * ((dh + 15) // 16) * 512 + 3072 <= 160 * 1024
 
 
 def flash_plan(B, N):
@@ -1422,7 +1389,7 @@ def _flash_ws(device, floats):
     return ent
 
 
-FLASH_KEEPBITS = os.environ.get("SPE_FLASH_KEEPBITS", "1") != "0"      # developer knob (A/B)
+FLASH_KEEPBITS = True      # module attribute (tests/test_round4_gpu.py runs both settings), not an environment knob
 
 
 def talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, offset, want16=False, want16lo=False, want_bits=False):
@@ -1479,6 +1446,29 @@ def talking_bwdq_pass1(Qf, dOf, Kf, Vf, Wl, Ww, c0, keepbits, B, H, N, dh, p_dro
     Drows = torch.empty((B, c0.shape[1], H), device=dev, dtype=torch.float32)
     _call("spe_talking_bwdq_pass1", _p(Qf), _p(dOf), _p(Kf), _p(Vf), _p(Wl), _p(Ww), _p(c0), c0.shape[1], _p(ws_d), _p(ws_w), _p(Drows),
           _p(keepbits), B, H, N, dh, max(8, FLASH_NWG - _CU_RESERVE), float(p_drop), _st())
+    return Drows, ws_w
+
+
+def bwdk_supported(H, dh):
+    DT = (dh + 15) // 16
+    return H in (4, 8) and dh <= 64 and 7 * H * DT * 512 + 2048 + 2 * 4 * 16 * H * 4 + 512 + 4 * 3 * 4 * H * 144 <= 160 * 1024
+
+
+def talking_bwdk_pass1(Qf, dOf, dO16, Kf, Vf, Wl, Ww, bw, c0, keepbits, dv4, dv16, B, H, N, dh, p_drop):
+    """KEY-major backward pass 1 + dV in one launch (csrc/attn_flash_bwd.hip, talking_bwdk_kernel) -> (Drows [B, Np, H], ws_w [4 nwg, 2 (H H + H)]
+    with its dWw / dbw half filled); dv = P'd^T dO lands in dv4 (fp32 view [B,N,H,dh]) and / or dv16 (bf16 view, same strides)."""
+    ref = dv4 if dv4 is not None else dv16
+    assert ref.stride(3) == 1 and (dv4 is None or dv16 is None or dv4.stride() == dv16.stride())
+    dev = Qf.device
+    _, nwg, nmaj = bwdq_plan(B, N)
+    Np = c0.shape[1]
+    ws_d = torch.empty((B * nmaj, Np, H), device=dev, dtype=torch.float32)
+    ws_v = _flash_ws(dev, B * nmaj * FLASH_SLOTS * 4 * H * 256 * ((dh + 15) // 16))
+    ws_w = torch.empty((4 * nwg, 2 * (H * H + H)), device=dev, dtype=torch.float32)
+    Drows = torch.empty((B, Np, H), device=dev, dtype=torch.float32)
+    _call("spe_talking_bwdk_pass1", _p(Qf), _p(dOf), _p(dO16), _p(Kf), _p(Vf), _p(Wl), _p(Ww), _p(bw), _p(c0), Np, _p(ws_d), _p(ws_v), _p(ws_w),
+          _p(Drows), _p(dv4), _p(dv16), ref.stride(0), ref.stride(1), ref.stride(2), _p(keepbits), B, H, N, dh, max(8, FLASH_NWG - _CU_RESERVE),
+          float(p_drop), _st())
     return Drows, ws_w
 
 

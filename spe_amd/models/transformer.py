@@ -20,7 +20,7 @@ from .attention import MultiheadAttention
 from .layers import MLP, Dropout, LayerNorm, Linear
 
 
-MEMSIDE_BATCH = __import__("os").environ.get("SPE_MEMSIDE_BATCH", "1") != "0"
+MEMSIDE_BATCH = True
 
 
 def gen_sineembed_for_position(pos_tensor, d_model=256):

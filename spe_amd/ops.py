@@ -412,9 +412,10 @@ class _TalkingHeadsAttention(Function):
 
 
 # developer knob (A/B): 0 = round-3 backward passes 1 / 2 + the streaming dQ contraction ; 1 = both passes on the flash skeleton
-# (csrc/attn_flash_bwd.hip) ; 2 (default) = pass 1 on the round-3 kernel (two waves per SIMD: faster for the pass without dQ accumulators),
-# pass 2 + dQ on the flash skeleton.  Measured in the cfg2 step, same box: 53.4 / 53.5 ms (0), 52.6 (1), 52.0 / 52.9 (2).
-BWDQ_MODE = int(os.environ.get("SPE_BWDQ", "2"))
+# (csrc/attn_flash_bwd.hip) ; 2 = pass 1 on the round-3 kernel (two waves per SIMD: faster for the pass without dQ accumulators),
+# pass 2 + dQ on the flash skeleton ; 3 = KEY-major pass 1 + dV in one launch (spe_talking_bwdk_pass1), pass 2 + dQ on the flash skeleton.
+# Measured in the cfg2 step, same box: 53.4 / 53.5 ms (0), 52.6 (1), 52.0 / 52.9 (2); 52.8 / 52.6 (2) against 50.8 / 50.5 (3, the default).
+BWDQ_MODE = int(os.environ.get("SPE_BWDQ", "3"))
 BWDQ = BWDQ_MODE != 0
 
 
@@ -513,7 +514,12 @@ class _TalkingHeadsAttentionFused(Function):
         # q-major passes on the flash skeleton (csrc/attn_flash_bwd.hip): pass 2 also accumulates dQ in registers - the streaming dQ
         # contraction and one of the two reads of dS are gone
         bwdq = flash and BWDQ and K.bwdq_supported(H, dh) and (p_drop <= 0 or kbits is not None)
-        if bwdq and BWDQ_MODE == 2:
+        bwdk = bwdq and BWDQ_MODE == 3 and K.bwdk_supported(H, dh)
+        if bwdk:
+            # KEY-major pass 1 + dV in one walk (S, S', P recomputed once for D, dWw, dbw AND dV), then pass 2 + dQ on the flash skeleton
+            Drows, ws_w = K.talking_bwdk_pass1(Qf, dOf, dO16, Kf, Vf, Wl, Ww, bw, Pd, kbits, f32(dv), b16(dv), B, H, N, dh, p_drop)
+            K.talking_bwdq_pass2(Qf, dOf, Kf, Vf, K16, Wl, Ww, Pd, Drows, ws_w, dS, f32(dq), b16(dq), scale, kbits, B, H, N, dh, p_drop)
+        elif bwdq and BWDQ_MODE == 2:
             # pass 1 on the round-3 kernel (two waves per SIMD: faster for the pass that has no dQ accumulators), pass 2 + dQ on the flash skeleton
             ws_stats = torch.empty((B * nt * 8 * H * 32,), device=dO.device, dtype=torch.float32)
             ws_w1 = torch.empty((nwg, nw), device=dO.device, dtype=torch.float32)
@@ -533,7 +539,9 @@ class _TalkingHeadsAttentionFused(Function):
             K.talking_fused(3, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, None, ws_w, dS, B, H, N, dh, p_drop, seed, off, keepbits=kbits)
         # dV[key,d] = sum_q P'd[q,key] dO[q,d] - issued here, between backward pass 2 and the contractions that re-read
         # its 554 MB of dS: a streaming read right after a pass that wrote that much runs ~20 % slower (measured)
-        if flash:       # Pd holds the row constants c0: P'd is recomputed tile by tile inside the dV pass
+        if bwdk:
+            pass
+        elif flash:       # Pd holds the row constants c0: P'd is recomputed tile by tile inside the dV pass
             K.talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, Pd, f32(dv), p_drop, seed, off, dv16=b16(dv))
         else:
             K.attn_contract(Pd, dO16, f32(dv), True, alpha=1.0 / K.PD_SCALE, out16=b16(dv))
@@ -589,7 +597,7 @@ class _QkvTalkingAttention(Function):
         return dx, dW, db.view_as(bq), dWl, dbl, dWw, dbw, None, None, None
 
 
-QKV_FUSED = os.environ.get("SPE_QKV_FUSED", "1") != "0"
+QKV_FUSED = True        # module attribute, not an environment knob
 
 
 def qkv_talking_attention_ok(x, Wq, bq, num_heads):
@@ -637,7 +645,7 @@ class _MlpGelu(Function):
         return (dx.view(*dy.shape[:-1], W1.shape[1]) if dx is not None else None), dW1, db1, dW2, db2
 
 
-FUSE_LINEAR_RES = __import__("os").environ.get("SPE_FUSE_LINEAR_RES", "1") != "0"
+FUSE_LINEAR_RES = True
 
 
 class _LinearRes(Function):
@@ -681,7 +689,7 @@ class _LinearRes(Function):
         return (dx.view(*dout.shape[:-1], W.shape[1]) if dx is not None else None), dW, db, dout, dg.view_as(gamma), None, None
 
 
-FUSE_DROP = os.environ.get("SPE_FUSE_DROP", "1") != "0"      # developer knob (A/B): dropout / DropPath inside the fused residual nodes
+FUSE_DROP = True      # dropout / DropPath inside the fused residual nodes (module attribute: tests/test_round4_gpu.py runs both settings)
 
 
 def linear_residual(x, W, b, xres, gamma, sample_scale=None, p_drop=0.0):
@@ -880,29 +888,6 @@ class _AttentionFlash(Function):
         return dq, dk_, dv_, None, None, None
 
 
-class _AttentionSmall(Function):
-    """softmax(scale q k^T + key_padding_mask) [dropout] v over a few rows (the decoder's 100-query self-attention, reference
-    models/transformer.py:368-386): one launch each way, everything in the LDS of one workgroup per (batch, head), plain fp32
-    (csrc/mha_small.hip) - instead of two GEMMs + a softmax launch forward and four GEMMs + a softmax launch backward."""
-
-    @staticmethod
-    @K.forward_scope
-    def forward(ctx, q, k, v, mask_u8, scale, p_drop):
-        seed, off = K.next_rng() if p_drop > 0 else (0, 0)
-        O, P = K.mha_small_fwd(q, k, v, mask_u8, scale, p_drop, seed, off)
-        ctx.meta = (scale, p_drop, seed, off)
-        ctx.save_for_backward(q, k, v, P)
-        return O
-
-    @staticmethod
-    @K.backward_scope
-    def backward(ctx, dO):
-        q, k, v, P = ctx.saved_tensors
-        scale, p_drop, seed, off = ctx.meta
-        dq, dk_, dv_ = K.mha_small_bwd(q, k, v, P, dO.contiguous(), scale, p_drop, seed, off)
-        return dq, dk_, dv_, None, None, None
-
-
 class MemoryKV:
     """What the memory-side node hands to the cross-attention nodes of the decoder layers (not a tensor: fragments + the shared
     gradient buffers the layers' backward passes fill)."""
@@ -1070,8 +1055,8 @@ def cross_attention_kv(q, tok, holder, layer, key_padding_mask, scale, p_drop):
     return _CrossAttentionKV.apply(q, tok, holder, layer, m, float(scale), float(p_drop))
 
 
-MEMKV = __import__("os").environ.get("SPE_MEMKV", "1") != "0"
-FLASH_MHA = __import__("os").environ.get("SPE_FLASH_MHA", "1") != "0"
+MEMKV = True
+FLASH_MHA = True       # module attribute (tests and tools/error_budget.py flip it), not an environment knob
 FLASH_MIN_KEYS = 512
 
 
@@ -1085,9 +1070,6 @@ def attention(q, k, v, key_padding_mask=None, scale=1.0, p_drop=0.0, need_map=Fa
     if (FLASH_MHA and not need_map and K.get_precision() != "bf16x3" and q.is_cuda and q.shape[3] <= 96 and v.shape[3] <= 64
             and k.shape[1] >= FLASH_MIN_KEYS and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1):
         return _AttentionFlash.apply(q, k, v, m, float(scale), float(p_drop)), None
-    if (not need_map and q.is_cuda and q.dtype == torch.float32 and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
-            and K.mha_small_ok(q.shape[1], k.shape[1], q.shape[3], v.shape[3])):
-        return _AttentionSmall.apply(q, k, v, m, float(scale), float(p_drop)), None
     return _Attention.apply(q, k, v, m, float(scale), float(p_drop), need_map)
 
 

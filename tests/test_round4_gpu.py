@@ -97,51 +97,6 @@ def test_launch_from_second_stream_is_ordered_behind_the_first(dev):
         assert torch.equal(o, ref)
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk,dk,dv,p,masked", [(4, 8, 100, 100, 48, 48, 0.0, False), (2, 4, 7, 7, 8, 8, 0.0, False),
-                                                    (2, 4, 37, 61, 24, 16, 0.0, True), (2, 8, 100, 100, 48, 48, 0.1, False),
-                                                    (2, 2, 33, 40, 16, 40, 0.25, True)])
-def test_small_mha_matches_fp64(dev, B, H, Lq, Lk, dk, dv, p, masked):
-    """spe_mha_small_fwd / _bwd (the decoder's 100-query self-attention as one launch each way; reference models/attention.py:277-383)
-    against an fp64 restatement: forward output, saved probabilities and all three gradients; key padding mask; with dropout the keep
-    mask is recovered by a second forward on v = identity (same seed / offset -> O = Pd) and the fp64 reference uses THAT mask, so
-    forward and backward must regenerate it identically."""
-    from spe_amd import kernels as K
-    g = torch.Generator().manual_seed(Lq * 7 + Lk)
-    q = torch.randn(B, Lq, H, dk, generator=g).to(dev); k = torch.randn(B, Lk, H, dk, generator=g).to(dev)
-    v = torch.randn(B, Lk, H, dv, generator=g).to(dev); dO = torch.randn(B, Lq, H * dv, generator=g).to(dev)
-    mask = None
-    if masked:
-        mask = torch.zeros(B, Lk, dtype=torch.uint8)
-        mask[0, Lk - 5:] = 1
-        mask[1, 3] = 1
-        mask = mask.to(dev)
-    scale = dk ** -0.5
-    seed, off = 99, 7
-    O, P = K.mha_small_fwd(q, k, v, mask, scale, p, seed, off)
-    dq, dk_, dv_ = K.mha_small_bwd(q, k, v, P, dO, scale, p, seed, off)
-    keep = torch.ones(B, H, Lq, Lk, dtype=torch.float64, device=dev)
-    if p > 0:
-        eye = torch.zeros(B, Lk, H, Lk, device=dev)
-        eye[:, torch.arange(Lk), :, torch.arange(Lk)] = 1.0
-        Opd, P2 = K.mha_small_fwd(q, k, eye, mask, scale, p, seed, off)         # O = Pd (same dropout stream: it depends on (b, h, q, key) only)
-        Pd = Opd.view(B, Lq, H, Lk).permute(0, 2, 1, 3).double()
-        Pn = P2[..., :Lk].double()
-        keep = torch.where(Pn > 0, Pd / Pn.clamp_min(1e-300), torch.zeros_like(Pd))
-        rate = 1.0 - float((keep[Pn > 0] > 0.5).double().mean())           # over the unmasked keys
-        assert abs(rate - p) < 0.05, rate
-        assert float((keep[keep > 0.5] - 1.0 / (1.0 - p)).abs().max()) < 1e-5
-    qd, kd, vd = (t.double().requires_grad_() for t in (q, k, v))
-    S = torch.einsum("bqhd,bkhd->bhqk", qd, kd) * scale
-    if mask is not None:
-        S = S.masked_fill(mask.bool()[:, None, None, :], float("-inf"))
-    Pr = torch.softmax(S, -1)
-    Or = torch.einsum("bhqk,bkhd->bqhd", Pr * keep, vd).reshape(B, Lq, H * dv)
-    gq, gk, gv = torch.autograd.grad(Or, (qd, kd, vd), dO.double())
-    rel = lambda a, b: float((a.double() - b).norm() / b.norm())
-    assert rel(O, Or) < 1e-5 and rel(P[..., :Lk], Pr) < 1e-5
-    assert rel(dq, gq) < 1e-5 and rel(dk_, gk) < 1e-5 and rel(dv_, gv) < 1e-5, (rel(dq, gq), rel(dk_, gk), rel(dv_, gv))
-
-
 @pytest.mark.gpu
 def test_group_linear_matches_separate_linears():
     """ops.group_linear (one launch each way for several Linears on one input: the decoder's query-side projections, reference

@@ -100,8 +100,60 @@ def test_flash_skeleton_backward_passes_match_round3_kernels(dev, B, H, N, dh, p
     assert torch.equal(Dn, Dn2) and torch.equal(dSn.view(torch.int16), dSn2.view(torch.int16)) and torch.equal(dqn, dqn2) and torch.equal(wn, wn2)
 
 
+@pytest.mark.parametrize("B,H,N,dh,p_drop", [(1, 8, 100, 48, 0.0), (2, 4, 196, 48, 0.0), (2, 8, 1100, 48, 0.1), (1, 4, 300, 32, 0.05),
+                                               (2, 8, 400, 16, 0.0), (1, 8, 2070, 48, 0.0), (1, 8, 64, 64, 0.2)])
+def test_key_major_pass1_and_dv_match_the_separate_passes(dev, B, H, N, dh, p_drop):
+    """spe_talking_bwdk_pass1 (key-major: one walk computes D, dWw, dbw AND dV with S, S', P recomputed once) against the launches it
+    replaces on the same fragments, statistics and dropout flags: spe_talking_fused mode 2 + spe_attn_merge (D, dWw, dbw) and
+    spe_talking_flash_dv (dV): equal to rounding (other summation orders; P' is mixed from bf16(P) instead of fp16(P 2^8)); rows >= N of the
+    padded D rows are zero; the bf16 copy of dV is the rounded fp32 result; ragged N, both head counts, every head-dim decomposition, a
+    single-tile-per-major case; bitwise reproducible run to run."""
+    from spe_amd import kernels as K
+    if not (K.bwdk_supported(H, dh) and K.flash_supported(H, dh)):
+        pytest.skip("shape not on the key-major backward pass")
+    x = _inputs(B, H, N, dh, p_drop, dev)
+    g = torch.Generator().manual_seed(2)
+    C = H * dh
+    dO = torch.randn(B, N, C, generator=g).to(dev)
+    dO4 = dO.view(B, N, H, dh)
+    dOf, dO16 = K.attn_pack_multi([(dO4, 1.0, 32), (dO4, 1.0, 16)])
+    spw, nwg = K.fused_plan(B, N, 2)
+    nw = 2 * (H * H + H)
+    hh = H * H
+    # the separate passes
+    ws_w = torch.zeros(nwg, nw, device=dev)
+    K.talking_fused(2, x["Qf"], x["Kf"], x["Vf"], dOf, x["Wl"], x["bl"], x["Ww"], x["bw"], x["M"], x["IL"], None, x["ws"], ws_w, None, B, H, N, dh,
+                    p_drop, x["seed"], x["off"], keepbits=x["bits"])
+    Do, _ = K.attn_merge(x["ws"], B, H, N, spw, 2)
+    wo = ws_w.sum(0)
+    dvo = torch.zeros(B, N, H, dh, device=dev)
+    K.talking_flash_dv(x["Qf"], x["Kf"], dO16, x["Wl"], x["Ww"], x["bw"], x["c0"], dvo, p_drop, x["seed"], x["off"])
+
+    def new():
+        dv = torch.full((B, N, H, dh), float("nan"), device=dev)
+        dv16 = torch.zeros(B, N, H, dh, device=dev, dtype=torch.bfloat16)
+        Drows, w = K.talking_bwdk_pass1(x["Qf"], dOf, dO16, x["Kf"], x["Vf"], x["Wl"], x["Ww"], x["bw"], x["c0"], x["bits"], dv, dv16, B, H, N, dh, p_drop)
+        return Drows, w.sum(0), dv, dv16
+
+    Drows, wn, dvn, dv16 = new()
+    Drows2, wn2, dvn2, _ = new()
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        a, b = a.double(), b.double()
+        return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    assert all(torch.isfinite(t).all() for t in (Drows, wn, dvn))
+    assert (Drows[:, N:] == 0).all()
+    assert rel(Drows[:, :N].permute(0, 2, 1), Do) <= 2e-4, rel(Drows[:, :N].permute(0, 2, 1), Do)
+    assert rel(wn[hh + H:2 * hh + H], wo[hh + H:2 * hh + H]) <= 1e-3          # dWw
+    assert rel(wn[2 * hh + H:], wo[2 * hh + H:]) <= 1e-3                      # dbw
+    assert rel(dvn, dvo) <= 4e-3, rel(dvn, dvo)                                # bf16(P) in the proj_w mix: 2^-9 per element, random
+    assert torch.equal(dv16.float(), dvn.to(torch.bfloat16).float())
+    assert torch.equal(Drows, Drows2) and torch.equal(wn[hh + H:], wn2[hh + H:]) and torch.equal(dvn, dvn2)      # (the [dWl | dbl] half of ws_w is pass 2's)
+
+
 def test_flash_skeleton_backward_in_the_attention_node(dev):
-    """The attention autograd node with the flash-skeleton pass 2 (default), with both flash-skeleton passes and with the round-3 passes:
+    """The attention autograd node with the flash-skeleton pass 2, with both flash-skeleton passes, with the key-major pass 1 + dV and with the round-3 passes:
     the same gradients to rounding, with attention dropout on (the flags come from the flash forward in all three)."""
     from spe_amd import kernels as K, ops
     K.set_precision("bf16s")
@@ -117,7 +169,7 @@ def test_flash_skeleton_backward_in_the_attention_node(dev):
     res = {}
     saved = (ops.BWDQ, ops.BWDQ_MODE)
     try:
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 3):
             ops.BWDQ, ops.BWDQ_MODE = mode != 0, mode
             K.manual_seed(31)
             qkv = qkv0.clone().requires_grad_(True)
@@ -128,7 +180,7 @@ def test_flash_skeleton_backward_in_the_attention_node(dev):
             res[mode] = (O.detach().clone(), qkv.grad.clone(), Wl.grad.clone(), Ww.grad.clone(), bw.grad.clone())
     finally:
         ops.BWDQ, ops.BWDQ_MODE = saved
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         assert torch.equal(res[mode][0], res[0][0])
         for a, b in zip(res[mode][1:], res[0][1:]):
             assert (a - b).norm() <= 1e-3 * b.norm(), (mode, float((a - b).norm() / b.norm()))
@@ -370,3 +422,37 @@ def test_dropout_streams_have_the_reference_semantics_at_script_rates(dev):
     fk = float((ss != 0).float().mean())
     assert abs(fk - 0.8) < 4 * (0.2 * 0.8 / ss.numel()) ** 0.5
     assert ops.drop_path_scale(8, 0.2, False, dev) is None and ops.drop_path_scale(8, 0.0, True, dev) is None
+
+
+def test_batched_weight_refresh_follows_recreated_cache_entries(dev):
+    """kernels._refresh_weights16 re-converts every cached bf16 weight copy in one launch from a device job table it keeps between steps.  A
+    cache entry that is re-created under an unchanged key - a second model whose flat parameter buffer landed on the address of a freed
+    one, as happens between two test cases or two models built in one process - has NEW output buffers: the table must be rebuilt, not
+    reused (it was: the refresh then wrote the copies into freed memory and left the live ones stale; found by the 30-step trajectory
+    test running after another model of the same shape)."""
+    import gc
+    from spe_amd import kernels as K
+    K.set_precision("bf16s")
+    g = torch.Generator().manual_seed(5)
+    shape = (384, 768)
+    W = torch.randn(shape, generator=g).to(dev)
+    ptr = W.data_ptr()
+    K.weight16(W, lo=True)
+    W.data.mul_(1.5)                      # an update through raw pointers (what FlatAdamW does): no version bump ...
+    K.weights_changed()                   # ... the epoch says so
+    a = K.weight16(W, lo=True)            # batched refresh: builds the job table
+    assert torch.equal(a[0].float(), W.to(torch.bfloat16).float())
+    del W, a
+    gc.collect()
+    W2 = torch.randn(shape, generator=g).to(dev)
+    if W2.data_ptr() != ptr:
+        pytest.skip("the allocator did not hand the freed block out again")
+    K.weight16(W2, lo=True)               # same key, dead owner: the entry is re-created with new buffers
+    W2.data.mul_(-2.0)
+    K.weights_changed()
+    b = K.weight16(W2, lo=True)           # batched refresh again: same keys as the cached table
+    torch.cuda.synchronize()
+    hi = W2.to(torch.bfloat16)
+    assert torch.equal(b[0].float(), hi.float())
+    assert torch.equal(b[1].float(), hi.t().float())
+    assert torch.equal(b[2].float(), (W2 - hi.float()).to(torch.bfloat16).float())

@@ -1,7 +1,7 @@
 """bf16 NT GEMMs of the cfg2 hot path at their model shapes: time, TFLOP/s (algorithmic 2MNK), % of the 2.5 PF bf16 MFMA peak,
 error against fp64, for the single-term (backward) and the split-operand (bf16s forward) products and the fused epilogues.
 
-    python tools/bench_nt.py                 # GPU box; SPE_GEMM_NT2=0 selects the gemm_bf16.hip kernels (A/B in two processes)
+    python tools/bench_nt.py                 # GPU box
 """
 import os
 import sys
@@ -82,7 +82,6 @@ def case(name, M, N, Kd, mode):
 
 
 def main():
-    print("SPE_GEMM_NT2 =", os.environ.get("SPE_GEMM_NT2", "1"))
     R = 8300
     case("qkv fwd", R, 1152, 384, "plain3")
     case("fc1 fwd + gelu", R, 1536, 384, "gelu3")
