@@ -690,7 +690,8 @@ __global__ __launch_bounds__(256) void bwdq_dq_merge_kernel(const float* __restr
 // passes', so that bf16(P'd) in the accumulator layout IS the B operand of the dV product.  Per tile:
 //   S, S' (fp32 mix), P = exp2 ; dP' = dropout (dO V^T) ; dP = Ww^T dP' ; D[q, h'] = sum_key dP P: a 16-lane row reduction (4 DPP steps)
 //   per (query row, head), summed over the workgroup's 4 key tiles through LDS one step later, one 512-B row block per (major, q-tile)
-//   -> ws_d ; dWw / dbw outer products (the same transpose tiles as pass 1) ; P' = Ww P + bw on bf16(P), dropout, dV += P'd^T dO.
+//   -> ws_d ; dWw / dbw outer products (the same transpose tiles as pass 1) ; P' = Ww P + bw in fp16 on P * 2^8 (the flash forward's
+//   arithmetic), dropout, bf16, dV += P'd^T dO.
 // No mask instance: a key >= N has K = V = 0 (zero-padded records), so dP' = dP = 0 there and its dV rows are dropped by the merge; a query
 // >= N has Q = dO = 0 and c0 = 0 (finite P, zero dO).  Replaces spe_talking_fused mode 2 + spe_attn_merge + spe_talking_flash_rows +
 // spe_talking_flash_dv + its merge: S, S', P are recomputed once for both results instead of twice.
@@ -774,13 +775,15 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
     fl_mixA_f32<H, false>(a.Wl, lane, Al4);
     fls16x4_t Awt[H / 4][H / 4];                    // dP = Ww^T dP' (bf16, 4x4x4)
     fl_mixA_16<H, true, false>(a.Ww, lane, 1.0f, Awt);
-    fls16x4_t Awp[H / 4][H / 4];                    // P' = Ww P + bw (bf16, 4x4x4)
-    fl_mixA_16<H, false, false>(a.Ww, lane, 1.0f, Awp);
+    // P travels as P * 2^8 through this kernel (the exponent starts from c0 + 8), like in the flash forward / dV pass: the proj_w mix runs in
+    // fp16 on values that stay normal numbers; D, dWw and dV carry the factor and drop it where they leave (d_flush, the ws_w row, the merge)
+    fls16x4_t Awp[H / 4][H / 4];                    // P' 2^8 = Ww (P 2^8) + bw 2^8 (fp16, 4x4x4)
+    fl_mixA_16<H, false, true>(a.Ww, lane, 1.0f, Awp);
     f32x4_t vbw[H / 4];
 #pragma unroll
     for (int gh = 0; gh < H / 4; ++gh)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) vbw[gh][i] = a.bw[4 * gh + i];
+        for (int i = 0; i < 4; ++i) vbw[gh][i] = a.bw[4 * gh + i] * FL_PD_SCALE;
 
     // weight-gradient outer products: X = dP' (front operand, double-buffered by tile parity), Y = P (back operand) - see talking_bwdq_kernel
     constexpr int GWR = FLB_GWR, GWT = 4 * H * GWR;
@@ -881,7 +884,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = *reinterpret_cast<const f32x4_t*>(cr + (r * H + 4 * gh) * 4);
+                    for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = *reinterpret_cast<const f32x4_t*>(cr + (r * H + 4 * gh) * 4) + 8.0f;      // exp2(. + 8) = P * 2^8
             }
             f32x4_t c[HB];
             static_assert(HB == 4, "chunk of 4 heads");
@@ -983,13 +986,20 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             }
-            // P' = Ww P + bw on bf16(P)
+            // P' 2^8 = Ww (P 2^8) + bw 2^8 on fp16 operands (P 2^8 <= 256: no saturation needed)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float x[H];
+                fls16x4_t bv[H / 4];
 #pragma unroll
-                for (int g = 0; g < H; ++g) x[g] = sp[r][g >> 2][g & 3];
-                fl_mix_16<H, false>(x, Awp, vbw, pp[r]);
+                for (int hh = 0; hh < H / 4; ++hh) bv[hh] = fl_pack4_f16(sp[r][hh][0], sp[r][hh][1], sp[r][hh][2], sp[r][hh][3]);
+#pragma unroll
+                for (int gh = 0; gh < H / 4; ++gh) {
+                    f32x4_t d = vbw[gh];
+#pragma unroll
+                    for (int hh = 0; hh < H / 4; ++hh)
+                        d = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(flf16x4_t, Awp[gh][hh]), __builtin_bit_cast(flf16x4_t, bv[hh]), d, 0, 0, 0);
+                    pp[r][gh] = d;
+                }
             }
         };
         auto back_dv = [&](int i, f32x4_t (&pp)[4][H / 4], const uint32_t (&kb)[4]) {
@@ -1024,7 +1034,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
                 float acc = src[0];
 #pragma unroll
                 for (int w = 1; w < NW; ++w) acc += (w < nvw) ? src[w * (DXB / 4)] : 0.f;
-                a.ws_d[((long)bm * a.Np + (qt0 + i) * 16) * H + wave * PER + lane] = acc;
+                a.ws_d[((long)bm * a.Np + (qt0 + i) * 16) * H + wave * PER + lane] = acc * (1.0f / FL_PD_SCALE);
             }
         };
         auto front = [&](int i, f32x4_t (&sp)[4][H / 4], f32x4_t (&dp)[4][H / 4], uint32_t (&kb)[4]) {
@@ -1131,8 +1141,8 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int g = 4 * (lane >> 4) + r;
-            if (g < H && nn < H) row[g * H + nn] = dsum[r];
-            if (g < H && nn == H) row[H * H + g] = dsum[r];
+            if (g < H && nn < H) row[g * H + nn] = dsum[r] * (1.0f / FL_PD_SCALE);          // dWw: Y was P * 2^8
+            if (g < H && nn == H) row[H * H + g] = dsum[r];                                     // dbw: the ones column
         }
     }
 }
@@ -1313,7 +1323,7 @@ extern "C" int spe_talking_bwdk_pass1(const void* Qf, const void* dOf, const voi
     const int DT = (dh + 15) / 16;
     const long nvec = (long)B * p.nmaj * FLB_NW * H * DT * 64;
     hipLaunchKernelGGL(bwdq_dq_merge_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, ws_v, dv, reinterpret_cast<unsigned short*>(dv16),
-                       ob, on, oh, B, H, N, nt, dh, DT, p.nmaj, p.spw, 1.0f, nvec);
+                       ob, on, oh, B, H, N, nt, dh, DT, p.nmaj, p.spw, 1.0f / FL_PD_SCALE, nvec);
     SPE_CHECK_LAUNCH();
     return 0;
 }

@@ -298,20 +298,28 @@ def test_training_trajectory_matches_reference(dev, name, prec):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec", ["bf16s", "bf16x3"])
-def test_long_training_trajectory_stays_near_reference(dev, prec):
+def test_long_training_trajectory_stays_near_reference(dev):
     """THIRTY optimizer steps of the reference's loop at cfg2_depth2 (N = 4150 tokens; tests/golden/traj30_cfg2_depth2.pt, tools/gen_traj_golden.py
-    cfg2_depth2:30), replayed by the product with the recorded one-to-many targets: the benchmark mode's single-bf16 backward feeds AdamW
-    for 30 steps, so this bounds how far its loss curve drifts from the reference's - every step within 2 % (bf16s; round 4 only showed 5
-    steps, with the error growing to 3.9e-3 at the fifth) resp. 5e-3 (bf16x3, the 3-term parity mode)."""
+    cfg2_depth2:30), replayed by the product with the recorded one-to-many targets, in the 3-term parity mode (bf16x3: ~1e-5 per step) and in
+    the benchmark mode (bf16s: single-bf16 backward feeding AdamW).  What the fixture shows (round 5, profiles/r05_traj30.json): this
+    trajectory - one repeated batch, gradient norm 9400 clipped to 0.1, loss 101 -> 16 - is CHAOTIC from its sixth step on: the parity
+    mode, which follows the reference to 1e-4 through step 4, departs from it by 4-5 % at steps 6-11 as well (any other summation order
+    does), so a per-step bound below that is not a property of the arithmetic.  Asserted: step 0 at north_star's 1e-3; the steps before the
+    departure within 1e-3 (bf16x3) / 1e-2 (bf16s); every later step within 15 % in both modes; the benchmark mode drifts no further than
+    three times the parity mode's worst step; both curves end near the reference's (final loss within 15 %, a sixth of the first)."""
     path = os.path.join(GOLD, "traj30_cfg2_depth2.pt")
     blob = torch.load(path, weights_only=False)
     assert len(blob["steps"]) == 30
-    rec = _replay_trajectory(dev, "cfg2_depth2", prec, blob, tag="traj30")
-    errs = rec["loss_rel_err_per_step"]
-    assert errs[0] < 1e-3, errs
-    bound = 2e-2 if prec == "bf16s" else 5e-3
-    assert max(errs) < bound, (max(errs), errs.index(max(errs)), errs)
+    recs = {prec: _replay_trajectory(dev, "cfg2_depth2", prec, blob, tag="traj30") for prec in ("bf16x3", "bf16s")}
+    worst = {}
+    for prec, rec in recs.items():
+        errs = rec["loss_rel_err_per_step"]
+        assert errs[0] < 1e-3, (prec, errs)
+        assert max(errs[:5]) < (1e-2 if prec == "bf16s" else 1e-3), (prec, errs[:5])
+        assert max(errs) < 0.15, (prec, max(errs), errs.index(max(errs)), errs)
+        assert rec["product_losses"][-1] < rec["product_losses"][0] / 5.0
+        worst[prec] = max(errs)
+    assert worst["bf16s"] <= 3.0 * max(worst["bf16x3"], 2e-2), worst
 
 
 @pytest.mark.gpu

@@ -304,15 +304,17 @@ def test_deferred_reductions_match_tree_sums_and_handle_shared_parameters(dev):
                 red.finish()
                 out.append((snap, [p.grad.clone() for p in params], pending_after_backward))
             deferring = red._defer
+            shared = {n for n, p in zip(names, params) if getattr(p, "_spe_shared", False)}      # (remove() clears the per-parameter marks)
             red.remove()
-            return out, deferring
+            return out, deferring, shared
         finally:
             K.DEFER_REDUCE = old
 
-    ref, d0 = grads(False, 2)
-    got, d1 = grads(True, 3)
+    ref, d0, _ = grads(False, 2)
+    got, d1, shared = grads(True, 3)
     assert not d0 and d1
-    assert getattr(net.norm.weight, "_spe_shared", False) and getattr(net.norm.bias, "_spe_shared", False)
+    assert {"norm.weight", "norm.bias"} <= shared
+    assert not hasattr(net.norm.weight, "_spe_shared")       # the marks of a removed reducer do not survive into the next one
     for step in (1, 2):                                      # steps with deferral active
         snap, fin, pend = got[step]
         assert pend == 0

@@ -105,7 +105,7 @@ def test_flash_skeleton_backward_passes_match_round3_kernels(dev, B, H, N, dh, p
 def test_key_major_pass1_and_dv_match_the_separate_passes(dev, B, H, N, dh, p_drop):
     """spe_talking_bwdk_pass1 (key-major: one walk computes D, dWw, dbw AND dV with S, S', P recomputed once) against the launches it
     replaces on the same fragments, statistics and dropout flags: spe_talking_fused mode 2 + spe_attn_merge (D, dWw, dbw) and
-    spe_talking_flash_dv (dV): equal to rounding (other summation orders; P' is mixed from bf16(P) instead of fp16(P 2^8)); rows >= N of the
+    spe_talking_flash_dv (dV): equal to rounding (other summation orders); rows >= N of the
     padded D rows are zero; the bf16 copy of dV is the rounded fp32 result; ragged N, both head counts, every head-dim decomposition, a
     single-tile-per-major case; bitwise reproducible run to run."""
     from spe_amd import kernels as K
@@ -147,7 +147,7 @@ def test_key_major_pass1_and_dv_match_the_separate_passes(dev, B, H, N, dh, p_dr
     assert rel(Drows[:, :N].permute(0, 2, 1), Do) <= 2e-4, rel(Drows[:, :N].permute(0, 2, 1), Do)
     assert rel(wn[hh + H:2 * hh + H], wo[hh + H:2 * hh + H]) <= 1e-3          # dWw
     assert rel(wn[2 * hh + H:], wo[2 * hh + H:]) <= 1e-3                      # dbw
-    assert rel(dvn, dvo) <= 4e-3, rel(dvn, dvo)                                # bf16(P) in the proj_w mix: 2^-9 per element, random
+    assert rel(dvn, dvo) <= 5e-4, rel(dvn, dvo)                                # the same fp16 proj_w mix on P 2^8, other summation order
     assert torch.equal(dv16.float(), dvn.to(torch.bfloat16).float())
     assert torch.equal(Drows, Drows2) and torch.equal(wn[hh + H:], wn2[hh + H:]) and torch.equal(dvn, dvn2)      # (the [dWl | dbl] half of ws_w is pass 2's)
 
