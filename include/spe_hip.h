@@ -100,6 +100,10 @@ int spe_gemm_tile(int M, int N, int nbatch);
  * the SPLIT operand of precision mode bf16s (see spe_gemm_bf16nt). */
 int spe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                       float* rstd, long R, int C, float eps, void* y16, void* y16lo, spe_stream_t stream);
+/* spe_layernorm_fwd_h (round 5): the same, with the second 16-bit copy yh16 = IEEE fp16(y) (saturating) instead of the low part - the
+ * operand of a single-term fp16 forward product (the backbone MLP's fc1 in precision mode bf16s); y16 stays the backward's bf16 operand. */
+int spe_layernorm_fwd_h(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                        float* rstd, long R, int C, float eps, void* y16, void* yh16, spe_stream_t stream);
 int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                       const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,
                       const float* add, spe_stream_t stream);
@@ -167,7 +171,11 @@ int spe_gemm_bf16tn(const void* A16, const void* B16, float* C, int M, int N, in
  * the LayerScale residual of the block is applied by the epilogue, C = res[m][n] + rgamma[n] * v (res [M][ldc]), while C2
  * keeps v for the gamma gradient.  half_flags bit 0: C2 is stored as IEEE fp16 [M][ldc] (saturating) instead of fp32; bit 1: aux
  * holds IEEE fp16 [M][ldc] - the saved pre-activation of the MLP, of which only gelu'(.) is ever taken.  Used by the fused MLP of the
- * backbone block (reference models/cait.py:405-416 = timm Mlp fc1 -> GELU -> fc2 inside x + gamma_2 * mlp(norm2(x)), and its autograd). */
+ * backbone block (reference models/cait.py:405-416 = timm Mlp fc1 -> GELU -> fc2 inside x + gamma_2 * mlp(norm2(x)), and its autograd).
+ * half_flags bits 2 / 3 (round 5: that MLP's FORWARD products in precision mode bf16s; profiles/r05_error_budget.jsonl - fp16 operands in
+ * fc1 + fc2 alone cost <= 2.6e-4 on every weighted loss key at cfg2 / cfg5 full depth): bit 2 = A16 / B16 hold IEEE fp16, the product is
+ * single-term on v_mfma_f32_16x16x32_f16 (no low parts; M >= 2048, K % 64 == 0) ; bit 3 (needs bit 2) = out16lo receives IEEE fp16(v)
+ * (saturating) - the operand of the NEXT fp16 product - next to out16 = bf16(v), the backward's operand. */
 int spe_gemm_bf16nt_ex(const void* A16, const void* B16, const void* A16lo, const void* B16lo, float* C, const float* bias,
                        float* C2, void* out16, void* out16lo, long ld16, void* out16T, long ld16t, float* colsum, const float* aux,
                        const float* res, const float* rgamma, int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act,
@@ -184,11 +192,13 @@ int spe_gemm_bf16nt_exd(const void* A16, const void* B16, const void* A16lo, con
                         spe_stream_t stream);
 int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, void* out_lo, long ldo, void* outT, long ldt, float* colsum,
                  const float* aux, int act, spe_stream_t stream);
+/* spe_cvt_bf16_h (round 5): out = bf16(x), out_h = IEEE fp16(x) (saturating; same layout as out), outT as above - one pass. */
+int spe_cvt_bf16_h(const float* x, long ldx, int R, int C, void* out, void* out_h, long ldo, void* outT, long ldt, spe_stream_t stream);
 /* spe_cvt_bf16_multi: the row-major and transposed bf16 copies of njobs contiguous fp32 matrices in ONE launch (every
- * Linear weight after an optimizer step).  jobs_dev: device array of njobs records of 56 bytes
- *   { const float* x; void* out; void* outT; long ldt; int R, C, tile0, tiles_c; void* out_lo; }     out, out_lo [R][C], outT [C][ldt], ldt >= R;
+ * Linear weight after an optimizer step).  jobs_dev: device array of njobs records of 64 bytes
+ *   { const float* x; void* out; void* outT; long ldt; int R, C, tile0, tiles_c; void* out_lo; long flags; }     out, out_lo [R][C], outT [C][ldt], ldt >= R;
  * tiles_c = ceil(C/64), tile0 = running sum of tiles_c * ceil(max(R, ldt)/64) over the preceding jobs; total_tiles = that
- * sum over all jobs.  out, out_lo or outT may be NULL per job. */
+ * sum over all jobs.  out, out_lo or outT may be NULL per job.  flags bit 0: out_lo receives IEEE fp16(x) instead of the low part. */
 int spe_cvt_bf16_multi(const void* jobs_dev, int njobs, int total_tiles, spe_stream_t stream);
 
 /* ---- masked softmax over scores[B,H,Nq,ld] (Nk valid columns per row).

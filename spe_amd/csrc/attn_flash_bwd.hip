@@ -1156,7 +1156,15 @@ __global__ __launch_bounds__(256) void bwdk_rows_merge_kernel(const float* __res
     if (q >= N) { out[i] = 0.f; return; }
     const float* src = ws + (long)b * nmaj * per + (i - (long)b * per);
     float acc = 0.f;
-    for (int m = 0; m < nmaj; ++m) acc += src[(long)m * per];
+    int m = 0;
+    for (; m + 8 <= nmaj; m += 8) {          // eight loads in flight, added in index order
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[(long)(m + k) * per];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k];
+    }
+    for (; m < nmaj; ++m) acc += src[(long)m * per];
     out[i] = acc;
 }
 

@@ -164,4 +164,22 @@ __device__ __forceinline__ void spe_drop_scale4(uint64_t seed, uint64_t offset, 
     for (int i = 0; i < 4; ++i) out[i] = ((float)(o[i] >> 8) * (1.0f / 16777216.0f) >= p) ? inv : 0.0f;
 }
 
+// second 16-bit copy of 4 values next to their bf16 copy h: the low part of a split bf16 operand, bf16(v - bf16(v)), or - lo_f16 - the
+// IEEE fp16 copy (saturating, NaN kept) that single-term fp16 forward products read (round 5: the backbone MLP of precision mode bf16s)
+__device__ __forceinline__ uint2 spe_second16(const float (&v)[4], uint2 hi_bits, bool lo_f16) {
+    typedef __bf16 spe_bf16x4s_t __attribute__((ext_vector_type(4)));
+    typedef _Float16 spe_h4s_t __attribute__((ext_vector_type(4)));
+    if (lo_f16) {
+        spe_h4s_t h;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h[k] = (_Float16)((v[k] != v[k]) ? v[k] : __builtin_amdgcn_fmed3f(v[k], -65504.f, 65504.f));
+        return __builtin_bit_cast(uint2, h);
+    }
+    const spe_bf16x4s_t hb = __builtin_bit_cast(spe_bf16x4s_t, hi_bits);
+    spe_bf16x4s_t l;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) l[k] = (__bf16)(v[k] - (float)hb[k]);
+    return __builtin_bit_cast(uint2, l);
+}
+
 #define SPE_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -40,7 +40,8 @@ struct Gemm16Args {
     // the stream of spe_dropout on the row-major [M, N] tensor; with res: C = res + sscale[m / rps] * rgamma * v.  C2 keeps the raw v.
     float drop_p; uint64_t drop_seed, drop_off;
     const float* sscale; long rps;
-    int h16;                               // bit 0: A / B hold IEEE fp16 (single-term product on v_mfma_f32_16x16x32_f16) ; bit 1: C is IEEE fp16 [M][ldc] (plain epilogue)
+    int h16;                               // bit 0: A / B hold IEEE fp16 (single-term product on v_mfma_f32_16x16x32_f16) ; bit 1: C is IEEE fp16 [M][ldc] (plain epilogue) ;
+                                           // bit 2: out16lo receives IEEE fp16(v) instead of bf16(v - bf16(v)) (extended epilogue; SPLIT there = "a second 16-bit tile is staged")
 };
 
 typedef _Float16 ep_h4_t __attribute__((ext_vector_type(4)));
@@ -207,12 +208,7 @@ __device__ __forceinline__ void gemm16_epilogue_ex(const Gemm16Args& p, f32x4_t 
             const uint2 u = __builtin_bit_cast(uint2, hb);
             *reinterpret_cast<uint2*>(sR + ml * LR + nl) = u;
             if constexpr (SPLIT) {
-                if (p.out16lo) {
-                    bf16x4v_t lb;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) lb[r] = (__bf16)(v[r] - (float)hb[r]);
-                    *reinterpret_cast<uint2*>(sRl + ml * LR + nl) = __builtin_bit_cast(uint2, lb);
-                }
+                if (p.out16lo) *reinterpret_cast<uint2*>(sRl + ml * LR + nl) = spe_second16(v, u, (p.h16 & 4) != 0);      // low part, or the fp16 copy
             }
             // transposed copy: one MFMA against the identity moves the lane ownership from (row m, 4 columns) to
             // (column n, 4 rows) - exact in bf16 - so the transposed tile is staged with 8-B writes as well

@@ -430,7 +430,9 @@ static int gemm_bf16nt_ex_impl(const void* A16, const void* B16, const void* A16
     if (K <= 0) return -4;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if (!al16(A16) || !al16(B16) || !al16(A16lo) || !al16(B16lo) || (lda & 7) || (ldb & 7) || (K & 7)) return -2;
-    if ((A16lo != nullptr) != (B16lo != nullptr) || (out16lo && !A16lo)) return -2;
+    // half_flags bit 2: A16 / B16 hold IEEE fp16 (single-term product; no low parts) ; bit 3: out16lo receives IEEE fp16(v) (no low parts needed)
+    const bool op_f16 = (half_flags & 4) != 0, lo_f16 = (half_flags & 8) != 0;
+    if ((A16lo != nullptr) != (B16lo != nullptr) || (out16lo && !A16lo && !lo_f16) || (op_f16 && A16lo)) return -2;
     if (out16T && ld16t < M) return -2;
     if (aux && act != 1 && act != 2) return -2;
     if ((res != nullptr) != (rgamma != nullptr) || (res && (!C || act != 0 || aux))) return -2;
@@ -445,8 +447,9 @@ static int gemm_bf16nt_ex_impl(const void* A16, const void* B16, const void* A16
     p.out16 = reinterpret_cast<unsigned short*>(out16); p.ld16 = ld16;
     p.out16T = reinterpret_cast<unsigned short*>(out16T); p.ld16t = ld16t;
     p.colsum = colsum; p.aux = aux; p.res = res; p.rgamma = rgamma;
-    if (half_flags & ~3) return -2;
-    p.half_flags = half_flags;
+    if (half_flags & ~15) return -2;
+    p.half_flags = half_flags & 3;
+    p.h16 = (op_f16 ? 1 : 0) | (lo_f16 ? 4 : 0);
     p.ws = spe_detws();
     if (colsum) DET_CHECK(p.ws, (N + 63) / 64, (M + 63) / 64, 64);      // bound for the smallest tiles
     // the transposed copy's zero columns M..ld16t-1 are written by the last row tile: it must reach ld16t
@@ -455,6 +458,7 @@ static int gemm_bf16nt_ex_impl(const void* A16, const void* B16, const void* A16
     const bool reach64 = !out16T || ld16t <= (long)((M + 63) / 64) * 64;
     if (!reach128 && !reach64) return -2;
     { const int rc = spe_nt2_dispatch(p, true, stream); if (rc != SPE_NT2_NA) return rc; }
+    if (p.h16) return -2;                    // fp16 operands / fp16 second copy: the LDS-DMA kernels only
     if (p.Alo) return reach64 ? launch_gemm16<64, 64, true, 0, 0, true>(p, stream) : -2;
     {   // developer knob: SPE_GEMM16_TILE also applies here
         static const int forced = getenv("SPE_GEMM16_TILE") ? atoi(getenv("SPE_GEMM16_TILE")) : 0;
@@ -483,7 +487,8 @@ static int gemm_bf16nt_ex_impl(const void* A16, const void* B16, const void* A16
 __device__ __forceinline__ void cvt_bf16_tile(const float* __restrict__ x, long ldx, int R, int C,
                                               unsigned short* __restrict__ out, unsigned short* __restrict__ out_lo, long ldo,
                                               unsigned short* __restrict__ outT, long ldt, float* __restrict__ colsum,
-                                              const float* __restrict__ aux, int act, const int r0, const int c0, const DetWs& ws) {
+                                              const float* __restrict__ aux, int act, const int r0, const int c0, const DetWs& ws,
+                                              const bool lo_f16 = false) {
     __shared__ unsigned short tile[64][66];
     __shared__ float csum[16][64];
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -527,10 +532,8 @@ __device__ __forceinline__ void cvt_bf16_tile(const float* __restrict__ x, long 
                 for (int j = 0; j < 4; ++j) if (c + j < C) out[(long)r * ldo + c + j] = e[j];
             }
         }
-        if (out_lo && r < R) {          // low part of the split operand: bf16(x - bf16(x)), same layout as `out`
-            bf16x4v_t l;
-            l[0] = (__bf16)(v[0] - (float)h[0]); l[1] = (__bf16)(v[1] - (float)h[1]); l[2] = (__bf16)(v[2] - (float)h[2]); l[3] = (__bf16)(v[3] - (float)h[3]);
-            const uint2 ul = __builtin_bit_cast(uint2, l);
+        if (out_lo && r < R) {          // low part of the split operand: bf16(x - bf16(x)), same layout as `out` (lo_f16: the IEEE fp16 copy)
+            const uint2 ul = spe_second16(v, u, lo_f16);
             if (c + 3 < C && ((ldo & 3) == 0)) *reinterpret_cast<uint2*>(out_lo + (long)r * ldo + c) = ul;
             else {
                 const unsigned short e[4] = {(unsigned short)(ul.x & 0xffff), (unsigned short)(ul.x >> 16), (unsigned short)(ul.y & 0xffff), (unsigned short)(ul.y >> 16)};
@@ -581,15 +584,15 @@ __device__ __forceinline__ void cvt_bf16_tile(const float* __restrict__ x, long 
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ x, long ldx, int R, int C,
                                                        unsigned short* __restrict__ out, unsigned short* __restrict__ out_lo, long ldo,
                                                        unsigned short* __restrict__ outT, long ldt, float* __restrict__ colsum,
-                                                       const float* __restrict__ aux, int act, DetWs ws) {
-    cvt_bf16_tile(x, ldx, R, C, out, out_lo, ldo, outT, ldt, colsum, aux, act, blockIdx.y * 64, blockIdx.x * 64, ws);
+                                                       const float* __restrict__ aux, int act, DetWs ws, bool lo_f16) {
+    cvt_bf16_tile(x, ldx, R, C, out, out_lo, ldo, outT, ldt, colsum, aux, act, blockIdx.y * 64, blockIdx.x * 64, ws, lo_f16);
 }
 
 // Many contiguous matrices in one launch (the bf16 copies of every Linear weight after an optimizer step: ~190
 // launch-bound conversions of 0.1-0.6 M elements otherwise).  jobs (device memory, built once by the host side):
 // tile0 = first 64x64 tile of the job in the launch, ascending; a workgroup finds its job by bisection.
-struct CvtJob { const float* x; unsigned short* out; unsigned short* outT; long ldt; int R, C, tile0, tiles_c; unsigned short* out_lo; };
-static_assert(sizeof(CvtJob) == 56, "spe_cvt_job_t layout");
+struct CvtJob { const float* x; unsigned short* out; unsigned short* outT; long ldt; int R, C, tile0, tiles_c; unsigned short* out_lo; long flags; };   // flags bit 0: out_lo receives IEEE fp16(x)
+static_assert(sizeof(CvtJob) == 64, "spe_cvt_job_t layout");
 __global__ __launch_bounds__(256) void cvt_bf16_multi_kernel(const CvtJob* __restrict__ jobs, int njobs) {
     const int t = blockIdx.x;
     int lo = 0, hi = njobs - 1;
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(256) void cvt_bf16_multi_kernel(const CvtJob* __res
     }
     const CvtJob j = jobs[lo];
     const int lt = t - j.tile0;
-    cvt_bf16_tile(j.x, j.C, j.R, j.C, j.out, j.out_lo, j.C, j.outT, j.ldt, nullptr, nullptr, 0, (lt / j.tiles_c) * 64, (lt % j.tiles_c) * 64, DetWs{});
+    cvt_bf16_tile(j.x, j.C, j.R, j.C, j.out, j.out_lo, j.C, j.outT, j.ldt, nullptr, nullptr, 0, (lt / j.tiles_c) * 64, (lt % j.tiles_c) * 64, DetWs{}, (j.flags & 1) != 0);
 }
 
 // C-ABI: see include/spe_hip.h (spe_cvt_bf16_multi).
@@ -612,8 +615,18 @@ extern "C" int spe_cvt_bf16_multi(const void* jobs_dev, int njobs, int total_til
 }
 
 // C-ABI: see include/spe_hip.h (spe_cvt_bf16).
+static int cvt_bf16_launch(const float* x, long ldx, int R, int C, void* out, void* out_lo, long ldo, void* outT, long ldt, float* colsum,
+                           const float* aux, int act, bool lo_f16, hipStream_t stream);
 extern "C" int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, void* out_lo, long ldo, void* outT, long ldt, float* colsum,
                             const float* aux, int act, hipStream_t stream) {
+    return cvt_bf16_launch(x, ldx, R, C, out, out_lo, ldo, outT, ldt, colsum, aux, act, false, stream);
+}
+// C-ABI: see include/spe_hip.h (spe_cvt_bf16_h): bf16 copy + IEEE fp16 copy of x from one pass.
+extern "C" int spe_cvt_bf16_h(const float* x, long ldx, int R, int C, void* out, void* out_h, long ldo, void* outT, long ldt, hipStream_t stream) {
+    return cvt_bf16_launch(x, ldx, R, C, out, out_h, ldo, outT, ldt, nullptr, nullptr, 0, true, stream);
+}
+static int cvt_bf16_launch(const float* x, long ldx, int R, int C, void* out, void* out_lo, long ldo, void* outT, long ldt, float* colsum,
+                           const float* aux, int act, bool lo_f16, hipStream_t stream) {
     if (R <= 0 || C <= 0) return 0;
     if (!out && !out_lo && !outT && !colsum) return 0;
     if (outT && ldt < R) return -2;
@@ -627,7 +640,7 @@ extern "C" int spe_cvt_bf16(const float* x, long ldx, int R, int C, void* out, v
     else if (colsum) DET_CHECK(ws, (C + 63) / 64, (R + 63) / 64, 64);
     hipLaunchKernelGGL(cvt_bf16_kernel, grid, dim3(256), 0, stream, x, ldx, R, C, reinterpret_cast<unsigned short*>(out),
                        reinterpret_cast<unsigned short*>(out_lo), ldo,
-                       reinterpret_cast<unsigned short*>(outT), ldt, colsum, aux, act, ws);
+                       reinterpret_cast<unsigned short*>(outT), ldt, colsum, aux, act, ws, lo_f16);
     if (region) det_defer_commit(region, (C + 63) / 64, (R + 63) / 64, 64, 1, sg, 1);
     SPE_CHECK_LAUNCH();
     return 0;

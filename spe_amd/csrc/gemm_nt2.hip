@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(Gemm16Args p) {
         for (int j = 0; j < NFN; ++j) asm volatile("" :: "v"(acc[i][j]));      // timing experiment: no epilogue
     return;
 #endif
-    if constexpr (EX) gemm16_epilogue_ex<BM, BN, SPLIT, false>(p, acc, smem16, m0, n0);
+    if constexpr (EX) gemm16_epilogue_ex<BM, BN, SPLIT || F16, false>(p, acc, smem16, m0, n0);      // (fp16 operands: the second 16-bit tile is the fp16 copy of the result)
     else if (F16 && (p.h16 & 2) && (p.N & 7) == 0 && (p.ldc & 7) == 0) gemm16_epilogue_h16<BM, BN>(p, acc, smem16, m0, n0);
     else gemm16_epilogue_plain<BM, BN>(p, acc, p.C, m0, n0);
 }
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(Gemm16Args p) {
 template <int BM, int BN, int BK, int NST, bool SPLIT, bool EX, bool F16 = false>
 static int launch_nt2(const Gemm16Args& p, hipStream_t stream, int mpan = 0) {
     constexpr int ring = NST * ((BM + BN) / (64 / (BK / 8))) * (SPLIT ? 2 : 1) * 1024;
-    constexpr int epi = EX ? BM * (BN + 8) * 2 * (SPLIT ? 2 : 1) : 0;
+    constexpr int epi = EX ? BM * (BN + 8) * 2 * ((SPLIT || F16) ? 2 : 1) : 0;
     constexpr int smem = ring > epi ? ring : epi;
     static bool attr_set = false;
     if (!attr_set) {
@@ -214,8 +214,16 @@ int spe_nt2_dispatch(const Gemm16Args& p, bool ex, hipStream_t stream) {
     static const int enabled = getenv("SPE_GEMM_NT2") ? atoi(getenv("SPE_GEMM_NT2")) : 1;      // developer knob (A/B against gemm_bf16.hip)
     const bool split = p.Alo != nullptr;
     if (!enabled || p.M < 2048 || p.splitk != 1 || p.out16T || (p.K % 64) != 0 || p.K < 128 || p.N < 64) return SPE_NT2_NA;
-    if (p.h16 & 1) {        // fp16 single-term operands (the decoder's memory-side projections): wide tiles, plain epilogue only
-        if (ex || split) return -2;
+    if (!(p.h16 & 1) && (p.h16 & 4)) return -2;        // the fp16 second copy comes with fp16 operands only
+    if ((p.h16 & 1) && ex) {
+        // fp16 single-term operands with the extended epilogue (round 5: the backbone MLP's forward products in precision mode bf16s -
+        // fc1 + GELU emitting the bf16 copy for the backward and the fp16 copy for fc2, fc2 + LayerScale residual)
+        if (split) return -2;
+        if (p.N >= 1024) return launch_nt2<128, 128, 64, 2, false, true, true>(p, stream);
+        return launch_nt2<128, 64, 64, 2, false, true, true>(p, stream);
+    }
+    if (p.h16 & 1) {        // fp16 single-term operands (the decoder's memory-side projections): wide tiles, plain epilogue
+        if (split) return -2;
         const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128), t160 = (long)((p.M + 159) / 160) * ((p.N + 127) / 128);
         if (((t160 + 511) / 512) * 160 < ((t128 + 511) / 512) * 128) return launch_nt2<160, 128, 64, 2, false, false, true>(p, stream);
         return launch_nt2<128, 128, 64, 2, false, false, true>(p, stream);

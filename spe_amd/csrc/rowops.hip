@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
                                                      long R, int C, float eps, unsigned short* __restrict__ y16,
-                                                     unsigned short* __restrict__ y16lo) {
+                                                     unsigned short* __restrict__ y16lo, bool lo_f16) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
@@ -58,10 +58,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 bf16x4l_t h;
                 h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
                 *reinterpret_cast<uint2*>(y16 + row * C + 4 * c) = __builtin_bit_cast(uint2, h);
-                if (y16lo) {    // low part of the split operand (precision mode bf16s): bf16(y - bf16(y))
-                    bf16x4l_t l;
-                    l[0] = (__bf16)(o.x - (float)h[0]); l[1] = (__bf16)(o.y - (float)h[1]); l[2] = (__bf16)(o.z - (float)h[2]); l[3] = (__bf16)(o.w - (float)h[3]);
-                    *reinterpret_cast<uint2*>(y16lo + row * C + 4 * c) = __builtin_bit_cast(uint2, l);
+                if (y16lo) {    // low part of the split operand (precision mode bf16s): bf16(y - bf16(y)) - or the fp16 copy (lo_f16)
+                    const float ov[4] = {o.x, o.y, o.z, o.w};
+                    *reinterpret_cast<uint2*>(y16lo + row * C + 4 * c) = spe_second16(ov, __builtin_bit_cast(uint2, h), lo_f16);
                 }
             }
         }
@@ -218,7 +217,7 @@ __global__ __launch_bounds__(256) void ln_fwd_hw_kernel(const float* __restrict_
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         float* __restrict__ mean, float* __restrict__ rstd,
                                                         long R, float eps, unsigned short* __restrict__ y16,
-                                                        unsigned short* __restrict__ y16lo) {
+                                                        unsigned short* __restrict__ y16lo, bool lo_f16) {
     constexpr int C4 = 32 * NV, C = 4 * C4;
     const int lane = threadIdx.x & 63, hl = lane & 31;
     const long stride = (long)gridDim.x * 8;
@@ -277,9 +276,8 @@ __global__ __launch_bounds__(256) void ln_fwd_hw_kernel(const float* __restrict_
                     h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
                     *reinterpret_cast<uint2*>(y16 + row * C + 4 * c) = __builtin_bit_cast(uint2, h);
                     if (y16lo) {
-                        bf16x4h_t l;
-                        l[0] = (__bf16)(o.x - (float)h[0]); l[1] = (__bf16)(o.y - (float)h[1]); l[2] = (__bf16)(o.z - (float)h[2]); l[3] = (__bf16)(o.w - (float)h[3]);
-                        *reinterpret_cast<uint2*>(y16lo + row * C + 4 * c) = __builtin_bit_cast(uint2, l);
+                        const float ov[4] = {o.x, o.y, o.z, o.w};
+                        *reinterpret_cast<uint2*>(y16lo + row * C + 4 * c) = spe_second16(ov, __builtin_bit_cast(uint2, h), lo_f16);
                     }
                 }
             }
@@ -301,30 +299,38 @@ extern "C" int spe_layernorm_res_fwd(const float* x, const float* z, const float
     return 0;
 }
 
-extern "C" int spe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                                 float* rstd, long R, int C, float eps, void* y16, void* y16lo, hipStream_t st) {
+static int ln_fwd_launch(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                         float* rstd, long R, int C, float eps, void* y16, void* y16lo, bool lo_f16, hipStream_t st) {
     if (R <= 0) return 0;
     if ((C & 3) || C > 256 * LN_MAXV || (y16lo && !y16)) return -2;
-    static const int hw = getenv("SPE_LN_HALFWAVE") ? atoi(getenv("SPE_LN_HALFWAVE")) : 1;       // 0: wave-per-row kernel (A/B)
-    if (hw && (C % 128) == 0 && C <= 512) {
-        static const int ln_wg = getenv("SPE_LN_WG") ? atoi(getenv("SPE_LN_WG")) : 512;
-        long nwg_ = (R + 7) / 8; if (nwg_ > ln_wg) nwg_ = ln_wg;
+    if ((C % 128) == 0 && C <= 512) {          // half-wave-per-row kernel
+        long nwg_ = (R + 7) / 8; if (nwg_ > 512) nwg_ = 512;
         const dim3 grid((unsigned)nwg_);
         unsigned short* h16 = reinterpret_cast<unsigned short*>(y16);
         unsigned short* l16 = reinterpret_cast<unsigned short*>(y16lo);
         switch (C / 128) {
-            case 1: hipLaunchKernelGGL(ln_fwd_hw_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16, l16); break;
-            case 2: hipLaunchKernelGGL(ln_fwd_hw_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16, l16); break;
-            case 3: hipLaunchKernelGGL(ln_fwd_hw_kernel<3>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16, l16); break;
-            default: hipLaunchKernelGGL(ln_fwd_hw_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16, l16); break;
+            case 1: hipLaunchKernelGGL(ln_fwd_hw_kernel<1>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16, l16, lo_f16); break;
+            case 2: hipLaunchKernelGGL(ln_fwd_hw_kernel<2>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16, l16, lo_f16); break;
+            case 3: hipLaunchKernelGGL(ln_fwd_hw_kernel<3>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16, l16, lo_f16); break;
+            default: hipLaunchKernelGGL(ln_fwd_hw_kernel<4>, grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, eps, h16, l16, lo_f16); break;
         }
         SPE_CHECK_LAUNCH();
         return 0;
     }
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, R, C, eps,
-                       reinterpret_cast<unsigned short*>(y16), reinterpret_cast<unsigned short*>(y16lo));
+                       reinterpret_cast<unsigned short*>(y16), reinterpret_cast<unsigned short*>(y16lo), lo_f16);
     SPE_CHECK_LAUNCH();
     return 0;
+}
+// C-ABI: see include/spe_hip.h
+extern "C" int spe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                 float* rstd, long R, int C, float eps, void* y16, void* y16lo, hipStream_t st) {
+    return ln_fwd_launch(x, gamma, beta, y, mean, rstd, R, C, eps, y16, y16lo, false, st);
+}
+// ... with the second 16-bit copy as IEEE fp16 (the operand of a single-term fp16 forward product) instead of the low part of the split
+extern "C" int spe_layernorm_fwd_h(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                   float* rstd, long R, int C, float eps, void* y16, void* yh16, hipStream_t st) {
+    return ln_fwd_launch(x, gamma, beta, y, mean, rstd, R, C, eps, y16, yh16, true, st);
 }
 static int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
                          float* dgamma, float* dbeta, long R, int C, const float* add, float* dz, float p, uint64_t seed,

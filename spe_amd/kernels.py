@@ -359,7 +359,7 @@ def _lin16_ok(R, N, K):
     return LINEAR16 and _PRECISION != 1 and R >= LINEAR16_MIN_ROWS and N % 8 == 0 and K % 8 == 0
 
 
-def cvt_bf16(x2, want=True, wantT=False, ldt=None, colsum_out=None, act_aux=None, act=0, out=None, ldo=None, out_lo=None):
+def cvt_bf16(x2, want=True, wantT=False, ldt=None, colsum_out=None, act_aux=None, act=0, out=None, ldo=None, out_lo=None, lo_f16=False):
     """bf16 (RNE) copies of a contiguous fp32 [R, C]: row-major [R, C] and/or the transpose [C, ldt] (zero padded);
     colsum_out (zeroed or running fp32 [C]) += column sums of x2 from the same pass.  out / ldo: write the row-major copy
     into a column block of a wider bf16 matrix (row stride ldo) instead of a fresh tensor.  out_lo (same layout as out):
@@ -373,6 +373,10 @@ def cvt_bf16(x2, want=True, wantT=False, ldt=None, colsum_out=None, act_aux=None
     if wantT:
         ldt = ldt or ((R + 63) // 64) * 64
         outT = torch.empty((C, ldt), device=x2.device, dtype=torch.bfloat16)
+    if lo_f16:          # out_lo (an fp16 tensor) receives IEEE fp16(x): the operand of a single-term fp16 forward product
+        assert colsum_out is None and act_aux is None and out_lo is not None and out_lo.dtype == torch.float16
+        _call("spe_cvt_bf16_h", _p(x2), x2.stride(0), R, C, _p(out), _p(out_lo), ldo or C, _p(outT), ldt or 0, _st())
+        return out, outT
     _call("spe_cvt_bf16", _p(x2), x2.stride(0), R, C, _p(out), _p(out_lo), ldo or C, _p(outT), ldt or 0, _p(colsum_out), _p(act_aux),
           int(act), _st())
     return out, outT
@@ -400,14 +404,16 @@ def _refresh_weights16():
         return
     # the table is reused only while every entry still converts the same storage into the SAME output buffers: an entry re-created
     # under an unchanged key (a later model whose flat parameter buffer landed on the address of a freed one) has new buffers
-    sig = tuple((k, e[3].data_ptr(), e[4].data_ptr(), e[5].data_ptr() if e[5] is not None else 0) for k, _, e in live)
+    sig = tuple((k, e[3].data_ptr(), e[4].data_ptr(), e[5].data_ptr() if e[5] is not None else 0, e[5].dtype if e[5] is not None else None)
+                for k, _, e in live)
     if _W16_TABLE is None or _W16_TABLE[0] != sig:
         rec = np.zeros(len(live), dtype=np.dtype([("x", "<u8"), ("out", "<u8"), ("outT", "<u8"), ("ldt", "<i8"), ("R", "<i4"),
-                                                   ("C", "<i4"), ("tile0", "<i4"), ("tiles_c", "<i4"), ("out_lo", "<u8")]))
+                                                   ("C", "<i4"), ("tile0", "<i4"), ("tiles_c", "<i4"), ("out_lo", "<u8"), ("flags", "<i8")]))
         t0 = 0
         for i, ((ptr, R, C), _, e) in enumerate(live):
             tc = (C + 63) // 64
-            rec[i] = (ptr, e[3].data_ptr(), e[4].data_ptr(), e[4].shape[1], R, C, t0, tc, e[5].data_ptr() if e[5] is not None else 0)
+            rec[i] = (ptr, e[3].data_ptr(), e[4].data_ptr(), e[4].shape[1], R, C, t0, tc, e[5].data_ptr() if e[5] is not None else 0,
+                      1 if (e[5] is not None and e[5].dtype == torch.float16) else 0)          # (an fp16 second copy: weight16(..., f16=True))
             t0 += tc * ((max(R, e[4].shape[1]) + 63) // 64)
         table = host_table(rec.view(np.uint8), live[0][2][3].device)
         _W16_TABLE = (sig, table, len(live), t0)
@@ -432,11 +438,13 @@ def host_table(bytes_np, device):
     return dev
 
 
-def weight16(W, lo=False):
+def weight16(W, lo=False, f16=False):
     """(W16 [N,K], W16T [K,N]) of a contiguous 2-D weight (or 2-D view of one: the patch-embedding filter), cached until
     the optimizer (or a state-dict load) changes it; lo=True: (W16, W16T, W16lo [N,K]) with W16lo = bf16(W - W16), the low
-    part of the split forward operand (precision mode bf16s).  Cache key: (address, shape); an entry lives as long as the
-    tensor that owns the storage.  The first lookup after weights_changed() refreshes every cached copy in one launch."""
+    part of the split forward operand (precision mode bf16s) - or, f16=True, the IEEE fp16 copy of W (the operand of the
+    single-term fp16 forward products of the backbone MLP; such a weight never needs its low part).  Cache key: (address, shape);
+    an entry lives as long as the tensor that owns the storage.  The first lookup after weights_changed() refreshes every cached
+    copy in one launch."""
     import weakref
     key = (W.data_ptr(), W.shape[0], W.shape[1])
     ent = _W16.get(key)
@@ -446,13 +454,15 @@ def weight16(W, lo=False):
             if _W16_BATCH and ent[2] != _W16_EPOCH and _W16_REFRESHED != _W16_EPOCH:
                 _refresh_weights16()
                 ent = _W16.get(key, ent)
-            if ent[1] == owner._version and ent[2] == _W16_EPOCH and (ent[5] is not None or not lo):
+            if ent[1] == owner._version and ent[2] == _W16_EPOCH and (not lo or (ent[5] is not None and (ent[5].dtype == torch.float16) == f16)):
                 return (ent[3], ent[4], ent[5]) if lo else (ent[3], ent[4])
+            if not lo and ent[5] is not None and ent[5].dtype == torch.float16:
+                f16 = True          # a stale entry of an fp16-forward weight looked up by its backward: it stays one
     owner = W._base if W._base is not None else W
-    want_lo = lo or _PRECISION == 2
+    want_lo = lo or f16 or _PRECISION == 2
     with torch.no_grad():
-        W16lo = torch.empty(W.shape, device=W.device, dtype=torch.bfloat16) if want_lo else None
-        W16, W16T = cvt_bf16(W.detach(), True, True, ldt=W.shape[0], out_lo=W16lo)
+        W16lo = torch.empty(W.shape, device=W.device, dtype=torch.float16 if f16 else torch.bfloat16) if want_lo else None
+        W16, W16T = cvt_bf16(W.detach(), True, True, ldt=W.shape[0], out_lo=W16lo, lo_f16=f16)
     if len(_W16) > 4096:
         _W16.clear()
     _W16[key] = (weakref.ref(owner), owner._version, _W16_EPOCH, W16, W16T, W16lo)
@@ -577,12 +587,16 @@ def gemm16_tn(A16, B16, C, M, N, R, lda, ldb, ldc, alpha=1.0, splitk=1):
 
 
 def gemm16_ex(A16, B16, M, N, K, lda, ldb, bias=None, C=None, C2=None, out16=None, out16T=None, colsum=None, aux=None,
-              alpha=1.0, act=0, res=None, rgamma=None, Alo=None, Blo=None, out16lo=None, drop=None, sscale=None, rps=1):
+              alpha=1.0, act=0, res=None, rgamma=None, Alo=None, Blo=None, out16lo=None, drop=None, sscale=None, rps=1, op_f16=False):
     """spe_gemm_bf16nt_ex: v = alpha * A16 @ B16.T + bias; C2 = v; v = act(v) or v * act'(aux); optional fp32 C [M,N], bf16
     out16 [M,N], bf16 transposed out16T [N, ldt] (zero padded), colsum [N] += column sums.  All fp32 tensors have ld = N.
     Alo / Blo: low parts of split operands; out16lo [M,N]: bf16(v - out16), the low part of the result for the next split GEMM.
     C2 / aux may be fp16 tensors (the saved pre-activation of the fused MLP): flagged to the library by their dtype."""
     half_flags = (1 if (C2 is not None and C2.dtype == torch.float16) else 0) | (2 if (aux is not None and aux.dtype == torch.float16) else 0)
+    if op_f16:          # A16 / B16 hold IEEE fp16 (single-term product); an fp16 out16lo tensor receives fp16(v), the next fp16 product's operand
+        assert A16.dtype == torch.float16 and B16.dtype == torch.float16 and Alo is None and Blo is None
+        half_flags |= 4 | (8 if out16lo is not None else 0)
+        assert out16lo is None or out16lo.dtype == torch.float16
     if (drop is not None and drop[0] > 0) or sscale is not None:
         # drop = (p, seed, offset): dropout after the activation / derivative; sscale [B] (+ rps rows per sample): DropPath scale on the residual
         pd, sd, of = drop if (drop is not None and drop[0] > 0) else (0.0, 0, 0)
@@ -670,6 +684,19 @@ def linear_res_bwd(dout2, saved, W, gamma, need_dx=True, grad_bufs=(None, None, 
 MLP_PRE_F16 = False      # module attribute (tests/test_kernels_gpu.py runs both settings), not an environment knob
 
 
+# Round 5: the FORWARD products of the backbone MLP (fc1, fc2: two thirds of the forward Linear FLOPs of a block) in precision mode bf16s run
+# on single-term IEEE fp16 operands instead of split bf16 pairs - one matrix instruction and half the operand bytes per product instead of
+# three and two.  Error budget (tools/error_budget.py mlp_fp16, profiles/r05_error_budget.jsonl): fp16 operands in fc1 + fc2 alone move the
+# worst weighted loss key by 1.3e-4 (cfg2 full depth) / 2.6e-4 (cfg5 full depth), pred_logits by 8.6e-5 - the other families (qkv 4.2e-4,
+# proj 6.4e-4 on their worst key) keep the split.  The producers emit the fp16 copy in the slot of the low part (LayerNorm, the fc1
+# epilogue, the weight copies); the backward still reads the bf16 copies.  Module attribute (tests run both settings), not an environment knob.
+MLP_F16 = True
+
+
+def mlp_f16_ok(R, K, Hd, N):
+    return MLP_F16 and split_fwd() and R >= 2048 and K % 64 == 0 and Hd % 64 == 0 and N % 8 == 0
+
+
 def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True, src=None, drop1=None, drop2=None, sscale=None, rps=1):
     """y = fc2(gelu(fc1(x2))) with every intermediate that the next GEMM needs emitted as bf16 by the producing GEMM's
     epilogue: fc1 writes the fp32 pre-activation (for the backward) and the bf16 activation h16 / h16T, never the fp32
@@ -679,6 +706,18 @@ def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True, src=None, 
     dev = x2.device
     # save = False (no gradient wanted: inference): none of the tensors that only the backward reads is produced
     sp = split_fwd()                         # bf16s forward: both products on (hi, lo) operand pairs, fc1 emits gelu(pre) as a pair
+    if res is not None and DW_TN and mlp_f16_ok(R, K, Hd, N):
+        # ... or on single-term fp16 operands: x as (bf16 for the backward, fp16), fc1 emits gelu(pre) as (bf16 for the backward, fp16 for fc2)
+        x16, _, xh = act16(x2, False, src, want_lo=True, lo_f16=True)
+        pre = torch.empty((R, Hd), device=dev, dtype=torch.float16 if MLP_PRE_F16 else torch.float32) if save else None
+        h16 = torch.empty((R, Hd), device=dev, dtype=torch.bfloat16)
+        hh = torch.empty((R, Hd), device=dev, dtype=torch.float16)
+        W1h, W2h = weight16(W1, lo=True, f16=True)[2], weight16(W2, lo=True, f16=True)[2]
+        gemm16_ex(xh, W1h, R, Hd, K, K, K, bias=b1, C2=pre, out16=h16, act=2, out16lo=hh, drop=drop1, op_f16=True)
+        out = torch.empty((R, N), device=dev, dtype=torch.float32)
+        y = torch.empty((R, N), device=dev, dtype=torch.float16 if MLP_PRE_F16 else torch.float32) if save else None
+        gemm16_ex(hh, W2h, R, N, Hd, Hd, Hd, bias=b2, C=out, C2=y, res=res, rgamma=gamma, drop=drop2, sscale=sscale, rps=rps, op_f16=True)
+        return out, (x16, pre, h16, y)
     x16, x16T, x16lo = act16(x2, save and not DW_TN, src, want_lo=sp)
     Rp = ((R + 63) // 64) * 64
     # the pre-activation is kept for gelu'(.) of the backward only: fp16 (11 significant bits: the derivative is exact to ~3e-4,
@@ -774,7 +813,7 @@ def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, 
     return dx, dW1, db1, dW2, db2
 
 
-def act16(x2, wantT, src=None, want_lo=False):
+def act16(x2, wantT, src=None, want_lo=False, lo_f16=False):
     """bf16 copies (row-major, transposed when wantT, and the low part of the split operand when want_lo) of an activation
     [R,K] -> (x16, x16T, x16lo).  `src`: the tensor object the caller holds (x2 is a reshape of it) - the copies are
     remembered ON that object (attribute, checked against its version counter), so an activation that feeds several Linears
@@ -783,10 +822,11 @@ def act16(x2, wantT, src=None, want_lo=False):
     if src is not None:
         ent = getattr(src, "_spe16", None)
         if (ent is not None and ent[0] == src._version and ent[1].shape == x2.shape and (ent[2] is not None or not wantT)
-                and (ent[3] is not None or not want_lo)):
+                and (not want_lo or (ent[3] is not None and (ent[3].dtype == torch.float16) == lo_f16))):
             return ent[1], ent[2], (ent[3] if want_lo else None)
-    x16lo = torch.empty(x2.shape, device=x2.device, dtype=torch.bfloat16) if want_lo else None
-    x16, x16T = cvt_bf16(x2, True, wantT, out_lo=x16lo)
+    # lo_f16: the second copy is IEEE fp16(x) - the operand of a single-term fp16 product - instead of the low part of the split
+    x16lo = torch.empty(x2.shape, device=x2.device, dtype=torch.float16 if lo_f16 else torch.bfloat16) if want_lo else None
+    x16, x16T = cvt_bf16(x2, True, wantT, out_lo=x16lo, lo_f16=lo_f16 and want_lo)
     if src is not None:
         src._spe16 = (src._version, x16, x16T, x16lo)
     return x16, x16T, x16lo
@@ -968,17 +1008,19 @@ def act_bwd(dy, aux, mode):
 
 
 # ---- LayerNorm ------------------------------------------------------------------------------
-def layernorm_fwd(x2, g, b, eps, want16=False):
+def layernorm_fwd(x2, g, b, eps, want16=False, f16=False):
     """-> (y, mean, rstd[, y16, y16lo]); want16: also the bf16 copy of y (what act16 would convert) from the same pass, and
-    in the bf16s forward the low part of the split operand (else y16lo is None)."""
+    in the bf16s forward the low part of the split operand (else y16lo is None) - or, f16, the IEEE fp16 copy in its place (the
+    consumer is a single-term fp16 product: the backbone MLP)."""
     _chk(x2, g, b)
     R, C = x2.shape
     y = torch.empty_like(x2)
     mean = torch.empty((R,), device=x2.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     y16 = torch.empty((R, C), device=x2.device, dtype=torch.bfloat16) if want16 else None
-    y16lo = torch.empty((R, C), device=x2.device, dtype=torch.bfloat16) if (want16 and split_fwd()) else None
-    _call("spe_layernorm_fwd", _p(x2), _p(g), _p(b), _p(y), _p(mean), _p(rstd), R, C, float(eps), _p(y16), _p(y16lo), _st())
+    f16 = f16 and want16 and split_fwd()
+    y16lo = torch.empty((R, C), device=x2.device, dtype=torch.float16 if f16 else torch.bfloat16) if (want16 and split_fwd()) else None
+    _call("spe_layernorm_fwd_h" if f16 else "spe_layernorm_fwd", _p(x2), _p(g), _p(b), _p(y), _p(mean), _p(rstd), R, C, float(eps), _p(y16), _p(y16lo), _st())
     return (y, mean, rstd, y16, y16lo) if want16 else (y, mean, rstd)
 
 

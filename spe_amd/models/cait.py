@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import kernels as K
 from .. import ops
 from .layers import Dropout, LayerNorm, Linear, trunc_normal_
 
@@ -120,7 +121,10 @@ class LayerScale_Block(nn.Module):
         else:
             x = ops.layerscale_residual(xs, self.attn(y), self.gamma_1, ss1)
         ss = ops.drop_path_scale(B, self.drop_path, self.training, x.device)
-        y, xs = self.norm2.skip(x) if skip else (self.norm2(x), x)
+        # the MLP of precision mode bf16s runs its forward products on fp16 operands: its LayerNorm emits the fp16 copy instead of the low part
+        mlp16 = isinstance(self.mlp, Mlp) and x.is_cuda and K.mlp_f16_ok(x.numel() // x.shape[-1], x.shape[-1], self.mlp.fc1.weight.shape[0],
+                                                                        self.mlp.fc2.weight.shape[0])
+        y, xs = self.norm2.skip(x, mlp16) if skip else (self.norm2(x), x)
         if isinstance(self.mlp, Mlp):
             return ops.mlp_gelu_residual(y, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight,
                                          self.mlp.fc2.bias, xs, self.gamma_2, ss, self.mlp.drop.p if self.training else 0.0)

@@ -257,12 +257,13 @@ class _LayerNormSkip(Function):
 
     @staticmethod
     @K.forward_scope
-    def forward(ctx, x, g, b, eps):
+    def forward(ctx, x, g, b, eps, f16=False):
         x2 = x.reshape(-1, x.shape[-1])
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         if K.produces16(*x2.shape):          # the Linear behind this norm runs on bf16 copies: emit its operand here
-            y, mean, rstd, y16, y16lo = K.layernorm_fwd(x2, g, b, eps, want16=True)
+            # (f16: the consumer is a single-term fp16 product - the MLP of precision mode bf16s -: the fp16 copy instead of the low part)
+            y, mean, rstd, y16, y16lo = K.layernorm_fwd(x2, g, b, eps, want16=True, f16=f16)
             yv = y.view(x.shape)
             K.attach16(yv, y16, y16lo)
         else:
@@ -278,7 +279,7 @@ class _LayerNormSkip(Function):
         x2, g, mean, rstd = ctx.saved_tensors
         gp, bp = ctx.params
         if dy is None:                       # only the skip path was used
-            return dskip, None, None, None
+            return dskip, None, None, None, None
         dy2 = dy.reshape(-1, dy.shape[-1])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
@@ -288,12 +289,12 @@ class _LayerNormSkip(Function):
             if not add.is_contiguous():
                 add = add.contiguous()
         dx, dg, db = K.layernorm_bwd(dy2, x2, g, mean, rstd, dg_out=K.grad_buffer(gp), db_out=K.grad_buffer(bp), add=add)
-        return dx.view(dy.shape), dg.view_as(gp), db.view_as(bp), None
+        return dx.view(dy.shape), dg.view_as(gp), db.view_as(bp), None, None
 
 
-def layer_norm_skip(x, g, b, eps):
+def layer_norm_skip(x, g, b, eps, f16=False):
     """-> (LN(x), x): use the second result as the residual operand of the branch (see _LayerNormSkip)."""
-    return _LayerNormSkip.apply(x, g, b, eps)
+    return _LayerNormSkip.apply(x, g, b, eps, f16)
 
 
 # ---------------------------------------------------------------------------------------------

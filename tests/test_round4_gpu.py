@@ -168,8 +168,12 @@ def test_block_with_training_rates_fused_equals_composite(dev):
     x0 = torch.randn(B, N, C, device=dev)
     w = torch.randn(B, N, C, device=dev)
     res = {}
-    for fused in (True, False):
-        ops.FUSE_DROP = fused
+    mlp_f16 = K.MLP_F16
+    for fused in (True, False, "f16"):
+        # (the comparison of the two compositions runs with the MLP on the split operands both take; the third pass is the fused path as
+        # shipped - round 5: its MLP forward on single-term fp16 operands - against the split one)
+        ops.FUSE_DROP = fused is not False
+        K.MLP_F16 = fused == "f16"
         try:
             outs = []
             for trial in range(3):                       # three DropPath draws (kept / dropped samples differ)
@@ -183,6 +187,10 @@ def test_block_with_training_rates_fused_equals_composite(dev):
             res[fused] = outs
         finally:
             ops.FUSE_DROP = True
+            K.MLP_F16 = mlp_f16
+    for (yh, dxh, gh), (yf, dxf, gf) in zip(res["f16"], res[True]):
+        assert (yh - yf).norm() <= 3e-4 * yf.norm(), float((yh - yf).norm() / yf.norm())
+        assert (dxh - dxf).norm() <= 3e-3 * dxf.norm(), float((dxh - dxf).norm() / dxf.norm())
     for (yf, dxf, gf), (yc, dxc, gc) in zip(res[True], res[False]):
         assert (yf - yc).norm() <= 1e-5 * yc.norm(), float((yf - yc).norm() / yc.norm())
         assert (dxf - dxc).norm() <= 3e-3 * dxc.norm(), float((dxf - dxc).norm() / dxc.norm())

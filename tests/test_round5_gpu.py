@@ -456,3 +456,57 @@ def test_batched_weight_refresh_follows_recreated_cache_entries(dev):
     assert torch.equal(b[0].float(), hi.float())
     assert torch.equal(b[1].float(), hi.t().float())
     assert torch.equal(b[2].float(), (W2 - hi.float()).to(torch.bfloat16).float())
+
+
+def test_mlp_forward_on_fp16_operands(dev):
+    """Round 5: in precision mode bf16s the backbone MLP's forward products run on single-term IEEE fp16 operands (spe_layernorm_fwd_h /
+    spe_cvt_bf16_h / the fp16 second copy of spe_gemm_bf16nt_ex and of the weight copies) instead of split bf16 pairs; the backward
+    reads the same bf16 copies as before.  Reference: timm Mlp inside models/cait.py:405-416.  Against an fp64 evaluation and against
+    the split path: the output within 3e-4 (the split path: 1e-5), the gradients as close as their bf16 backward allows; the fp16 weight
+    copies follow an optimizer-style raw update through the batched refresh."""
+    from spe_amd import kernels as K, ops
+    from spe_amd.models.layers import LayerNorm
+    K.set_precision("bf16s")
+    g = torch.Generator().manual_seed(12)
+    B, N, C, Hd = 2, 1100, 384, 1536
+    mk = lambda *s, sc=1.0: torch.nn.Parameter((torch.randn(*s, generator=g) * sc).to(dev))
+    W1, b1, W2, b2, gamma = mk(Hd, C, sc=0.05), mk(Hd, sc=0.1), mk(C, Hd, sc=0.05), mk(C, sc=0.1), mk(C, sc=0.5)
+    norm = LayerNorm(C).to(dev)
+    x0 = torch.randn(B, N, C, generator=g).to(dev)
+    go = torch.randn(B, N, C, generator=g).to(dev)
+    saved = K.MLP_F16
+    res = {}
+    try:
+        for f16 in (True, False):
+            K.MLP_F16 = f16
+            x = x0.clone().requires_grad_(True)
+            ok = K.mlp_f16_ok(B * N, C, Hd, C)
+            assert ok == f16
+            y, xs = norm.skip(x, ok)
+            assert (y._spe16[3].dtype == torch.float16) == f16          # LayerNorm emitted the fp16 copy in place of the low part
+            out = ops.mlp_gelu_residual(y, W1, b1, W2, b2, xs, gamma)
+            gr = torch.autograd.grad(out, [x, W1, b1, W2, b2, gamma], go)
+            res[f16] = (out.detach(), gr)
+    finally:
+        K.MLP_F16 = saved
+    xd = x0.double()
+    yn = torch.nn.functional.layer_norm(xd, (C,), norm.weight.double(), norm.bias.double(), norm.eps)
+    ref = xd + gamma.double() * (torch.nn.functional.gelu(yn @ W1.double().t() + b1.double()) @ W2.double().t() + b2.double())
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+    assert rel(res[False][0], ref) < 2e-5
+    assert 1e-6 < rel(res[True][0], ref) < 3e-4, rel(res[True][0], ref)
+    for a, b, nm in zip(res[True][1], res[False][1], ["x", "W1", "b1", "W2", "b2", "gamma"]):
+        assert rel(a, b) < 3e-3, (nm, rel(a, b))
+    # the fp16 weight copy follows a raw update (FlatAdamW writes through pointers and bumps the epoch)
+    K.MLP_F16 = True
+    try:
+        W1.data.mul_(1.25)
+        K.weights_changed()
+        w = K.weight16(W1, lo=True, f16=True)
+        assert w[2].dtype == torch.float16 and torch.equal(w[2], W1.detach().to(torch.float16)) and torch.equal(w[0], W1.detach().to(torch.bfloat16))
+        assert torch.equal(K.weight16(W1)[1], W1.detach().to(torch.bfloat16).t())        # the backward's lookup keeps the entry
+        assert K.weight16(W1, lo=True, f16=True)[2].data_ptr() == w[2].data_ptr()
+    finally:
+        K.MLP_F16 = saved

@@ -17,6 +17,7 @@ emulation in this tool only, no product code involved.  The case's reference fix
   lin_bf16     x, W of every Linear with >= 128 rows rounded to bf16       (single-term GEMMs)
   bblin_bf16 / declin_bf16   the same for the backbone's / the decoder's (incl. memory-side projections) Linears only
   lin_fp16     x, W of every Linear with >= 128 rows rounded to fp16
+  mlp_fp16 / qkv_fp16 / proj_fp16   the same for ONE family of backbone Linears (fc1 + fc2, qkv, the output projection; round 5)
   a+b          several at once, e.g. qk_bf16+pd_bf16+mixw_bf16 = the bf16 fused attention forward
 Results: one JSON line per (case, variant) -> stdout and gpurun_out/error_budget.jsonl.
 """
@@ -110,12 +111,17 @@ PRODUCT = ("bf16s", "bf16s_noflash", "bf16")
 
 
 def _linear_fwd(x2, W, b, act=0, want_pre=False, save_for_dw=True, src=None):
-    if x2.shape[0] >= 128 and not K._IN_BWD:
+    if x2.shape[0] >= 128 and not K._in_bwd():
         if "lin_bf16" in EMU or ("bblin_bf16" in EMU and not IN_DEC[0]) or ("declin_bf16" in EMU and IN_DEC[0]):
             y, pre, _ = _orig_linear_fwd(rnd(x2, torch.bfloat16), rnd(W, torch.bfloat16), b, act, want_pre, save_for_dw, None)
             return y, pre, x2
-        if "lin_fp16" in EMU:
+        n_out, n_in = W.shape
+        fam = None if IN_DEC[0] else ("mlp" if (n_out == 4 * n_in or n_in == 4 * n_out) else ("qkv" if n_out == 3 * n_in else ("proj" if n_out == n_in else None)))
+        if "lin_fp16" in EMU or (fam is not None and (fam + "_fp16") in EMU):
             y, pre, _ = _orig_linear_fwd(rnd(x2, torch.float16), rnd(W, torch.float16), b, act, want_pre, save_for_dw, None)
+            return y, pre, x2
+        if fam is not None and (fam + "_xfp16") in EMU:          # the activation alone in fp16 (the weight keeps its split)
+            y, pre, _ = _orig_linear_fwd(rnd(x2, torch.float16), W, b, act, want_pre, save_for_dw, None)
             return y, pre, x2
     return _orig_linear_fwd(x2, W, b, act, want_pre, save_for_dw, src)
 
