@@ -479,7 +479,7 @@ extern "C" int spe_attn_pack_multi(int njobs, const float* const* xs, const long
     }
     a.B = B; a.H = H;
     {   // wave-per-record kernel when every job has 16-B aligned rows and dh <= 64
-        static const int recpath = getenv("SPE_PACK_REC") ? atoi(getenv("SPE_PACK_REC")) : 1;      // 0: per-unit kernel (A/B)
+        static const int recpath = SPE_KNOB("SPE_PACK_REC", 1);      // 0: per-unit kernel (A/B)
         bool ok = recpath != 0;
         long nrec = 0;
         for (int i = 0; i < njobs && ok; ++i) {
@@ -518,7 +518,7 @@ static int launch_contract(const void* T, const void* X, float* out, long ob, lo
         if (over > 0 && l <= 2 && l < ngrp && bhn * l * 4 <= 256 && bhn * l * 4 * (CONTRACT_R * DT * 256) <= ws_floats) nlo = (int)l;
     }
     const int nfull = ngrp - nlo;
-    static const int use_ring = getenv("SPE_CONTRACT_LDS") ? atoi(getenv("SPE_CONTRACT_LDS")) : 1;   // 0: register-load loop (A/B)
+    static const int use_ring = SPE_KNOB("SPE_CONTRACT_LDS", 1);   // 0: register-load loop (A/B)
     if (use_ring) {
         const int smem_r = (4 * CL_D * CL_SLOT > 2 * CONTRACT_R * DT * 64 * 16) ? 4 * CL_D * CL_SLOT : 2 * CONTRACT_R * DT * 64 * 16;
         static bool attr_set = false;

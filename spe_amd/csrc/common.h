@@ -182,4 +182,13 @@ __device__ __forceinline__ uint2 spe_second16(const float (&v)[4], uint2 hi_bits
     return __builtin_bit_cast(uint2, l);
 }
 
+// Tuning switches of the launchers.  The shipped library has none: every SPE_KNOB is its default, a compile-time constant.  The timing-
+// experiment builds of tools/ab.py (-DSPE_ABLATE) read them from the environment, so that an A/B needs no rebuild per setting.
+#ifdef SPE_ABLATE
+#include <cstdlib>
+#define SPE_KNOB(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define SPE_KNOB(name, dflt) (dflt)
+#endif
+
 #define SPE_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

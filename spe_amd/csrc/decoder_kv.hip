@@ -213,7 +213,7 @@ extern "C" int spe_colsum_bf16_blocks(const void* x, long ld, long R, int nblk, 
     for (int i = 0; i < nblk; ++i) a.out[i] = outs[i];
     if (((nblk * blkC) & 7) == 0 && (ld & 7) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         const int gx = (nblk * blkC + 255) / 256;
-        static const int ry_max = getenv("SPE_COLSUM_RY") ? atoi(getenv("SPE_COLSUM_RY")) : 96;       // developer knob (tuning)
+        static const int ry_max = SPE_KNOB("SPE_COLSUM_RY", 96);       // developer knob (tuning)
         long ry = (R + 63) / 64; if (ry > ry_max) ry = ry_max; if (ry < 1) ry = 1;
         while (gx * ry > 1024 && ry > 16) ry /= 2;            // a few workgroups per CU are enough; the slabs cost a reduction each
         DetWs ws = spe_detws();

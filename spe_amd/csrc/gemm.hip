@@ -441,7 +441,7 @@ static int launch_gemm_t(const GemmArgs& p, int nbatch, hipStream_t stream) {
 // workgroups, half the registers, twice the L2 re-reads) otherwise and for skinny outputs (N <= 64: the per-head attention contractions).
 extern "C" int spe_gemm_tile(int M, int N, int nbatch) {
     static int forced = -1;
-    if (forced < 0) { const char* e = getenv("SPE_GEMM_TILE"); forced = e ? atoi(e) : 0; }
+    if (forced < 0) forced = SPE_KNOB("SPE_GEMM_TILE", 0);
     if (forced == 64 || forced == 128) return forced;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nbatch;
     return (t128 >= 256 && N > 64 && M > 64) ? 128 : 64;

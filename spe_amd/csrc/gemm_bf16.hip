@@ -362,7 +362,7 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, const void* A16
         return launch_gemm16<64, 64, false, 0, 0, true>(p, stream);
     }
     {   // developer knob (tools/bench_gemm.py): SPE_GEMM16_TILE = 1 / 2 / 3 forces 128x128 / 128x64 / 64x64
-        static const int forced = getenv("SPE_GEMM16_TILE") ? atoi(getenv("SPE_GEMM16_TILE")) : 0;
+        static const int forced = SPE_KNOB("SPE_GEMM16_TILE", 0);
         if (forced == 1) return launch_gemm16<128, 128>(p, stream);
         if (forced == 2) return launch_gemm16<128, 64>(p, stream);
         if (forced == 3) return launch_gemm16<64, 64>(p, stream);
@@ -377,7 +377,7 @@ extern "C" int spe_gemm_bf16nt(const void* A16, const void* B16, const void* A16
         // input gradient): 128x64 tiles fed by the LDS-DMA ring - half the A-panel re-reads of the 64x64 tiles and 2 tiles
         // in flight per workgroup (K = 1536: 30.5 -> 25.6 us, K = 1152: 23.3 -> 20.7, K = 4608: 85 -> 64; with more stages
         // or on the K = 384 products the lost occupancy costs more than the ring brings).  SPE_GEMM16_RING=0 disables it (A/B).
-        static const int ring = getenv("SPE_GEMM16_RING") ? atoi(getenv("SPE_GEMM16_RING")) : 1;
+        static const int ring = SPE_KNOB("SPE_GEMM16_RING", 1);
         if (ring > 1 && (K % GB_BK) == 0) {          // developer knob: force a ring configuration for every activation-sized product
             if (ring == 1282) return launch_gemm16<128, 128, false, 0, 2>(p, stream);
             if (ring == 1283) return launch_gemm16<128, 128, false, 0, 3>(p, stream);
@@ -461,13 +461,13 @@ static int gemm_bf16nt_ex_impl(const void* A16, const void* B16, const void* A16
     if (p.h16) return -2;                    // fp16 operands / fp16 second copy: the LDS-DMA kernels only
     if (p.Alo) return reach64 ? launch_gemm16<64, 64, true, 0, 0, true>(p, stream) : -2;
     {   // developer knob: SPE_GEMM16_TILE also applies here
-        static const int forced = getenv("SPE_GEMM16_TILE") ? atoi(getenv("SPE_GEMM16_TILE")) : 0;
+        static const int forced = SPE_KNOB("SPE_GEMM16_TILE", 0);
         if (forced == 1 && reach128) return launch_gemm16<128, 128, true>(p, stream);
         if (forced == 2 && reach128) return launch_gemm16<128, 64, true>(p, stream);
         if (forced == 3 && reach64) return launch_gemm16<64, 64, true>(p, stream);
     }
     {   // see spe_gemm_bf16nt
-        static const int ring = getenv("SPE_GEMM16_RING") ? atoi(getenv("SPE_GEMM16_RING")) : 1;
+        static const int ring = SPE_KNOB("SPE_GEMM16_RING", 1);
         if (ring && M >= 2048 && reach128 && (K % GB_BK) == 0 && K >= 1024 && N <= 512) return launch_gemm16<128, 64, true, 0, 3>(p, stream);
     }
     if (M >= 2048 && reach64) return launch_gemm16<64, 64, true>(p, stream);

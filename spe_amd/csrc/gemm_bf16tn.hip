@@ -191,7 +191,7 @@ extern "C" int spe_gemm_bf16tn(const void* A16, const void* B16, float* C, int M
     p.rt_per_split = (rtiles + splitk - 1) / splitk;
     // decoder-size problems (a few hundred rows, no split): 64x64 tiles put 4x the workgroups on the chip (384 x 384: 36 instead of 9)
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splitk;
-    static const int small_max = getenv("SPE_TN_SMALL_TILES") ? (atoi(getenv("SPE_TN_SMALL_TILES")) <= 1 ? (atoi(getenv("SPE_TN_SMALL_TILES")) ? 256 : 64) : atoi(getenv("SPE_TN_SMALL_TILES"))) : 256;     // developer knob (A/B): 0 / 1 / threshold
+    static const int small_max = SPE_KNOB("SPE_TN_SMALL_TILES", 256);      // 128-tiles x splits below this: 64 x 64 tiles
     // fewer than half the 512 resident workgroup slots with the wide tiles (a 384 x 384 weight gradient: 9 tiles x 16 splits):
     // 64 x 64 tiles, for which the caller sized the split (kernels.auto_splitk)
     if (t128 < small_max) return launch_tn<64, 64>(p, stream);

@@ -186,7 +186,7 @@ static int launch_nt2(const Gemm16Args& p, hipStream_t stream, int mpan = 0) {
     const int tiles_m = mpan > 0 ? mpan : (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     Gemm16Args q = p;
     q.mpan = mpan;
-    static const int stagger = getenv("SPE_NT2_STAGGER") ? atoi(getenv("SPE_NT2_STAGGER")) : 0;
+    static const int stagger = SPE_KNOB("SPE_NT2_STAGGER", 0);
     q.stagger = stagger;
     q.xcd_bind = 0;
     if (p.M >= p.N && tiles_m >= 16) q.xcd_bind = 1;
@@ -211,7 +211,7 @@ static int launch_nt2(const Gemm16Args& p, hipStream_t stream, int mpan = 0) {
 // multiple of the stage depth, a K split, or a transposed bf16 copy of the result.
 #define SPE_NT2_NA (-100)
 int spe_nt2_dispatch(const Gemm16Args& p, bool ex, hipStream_t stream) {
-    static const int enabled = getenv("SPE_GEMM_NT2") ? atoi(getenv("SPE_GEMM_NT2")) : 1;      // developer knob (A/B against gemm_bf16.hip)
+    static const int enabled = SPE_KNOB("SPE_GEMM_NT2", 1);      // developer knob (A/B against gemm_bf16.hip)
     const bool split = p.Alo != nullptr;
     if (!enabled || p.M < 2048 || p.splitk != 1 || p.out16T || (p.K % 64) != 0 || p.K < 128 || p.N < 64) return SPE_NT2_NA;
     if (!(p.h16 & 1) && (p.h16 & 4)) return -2;        // the fp16 second copy comes with fp16 operands only
@@ -228,16 +228,16 @@ int spe_nt2_dispatch(const Gemm16Args& p, bool ex, hipStream_t stream) {
         if (((t160 + 511) / 512) * 160 < ((t128 + 511) / 512) * 128) return launch_nt2<160, 128, 64, 2, false, false, true>(p, stream);
         return launch_nt2<128, 128, 64, 2, false, false, true>(p, stream);
     }
-    static const int wide_min = getenv("SPE_NT2_WIDE_MIN") ? atoi(getenv("SPE_NT2_WIDE_MIN")) : 1024;     // developer knob
+    static const int wide_min = SPE_KNOB("SPE_NT2_WIDE_MIN", 1024);     // developer knob
     // single-term products with the extended epilogue (fc2 dh: GELU derivative from the saved pre-activation, bf16 output, column
     // sums) are bound by that epilogue: 128 x 64 tiles at three workgroups per CU overlap it with other workgroups' main loops
     // (8300 x 1536 x 384: 63 -> 51 us); the split forward products and the plain-epilogue ones are faster on the wide tiles
-    static const int wide_min_ex1 = getenv("SPE_NT2_WIDE_MIN_EX1") ? atoi(getenv("SPE_NT2_WIDE_MIN_EX1")) : 2048;      // developer knob
+    static const int wide_min_ex1 = SPE_KNOB("SPE_NT2_WIDE_MIN_EX1", 2048);      // developer knob
     // ... and so are the split forward products with the extended epilogue (fc1 + GELU: fp16 pre-activation + hi / lo bf16 outputs):
     // 85 -> 73 us INSIDE the step on 128 x 64 tiles (the isolated launch prefers the wide tiles, 69 vs 76 us: measured in the step)
-    static const int wide_min_ex3 = getenv("SPE_NT2_WIDE_MIN_EX3") ? atoi(getenv("SPE_NT2_WIDE_MIN_EX3")) : 2048;           // developer knob
+    static const int wide_min_ex3 = SPE_KNOB("SPE_NT2_WIDE_MIN_EX3", 2048);           // developer knob
     const bool wide = p.N >= (ex ? (split ? wide_min_ex3 : wide_min_ex1) : wide_min);
-    static const int cfg = getenv("SPE_NT2_CFG") ? atoi(getenv("SPE_NT2_CFG")) : 0;      // developer knob: ring depth / stage depth variants
+    static const int cfg = SPE_KNOB("SPE_NT2_CFG", 0);      // developer knob: ring depth / stage depth variants
 #define NT2_GO(BK_, NST_, SP_)                                                                                                   \
     do {                                                                                                                         \
         if (ex) return wide ? launch_nt2<128, 128, BK_, NST_, SP_, true>(p, stream) : launch_nt2<128, 64, BK_, NST_, SP_, true>(p, stream);   \
@@ -246,7 +246,7 @@ int spe_nt2_dispatch(const Gemm16Args& p, bool ex, hipStream_t stream) {
     // Tile quantisation: 8300 rows make 65 row tiles of 128; 65 x 9 = 585 tiles (qkv forward) take 2 rounds on the 512 resident workgroup
     // slots for 1.14 rounds of work.  160-row tiles (52 x 9 = 468) fit one round of 1.25x larger tiles.  Plain epilogue only (the staged
     // epilogue of a 160 x 128 tile does not fit two workgroups per CU).
-    static const int tall = getenv("SPE_NT2_TALL") ? atoi(getenv("SPE_NT2_TALL")) : 1;      // developer knob (A/B)
+    static const int tall = SPE_KNOB("SPE_NT2_TALL", 1);      // developer knob (A/B)
     if (tall && !ex && wide && cfg == 0) {
         const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128), t160 = (long)((p.M + 159) / 160) * ((p.N + 127) / 128);
         const long c128 = ((t128 + 511) / 512) * 128, c160 = ((t160 + 511) / 512) * 160;
@@ -261,7 +261,7 @@ int spe_nt2_dispatch(const Gemm16Args& p, bool ex, hipStream_t stream) {
     // 55.7 -> 56.5 ms): one workgroup per CU moves its operands at a lower rate than two smaller ones, whatever the ring depth - the
     // imbalance of 1.52 workgroups per CU costs less than the lost overlap.  Kept for the record in the -DSPE_ABLATE builds only.
 #ifdef SPE_ABLATE
-    static const int bal = getenv("SPE_NT2_BALANCED") ? atoi(getenv("SPE_NT2_BALANCED")) : 0;      // developer knob (A/B)
+    static const int bal = SPE_KNOB("SPE_NT2_BALANCED", 0);      // developer knob (A/B)
 #else
     constexpr int bal = 0;
 #endif
@@ -288,7 +288,7 @@ int spe_nt2_dispatch(const Gemm16Args& p, bool ex, hipStream_t stream) {
     // per CU.  64 x 64 tiles (780 workgroups, three to four per CU) hide each other's load latency: qkv dx 19.4 -> 17.0 us, fc1 dx
     // 24.0 -> 21.5, the stacked decoder dx (K = 4608) 59.3 -> 53.1.  SPE_NT2_SHORT: bit 0 single-term plain, bit 1 split plain,
     // bit 2 split extended epilogue, bit 3 single-term extended epilogue (developer knob, A/B).
-    static const int short_rows = getenv("SPE_NT2_SHORT") ? atoi(getenv("SPE_NT2_SHORT")) : 9;      // in the step: fc2 dh 64.5 -> 56.3 us with bit 3; bits 1, 2 no gain
+    static const int short_rows = SPE_KNOB("SPE_NT2_SHORT", 9);      // in the step: fc2 dh 64.5 -> 56.3 us with bit 3; bits 1, 2 no gain
     if (!wide && cfg == 0) {
         if ((short_rows & 1) && !ex && !split) return launch_nt2<64, 64, 64, 2, false, false>(p, stream);
         if ((short_rows & 2) && !ex && split) return launch_nt2<64, 64, 32, 2, true, false>(p, stream);

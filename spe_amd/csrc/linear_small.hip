@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(LinSmallArgs p) {
 
 static int ls_latency_tiles() {       // grids up to this many workgroups take the one-round-trip configuration (SPE_LS_WIDE_MAX, tuning only)
     static int v = -1;
-    if (v < 0) { const char* e = getenv("SPE_LS_WIDE_MAX"); v = e ? atoi(e) : 320; }
+    if (v < 0) v = SPE_KNOB("SPE_LS_WIDE_MAX", 320);
     return v;
 }
 

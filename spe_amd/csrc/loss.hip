@@ -287,7 +287,7 @@ extern "C" int spe_hungarian(const float* cost, const int* toff, long* srow, lon
                              int Q, hipStream_t st) {
     if (L <= 0 || B <= 0 || Q <= 0) return 0;
     if (Q > HUNG_QMAX) return -2;
-    static const bool reg_path = !(getenv("SPE_HUNGARIAN_LDS") && atoi(getenv("SPE_HUNGARIAN_LDS")));      // developer knob (A/B): 1 = the LDS-state kernel
+    static const bool reg_path = !SPE_KNOB("SPE_HUNGARIAN_LDS", 0);      // (-DSPE_ABLATE builds: 1 = the LDS-state kernel)
     if (reg_path && Q <= 128) return launch_hungarian_reg<2>(cost, toff, srow, gidx, lidx, err, L, B, Q, st);
     if (reg_path && Q <= 320) return launch_hungarian_reg<5>(cost, toff, srow, gidx, lidx, err, L, B, Q, st);
     hipLaunchKernelGGL(hungarian_kernel, dim3(B, L), dim3(64), 0, st, cost, toff, srow, gidx, lidx, err, B, Q);

@@ -28,6 +28,7 @@ KERNELS = {
     "flash_merge": "flash_merge_kernel",
     "talking_bwdq_pass1": "talking_bwdq_kernel<8, 2, true, false, 1>",
     "talking_bwdq_pass2": "talking_bwdq_kernel<8, 2, true, false, 2>",
+    "talking_bwdk_pass1": "talking_bwdk_kernel<8, 2, true, false>",
 }
 
 

@@ -13,7 +13,11 @@ python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 taskset -c 0,1 python bench.py --no-cpu-baseline > $OUT/bench_2cores.json 2>/dev/null
 python bench.py --no-cpu-baseline > $OUT/bench_unpinned.json 2>/dev/null
 SPE_BWDQ=0 python bench.py --no-cpu-baseline > $OUT/bench_bwdq0.json 2>/dev/null
-SPE_BWDQ=1 python bench.py --no-cpu-baseline > $OUT/bench_bwdq1.json 2>/dev/null
+SPE_BWDQ=2 python bench.py --no-cpu-baseline > $OUT/bench_bwdq2.json 2>/dev/null
+SPE_BWDQ=3 python bench.py --no-cpu-baseline > $OUT/bench_bwdq3.json 2>/dev/null
+# two ranks on the one GPU over gloo (the data-parallel path end to end: bucketed all-reduce beside the backward, num_boxes all-reduce), fp32 and bf16 wire
+SPE_BENCH_BACKEND=gloo SPE_BENCH_DEVICE=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29711 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_gloo2.json 2>$OUT/bench_gloo2.err
+SPE_BENCH_BACKEND=gloo SPE_BENCH_DEVICE=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29712 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --wire bf16 > $OUT/bench_gloo2_bf16wire.json 2>$OUT/bench_gloo2_bf16wire.err
 python bench.py --enc-layers 3 --no-cpu-baseline > $OUT/bench_enc3.json 2>/dev/null
 python bench.py --backbone TSCAM_cait_S36 --layer-to-det 35 --height 1000 --width 1600 --batch 1 --no-cpu-baseline > $OUT/bench_cfg5.json 2>/dev/null
 python bench.py --enc-layers 3 --queries 300 --drop-path 0.2 --attn-drop 0.05 --backbone-drop 0.07 --no-cpu-baseline > $OUT/bench_script_rates_s24.json 2>$OUT/bench_script_rates_s24.err
@@ -29,6 +33,8 @@ python tools/aten_report.py --top 60 2>&1 | grep -v "^\[W\|Warn\|_warn" > $OUT/a
 cp $(find $OUT/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 bash tools/debug/decoder_window.sh > $OUT/decoder_window.txt 2>&1
 python tools/host_time.py 2>&1 | tail -2 > $OUT/host_time.txt
+taskset -c 0,1 python tools/host_time.py 2>&1 | tail -2 > $OUT/host_time_2cores.txt
+python tools/debug/bwdk_time.py 2>&1 | tail -4 > $OUT/bwdk_time.txt
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +20M -delete
 for f in $OUT/bench_*.json; do python - "$f" <<'PY'
 import json,sys
