@@ -49,6 +49,18 @@
 #ifndef FLB_SGB_V
 #define FLB_SGB_V 2
 #endif
+#ifndef FLB_RSFUSE
+#define FLB_RSFUSE 1                     // key-major kernel: the D reduce-scatter of tile i inside the score-product blocks of tile i + 1 (head dim 33 .. 48, 8 heads)
+#endif
+#ifndef FLB_SGB2
+#define FLB_SGB2 0                       // key-major kernel: interleave request for the region of front_q (second chunk) + back_ds
+#endif
+#ifndef FLB_SGB2_N
+#define FLB_SGB2_N 32
+#endif
+#ifndef FLB_SGB2_V
+#define FLB_SGB2_V 3
+#endif
 #ifndef FLB_DQAHEAD
 #define FLB_DQAHEAD 2                    // heads the 16-wide K operand loads of the dQ products run ahead of their matrix instructions
 #endif
@@ -62,6 +74,7 @@
 #define FLB_PHASE() do {} while (0)
 #endif
 #ifndef SPE_ABLATE
+#undef FLB_DBG_SAMETILE
 #undef FLB_DBG_NOGWM
 #undef FLB_DBG_NODQ
 #undef FLB_DBG_NOST
@@ -251,7 +264,11 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
 #ifdef FLB_DBG_NODMA
             if (i != 0) return;
 #endif
+#ifdef FLB_DBG_SAMETILE
+            const int kt = 0;                 // timing experiment: every workgroup streams the same tile (all L2 hits)
+#else
             const int kt = kt0 + i;
+#endif
 #pragma unroll
             for (int op = 0; op < ((PASS == 2) ? 3 : 2); ++op) {
                 const unsigned char* base = (op == 0) ? a.Kf : ((op == 1) ? a.Vf : a.K16);
@@ -756,6 +773,88 @@ __device__ __forceinline__ void flb_rowsum4(const f32x4_t (&t)[4], f32x4_t& o) {
           "v"(t[2][0]), "v"(t[2][1]), "v"(t[2][2]), "v"(t[2][3]), "v"(t[3][0]), "v"(t[3][1]), "v"(t[3][2]), "v"(t[3][3]));
 }
 
+// The score products of a chunk of 4 heads at head dim 33 .. 48 (8 matrix instructions: flb_score_*<1, true>) with the row-sum reduce-scatter of 4 heads
+// (flb_rowsum4: 32 DPP adds) in their shadow - four vector instructions behind every matrix instruction; a single wave per SIMD overlaps the two pipes only where
+// the instruction stream alternates, and an inline-assembly block is one unit for the scheduler.
+#define FLB_SCORE_RS_ASM(NAME, M32, M16)                                                                                                   \
+    __device__ __forceinline__ void NAME(const flu32x4_t (*k32)[1], const flu32x2_t* k16, const flu32x4_t (*q32)[1], const flu32x2_t* q16, \
+                                         f32x4_t* c, const f32x4_t (&t)[4], f32x4_t& o) {                                                  \
+        float a0, a1, a2, a3, b0, b1, b2, b3;                                                                                              \
+            asm("s_nop 1\n\t"   \
+                M32 " %0, %16, %24, 0\n\t"   \
+                "v_add_f32_dpp %4, %32, %32 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"   \
+                "v_add_f32_dpp %5, %33, %33 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"   \
+                "v_add_f32_dpp %6, %34, %34 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"   \
+                "v_add_f32_dpp %7, %35, %35 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"   \
+                M32 " %1, %17, %25, 0\n\t"   \
+                "v_add_f32_dpp %4, %40, %40 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"   \
+                "v_add_f32_dpp %5, %41, %41 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"   \
+                "v_add_f32_dpp %6, %42, %42 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"   \
+                "v_add_f32_dpp %7, %43, %43 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"   \
+                M32 " %2, %18, %26, 0\n\t"   \
+                "v_add_f32_dpp %8, %36, %36 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"   \
+                "v_add_f32_dpp %9, %37, %37 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"   \
+                "v_add_f32_dpp %10, %38, %38 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"   \
+                "v_add_f32_dpp %11, %39, %39 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"   \
+                M32 " %3, %19, %27, 0\n\t"   \
+                "v_add_f32_dpp %8, %44, %44 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"   \
+                "v_add_f32_dpp %9, %45, %45 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"   \
+                "v_add_f32_dpp %10, %46, %46 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"   \
+                "v_add_f32_dpp %11, %47, %47 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"   \
+                M16 " %0, %20, %28, %0\n\t"   \
+                "v_add_f32_dpp %12, %4, %4 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"   \
+                "v_add_f32_dpp %13, %5, %5 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"   \
+                "v_add_f32_dpp %14, %6, %6 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"   \
+                "v_add_f32_dpp %15, %7, %7 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"   \
+                M16 " %1, %21, %29, %1\n\t"   \
+                "v_add_f32_dpp %12, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"   \
+                "v_add_f32_dpp %13, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"   \
+                "v_add_f32_dpp %14, %10, %10 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"   \
+                "v_add_f32_dpp %15, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"   \
+                M16 " %2, %22, %30, %2\n\t"   \
+                "v_add_f32_dpp %12, %12, %12 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   \
+                "v_add_f32_dpp %13, %13, %13 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   \
+                "v_add_f32_dpp %14, %14, %14 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   \
+                "v_add_f32_dpp %15, %15, %15 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   \
+                M16 " %3, %23, %31, %3\n\t"   \
+                "v_add_f32_dpp %12, %12, %12 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"   \
+                "v_add_f32_dpp %13, %13, %13 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"   \
+                "v_add_f32_dpp %14, %14, %14 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"   \
+                "v_add_f32_dpp %15, %15, %15 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"   \
+            : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2),  \
+              "=&v"(b3), "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])                                                                 \
+            : "v"(k32[0][0]), "v"(k32[1][0]), "v"(k32[2][0]), "v"(k32[3][0]), "v"(k16[0]), "v"(k16[1]), "v"(k16[2]), "v"(k16[3]),          \
+              "a"(q32[0][0]), "a"(q32[1][0]), "a"(q32[2][0]), "a"(q32[3][0]), "a"(q16[0]), "a"(q16[1]), "a"(q16[2]), "a"(q16[3]),          \
+              "v"(t[0][0]), "v"(t[0][1]), "v"(t[0][2]), "v"(t[0][3]), "v"(t[1][0]), "v"(t[1][1]), "v"(t[1][2]), "v"(t[1][3]),              \
+              "v"(t[2][0]), "v"(t[2][1]), "v"(t[2][2]), "v"(t[2][3]), "v"(t[3][0]), "v"(t[3][1]), "v"(t[3][2]), "v"(t[3][3]));             \
+    }
+FLB_SCORE_RS_ASM(flb_score_rs_f16, "v_mfma_f32_16x16x32_f16", "v_mfma_f32_16x16x16_f16")
+FLB_SCORE_RS_ASM(flb_score_rs_bf16, "v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x16_bf16")
+
+// the same reduce-scatter from builtins (the scheduler can interleave them with matrix instructions; an inline-assembly block is one unit):
+// every stage adds the DPP-moved partner in all lanes and a select keeps the half each lane owns
+#ifndef FLB_DPP_BUILTIN
+#define FLB_DPP_BUILTIN 0
+#endif
+template <int CTRL>
+__device__ __forceinline__ float flb_dpp(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true)); }
+__device__ __forceinline__ void flb_rowsum4_b(const f32x4_t (&t)[4], f32x4_t& o, const bool hi8, const bool oddbank) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float s1[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float lo = t[p][k] + flb_dpp<0x128>(t[p][k]), hi = t[p + 2][k] + flb_dpp<0x128>(t[p + 2][k]);
+            s1[p] = hi8 ? hi : lo;
+        }
+        const float u0 = s1[0] + flb_dpp<0x141>(s1[0]), u1 = s1[1] + flb_dpp<0x141>(s1[1]);
+        float s2 = oddbank ? u1 : u0;
+        s2 += flb_dpp<0xB1>(s2);
+        s2 += flb_dpp<0x4E>(s2);
+        o[k] = s2;
+    }
+}
+
 template <int H, int DSTEPS, bool TAIL16, bool DROP>
 __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKArgs a) {
     constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
@@ -847,7 +946,11 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
 
         // the streamed operand tiles of q-tile qt0 + i: Q, dO fragments -> stage i & 1, 16-wide dO -> slot i % NK16, row constants -> c0 buffer i & 1
         auto issue_tiles = [&](int i) {
+#ifdef FLB_DBG_SAMETILE
+            const int qt = 0;                 // timing experiment: every workgroup streams the same tile (all L2 hits)
+#else
             const int qt = qt0 + i;
+#endif
 #pragma unroll
             for (int op = 0; op < 3; ++op) {
                 const unsigned char* base = (op == 0) ? a.Qf : ((op == 1) ? a.dOf : a.dO16);
@@ -877,7 +980,9 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
         auto load_q = [&](int i, int h0, Frags& o) { load_frags(smem + (i & 1) * STG, h0, o); };
         auto load_d = [&](int i, int g0, Frags& o) { load_frags(smem + (i & 1) * STG + TILEB, g0, o); };
         // ---- FRONT half of q-tile i (matrix-heavy), chunks of FLB_HB heads
-        auto front_q = [&](int i, auto h0_c, const Frags& qfr, f32x4_t (&sp)[4][H / 4]) {
+        // rs_t / rs_o (both or neither): the terms of a 4-head row-sum reduce-scatter of the PREVIOUS tile's back half, run in the shadow of this chunk's score
+        // products (head dim 33 .. 48 only), and its result
+        auto front_q = [&](int i, auto h0_c, const Frags& qfr, f32x4_t (&sp)[4][H / 4], const f32x4_t (*rs_t)[4] = nullptr, f32x4_t* rs_o = nullptr) {
             constexpr int h0 = decltype(h0_c)::value;
             if constexpr (h0 == 0) {        // the exponent starts from the row constants of query 4 (l >> 4) + r: broadcast LDS reads
                 const unsigned char* cr = smem + C0OFF + (i & 1) * 1024 + (4 * gk) * H * 4;
@@ -888,7 +993,10 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
             }
             f32x4_t c[HB];
             static_assert(HB == 4, "chunk of 4 heads");
-            flb_score_f16<FULL, TAIL16>(qfr.f, qfr.t, &ka[h0], &kta[h0], c);
+            if constexpr (FULL == 1 && TAIL16) {
+                if (rs_t) flb_score_rs_f16(qfr.f, qfr.t, &ka[h0], &kta[h0], c, *rs_t, *rs_o);
+                else flb_score_f16<FULL, TAIL16>(qfr.f, qfr.t, &ka[h0], &kta[h0], c);
+            } else flb_score_f16<FULL, TAIL16>(qfr.f, qfr.t, &ka[h0], &kta[h0], c);
             flb_fence4(c[0], c[1], c[2], c[3]);
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb) {
@@ -899,7 +1007,8 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
                     for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = __builtin_amdgcn_mfma_f32_4x4x1f32(Al4[gh][h0 + hb], cs[r], sp[r][gh], 0, 0, 0);
             }
         };
-        auto front_d = [&](int i, auto g0_c, const Frags& dfr, f32x4_t (&dp)[4][H / 4], const uint32_t (&kb)[4]) {
+        auto front_d = [&](int i, auto g0_c, const Frags& dfr, f32x4_t (&dp)[4][H / 4], const uint32_t (&kb)[4], const f32x4_t (*rs_t)[4] = nullptr,
+                           f32x4_t* rs_o = nullptr) {
             constexpr int g0 = decltype(g0_c)::value;
             unsigned char* gwf = gw_wr + (i & 1) * GWT;
             if constexpr (g0 == 0) {
@@ -909,7 +1018,10 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
                     for (int gh = 0; gh < H / 4; ++gh) dp[r][gh] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             }
             f32x4_t es[HB];
-            flb_score_bf16<FULL, TAIL16>(dfr.f, dfr.t, &va[g0], &vta[g0], es);
+            if constexpr (FULL == 1 && TAIL16) {
+                if (rs_t) flb_score_rs_bf16(dfr.f, dfr.t, &va[g0], &vta[g0], es, *rs_t, *rs_o);
+                else flb_score_bf16<FULL, TAIL16>(dfr.f, dfr.t, &va[g0], &vta[g0], es);
+            } else flb_score_bf16<FULL, TAIL16>(dfr.f, dfr.t, &va[g0], &vta[g0], es);
             flb_fence4(es[0], es[1], es[2], es[3]);
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb) {
@@ -950,17 +1062,30 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
 #pragma unroll
                     for (int k = 0; k < 4; ++k) sp[r][gh][k] = fl_exp2(sp[r][gh][k]);
         };
-        auto back_ds = [&](int i, f32x4_t (&sp)[4][H / 4], f32x4_t (&dp)[4][H / 4]) {
+        // D of q-tile i, head group gh: the lane's terms dP P ; the reduced sums -> this wave's block of the exchange buffer
+        auto d_terms = [&](int gh, f32x4_t (&sp)[4][H / 4], f32x4_t (&dp)[4][H / 4], f32x4_t (&t)[4]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = dp[r][gh] * sp[r][gh];
+        };
+        auto d_store = [&](int i, int gh, const f32x4_t& o) {
+            float* dx = reinterpret_cast<float*>(smem + DXOFF + ((i & 1) * NW + wave) * DXB) + (4 * gk + (gm >> 2)) * H;
+            if ((gm & 3) == 0) *reinterpret_cast<f32x4_t*>(dx + 4 * gh) = o;
+        };
+        auto back_ds = [&](int i, f32x4_t (&sp)[4][H / 4], f32x4_t (&dp)[4][H / 4], bool with_d = true) {
             unsigned char* gwb = gw_wr + 2 * GWT;
             // D[q][g] = sum over this tile's 16 keys (the lanes of a DPP row) of dP P: after the reduce-scatter every quad holds the sums of query
             // row 4 gk + (gm >> 2) -> this wave's block of the exchange buffer
             float* dx = reinterpret_cast<float*>(smem + DXOFF + ((i & 1) * NW + wave) * DXB) + (4 * gk + (gm >> 2)) * H;
 #pragma unroll
-            for (int gh = 0; gh < H / 4; ++gh) {
+            for (int gh = 0; gh < (with_d ? H / 4 : 0); ++gh) {
                 f32x4_t t[4], o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t[r] = dp[r][gh] * sp[r][gh];
+#if FLB_DPP_BUILTIN
+                flb_rowsum4_b(t, o, (gm & 8) != 0, (gm & 4) != 0);
+#else
                 flb_rowsum4(t, o);
+#endif
                 if ((gm & 3) == 0) *reinterpret_cast<f32x4_t*>(dx + 4 * gh) = o;
             }
 #pragma unroll
@@ -1066,17 +1191,30 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
             front_q(i + 1, std::integral_constant<int, 0>{}, fr0, spn);
             back_exp(sp);
             FLB_PHASE();
+            constexpr bool RSF = FLB_RSFUSE && H == 2 * HB && FULL == 1 && TAIL16;      // the D reduce-scatters of tile i ride on two score-product blocks of tile i + 1
+            f32x4_t rt[4], ro0, ro1;
             if constexpr (H > HB) {
                 load_d(i + 1, 0, fr0);
+                if constexpr (RSF) d_terms(0, sp, dp, rt);
                 __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
-                front_q(i + 1, std::integral_constant<int, HB>{}, fr1, spn);
+                if constexpr (RSF) front_q(i + 1, std::integral_constant<int, HB>{}, fr1, spn, &rt, &ro0);
+                else front_q(i + 1, std::integral_constant<int, HB>{}, fr1, spn);
             }
-            back_ds(i, sp, dp);
+            if constexpr (RSF) { d_store(i, 0, ro0); back_ds(i, sp, dp, false); d_terms(1, sp, dp, rt); }
+            else back_ds(i, sp, dp);
+#if FLB_SGB2
+#pragma unroll
+            for (int k = 0; k < FLB_SGB2_N; ++k) {          // interleave request: one matrix instruction, then FLB_SGB2_V vector instructions
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, FLB_SGB2_V, 0);
+            }
+#endif
             FLB_PHASE();
             if constexpr (H > HB) {
                 load_d(i + 1, HB, fr1);
                 __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
-                front_d(i + 1, std::integral_constant<int, 0>{}, fr0, dpn, kbn);
+                if constexpr (RSF) { front_d(i + 1, std::integral_constant<int, 0>{}, fr0, dpn, kbn, &rt, &ro1); d_store(i, 1, ro1); }
+                else front_d(i + 1, std::integral_constant<int, 0>{}, fr0, dpn, kbn);
             } else front_d(i + 1, std::integral_constant<int, 0>{}, fr1, dpn, kbn);
             back_gw(i, sp, pp);
             FLB_PHASE();
