@@ -107,6 +107,15 @@ int spe_layernorm_fwd_h(const float* x, const float* gamma, const float* beta, f
 int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                       const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,
                       const float* add, spe_stream_t stream);
+/* spe_layernorm_bwd_ls (round 5): spe_layernorm_bwd plus, in the same pass, the LayerScale backward of the node that CONSUMES dx - in a
+ * backbone block the input of a norm is out = res + ls_gamma * ls_y, the output of the previous branch's Linear (reference models/cait.py:
+ * 404-405), so dx is that node's `dout`: ls_dy16 [R][C] = bf16(ls_gamma * dx) (the operand of that Linear's backward GEMMs), ls_db[c] += sum_r
+ * ls_gamma[c] dx[r][c] (its bias gradient), ls_dg[c] += sum_r dx[r][c] ls_y[r][c] (the LayerScale gradient) - what
+ * spe_layerscale_residual_bwd16 computes from dx in a launch of its own.  ls_y fp32 [R][C]; no dropout / DropPath in that branch; C <= 512.
+ * The caller must know that dx has no other consumer (the sums land in the gradients before the consuming node runs). */
+int spe_layernorm_bwd_ls(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                         float* dgamma, float* dbeta, long R, int C, const float* add, const float* ls_y, const float* ls_gamma,
+                         void* ls_dy16, float* ls_db, float* ls_dg, spe_stream_t stream);
 
 /* ---- bf16-operand Linear GEMM (benchmark precision mode): C = act(alpha * A16 B16^T + bias), both operands
  * k-contiguous bf16 (lda, ldb, K multiples of 8; 16-B aligned bases), fp32 C / C2 (pre-activation) / bias.

@@ -69,30 +69,39 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // dx per row; dgamma/dbeta accumulated per wave in registers over a grid-stride row loop, combined through LDS, then across
 // the workgroups in a fixed order (det_reduce.h) and added to the running gradient.
-template <int NW>
+// LS (round 5): the LayerScale backward of the node that CONSUMES dx - dx is the `dout` of out = res + ls_gamma * ls_y (the branch Linear before this
+// norm's input, reference models/cait.py:404-405) - rides on the same pass: ls_dy16 = bf16(ls_gamma * dx) (the operand of that Linear's backward GEMMs),
+// ls_db += sum_r ls_gamma * dx (its bias gradient), ls_dg += sum_r dx * ls_y (the LayerScale gradient) - what spe_layerscale_residual_bwd16 would compute
+// from dx in a launch of its own after re-reading it.
+template <int NW, bool LS, int MAXV>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      long R, int C, const float* __restrict__ add, float* __restrict__ dz,
-                                                     float p, uint64_t seed, uint64_t offset, DetWs ws) {
-    extern __shared__ float red_raw[];                 // [2][NW][C + 4]
+                                                     float p, uint64_t seed, uint64_t offset, DetWs ws,
+                                                     const float* __restrict__ ls_y, const float* __restrict__ ls_gamma,
+                                                     unsigned short* __restrict__ ls_dy16, float* __restrict__ ls_db, float* __restrict__ ls_dg) {
+    extern __shared__ float red_raw[];                 // [2 (LS: 4)][NW][C + 4]
     const int ldr = C + 4;
     auto red = [&](int k, int wv, int c) -> float& { return red_raw[((long)k * NW + wv) * ldr + c]; };
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int C4 = C >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
-    float4 ag[LN_MAXV], ab[LN_MAXV];
+    float4 ag[MAXV], ab[MAXV];
+    float4 lg[LS ? MAXV : 1], lb[LS ? MAXV : 1];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
+    for (int i = 0; i < MAXV; ++i) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
+#pragma unroll
+    for (int i = 0; i < (LS ? MAXV : 1); ++i) { lg[i] = make_float4(0, 0, 0, 0); lb[i] = make_float4(0, 0, 0, 0); }
     for (long row = (long)blockIdx.x * NW + w; row < R; row += (long)gridDim.x * NW) {
         const float4* xr = reinterpret_cast<const float4*>(x + row * C);
         const float4* dr = reinterpret_cast<const float4*>(dy + row * C);
         const float mu = mean[row], rs = rstd[row];
-        float4 xh[LN_MAXV], dg[LN_MAXV];
+        float4 xh[MAXV], dg[MAXV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < MAXV; ++i) {
             const int c = lane + 64 * i;
             if (c < C4) {
                 const float4 xv = xr[c], dv = dr[c], g = g4[c];
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict
         float4* dxr = reinterpret_cast<float4*>(dx + row * C);
         const float4* ar = add ? reinterpret_cast<const float4*>(add + row * C) : nullptr;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < MAXV; ++i) {
             const int c = lane + 64 * i;
             if (c < C4) {
                 float4 o;
@@ -117,6 +126,16 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict
                 o.z = rs * (dg[i].z - s1 - xh[i].z * s2); o.w = rs * (dg[i].w - s1 - xh[i].w * s2);
                 if (ar) { const float4 a4 = ar[c]; o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w; }   // + gradient of the skip path
                 dxr[c] = o;
+                if constexpr (LS) {
+                    const float4 yv = reinterpret_cast<const float4*>(ls_y + row * C)[c], gg = reinterpret_cast<const float4*>(ls_gamma)[c];
+                    lg[i].x += o.x * yv.x; lg[i].y += o.y * yv.y; lg[i].z += o.z * yv.z; lg[i].w += o.w * yv.w;
+                    const float4 q = make_float4(o.x * gg.x, o.y * gg.y, o.z * gg.z, o.w * gg.w);
+                    lb[i].x += q.x; lb[i].y += q.y; lb[i].z += q.z; lb[i].w += q.w;
+                    typedef __bf16 bf16x4n_t __attribute__((ext_vector_type(4)));
+                    bf16x4n_t h;
+                    h[0] = (__bf16)q.x; h[1] = (__bf16)q.y; h[2] = (__bf16)q.z; h[3] = (__bf16)q.w;
+                    *reinterpret_cast<uint2*>(ls_dy16 + row * C + 4 * c) = __builtin_bit_cast(uint2, h);
+                }
                 if (dz) {          // gradient of the dropped branch of norm(x + dropout(z)): same mask as ln_res_fwd_kernel
                     float ks[4];
                     spe_drop_scale4(seed, offset, (uint64_t)(row * C + 4 * c), p, ks);
@@ -126,24 +145,32 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict
         }
     }
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
         if (c < C4) {
             red(0, w, 4 * c + 0) = ag[i].x; red(0, w, 4 * c + 1) = ag[i].y; red(0, w, 4 * c + 2) = ag[i].z; red(0, w, 4 * c + 3) = ag[i].w;
             red(1, w, 4 * c + 0) = ab[i].x; red(1, w, 4 * c + 1) = ab[i].y; red(1, w, 4 * c + 2) = ab[i].z; red(1, w, 4 * c + 3) = ab[i].w;
+            if constexpr (LS) {
+                red(2, w, 4 * c + 0) = lg[i].x; red(2, w, 4 * c + 1) = lg[i].y; red(2, w, 4 * c + 2) = lg[i].z; red(2, w, 4 * c + 3) = lg[i].w;
+                red(3, w, 4 * c + 0) = lb[i].x; red(3, w, 4 * c + 1) = lb[i].y; red(3, w, 4 * c + 2) = lb[i].z; red(3, w, 4 * c + 3) = lb[i].w;
+            }
         }
     }
     __syncthreads();
-    // the 16 waves' column sums in wave order, then across workgroups in a fixed order (det_reduce.h): dgamma / dbeta += total
-    det_reduce(ws, 0, blockIdx.x, gridDim.x, 2 * C, threadIdx.x, NW * 64,
+    // the 16 waves' column sums in wave order, then across workgroups in a fixed order (det_reduce.h): dgamma / dbeta (/ ls_dg / ls_db) += total
+    det_reduce(ws, 0, blockIdx.x, gridDim.x, (LS ? 4 : 2) * C, threadIdx.x, NW * 64,
                [&](int c) {
-                   const int k = c >= C, cc = k ? c - C : c;
+                   const int k = c / C, cc = c - k * C;
                    float t = 0.f;
 #pragma unroll
                    for (int wv = 0; wv < NW; ++wv) t += red(k, wv, cc);
                    return t;
                },
-               [&](int c, float t) { float* d = (c >= C) ? dbeta + (c - C) : dgamma + c; *d += t; });
+               [&](int c, float t) {
+                   const int k = c / C, cc = c - k * C;
+                   float* d = (k == 0) ? dgamma : ((k == 1) ? dbeta : ((k == 2) ? ls_dg : ls_db));
+                   d[cc] += t;
+               });
 }
 
 // Post-norm residual site of the DETR encoder / decoder layers, `norm(x + dropout(z))` (reference models/transformer.py:
@@ -334,29 +361,48 @@ extern "C" int spe_layernorm_fwd_h(const float* x, const float* gamma, const flo
 }
 static int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
                          float* dgamma, float* dbeta, long R, int C, const float* add, float* dz, float p, uint64_t seed,
-                         uint64_t offset, hipStream_t st) {
+                         uint64_t offset, hipStream_t st, const float* ls_y = nullptr, const float* ls_gamma = nullptr, void* ls_dy16 = nullptr,
+                         float* ls_db = nullptr, float* ls_dg = nullptr) {
     if (R <= 0) return 0;
     if ((C & 3) || C > 256 * LN_MAXV) return -2;
-    // 16 waves per workgroup, at most 256 workgroups: every workgroup ends with a 2*C-value partial for the cross-workgroup sum
+    const bool ls = ls_y != nullptr;
+    if (ls && (!ls_gamma || !ls_dy16 || !ls_db || !ls_dg || dz || C > 512 ||
+               ((reinterpret_cast<uintptr_t>(ls_y) | reinterpret_cast<uintptr_t>(ls_gamma) | reinterpret_cast<uintptr_t>(ls_dy16)) & 15))) return -2;
+    // 16 waves per workgroup, at most 256 workgroups: every workgroup ends with a 2*C-value (LS: 4*C) partial for the cross-workgroup sum
     constexpr int NW = 16;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           2 * NW * (256 * LN_MAXV + 4) * (int)sizeof(float));
+    static bool attr[3] = {false, false, false};
+    const int variant = ls ? 1 : (C <= 512 ? 2 : 0);
+    if (!attr[variant]) {
+        const void* fn = ls ? reinterpret_cast<const void*>(&ln_bwd_kernel<NW, true, 2>)
+                            : (C <= 512 ? reinterpret_cast<const void*>(&ln_bwd_kernel<NW, false, 2>) : reinterpret_cast<const void*>(&ln_bwd_kernel<NW, false, LN_MAXV>));
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           ls ? 4 * NW * (512 + 4) * (int)sizeof(float) : 2 * NW * (256 * LN_MAXV + 4) * (int)sizeof(float));
         if (e != hipSuccess) return (int)e;
-        attr = true;
+        attr[variant] = true;
     }
     long nb = (R + NW - 1) / NW; if (nb > 256) nb = 256;
     DetWs ws = spe_detws();
-    // deferred (destinations inside the registered bucket ranges): the workgroups leave their 2 C partials behind, dgamma / dbeta += totals at the next flush
-    const DetDeferSeg sg[2] = {{dgamma, C}, {dbeta, C}};
-    float* region = det_defer_try(1, nb, 2 * C, 2, sg, st);
-    if (region) ws.defer = region; else DET_CHECK(ws, 1, nb, 2 * C);
-    hipLaunchKernelGGL(ln_bwd_kernel<NW>, dim3((unsigned)nb), dim3(NW * 64), 2 * NW * (C + 4) * (int)sizeof(float), st, dy, x, gamma, mean,
-                       rstd, dx, dgamma, dbeta, R, C, add, dz, p, seed, offset, ws);
-    if (region) det_defer_commit(region, 1, nb, 2 * C, 2, sg, 1);
+    const int nk = ls ? 4 : 2;
+    // deferred (destinations inside the registered bucket ranges): the workgroups leave their partials behind, the totals land at the next flush
+    const DetDeferSeg sg[4] = {{dgamma, C}, {dbeta, C}, {ls_dg, C}, {ls_db, C}};
+    float* region = det_defer_try(1, nb, nk * C, nk, sg, st);
+    if (region) ws.defer = region; else DET_CHECK(ws, 1, nb, nk * C);
+    if (ls) hipLaunchKernelGGL((ln_bwd_kernel<NW, true, 2>), dim3((unsigned)nb), dim3(NW * 64), 4 * NW * (C + 4) * (int)sizeof(float), st, dy, x, gamma, mean,
+                               rstd, dx, dgamma, dbeta, R, C, add, dz, p, seed, offset, ws, ls_y, ls_gamma, reinterpret_cast<unsigned short*>(ls_dy16), ls_db, ls_dg);
+    else if (C <= 512) hipLaunchKernelGGL((ln_bwd_kernel<NW, false, 2>), dim3((unsigned)nb), dim3(NW * 64), 2 * NW * (C + 4) * (int)sizeof(float), st, dy, x, gamma, mean,
+                                          rstd, dx, dgamma, dbeta, R, C, add, dz, p, seed, offset, ws, nullptr, nullptr, nullptr, nullptr, nullptr);
+    else hipLaunchKernelGGL((ln_bwd_kernel<NW, false, LN_MAXV>), dim3((unsigned)nb), dim3(NW * 64), 2 * NW * (C + 4) * (int)sizeof(float), st, dy, x, gamma, mean,
+                            rstd, dx, dgamma, dbeta, R, C, add, dz, p, seed, offset, ws, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (region) det_defer_commit(region, 1, nb, nk * C, nk, sg, 1);
     SPE_CHECK_LAUNCH();
     return 0;
+}
+// C-ABI: see include/spe_hip.h (spe_layernorm_bwd_ls): LayerNorm backward + the LayerScale backward of the node that consumes dx, one pass.
+extern "C" int spe_layernorm_bwd_ls(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                                    float* dgamma, float* dbeta, long R, int C, const float* add, const float* ls_y, const float* ls_gamma,
+                                    void* ls_dy16, float* ls_db, float* ls_dg, hipStream_t st) {
+    if (!ls_y) return -2;
+    return ln_bwd_launch(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, add, nullptr, 0.f, 0, 0, st, ls_y, ls_gamma, ls_dy16, ls_db, ls_dg);
 }
 extern "C" int spe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                  const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,

@@ -654,16 +654,20 @@ def linear_res_fwd(x2, W, b, res, gamma, save=True, src=None, drop=None, sscale=
     return out, ((x16 if DW_TN else x16T), y)
 
 
-def linear_res_bwd(dout2, saved, W, gamma, need_dx=True, grad_bufs=(None, None, None), drop=None, sscale=None, rps=1):
-    """Backward of linear_res_fwd: (dx, dW, db, dgamma); gamma * dout only exists as the bf16 operands of the two GEMMs."""
+def linear_res_bwd(dout2, saved, W, gamma, need_dx=True, grad_bufs=(None, None, None), drop=None, sscale=None, rps=1, pre=None):
+    """Backward of linear_res_fwd: (dx, dW, db, dgamma); gamma * dout only exists as the bf16 operands of the two GEMMs.
+    pre = (dy16, db, dgamma): the LayerScale part was already taken by the LayerNorm backward that produced dout (layernorm_bwd ls=)."""
     xs, y = saved
     R, N = dout2.shape
     K = W.shape[1]
     gW, gb, gg = grad_bufs
     if _is_rowmajor_save(xs, R):
         Rp = ((R + 63) // 64) * 64
-        dy16, _, db, dg = layerscale_residual_bwd16(dout2, y, gamma, Rp, db_out=gb, dg_out=gg, want_rowmajor=True, want_T=False,
-                                                    drop=drop, sscale=sscale, rps=rps)
+        if pre is not None:
+            dy16, db, dg = pre
+        else:
+            dy16, _, db, dg = layerscale_residual_bwd16(dout2, y, gamma, Rp, db_out=gb, dg_out=gg, want_rowmajor=True, want_T=False,
+                                                        drop=drop, sscale=sscale, rps=rps)
         dW = _dw16_tn(dy16, xs, N, K, R, gW)
     else:
         Rp = xs.shape[1]
@@ -779,7 +783,7 @@ def _dw16_tn(dy16, x16, N, K, R, dW_out, lda=None):
 
 
 def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, None), gamma=None, dg_out=None,
-                 drop1=None, drop2=None, sscale=None, rps=1):
+                 drop1=None, drop2=None, sscale=None, rps=1, ls_pre=None):
     """Backward of mlp_gelu_fwd.  dy2 [R,N] fp32.  -> (dx, dW1, db1, dW2, db2).  The gradient w.r.t. the pre-activation
     exists only as the bf16 copies (row-major for dx, transposed for dW1) written by the dh GEMM's epilogue, which also
     applies gelu' and accumulates db1.  grad_bufs: zeroed bucket views for (dW1, db1, dW2, db2) or None."""
@@ -791,7 +795,10 @@ def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, 
     dev = dy2.device
     gW1, gb1, gW2, gb2 = grad_bufs
     dg = None
-    if gamma is not None:        # residual form: dy2 is d(out); the branch gradient gamma * dout only exists in bf16
+    if gamma is not None and ls_pre is not None and tn:      # the LayerScale part came with the LayerNorm backward that produced dy2 (layernorm_bwd ls=)
+        dy16, db2, dg = ls_pre
+        dy16T = None
+    elif gamma is not None:        # residual form: dy2 is d(out); the branch gradient gamma * dout only exists in bf16
         dy16, dy16T, db2, dg = layerscale_residual_bwd16(dy2, saved[3], gamma, Rp, db_out=gb2, dg_out=dg_out, want_T=not tn,
                                                          drop=drop2, sscale=sscale, rps=rps)
     else:
@@ -1035,13 +1042,26 @@ def attach16(t, x16, x16lo=None):
     t._spe16 = (t._version, x16, None, x16lo)
 
 
-def layernorm_bwd(dy2, x2, g, mean, rstd, dg_out=None, db_out=None, add=None):
-    """add [R,C]: gradient of the skip path around the normalised branch, summed into dx by the same kernel."""
+LN_LS_FUSE = True        # LayerScale backward of the consuming node inside the LayerNorm backward (module attribute: the tests run both settings)
+
+
+def layernorm_bwd(dy2, x2, g, mean, rstd, dg_out=None, db_out=None, add=None, ls=None):
+    """add [R,C]: gradient of the skip path around the normalised branch, summed into dx by the same kernel.
+    ls = (y [R,C] fp32, gamma [C], db_out, dg_out): dx is the `dout` of a node out = res + gamma * y whose output feeds ONLY this norm - its
+    LayerScale backward (layerscale_residual_bwd16 without rates) rides on the same pass -> (dx, dg, db, (dy16, ls_db, ls_dg))."""
     _chk(dy2, x2, g)
     R, C = x2.shape
     dx = torch.empty_like(x2)
     dg = _zeros_or(dg_out, C, x2.device)
     db = _zeros_or(db_out, C, x2.device)
+    if ls is not None:
+        y, lgam, ls_db_out, ls_dg_out = ls
+        dy16 = torch.empty((R, C), device=x2.device, dtype=torch.bfloat16)
+        ldb = _zeros_or(ls_db_out, C, x2.device)
+        ldg = _zeros_or(ls_dg_out, C, x2.device)
+        _call("spe_layernorm_bwd_ls", _p(dy2), _p(x2), _p(g), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), R, C, _p(add), _p(y), _p(lgam), _p(dy16),
+              _p(ldb), _p(ldg), _st())
+        return dx, dg, db, (dy16, ldb, ldg)
     _call("spe_layernorm_bwd", _p(dy2), _p(x2), _p(g), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), R, C, _p(add), _st())
     return dx, dg, db
 

@@ -107,7 +107,9 @@ class LayerScale_Block(nn.Module):
         self.gamma_1 = nn.Parameter(init_values * torch.ones(dim))
         self.gamma_2 = nn.Parameter(init_values * torch.ones(dim))
 
-    def forward(self, x):
+    def forward(self, x, single_out=False):
+        """single_out: the caller promises that the block's output feeds ONE LayerNorm-skip node (the next block's norm1) and nothing else - its
+        LayerScale backward then rides on that norm's backward (ops._LayerNormSkip); the attention branch's output always does (norm2 below)."""
         B = x.shape[0]
         # norm.skip(x) -> (LN(x), x): the residual operand comes back through the LayerNorm node, whose backward kernel
         # adds the skip-path gradient to the normalisation's (one launch less per branch than autograd's sum)
@@ -117,7 +119,7 @@ class LayerScale_Block(nn.Module):
         if isinstance(self.attn, Attention_talking_head):
             # output projection (+ proj_drop) + DropPath + LayerScale residual as one node (same arithmetic, same dropout stream)
             x = ops.linear_residual(self.attn.context(y), self.attn.proj.weight, self.attn.proj.bias, xs, self.gamma_1, ss1,
-                                    self.attn.proj_drop.p if self.training else 0.0)
+                                    self.attn.proj_drop.p if self.training else 0.0, single=skip)
         else:
             x = ops.layerscale_residual(xs, self.attn(y), self.gamma_1, ss1)
         ss = ops.drop_path_scale(B, self.drop_path, self.training, x.device)
@@ -127,8 +129,13 @@ class LayerScale_Block(nn.Module):
         y, xs = self.norm2.skip(x, mlp16) if skip else (self.norm2(x), x)
         if isinstance(self.mlp, Mlp):
             return ops.mlp_gelu_residual(y, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight,
-                                         self.mlp.fc2.bias, xs, self.gamma_2, ss, self.mlp.drop.p if self.training else 0.0)
+                                         self.mlp.fc2.bias, xs, self.gamma_2, ss, self.mlp.drop.p if self.training else 0.0, single=single_out)
         return ops.layerscale_residual(xs, self.mlp(y), self.gamma_2, ss)
+
+
+def _skip_norms(blk):
+    """The block starts with a LayerNorm-skip node (both norms are spe_amd LayerNorms): what `single_out` of the block before it relies on."""
+    return isinstance(blk, LayerScale_Block) and isinstance(blk.norm1, LayerNorm) and isinstance(blk.norm2, LayerNorm)
 
 
 class Multi_Class_Attention(nn.Module):
@@ -297,8 +304,10 @@ class TSCAM_cait(_TSCAMBase):
         hw = (H // self.patch_size, W // self.patch_size)
         x, cls_tokens = self._embed(x)
         x_feat = None
+        nb = len(self.blocks)
         for i, blk in enumerate(self.blocks):
-            x = blk(x)
+            # (a block output that only the next block's norm1 reads: not the tapped one, not the last)
+            x = blk(x, single_out=(i != self.layer_to_det and i + 1 < nb and _skip_norms(self.blocks[i + 1])))
             if i == self.layer_to_det:
                 x_feat = self.norm_to_det(x)
         x_logits, x_cls_logits = self._heads(x, cls_tokens)
@@ -330,12 +339,13 @@ class TSCAM_cait_two_branch(_TSCAMBase):
         hw = (H // self.patch_size, W // self.patch_size)
         x, cls_tokens = self._embed(x)
         x_feat = None
+        nb, nd = len(self.blocks), len(self.blocks_det)
         for i, blk in enumerate(self.blocks):
-            x = blk(x)
+            x = blk(x, single_out=(i + 1 != self.layer_to_det and i + 1 < nb and _skip_norms(self.blocks[i + 1])))
             if i + 1 == self.layer_to_det:
                 x_feat = x
-        for blk in self.blocks_det:
-            x_feat = blk(x_feat)
+        for i, blk in enumerate(self.blocks_det):
+            x_feat = blk(x_feat, single_out=(i + 1 < nd and _skip_norms(self.blocks_det[i + 1])))
         x_feat = self.norm_det(x_feat)
         x_logits, x_cls_logits = self._heads(x, cls_tokens)
         K = self.num_classes

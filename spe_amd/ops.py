@@ -270,6 +270,11 @@ class _LayerNormSkip(Function):
             y, mean, rstd = K.layernorm_fwd(x2, g, b, eps)
             yv = y.view(x.shape)
         ctx.params = (g, b)
+        # the node that produced x, when it is a LayerScale-residual Linear / MLP node whose output feeds ONLY this norm (its caller said so: `single`):
+        # this norm's backward then also takes that node's LayerScale backward - gamma * dx as bf16, the bias and gamma column sums - from the dx it is
+        # writing anyway (kernels.layernorm_bwd ls=), instead of that node re-reading dx in a launch of its own
+        prod = x.grad_fn if (K.LN_LS_FUSE and x.requires_grad) else None
+        ctx.prod = prod if (prod is not None and getattr(prod, "ls_single", False) and x2.shape[1] <= 512) else None
         ctx.save_for_backward(x2, g, mean, rstd)
         return yv, x.view_as(x)
 
@@ -288,6 +293,15 @@ class _LayerNormSkip(Function):
             add = dskip.reshape(-1, dskip.shape[-1])
             if not add.is_contiguous():
                 add = add.contiguous()
+        prod = ctx.prod
+        if prod is not None:
+            # (y, gamma) of the producing node and the bucket views of its bias / gamma gradients; the node finds the results in prod.ls_done
+            yls, gls, bpar, gpar = _ls_args(prod)
+            dx, dg, db, done = K.layernorm_bwd(dy2, x2, g, mean, rstd, dg_out=K.grad_buffer(gp), db_out=K.grad_buffer(bp), add=add,
+                                               ls=(yls, gls, K.grad_buffer(bpar), K.grad_buffer(gpar)))
+            dxv = dx.view(dy.shape)
+            prod.ls_done = (done, dx.data_ptr())
+            return dxv, dg.view_as(gp), db.view_as(bp), None, None
         dx, dg, db = K.layernorm_bwd(dy2, x2, g, mean, rstd, dg_out=K.grad_buffer(gp), db_out=K.grad_buffer(bp), add=add)
         return dx.view(dy.shape), dg.view_as(gp), db.view_as(bp), None, None
 
@@ -657,7 +671,7 @@ class _LinearRes(Function):
 
     @staticmethod
     @K.forward_scope
-    def forward(ctx, x, W, b, xres, gamma, sscale=None, p_drop=0.0):
+    def forward(ctx, x, W, b, xres, gamma, sscale=None, p_drop=0.0, single=False):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         if not x2.is_contiguous():
@@ -669,6 +683,11 @@ class _LinearRes(Function):
         # training rates of the block (cait.py:391 proj_drop, :404 drop_path) ride on the epilogue: dropout mask of spe_dropout's stream,
         # DropPath keep scale per sample
         ctx.drop = (float(p_drop), *K.next_rng()) if p_drop > 0 else None
+        # `single`: the caller promises that the output feeds one LayerNorm-skip node and nothing else - that norm's backward may then take this
+        # node's LayerScale backward along (ops._LayerNormSkip); only without rates, with fp32 saves and bias / gamma gradients wanted
+        ctx.ls_single = bool(single and train and p_drop <= 0 and sscale is None and not K.MLP_PRE_F16 and K.DW_TN and W.requires_grad
+                             and b.requires_grad and gamma.requires_grad)
+        ctx.ls_done = None
         ctx.rps = r2.shape[0] // xres.shape[0]
         out, saved = K.linear_res_fwd(x2, W, b, r2, gamma, save=train, src=x, drop=ctx.drop, sscale=sscale, rps=ctx.rps)
         ctx.params = (W, b, gamma)
@@ -685,23 +704,46 @@ class _LinearRes(Function):
         d2 = dout.reshape(-1, W.shape[0])
         if not d2.is_contiguous():
             d2 = d2.contiguous()
+        pre = _ls_taken(ctx, d2)
         bufs = tuple(K.grad_buffer(p) for p in ctx.params)
-        dx, dW, db, dg = K.linear_res_bwd(d2, (x16T, y), W, gamma, ctx.needs_input_grad[0], bufs, drop=ctx.drop, sscale=ss, rps=ctx.rps)
-        return (dx.view(*dout.shape[:-1], W.shape[1]) if dx is not None else None), dW, db, dout, dg.view_as(gamma), None, None
+        dx, dW, db, dg = K.linear_res_bwd(d2, (x16T, y), W, gamma, ctx.needs_input_grad[0], bufs, drop=ctx.drop, sscale=ss, rps=ctx.rps, pre=pre)
+        return (dx.view(*dout.shape[:-1], W.shape[1]) if dx is not None else None), dW, db, dout, dg.view_as(gamma), None, None, None
+
+def _ls_args(prod):
+    """(branch output y, gamma, bias parameter, gamma parameter) of a LayerScale-residual node (the ctx of a _LinearRes / _MlpGeluRes: an instance of
+    the generated backward class, which carries `_forward_cls`) for the LayerNorm backward that takes its LayerScale backward along."""
+    sv = prod.saved_tensors
+    if prod._forward_cls is _LinearRes:
+        return sv[1], sv[3], prod.params[1], prod.params[2]
+    return sv[3], sv[6], prod.params[3], prod.params[4]           # _MlpGeluRes
+
+
+def _ls_taken(ctx, d2):
+    """The (dy16, db, dgamma) a LayerNorm backward left for this node (see _LayerNormSkip), or None.  The sums are already in the gradients: the
+    incoming gradient must be the very tensor that backward wrote - anything else means the single-consumer promise was broken."""
+    done = getattr(ctx, "ls_done", None)
+    if done is None:
+        return None
+    ctx.ls_done = None
+    pre, ptr = done
+    if d2.data_ptr() != ptr:
+        raise RuntimeError("spe_amd.ops: a node was marked single=True but its output had more than one consumer (the LayerNorm backward already "
+                           "accumulated its bias / LayerScale gradients from a partial gradient)")
+    return pre
 
 
 FUSE_DROP = True      # dropout / DropPath inside the fused residual nodes (module attribute: tests/test_round4_gpu.py runs both settings)
 
 
-def linear_residual(x, W, b, xres, gamma, sample_scale=None, p_drop=0.0):
+def linear_residual(x, W, b, xres, gamma, sample_scale=None, p_drop=0.0, single=False):
     """xres + s * gamma * dropout(linear(x)): one fused node on the bf16-copy GEMM path (the training rates ride on its epilogue), else
-    linear, dropout and layerscale_residual."""
+    linear, dropout and layerscale_residual.  single: the result feeds ONE LayerNorm-skip node and nothing else (see _LinearRes)."""
     R = x.numel() // x.shape[-1]
     N, Kd = W.shape
     if (FUSE_LINEAR_RES and (FUSE_DROP or (sample_scale is None and p_drop <= 0)) and b is not None and W.is_contiguous()
             and gamma.is_contiguous() and N % 4 == 0 and N <= 1024 and K._lin16_ok(R, N, Kd)
             and (sample_scale is None or (sample_scale.is_contiguous() and R % xres.shape[0] == 0))):
-        return _LinearRes.apply(x, W, b, xres, gamma, sample_scale, p_drop)
+        return _LinearRes.apply(x, W, b, xres, gamma, sample_scale, p_drop, single)
     return layerscale_residual(xres, dropout(linear(x, W, b), p_drop, p_drop > 0), gamma, sample_scale)
 
 
@@ -712,7 +754,7 @@ class _MlpGeluRes(Function):
 
     @staticmethod
     @K.forward_scope
-    def forward(ctx, x, W1, b1, W2, b2, xres, gamma, sscale=None, p_drop=0.0):
+    def forward(ctx, x, W1, b1, W2, b2, xres, gamma, sscale=None, p_drop=0.0, single=False):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         if not x2.is_contiguous():
@@ -725,6 +767,9 @@ class _MlpGeluRes(Function):
         # sites draw their streams in that order, like the unfused composition
         ctx.drop1 = (float(p_drop), *K.next_rng()) if p_drop > 0 else None
         ctx.drop2 = (float(p_drop), *K.next_rng()) if p_drop > 0 else None
+        ctx.ls_single = bool(single and train and p_drop <= 0 and sscale is None and not K.MLP_PRE_F16 and K.DW_TN and W2.requires_grad
+                             and b2.requires_grad and gamma.requires_grad)          # see _LinearRes
+        ctx.ls_done = None
         ctx.rps = r2.shape[0] // xres.shape[0]
         out, saved = K.mlp_gelu_fwd(x2, W1, b1, W2, b2, res=r2, gamma=gamma, save=train, src=x, drop1=ctx.drop1, drop2=ctx.drop2,
                                     sscale=sscale, rps=ctx.rps)
@@ -743,15 +788,16 @@ class _MlpGeluRes(Function):
         if not d2.is_contiguous():
             d2 = d2.contiguous()
         W1p, b1p, W2p, b2p, gp = ctx.params
+        taken = _ls_taken(ctx, d2)
         bufs = tuple(K.grad_buffer(p) for p in (W1p, b1p, W2p, b2p))
         dx, dW1, db1, dW2, db2, dg = K.mlp_gelu_bwd(d2, (x16T, pre, h16T, y), W1, W2, ctx.needs_input_grad[0], bufs,
                                                      gamma=gamma, dg_out=K.grad_buffer(gp), drop1=ctx.drop1, drop2=ctx.drop2,
-                                                     sscale=ss, rps=ctx.rps)
+                                                     sscale=ss, rps=ctx.rps, ls_pre=taken)
         return ((dx.view(*dout.shape[:-1], W1.shape[1]) if dx is not None else None), dW1, db1, dW2, db2, dout,
-                dg.view_as(gamma), None, None)
+                dg.view_as(gamma), None, None, None)
 
 
-def mlp_gelu_residual(x, W1, b1, W2, b2, xres, gamma, sample_scale=None, p_drop=0.0):
+def mlp_gelu_residual(x, W1, b1, W2, b2, xres, gamma, sample_scale=None, p_drop=0.0, single=False):
     """xres + s * gamma * drop(fc2(drop(gelu(fc1(x))))).  One fused node when the MLP takes the bf16-copy path (dropout and the per-sample
     DropPath scale ride on the GEMM epilogues); otherwise the composition of the single operators (same arithmetic, same masks)."""
     R = x.numel() // x.shape[-1]
@@ -759,7 +805,7 @@ def mlp_gelu_residual(x, W1, b1, W2, b2, xres, gamma, sample_scale=None, p_drop=
             and gamma.is_contiguous() and W2.shape[0] % 4 == 0 and W1.shape[0] % 4 == 0 and W2.shape[0] <= 1024
             and K.mlp16_ok(R, W1.shape[1], W1.shape[0], W2.shape[0])
             and (sample_scale is None or (sample_scale.is_contiguous() and R % xres.shape[0] == 0))):
-        return _MlpGeluRes.apply(x, W1, b1, W2, b2, xres, gamma, sample_scale, p_drop)
+        return _MlpGeluRes.apply(x, W1, b1, W2, b2, xres, gamma, sample_scale, p_drop, single)
     if p_drop > 0:
         h = dropout(linear(x, W1, b1, ACT_GELU), p_drop, True)
         return layerscale_residual(xres, dropout(linear(h, W2, b2), p_drop, True), gamma, sample_scale)

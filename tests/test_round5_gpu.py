@@ -510,3 +510,54 @@ def test_mlp_forward_on_fp16_operands(dev):
         assert K.weight16(W1, lo=True, f16=True)[2].data_ptr() == w[2].data_ptr()
     finally:
         K.MLP_F16 = saved
+
+
+def test_layerscale_backward_rides_on_the_layernorm_backward(dev):
+    """Round 5: in a stack of backbone blocks the LayerScale backward of a residual node whose output feeds only the next LayerNorm
+    (spe_layerscale_residual_bwd16: gamma * dout as bf16, bias and gamma column sums) is taken by that LayerNorm's backward from the dx it
+    writes anyway (spe_layernorm_bwd_ls) - same gradients as the separate launches to summation order (reference: the autograd of
+    models/cait.py:404-416), fewer launches; a broken single-consumer promise raises instead of returning wrong gradients."""
+    import torch.nn as nn
+    from spe_amd import kernels as K, lib
+    from spe_amd.models.cait import LayerScale_Block
+    K.set_precision("bf16s")
+    torch.manual_seed(4)
+    C, H, B, N = 384, 8, 2, 1100
+    blocks = nn.ModuleList([LayerScale_Block(C, H, init_values=0.4) for _ in range(3)]).to(dev).train()
+    x0 = torch.randn(B, N, C, device=dev)
+    w = torch.randn(B, N, C, device=dev)
+
+    def run(fuse):
+        old = K.LN_LS_FUSE
+        K.LN_LS_FUSE = fuse
+        try:
+            x = x0.clone().requires_grad_(True)
+            for p in blocks.parameters():
+                p.grad = None
+            lib.count_launches(True)
+            y = x
+            for i, b in enumerate(blocks):
+                y = b(y, single_out=i + 1 < len(blocks))
+            (y * w).sum().backward()
+            counts = lib.count_launches(False)
+            return y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in blocks.named_parameters()}, counts
+        finally:
+            K.LN_LS_FUSE = old
+
+    yf, dxf, gf, cf = run(True)
+    yc, dxc, gc, cc = run(False)
+    assert torch.equal(yf, yc)
+    assert cf.get("spe_layernorm_bwd_ls", 0) == 5 and cc.get("spe_layernorm_bwd_ls", 0) == 0          # 3 attention branches + 2 block outputs
+    assert cc["spe_layerscale_residual_bwd16"] - cf.get("spe_layerscale_residual_bwd16", 0) == 5
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    assert rel(dxf, dxc) < 1e-6
+    for n in gc:
+        assert rel(gf[n], gc[n]) < 2e-5, (n, rel(gf[n], gc[n]))
+    # a promise that does not hold: the output is read by the next block AND by the loss
+    x = x0.clone().requires_grad_(True)
+    y1 = blocks[0](x, single_out=True)
+    y2 = blocks[1](y1)
+    with pytest.raises(RuntimeError, match="more than one consumer"):
+        ((y2 + y1) * w).sum().backward()
+    for p in blocks.parameters():
+        p.grad = None
