@@ -672,6 +672,7 @@ __global__ __launch_bounds__(NW * 64) void lsres_bwd_rows_kernel(const float* __
 // to ldt = R rounded up to 64), plus db[c] += sum_r dy (that Linear's bias gradient) and dgamma[c] += sum_r dout * y.
 // A workgroup of 16 waves owns 64-row tiles: wave w converts rows w, w+16, w+32, w+48 of the tile (16-B loads, 8-B bf16
 // stores) and stages them in LDS, then the tile leaves transposed as 16-B stores of 8 consecutive rows per column.
+template <int MAXV>
 __global__ __launch_bounds__(1024) void lsres_bwd16_kernel(const float* __restrict__ dout, const float* __restrict__ y,
                                                            const float* __restrict__ gamma, unsigned short* __restrict__ dy16,
                                                            unsigned short* __restrict__ dy16T, long ldt, float* __restrict__ db,
@@ -681,9 +682,9 @@ __global__ __launch_bounds__(1024) void lsres_bwd16_kernel(const float* __restri
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int C4 = C >> 2, ldl = C + 8;
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
-    float4 ag[LN_MAXV], ab[LN_MAXV], g[LN_MAXV];
+    float4 ag[MAXV], ab[MAXV], g[MAXV];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0);
         const int c = lane + 64 * i;
         g[i] = c < C4 ? g4[c] : make_float4(0, 0, 0, 0);
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(1024) void lsres_bwd16_kernel(const float* __restri
             const float4* yr = reinterpret_cast<const float4*>(y + (rv ? row : 0) * C);
             const uint2* yh = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(y) + (rv ? row : 0) * C);
 #pragma unroll
-            for (int i = 0; i < LN_MAXV; ++i) {
+            for (int i = 0; i < MAXV; ++i) {
                 const int c = lane + 64 * i;
                 if (c < C4) {
                     float4 d = make_float4(0, 0, 0, 0), yv = d;
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(1024) void lsres_bwd16_kernel(const float* __restri
     float* red = reinterpret_cast<float*>(lsT);
     const int ldr = C + 4;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
         if (c < C4) {
             *reinterpret_cast<float4*>(red + (long)w * ldr + 4 * c) = ag[i];
@@ -798,8 +799,9 @@ static int lsres_bwd16_launch(const float* dout, const void* y, int y_f16, const
     const int smem = tile_bytes > red_bytes ? tile_bytes : red_bytes;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lsres_bwd16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           64 * (256 * LN_MAXV + 8) * 2 > 32 * (256 * LN_MAXV + 4) * 4 ? 64 * (256 * LN_MAXV + 8) * 2 : 32 * (256 * LN_MAXV + 4) * 4);
+        constexpr int mx = 64 * (256 * LN_MAXV + 8) * 2 > 32 * (256 * LN_MAXV + 4) * 4 ? 64 * (256 * LN_MAXV + 8) * 2 : 32 * (256 * LN_MAXV + 4) * 4;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lsres_bwd16_kernel<LN_MAXV>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lsres_bwd16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
@@ -808,9 +810,13 @@ static int lsres_bwd16_launch(const float* dout, const void* y, int y_f16, const
     const DetDeferSeg sg[2] = {{dgamma, C}, {db, C}};
     float* region = det_defer_try(1, nb, 2 * C, 2, sg, st);        // deferred: dgamma / db += totals at the next flush
     if (region) ws.defer = region; else DET_CHECK(ws, 1, nb, 2 * C);
-    hipLaunchKernelGGL(lsres_bwd16_kernel, dim3((unsigned)nb), dim3(1024), smem, st, dout, reinterpret_cast<const float*>(y), gamma,
-                       reinterpret_cast<unsigned short*>(dy16), reinterpret_cast<unsigned short*>(dy16T), ldt, db, dgamma, R, C, ws, y_f16,
-                       p_drop, seed, offset, sscale, rps);
+    // (2 float4 per lane up to C = 512: fewer live registers per wave than the 4 the widest rows need)
+    if (C <= 512) hipLaunchKernelGGL(lsres_bwd16_kernel<2>, dim3((unsigned)nb), dim3(1024), smem, st, dout, reinterpret_cast<const float*>(y), gamma,
+                                     reinterpret_cast<unsigned short*>(dy16), reinterpret_cast<unsigned short*>(dy16T), ldt, db, dgamma, R, C, ws, y_f16,
+                                     p_drop, seed, offset, sscale, rps);
+    else hipLaunchKernelGGL(lsres_bwd16_kernel<LN_MAXV>, dim3((unsigned)nb), dim3(1024), smem, st, dout, reinterpret_cast<const float*>(y), gamma,
+                            reinterpret_cast<unsigned short*>(dy16), reinterpret_cast<unsigned short*>(dy16T), ldt, db, dgamma, R, C, ws, y_f16,
+                            p_drop, seed, offset, sscale, rps);
     if (region) det_defer_commit(region, 1, nb, 2 * C, 2, sg, 1);
     SPE_CHECK_LAUNCH();
     return 0;
