@@ -1271,11 +1271,18 @@ def attn_pack(x4, scale=1.0):
     return out
 
 
+_PLANS = {}          # work splits are pure functions of (shape, workgroup budget): asked once per shape, not once per block and step
+
+
 def fused_plan(B, N, mode):
     """(steps per workgroup, workgroups) the launcher uses for pass `mode` (sizes ws_w, parametrises attn_merge)."""
-    spw, nwg = ctypes.c_int(0), ctypes.c_int(0)
-    lib.call("spe_talking_fused_plan", B, N, FUSED_NWG[mode], int(mode), ctypes.byref(spw), ctypes.byref(nwg))
-    return spw.value, nwg.value
+    key = ("fused", B, N, mode, FUSED_NWG[mode])
+    r = _PLANS.get(key)
+    if r is None:
+        spw, nwg = ctypes.c_int(0), ctypes.c_int(0)
+        lib.call("spe_talking_fused_plan", B, N, FUSED_NWG[mode], int(mode), ctypes.byref(spw), ctypes.byref(nwg))
+        r = _PLANS[key] = (spw.value, nwg.value)
+    return r
 
 
 def talking_fused(mode, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, ws_stats, ws_w, outT, B, H, N, dh, p_drop, seed, offset, keepbits=None):
@@ -1427,9 +1434,13 @@ def flash_supported(H, dh):
 
 def flash_plan(B, N):
     """(steps per workgroup, workgroups, major tile groups per image, padded rows of the row-constant arrays)."""
-    spw, nwg, nmaj, npad = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-    lib.call("spe_talking_flash_plan", B, N, FLASH_NWG, ctypes.byref(spw), ctypes.byref(nwg), ctypes.byref(nmaj), ctypes.byref(npad))
-    return spw.value, nwg.value, nmaj.value, npad.value
+    key = ("flash", B, N, FLASH_NWG)
+    r = _PLANS.get(key)
+    if r is None:
+        spw, nwg, nmaj, npad = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        lib.call("spe_talking_flash_plan", B, N, FLASH_NWG, ctypes.byref(spw), ctypes.byref(nwg), ctypes.byref(nmaj), ctypes.byref(npad))
+        r = _PLANS[key] = (spw.value, nwg.value, nmaj.value, npad.value)
+    return r
 
 
 def flash_rows(in0, in1, bl, B, H, N, mode):
@@ -1494,9 +1505,16 @@ def bwdq_supported(H, dh):
 
 def bwdq_plan(B, N):
     """(steps per workgroup, workgroups, major (4 q-tile) groups per image) of the q-major backward passes."""
-    spw, nwg, nmaj = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-    lib.call("spe_talking_bwdq_plan", B, N, max(8, FLASH_NWG - _CU_RESERVE), ctypes.byref(spw), ctypes.byref(nwg), ctypes.byref(nmaj))
-    return spw.value, nwg.value, nmaj.value
+    budget = max(8, FLASH_NWG - _CU_RESERVE)
+    key = ("bwdq", B, N, budget)
+    r = _PLANS.get(key)
+    if r is None:
+        spw, nwg, nmaj = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        lib.call("spe_talking_bwdq_plan", B, N, budget, ctypes.byref(spw), ctypes.byref(nwg), ctypes.byref(nmaj))
+        if len(_PLANS) > 256:
+            _PLANS.clear()
+        r = _PLANS[key] = (spw.value, nwg.value, nmaj.value)
+    return r
 
 
 def talking_bwdq_pass1(Qf, dOf, Kf, Vf, Wl, Ww, c0, keepbits, B, H, N, dh, p_drop):
