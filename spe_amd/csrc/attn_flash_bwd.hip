@@ -161,6 +161,77 @@ __device__ __forceinline__ void flb_dq_mfma(f32x4_t* acc, const fls16x4_t* ka, f
 // the accumulators become readable (segment end)
 __device__ __forceinline__ void flb_acc_fence(f32x4_t& a) { asm volatile("s_nop 7\n\ts_nop 4" : "+a"(a)); }
 
+// S' += Wl S for a chunk of 4 heads and 8 output heads (32 v_mfma_f32_4x4x1 on the 8 accumulators sp[r][gh]) with 16 v_exp_f32 of ANOTHER tile's exponents in
+// their shadow - one after every second matrix instruction.  The exponentials are quarter-rate vector instructions (16 cycles each): left to the compiler they sat
+// in runs of 8-32 behind the mixes (a single wave per SIMD overlaps its matrix and vector streams only where the instruction stream alternates).  The accumulate
+// chains reuse an accumulator every 12th instruction; s_nop 7 at the end: the 2-pass results and the exponentials are read by ordinary vector instructions next.
+// MEASURED SLOWER and off (round 5, isolated at cfg2: key-major pass 375 -> 398 us, pass 2 365 -> 360 ... 373 us): the compiler's own placement of these matrix
+// instructions between the packing instructions of the back half is worth more than the exponentials' shadow.  Kept as the record of the experiment.
+#ifndef FLB_MIXEXP
+#define FLB_MIXEXP 0
+#endif
+__device__ __forceinline__ void flb_mix4_exp8(const float (&A)[2][8], const int h0, const f32x4_t (&c)[4], f32x4_t (&sp)[4][2], f32x4_t (&e0)[4][2], const int eg) {
+    // e0[r][eg][k]: the 16 exponents ; A[gh][h0 + hb] ; c[hb][r]
+#define FLB_E(r, k) "+v"(e0[r][eg][k])
+    asm(
+            "v_mfma_f32_4x4x1_16b_f32 %0, %24, %32, %0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %1, %28, %32, %1\n\t"
+            "v_exp_f32 %8, %8\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %2, %24, %33, %2\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %3, %28, %33, %3\n\t"
+            "v_exp_f32 %9, %9\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %4, %24, %34, %4\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %5, %28, %34, %5\n\t"
+            "v_exp_f32 %10, %10\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %6, %24, %35, %6\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %7, %28, %35, %7\n\t"
+            "v_exp_f32 %11, %11\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %0, %25, %36, %0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %1, %29, %36, %1\n\t"
+            "v_exp_f32 %12, %12\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %2, %25, %37, %2\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %3, %29, %37, %3\n\t"
+            "v_exp_f32 %13, %13\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %4, %25, %38, %4\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %5, %29, %38, %5\n\t"
+            "v_exp_f32 %14, %14\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %6, %25, %39, %6\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %7, %29, %39, %7\n\t"
+            "v_exp_f32 %15, %15\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %0, %26, %40, %0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %1, %30, %40, %1\n\t"
+            "v_exp_f32 %16, %16\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %2, %26, %41, %2\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %3, %30, %41, %3\n\t"
+            "v_exp_f32 %17, %17\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %4, %26, %42, %4\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %5, %30, %42, %5\n\t"
+            "v_exp_f32 %18, %18\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %6, %26, %43, %6\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %7, %30, %43, %7\n\t"
+            "v_exp_f32 %19, %19\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %0, %27, %44, %0\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %1, %31, %44, %1\n\t"
+            "v_exp_f32 %20, %20\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %2, %27, %45, %2\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %3, %31, %45, %3\n\t"
+            "v_exp_f32 %21, %21\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %4, %27, %46, %4\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %5, %31, %46, %5\n\t"
+            "v_exp_f32 %22, %22\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %6, %27, %47, %6\n\t"
+            "v_mfma_f32_4x4x1_16b_f32 %7, %31, %47, %7\n\t"
+            "v_exp_f32 %23, %23\n\t"
+            "s_nop 7"
+        : "+v"(sp[0][0]), "+v"(sp[0][1]), "+v"(sp[1][0]), "+v"(sp[1][1]), "+v"(sp[2][0]), "+v"(sp[2][1]), "+v"(sp[3][0]), "+v"(sp[3][1]),
+          FLB_E(0, 0), FLB_E(0, 1), FLB_E(0, 2), FLB_E(0, 3), FLB_E(1, 0), FLB_E(1, 1), FLB_E(1, 2), FLB_E(1, 3),
+          FLB_E(2, 0), FLB_E(2, 1), FLB_E(2, 2), FLB_E(2, 3), FLB_E(3, 0), FLB_E(3, 1), FLB_E(3, 2), FLB_E(3, 3)
+        : "v"(A[0][h0]), "v"(A[0][h0 + 1]), "v"(A[0][h0 + 2]), "v"(A[0][h0 + 3]), "v"(A[1][h0]), "v"(A[1][h0 + 1]), "v"(A[1][h0 + 2]), "v"(A[1][h0 + 3]),
+          "v"(c[0][0]), "v"(c[0][1]), "v"(c[0][2]), "v"(c[0][3]), "v"(c[1][0]), "v"(c[1][1]), "v"(c[1][2]), "v"(c[1][3]),
+          "v"(c[2][0]), "v"(c[2][1]), "v"(c[2][2]), "v"(c[2][3]), "v"(c[3][0]), "v"(c[3][1]), "v"(c[3][2]), "v"(c[3][3]));
+#undef FLB_E
+}
+
 template <int H, int DSTEPS, bool TAIL16, bool DROP, int PASS>
 __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdArgs a) {
     constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
@@ -303,7 +374,8 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
         };
         auto load_k = [&](int i, int h0, Frags& o) { load_frags(smem + (i & 1) * KVB, h0, o); };
         auto load_v = [&](int i, int g0, Frags& o) { load_frags(smem + (i & 1) * KVB + TILEB, g0, o); };
-        auto front_k = [&](int i, auto h0_c, const Frags& kfr, f32x4_t (&sp)[4][H / 4], auto mask_c) {
+        // ex (pipelined step, 8 heads): the exponents of the PREVIOUS tile's head group h0 / HB, exponentiated in the shadow of this chunk's mix
+        auto front_k = [&](int i, auto h0_c, const Frags& kfr, f32x4_t (&sp)[4][H / 4], auto mask_c, f32x4_t (*ex)[H / 4] = nullptr) {
             constexpr bool MASK = decltype(mask_c)::value;
             constexpr int h0 = decltype(h0_c)::value;
             unsigned char* gwf = gw_wr + (i & 1) * GWT;         // this tile's front operand of the outer product
@@ -332,6 +404,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
                 if constexpr (PASS == 2) *reinterpret_cast<fls16x4_t*>(gwf + (h0 + hb) * GWR) = fl_pack4<false>(cs[0], cs[1], cs[2], cs[3]);
 #endif
 #ifndef FLB_DBG_NOMIX1
+                if constexpr (FLB_MIXEXP && H == 8) { if (ex) continue; }          // (mixed below, all four heads in one block)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -341,6 +414,9 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
                 for (int r = 0; r < 4; ++r) sp[r][(h0 + hb) >> 2][(h0 + hb) & 3] += cs[r];
 #endif
             }
+#ifndef FLB_DBG_NOMIX1
+            if constexpr (FLB_MIXEXP && H == 8) { if (ex) flb_mix4_exp8(Al4, h0, c, sp, *reinterpret_cast<f32x4_t (*)[4][2]>(ex), h0 / HB); }
+#endif
         };
         auto front_v = [&](int i, auto g0_c, const Frags& vfr, f32x4_t (&dp)[4][H / 4], uint32_t kb) {
             constexpr int g0 = decltype(g0_c)::value;
@@ -523,13 +599,14 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
             const uint32_t kb = load_kb(i + 1);
             if constexpr (H > HB) load_k(i + 1, HB, fr1); else load_v(i + 1, 0, fr1);
             __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
-            front_k(i + 1, std::integral_constant<int, 0>{}, fr0, spn, std::false_type{});
-            back_exp(sp);
+            constexpr bool MXE = FLB_MIXEXP && H == 8;            // exp2 of tile i inside the mix blocks of tile i + 1
+            front_k(i + 1, std::integral_constant<int, 0>{}, fr0, spn, std::false_type{}, MXE ? sp : nullptr);
+            if constexpr (!MXE) back_exp(sp);
             FLB_PHASE();
             if constexpr (H > HB) {
                 load_v(i + 1, 0, fr0);
                 __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
-                front_k(i + 1, std::integral_constant<int, HB>{}, fr1, spn, std::false_type{});
+                front_k(i + 1, std::integral_constant<int, HB>{}, fr1, spn, std::false_type{}, MXE ? sp : nullptr);
             }
             back_ds(sp, dp);
             FLB_PHASE();
@@ -982,7 +1059,8 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
         // ---- FRONT half of q-tile i (matrix-heavy), chunks of FLB_HB heads
         // rs_t / rs_o (both or neither): the terms of a 4-head row-sum reduce-scatter of the PREVIOUS tile's back half, run in the shadow of this chunk's score
         // products (head dim 33 .. 48 only), and its result
-        auto front_q = [&](int i, auto h0_c, const Frags& qfr, f32x4_t (&sp)[4][H / 4], const f32x4_t (*rs_t)[4] = nullptr, f32x4_t* rs_o = nullptr) {
+        auto front_q = [&](int i, auto h0_c, const Frags& qfr, f32x4_t (&sp)[4][H / 4], const f32x4_t (*rs_t)[4] = nullptr, f32x4_t* rs_o = nullptr,
+                           f32x4_t (*ex)[H / 4] = nullptr) {
             constexpr int h0 = decltype(h0_c)::value;
             if constexpr (h0 == 0) {        // the exponent starts from the row constants of query 4 (l >> 4) + r: broadcast LDS reads
                 const unsigned char* cr = smem + C0OFF + (i & 1) * 1024 + (4 * gk) * H * 4;
@@ -998,6 +1076,9 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
                 else flb_score_f16<FULL, TAIL16>(qfr.f, qfr.t, &ka[h0], &kta[h0], c);
             } else flb_score_f16<FULL, TAIL16>(qfr.f, qfr.t, &ka[h0], &kta[h0], c);
             flb_fence4(c[0], c[1], c[2], c[3]);
+            if constexpr (FLB_MIXEXP && H == 8) {
+                if (ex) { flb_mix4_exp8(Al4, h0, c, sp, *reinterpret_cast<f32x4_t (*)[4][2]>(ex), h0 / HB); return; }
+            }
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb) {
                 const f32x4_t cs = c[hb];
@@ -1188,8 +1269,9 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
             load_kb(i + 1, kbn);
             if constexpr (H > HB) load_q(i + 1, HB, fr1); else load_d(i + 1, 0, fr1);
             __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
-            front_q(i + 1, std::integral_constant<int, 0>{}, fr0, spn);
-            back_exp(sp);
+            constexpr bool MXE = FLB_MIXEXP && H == 8;            // exp2 of tile i inside the mix blocks of tile i + 1
+            front_q(i + 1, std::integral_constant<int, 0>{}, fr0, spn, nullptr, nullptr, MXE ? sp : nullptr);
+            if constexpr (!MXE) back_exp(sp);
             FLB_PHASE();
             constexpr bool RSF = FLB_RSFUSE && H == 2 * HB && FULL == 1 && TAIL16;      // the D reduce-scatters of tile i ride on two score-product blocks of tile i + 1
             f32x4_t rt[4], ro0, ro1;
@@ -1197,8 +1279,8 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
                 load_d(i + 1, 0, fr0);
                 if constexpr (RSF) d_terms(0, sp, dp, rt);
                 __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
-                if constexpr (RSF) front_q(i + 1, std::integral_constant<int, HB>{}, fr1, spn, &rt, &ro0);
-                else front_q(i + 1, std::integral_constant<int, HB>{}, fr1, spn);
+                if constexpr (RSF) front_q(i + 1, std::integral_constant<int, HB>{}, fr1, spn, &rt, &ro0, MXE ? sp : nullptr);
+                else front_q(i + 1, std::integral_constant<int, HB>{}, fr1, spn, nullptr, nullptr, MXE ? sp : nullptr);
             }
             if constexpr (RSF) { d_store(i, 0, ro0); back_ds(i, sp, dp, false); d_terms(1, sp, dp, rt); }
             else back_ds(i, sp, dp);
