@@ -17,7 +17,7 @@ cd $GRAFT_REPO_ROOT
 python - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
-want = ("talking_fused_kernel", "talking_flash", "attn_contract", "talking_bwdq_kernel")
+want = ("talking_fused_kernel", "talking_flash", "attn_contract", "talking_bwdq_kernel", "talking_bwdk_kernel")
 for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if any(w in r["Name"] for w in want):
