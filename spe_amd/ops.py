@@ -300,7 +300,8 @@ class _LayerNormSkip(Function):
             dx, dg, db, done = K.layernorm_bwd(dy2, x2, g, mean, rstd, dg_out=K.grad_buffer(gp), db_out=K.grad_buffer(bp), add=add,
                                                ls=(yls, gls, K.grad_buffer(bpar), K.grad_buffer(gpar)))
             dxv = dx.view(dy.shape)
-            prod.ls_done = (done, dx.data_ptr())
+            # (address AND version: the engine may add a second consumer's gradient into this very buffer in place - same address, version + 1)
+            prod.ls_done = (done, dx.data_ptr(), dxv._version)
             return dxv, dg.view_as(gp), db.view_as(bp), None, None
         dx, dg, db = K.layernorm_bwd(dy2, x2, g, mean, rstd, dg_out=K.grad_buffer(gp), db_out=K.grad_buffer(bp), add=add)
         return dx.view(dy.shape), dg.view_as(gp), db.view_as(bp), None, None
@@ -704,7 +705,7 @@ class _LinearRes(Function):
         d2 = dout.reshape(-1, W.shape[0])
         if not d2.is_contiguous():
             d2 = d2.contiguous()
-        pre = _ls_taken(ctx, d2)
+        pre = _ls_taken(ctx, dout if dout.is_contiguous() else d2)
         bufs = tuple(K.grad_buffer(p) for p in ctx.params)
         dx, dW, db, dg = K.linear_res_bwd(d2, (x16T, y), W, gamma, ctx.needs_input_grad[0], bufs, drop=ctx.drop, sscale=ss, rps=ctx.rps, pre=pre)
         return (dx.view(*dout.shape[:-1], W.shape[1]) if dx is not None else None), dW, db, dout, dg.view_as(gamma), None, None, None
@@ -725,8 +726,8 @@ def _ls_taken(ctx, d2):
     if done is None:
         return None
     ctx.ls_done = None
-    pre, ptr = done
-    if d2.data_ptr() != ptr:
+    pre, ptr, ver = done
+    if d2.data_ptr() != ptr or d2._version != ver:
         raise RuntimeError("spe_amd.ops: a node was marked single=True but its output had more than one consumer (the LayerNorm backward already "
                            "accumulated its bias / LayerScale gradients from a partial gradient)")
     return pre
@@ -788,7 +789,7 @@ class _MlpGeluRes(Function):
         if not d2.is_contiguous():
             d2 = d2.contiguous()
         W1p, b1p, W2p, b2p, gp = ctx.params
-        taken = _ls_taken(ctx, d2)
+        taken = _ls_taken(ctx, dout if dout.is_contiguous() else d2)
         bufs = tuple(K.grad_buffer(p) for p in (W1p, b1p, W2p, b2p))
         dx, dW1, db1, dW2, db2, dg = K.mlp_gelu_bwd(d2, (x16T, pre, h16T, y), W1, W2, ctx.needs_input_grad[0], bufs,
                                                      gamma=gamma, dg_out=K.grad_buffer(gp), drop1=ctx.drop1, drop2=ctx.drop2,

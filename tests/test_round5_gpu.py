@@ -559,5 +559,12 @@ def test_layerscale_backward_rides_on_the_layernorm_backward(dev):
     y2 = blocks[1](y1)
     with pytest.raises(RuntimeError, match="more than one consumer"):
         ((y2 + y1) * w).sum().backward()
+    # ... also when the other consumer's gradient arrives SECOND (the engine may then add it into the norm's dx in place: same address, new version)
+    x = x0.clone().requires_grad_(True)
+    y1 = blocks[0](x, single_out=True)
+    side = y1 * 2.0                            # created before the next block: its backward runs after that block's
+    y2 = blocks[1](y1)
+    with pytest.raises(RuntimeError, match="more than one consumer"):
+        ((y2 + side) * w).sum().backward()
     for p in blocks.parameters():
         p.grad = None
