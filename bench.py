@@ -205,10 +205,11 @@ def roofline_inputs():
 
 def parity_record():
     """Measured errors of the benchmarked precision mode against the REFERENCE at cfg2's token count
-    (tests/test_config_golden.py on the GPU box -> profiles/parity_r05.json)."""
-    obj, prov = _load_profile("parity_r05.json")
+    (tests/test_config_golden.py on the GPU box -> tools/parity_summary.py -> profiles/parity_r06.json; the record names the measurement pass -
+    the gpurun call whose `pytest -m gpu` produced it - in its `label`)."""
+    obj, prov = _load_profile("parity_r06.json")
     if not obj:
-        obj, prov = _load_profile("parity_r03.json")
+        obj, prov = _load_profile("parity_r05.json")
     return obj, prov
 
 
@@ -315,20 +316,20 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    # kernels timed live with HIP events on the launch stream: the dominant kernel (backward pass 2 of the fused
-    # talking-heads attention), the HBM-bound contraction kernel and north_star's decoder cross-attention GEMM (the
+    # kernels timed live with HIP events on the launch stream: the dominant kernel (the query-major backward kernel of the fused
+    # talking-heads attention: dS, dWl, dbl, dQ), the HBM-bound dK contraction and north_star's decoder cross-attention GEMM (the
     # memory-side projections ca_kcontent / ca_v / ca_kpos of reference models/transformer.py:389-419:
     # [B*S, d] x [d, d] = [8300 x 384] x [384 x 384] at cfg2)
-    DOM, HBMK = "spe_talking_fused", "spe_attn_contract"
-    DOMQ = "spe_talking_bwdq_pass2"       # round 5: backward pass 2 + dQ on the flash skeleton (the default; spe_talking_fused mode 3 when SPE_BWDQ=0)
-    FLF, FLV = "spe_talking_flash_fwd", "spe_talking_flash_dv"
-    BWDK = "spe_talking_bwdk_pass1"       # round 5: KEY-major backward pass 1 + dV in one launch (the default; SPE_BWDQ=2: round-3 pass 1 + spe_talking_flash_dv)
+    HBMK = "spe_attn_contract"
+    DOMQ = "spe_talking_bwdq_pass2"       # query-major backward kernel + its dQ merge
+    FLF, STATS = "spe_talking_flash_fwd", "spe_talking_stats"
+    BWDK = "spe_talking_bwdk_pass1"       # key-major backward kernel (D, dWw, dbw, dV) + its merges
     body = model.backbone[0].body
     S_rows, d_model = a.batch * (a.height // 16) * (a.width // 16), body.embed_dim
     n_dec = args.dec_layers
     CAG_N = 2 * n_dec * d_model          # ca_kcontent + ca_v of all decoder layers in one launch (ops.multi_linear)
     CAG = f"spe_gemm_bf16nt:{S_rows},{CAG_N},{d_model}"
-    K.enable_timing([DOM, DOMQ, HBMK, CAG, FLF, FLV, BWDK])
+    K.enable_timing([DOMQ, HBMK, CAG, FLF, STATS, BWDK])
     reducer.measure = True
     sync()
     t0 = time.perf_counter()
@@ -380,16 +381,11 @@ def main():
         par_all, par_prov = parity_record()
         kin = rin.get("kernels", {})
         pk = rin.get("peaks_measured", {})
-        # K.timing_results() keys fused launches by mode: "spe_talking_fused:3" = backward pass 2
-        launches, mean_ms = K_res.get(DOM + ":3", (0, 0.0))
-        lq, mq = K_res.get(DOMQ, (0, 0.0))
-        dom_q = lq > 0                   # the flash-skeleton pass 2 ran: it also accumulates dQ = dS K (the streaming dQ contraction is gone)
-        if dom_q:
-            launches, mean_ms = lq, mq
-        # MFMA work of one launch: S = QK^T (a recomputation: SURVEY 8(d) does not count it), dP' = dO V^T (algorithmic) and - flash-skeleton
-        # pass 2 - dQ = dS K (algorithmic) for all heads, 2*N*N*dh FLOP each.  `achieved` = the algorithmic products, `executed` adds the recomputed S.
+        launches, mean_ms = K_res.get(DOMQ, (0, 0.0))
+        # MFMA work of one launch: S = QK^T (a recomputation: SURVEY 8(d) does not count it), dP' = dO V^T (algorithmic) and dQ = dS K
+        # (algorithmic) for all heads, 2*N*N*dh FLOP each.  `achieved` = the algorithmic products, `executed` adds the recomputed S.
         mf = (2.0 * N * N * dh_) * Hh * a.batch
-        n_alg = 2 if dom_q else 1
+        n_alg = 2
         ach = (n_alg + 1) * mf / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
         ach_alg = n_alg * mf / (mean_ms * 1e-3) / 1e12 if mean_ms > 0 else 0.0
         # the PATH's algorithmic FLOPs per image (forward 1.16 TF at enc_layers 0 + 0.044 TF per encoder layer, x3 for fwd + bwd) x images / s
@@ -422,9 +418,10 @@ def main():
             "metric": "images/sec (whole node) at 3x800x1333 bs=2/GPU", "value": imgs / dt, "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "precision": a.precision, "data": "synthetic",
-            "precision_note": {"bf16s": "MFMA operands: forward GEMMs split bf16 (hi + lo, 3 products), attention forward fp16, "
-                                        "every backward product single bf16; fp32 accumulation / residual stream / statistics / losses",
+            "dtype": "bf16/fp16 operands, fp32 accumulate", "precision": a.precision, "data": "synthetic",
+            "precision_note": {"bf16s": "MFMA operands: forward qkv / proj / decoder Linear GEMMs split bf16 (hi + lo, 3 products), backbone MLP, attention forward "
+                                        "and the decoder's memory-side projections IEEE fp16 (single term), every backward product single bf16; fp32 accumulation / "
+                                        "residual stream / statistics / losses",
                                "bf16": "single bf16 MFMA operands (attention forward fp16), fp32 accumulation",
                                "bf16x3": "3-term split bf16 operands everywhere, fp32 materialised attention"}[a.precision],
             "config": {"workload": f"{a.backbone} (C={body.embed_dim}, depth {body.depth}, {Hh} heads) + {a.enc_layers}-layer encoder + 6-layer "
@@ -435,13 +432,13 @@ def main():
                        "drop_rates": {"decoder": 0.1, "drop_path": a.drop_path, "attn_drop": a.attn_drop, "backbone_drop": a.backbone_drop}},
             "per_rank_ms_per_step": [t_ / a.steps * 1e3 for t_ in per_rank],
             "dp": {"cu_reserve": reducer.cu_reserve, "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
-                   "fused_attention_workgroups": K.FUSED_NWG[3]},
+                   "stats_pass_workgroups": K.STATS_NWG},
             "dist": dist_info,
             "hbm_peak_allocated_gb": round(peak_mem / 1e9, 2),           # torch allocator high-water mark through the timed steps (of 288 GB)
             "allreduce_exposed_ms_per_step": max(exposed), "allreduce_exposed_ms_per_rank": exposed,
             "roofline": {"bound": "mfma",
-                         "kernel": ("talking_bwdq_kernel<8,2,tail,PASS 2> + its dQ merge (attention backward pass 2 with dQ = dS K accumulated in registers)" if dom_q
-                                    else "talking_fused_kernel<8,2,3> (attention backward pass 2)"), "launches": launches,
+                         "kernel": "talking_bwdq_kernel<8,2,tail> + its dQ merge (query-major attention backward: dS, dWl, dbl, dQ = dS K accumulated in registers)",
+                         "launches": launches,
                          # algorithmic work only (dP' = dO V^T, and dQ = dS K when the flash-skeleton pass ran); the recomputed S = Q K^T is `executed`
                          "avg_ms": mean_ms, "achieved": ach_alg, "executed": ach, "peak": 2500.0,
                          "peak_measured": pk.get("mfma_f16_16x16x32_tflops", pk.get("mfma_bf16_tflops")), "unit": "TFLOP/s", "frac": ach_alg / 2500.0,
@@ -450,21 +447,18 @@ def main():
                          "path_tflop_per_image": path_tf_per_img,
                          "path_achieved": (path_tf_per_img * imgs / dt / world) if path_tf_per_img else None,
                          "path_frac": (path_tf_per_img * imgs / dt / world / 2500.0) if path_tf_per_img else None,
-                         "traffic": kin.get("talking_bwdq_pass2" if dom_q else "talking_fused_mode3", {}).get("traffic_bytes"),   # bytes/launch, PMC (profiles/roofline_inputs.json)
+                         "traffic": kin.get("talking_bwdq_pass2", {}).get("traffic_bytes"),   # bytes/launch, PMC (profiles/roofline_inputs.json)
                          "traffic_provenance": rin_prov,
-                         "limiter": "instruction issue + exposed waits of ONE wave per SIMD" if dom_q else "latency at two waves per SIMD",
+                         "limiter": "instruction issue + exposed waits of ONE wave per SIMD",
                          "note": ("priced against the MFMA roofline (its arithmetic is matrix work), bound by something else: one wave per SIMD (512 registers: Q / dO "
-                                  "fragments and the 96 dQ accumulators in AccVGPRs) issues <= 1 instruction per ~4.6 cycles; per 16x16 tile ~620 instructions, "
-                                  "matrix pipe busy ~1900 of ~6100 cycles, the wave issuing 46 %, issue-stalled 30 %, waiting 23 % (profiles/r05_fused_pmc.txt, DESIGN.md 4.1)"
-                                  if dom_q else
-                                  "priced against the MFMA roofline, bound by latency: operand-fragment round trips and MFMA->VALU dependencies are exposed at the 2 waves/SIMD "
-                                  "that 256 registers allow (waves 30 % issuing / 30 % issue-stalled / 40 % waiting: profiles/r05_fused_pmc.txt)"),
+                                  "fragments and the 96 dQ accumulators in AccVGPRs) issues in order; per 16x16 tile of all heads 545 instructions of which 168 are matrix "
+                                  "instructions = 2352 matrix-pipe cycles of ~6000 (profiles/r06_bwd_isa_hist.txt, profiles/r05_fused_pmc.txt, DESIGN.md 4.1)"),
                          "valu_achieved": valu, "valu_peak": 157.3,
                          "valu_frac": valu / 157.3,
-                         "hbm_kernel": {"bound": "hbm", "kernel": "attn_contract_kernel<3,*> (PV / dV / dQ / dK over blocked bf16 scores)",
+                         "hbm_kernel": {"bound": "hbm", "kernel": "attn_contract_kernel<3,true,*> (dK = scale dS^T Q: the one streaming read of the blocked bf16 dS)",
                                         "launches": c_launch, "avg_ms": c_ms, "achieved": c_bw, "peak": 8000.0,
                                         "peak_measured": pk.get("hbm_read_gbs"), "unit": "GB/s",
-                                        "frac": c_bw / 8000.0, "traffic": kin.get("attn_contract", {}).get("traffic_bytes")},
+                                        "frac": c_bw / 8000.0, "traffic": kin.get("attn_contract_T", {}).get("traffic_bytes")},
                          "decoder_ca_gemm": {"kernel": (f"gemm_nt2_kernel<160,128,64,2,single,fp16 operands,fp16 out> " if kv16 else
                                                         f"gemm_nt2_kernel<128,128,{32 if split_fwd else 64},2,{'split' if split_fwd else 'single'}> ") +
                                                        f"[{S_rows}x{d_model}]x[{d_model}x{CAG_N}]: ca_kcontent + ca_v projections of the memory for all "
@@ -481,10 +475,10 @@ def main():
                                                      "that do not overlap it (profiles/r03_gemm_ablation.txt); parity at cfg2_full / cfg5_full unchanged "
                                                      "(outputs <= 1.6e-4, weighted loss keys <= 4.4e-4)"}},
             "precision_contract": par_all.get(a.precision), "precision_contract_provenance": par_prov,
-            # the flash-style attention passes (no N x N tensor in HBM): forward O = P'd V and the backward's dV = P'd^T dO, timed live
-            "flash_attention": {"forward": {"launches": K_res.get(FLF, (0, 0.0))[0], "avg_ms": K_res.get(FLF, (0, 0.0))[1]},
-                                "dv": {"launches": K_res.get(FLV, (0, 0.0))[0], "avg_ms": K_res.get(FLV, (0, 0.0))[1]},
-                                # key-major backward pass 1 + dV in one walk (D, dWw, dbw and dV = P'd^T dO; replaces the round-3 pass 1 and the dV pass above)
+            # the other attention kernels (no N x N tensor in HBM but the backward's dS), timed live
+            "flash_attention": {"stats": {"launches": K_res.get(STATS, (0, 0.0))[0], "avg_ms": K_res.get(STATS, (0, 0.0))[1]},
+                                "forward": {"launches": K_res.get(FLF, (0, 0.0))[0], "avg_ms": K_res.get(FLF, (0, 0.0))[1]},
+                                # key-major backward kernel: D, dWw, dbw and dV = P'd^T dO in one walk
                                 "bwd_pass1_dv": {"launches": K_res.get(BWDK, (0, 0.0))[0], "avg_ms": K_res.get(BWDK, (0, 0.0))[1]},
                                 "note": "kernel + its partial-result merge(s) per launch; P'd is neither stored nor saved for the backward"},
             # what ran: entry points of libspe_hip.so launched in one step, and every SPE_* developer knob that was set

@@ -13,8 +13,8 @@
  *   - `stream` is the hipStream_t the work is enqueued on; calls are asynchronous;
  *   - return value: 0 on success, a positive hipError_t on launch failure, a negative value
  *     for an unsupported argument combination; no exception crosses the boundary;
- *   - dropout masks are a pure function of (seed, offset, element index) - Philox4x32-10 -
- *     so forward and backward regenerate the same mask and nothing is stored.
+ *   - dropout masks are a pure function of (seed, offset, element index) - Philox4x32 with 7 rounds (csrc/common.h) -
+ *     so forward and backward regenerate the same mask (the attention's backward loads the 1-bit keep flags its forward stored).
  */
 #ifndef SPE_HIP_H
 #define SPE_HIP_H
@@ -32,7 +32,9 @@ typedef struct ihipStream_t* spe_stream_t; /* == hipStream_t */
  * takes `fmt`, spe_attn_pack_multi kinds carry an element-format bit, spe_talking_fused expects fp16 Q / K fragments and writes
  * fp16 P'd blocks; split-operand GEMM entry points); 4: deterministic reductions - spe_set_reduce_workspace is new and required
  * before any entry point that sums across workgroups, spe_box_loss takes L, spe_linear_small_fwd / _bwd are new; 5 (round 4):
- * the flash-style talking-heads entry points spe_talking_flash_* are new; 6 (round 5): spe_talking_bwdq_* are new */
+ * the flash-style talking-heads entry points spe_talking_flash_* are new; 6 (round 5): spe_talking_bwdq_* are new; 7 (round 6): ONE attention
+ * backward composition - spe_talking_fused(_bits / _plan), spe_attn_merge, spe_talking_flash_rows, spe_talking_flash_dv, spe_talking_bwdq_pass1 removed,
+ * spe_talking_stats(_plan) new (the statistics pass alone) */
 int spe_abi_version(void);
 
 /* ---- reduction workspace --------------------------------------------------------------------
@@ -231,113 +233,84 @@ int spe_talking_softmax_bwd(const float* dPd, const float* P, const float* S, co
                             float* dS, float* ws, int nblocks, int B, int H, int Nq, int Nk, long ld,
                             float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
 
-/* ---- fused talking-heads attention scores (reference models/cait.py:377-389 + autograd): no fp32
- * N x N tensor in HBM.  spe_attn_pack writes bf16 MFMA operand fragment records, per (b, h, 16-row tile):
+/* ---- fused talking-heads attention (reference models/cait.py:377-389 + autograd): qkv -> softmax(proj_l(scale q k^T)) -> proj_w -> attn_drop -> @ v
+ * with NO N x N tensor in HBM for the forward (the backward's dS is the only one, bf16).  ONE composition:
+ *   forward : spe_attn_pack_multi -> spe_talking_stats -> spe_attn_merge_rows -> spe_talking_flash_fwd
+ *   backward: spe_attn_pack_multi(dO) -> spe_talking_bwdk_pass1 (D, dWw, dbw, dV) -> spe_talking_bwdq_pass2 (dS, dWl, dbl, dQ)
+ *             -> spe_talking_wgrad_reduce -> spe_attn_contract(trans = 1) (dK)
+ * (rounds 1-5 carried four backward compositions behind a developer switch - spe_talking_fused modes 1-3, spe_talking_fused_bits, spe_attn_merge,
+ * spe_talking_flash_rows, spe_talking_flash_dv, spe_talking_bwdq_pass1; ABI 7 removed them: profiles/HISTORY_r05.md.)
+ *
+ * Operand format.  spe_attn_pack / spe_attn_pack_multi write 16-bit MFMA operand fragment records, per (b, h, 16-row tile):
  *   FULL steps of [lane][8] = scale * x[b, tile*16 + (lane&15), h, st*32 + (lane>>4)*8 + i], then - when dh % 32 is in
  *   1..16 - one 16-wide tail step of [lane][4] = scale * x[.., FULL*32 + (lane>>4)*4 + i]   (dh = 48: 1.5 KB/record)
- * from x[b][n][h][d] (element strides sb, sn, sh).  spe_talking_fused(mode):
- *   0: partial softmax statistics of S' = proj_l(scale q k^T) per (b,g,q)        -> ws_stats
- *   1: P'd = fp16(2^8 * attn_drop(proj_w(softmax(S'))))                            -> outT (blocks, scaled by 256)
- *   2: backward pass 1: dP' = (dO V^T)*keepscale, dWw/dbw partials -> ws_w, D = sum_k dP.P partials -> ws_stats
- *   3: backward pass 2: dS' = P(dP - D), dWl/dbl partials -> ws_w, dS = bf16(proj_l^T dS') -> outT (blocks)
- * spe_attn_merge reduces ws_stats to M/IL (mode 0: row max, 1/row sum) or D (mode 2).
- * ws_stats: B*nt*8*H*32 floats (nt = ceil(N/16)); ws_w: nwg_used rows of 2*(H*H+H) = [dWl|dbl|dWw|dbw]
- * (column-sum them with spe_colsum, or spe_talking_wgrad_reduce: the four sums written to four gradient buffers); outT: bf16 16x16 blocks [B,H,nt,nt][64][4], lane l of block (qt,kt) =
- * query qt*16+(l&15), keys kt*16+4*(l>>4)+i.  The Q fragments must be packed with scale*log2(e) (the kernels
- * work in the log2 domain; M is the log2-domain row max).
- * Element formats: Qf and Kf are FP16 fragments (spe_attn_pack_multi kinds 0 + 16), Vf and dOf BF16 (kind 0); the forward
- * quantities are O(1) and take the 3 extra mantissa bits, gradients keep bf16's range.  outT of mode 1 is fp16, of mode 3 bf16.
- * Supported: H in {4,8}, head dim <= 64.  Returns -2 otherwise (use the materialised path). */
+ * from x[b][n][h][d] (element strides sb, sn, sh).  Qf and Kf are FP16 records (spe_attn_pack_multi kinds 0 + 16; Qf packed with scale * log2(e):
+ * the kernels work in the log2 domain), Vf and dOf BF16 (kind 0): the forward quantities are O(1) and take the 3 extra mantissa bits, gradients
+ * keep bf16's range.  Blocked score tensors (dS): bf16 16 x 16 blocks [B,H,nt,nt][64][4], nt = ceil(N/16), lane l of block (qt,kt) = query
+ * qt*16+(l&15), keys kt*16+4*(l>>4)+i.
+ *
+ * spe_talking_stats: partial softmax statistics (running max, sum of exp2) of S' = proj_l(scale q k^T) per (b, g, q) -> ws_stats
+ *   (B*nt*8*H*32 floats); spe_talking_stats_plan: the launcher's work split for an `nwg` workgroup budget (workgroups walk (q-tile pair, key tile)
+ *   steps) - steps per workgroup (the value spe_attn_merge_rows needs) and workgroups used.
+ * spe_attn_merge_rows: merges ws_stats into M (log2-domain row max), IL (1 / row sum) [B,H,N] and the row constants rows [B][Np][H] =
+ *   bl[g] log2(e) - M + log2(IL), zero for the rows N .. Np-1 (the addend that turns Wl S into log2 P).  Np: multiple of 16, >= 16 ceil(N / 16).
+ * spe_talking_wgrad_reduce: column sums of ws_w (nwg rows of 2*(H*H+H) = [dWl|dbl|dWw|dbw]) STORED (not accumulated) into the four gradient
+ *   buffers in fixed order; a NULL destination is skipped.
+ * Supported: H in {4,8}, head dim <= 64 and the LDS bound below.  Returns -2 otherwise (use the materialised path: spe_talking_softmax_*). */
 int spe_attn_pack(const float* x, long sb, long sn, long sh, int B, int N, int H, int dh, float scale,
                   void* out, spe_stream_t stream);
-/* the launcher's work split for pass `mode` (workgroups walk (q-tile group, key tile) steps; the forward passes group two
- * q-tiles per workgroup): steps per workgroup - the value spe_attn_merge needs for the same mode - and workgroups used */
-int spe_talking_fused_plan(int B, int N, int nwg, int mode, int* steps_per_wg, int* nwg_used);
-int spe_talking_fused(int mode, const void* Qf, const void* Kf, const void* Vf, const void* dOf,
-                      const float* Wl, const float* bl, const float* Ww, const float* bw,
-                      const float* M, const float* IL, const float* D, float* ws_stats, float* ws_w, void* outT,
-                      int B, int H, int N, int dh, int nwg, float p_drop, uint64_t seed, uint64_t offset,
-                      spe_stream_t stream);
-/* spe_talking_fused with the dropout keep flags of spe_talking_flash_fwd (keepbits; modes 2 and 3 with p_drop > 0): the masks are loaded -
- * one dword per lane and tile - instead of regenerated; keepbits == NULL: identical to spe_talking_fused. */
-int spe_talking_fused_bits(int mode, const void* Qf, const void* Kf, const void* Vf, const void* dOf,
-                           const float* Wl, const float* bl, const float* Ww, const float* bw,
-                           const float* M, const float* IL, const float* D, float* ws_stats, float* ws_w, void* outT, const void* keepbits,
-                           int B, int H, int N, int dh, int nwg, float p_drop, uint64_t seed, uint64_t offset,
-                           spe_stream_t stream);
-int spe_attn_merge(const float* ws, float* out0, float* out1, int B, int H, int N, int steps_per_wg, int mode,
-                   spe_stream_t stream);
-/* mode-0 merge that ALSO writes the flash kernels' row constants rows [B][Np][H] = bl[g] log2(e) - M + log2(IL), zero for the rows
- * N .. Np-1 (what spe_talking_flash_rows mode 0 computes from M / IL in a launch of its own).  Np: multiple of 16, >= 16 ceil(N / 16). */
+int spe_talking_stats_plan(int B, int N, int nwg, int* steps_per_wg, int* nwg_used);
+int spe_talking_stats(const void* Qf, const void* Kf, const float* Wl, const float* bl, float* ws_stats,
+                      int B, int H, int N, int dh, int nwg, spe_stream_t stream);
 int spe_attn_merge_rows(const float* ws, float* M, float* IL, const float* bl, float* rows, int Np, int B, int H, int N,
                         int steps_per_wg, spe_stream_t stream);
 int spe_talking_wgrad_reduce(const float* ws_w, int nwg, int H, float* dWl, float* dbl, float* dWw, float* dbw,
                              spe_stream_t stream);
 
-/* ---- flash-style talking-heads attention (reference models/cait.py:377-389 + autograd): the same operator as spe_talking_fused
- * with NO N x N tensor in HBM for the forward and for dV - P' goes from the head mix straight into the matrix instructions that
- * consume it, the result accumulates in registers.
+/* ---- flash forward: P' goes from the head mix straight into the matrix instructions that consume it, the result accumulates in registers.
  * spe_talking_flash_plan: the launcher's flattened work split for an `nwg` workgroup budget (a workgroup keeps 8 tiles of 16 rows
  *   resident and streams the tiles of the other axis): steps per workgroup, workgroups launched, major tile groups per image, and
  *   Np = the padded row count of the row-constant arrays.  The partial-result workspace `ws` holds
  *   B * nmajor * 8 (slots) * 128 * H * 16 * ceil(dh / 16) floats.
- * spe_talking_flash_rows: query-major row constants [B][Np][H], rows >= N zero.  mode 0: out[b][q][g] = bl[g] log2(e) - in0[b][g][q]
- *   + log2(in1[b][g][q]) from the M / IL of spe_attn_merge (the addend that turns Wl S into log2 P); mode 1: out = in0 transposed.
  * spe_talking_flash_fwd: O[b, q, g*dh + d] = sum_key P'd[b,g][q,key] v[b, key, g, d] with P'd = attn_drop(proj_w(softmax(proj_l(
  *   scale q k^T)))); Qf / Kf fp16 fragments (spe_attn_pack_multi kind 0 + 16, Qf packed with scale * log2(e)), V16 fp16 (kind
- *   1 + 16), c0 from spe_talking_flash_rows mode 0.  O16 / O16lo (optional): bf16(O) and bf16(O - bf16(O)), same addressing - the
- *   operand of the output projection.  keepbits (optional, p_drop > 0): uint32 [B][nt][nt][64], nt = ceil(N / 16) - the dropout keep flags of
- *   every 16 x 16 tile in the lane layout of the q-major passes (bit hp * 8 + 2 r + e: key 4 (lane >> 4) + r, head 2 hp + e of query lane & 15);
- *   spe_talking_fused_bits then loads them in backward passes 1 and 2 instead of regenerating the masks.
- * spe_talking_flash_dv: dv[b, key, g, :] = sum_q P'd[b,g][q,key] dO[b, q, g, :] (element strides ob, on, oh of dv) - the same walk
- *   with the key tiles resident: P'd is RECOMPUTED from the forward's fragments, statistics and dropout stream (nothing N x N is
- *   saved for the backward); dO16 = spe_attn_pack_multi kind 1 (bf16).  dv16 (optional): bf16(dv) with the same element strides - the
- *   operand of the qkv Linear's backward GEMMs; dv may then be NULL (as `out` of spe_attn_contract may when out16 is given).
+ *   1 + 16), c0 = the row constants of spe_attn_merge_rows.  O16 / O16lo (optional): bf16(O) and bf16(O - bf16(O)), same addressing - the
+ *   operand of the output projection.  keepbits (p_drop > 0 and a backward will follow): uint32 [B][nt][nt][64] - the dropout keep flags of
+ *   every 16 x 16 tile (bit hp * 8 + 2 r + e of lane l: query l & 15, key 4 (l >> 4) + r, head 2 hp + e); the backward kernels LOAD them
+ *   (one dword per lane and tile) instead of regenerating the masks.
  * Supported: H in {4, 8}, 13 * H * ceil(dh / 16) * 512 + 3072 bytes of LDS <= 160 KB; -2 otherwise. */
-int spe_talking_flash_rows(const float* in0, const float* in1, const float* bl, float* out, int B, int H, int N, int Np, int mode,
-                           spe_stream_t stream);
 int spe_talking_flash_plan(int B, int N, int nwg, int* steps_per_wg, int* nwg_used, int* nmajor, int* rows_padded);
 int spe_talking_flash_fwd(const void* Qf, const void* Kf, const void* V16, const float* Wl, const float* Ww, const float* bw,
                           const float* c0, int Np, float* ws, float* O, void* O16, void* O16lo, void* keepbits, int B, int H, int N, int dh,
                           int nwg, float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
-int spe_talking_flash_dv(const void* Qf, const void* Kf, const void* dO16, const float* Wl, const float* Ww, const float* bw,
-                         const float* c0, int Np, float* ws, float* dv, void* dv16, long ob, long on, long oh, int B, int H, int N, int dh,
-                         int nwg, float p_drop, uint64_t seed, uint64_t offset, spe_stream_t stream);
 
-/* ---- query-major backward passes of the talking-heads attention on the flash skeleton (round 5; reference: the autograd of
- * models/cait.py:377-389 - proj_l, softmax, proj_w, attn_drop - i.e. what spe_talking_fused modes 2 / 3 and the dQ contraction of
- * spe_attn_contract compute, csrc/attn_flash_bwd.hip).  A workgroup of 4 waves (one per SIMD, 512 registers each) keeps 4 q-tiles'
- * Q / dO fragment records in registers and streams the key-side tiles through LDS.
- * spe_talking_bwdq_plan: the work split for an `nwg` workgroup budget - steps per workgroup, workgroups launched, major (4 q-tile) groups per
- *   image.  Workspaces: ws_d B * nmajor * 8 * 4 * H * 16 floats, ws_q B * nmajor * 8 * 4 * H * ceil(dh / 16) * 256 floats, ws_w
+/* ---- the two backward kernels (reference: the autograd of models/cait.py:377-389 - proj_l, softmax, proj_w, attn_drop; csrc/attn_flash_bwd.hip).
+ * A workgroup of 4 waves, ONE wave per SIMD (512 registers each): a wave keeps its tile's fragment records and 96 accumulators in AccVGPRs and
+ * streams the tiles of the other axis through LDS.
+ * spe_talking_bwdq_plan: the work split for an `nwg` workgroup budget - steps per workgroup, workgroups launched, major (4-tile) groups per
+ *   image.  Workspaces: ws_q / ws_v B * nmajor * 8 * 4 * H * ceil(dh / 16) * 256 floats, ws_d B * nmajor * Np * H floats, ws_w
  *   (nwg_used * 4) rows of 2 * (H * H + H) floats - row layout [dWl | dbl | dWw | dbw], pass 2 fills the first half, pass 1 the second;
  *   spe_talking_wgrad_reduce(ws_w, 4 * nwg_used, ...) sums them.
- * spe_talking_bwdq_pass1: Drows[b][q][h'] = sum_key dP[h'] P[h'] ([B][Np][H], rows >= N zero), dWw / dbw partials.  Qf, Kf fp16 fragment
- *   records (the forward's), dOf, Vf bf16 fragment records (spe_attn_pack_multi kind 0), c0 [B][Np][H] of spe_attn_merge_rows.
- * spe_talking_bwdq_pass2: dS = proj_l^T (P (dP - D)) as bf16 16 x 16 blocks (the layout of spe_talking_fused mode 3: the dK contraction
- *   reads them), dWl / dbl partials, and dq[b, q, h, :] = scale * sum_key dS[b,h][q,key] k[b, key, h, :] accumulated in registers (element
- *   strides ob, on, oh; dq fp32 and / or dq16 bf16 with the same addressing, either may be NULL).  K16 = bf16 k in the 16-wide layout
- *   (spe_attn_pack_multi kind 1).
- * spe_talking_bwdk_pass1 (KEY-major: a wave keeps one key tile's K / V records and 96 dV accumulators in registers and streams the q-tiles):
- *   backward pass 1 AND the dV pass of the same autograd in one walk - Drows and the dWw / dbw partials as spe_talking_bwdq_pass1, plus
- *   dv[b, key, h, :] = sum_q P'd[b,h][q,key] dO[b, q, h, :] (P'd = dropout(proj_w(P)), recomputed; element strides ob, on, oh; dv fp32 and /
- *   or dv16 bf16, either may be NULL): replaces spe_talking_fused mode 2 + spe_attn_merge + spe_talking_flash_rows + spe_talking_flash_dv.
- *   dO16 = bf16 dO in the 16-wide layout (spe_attn_pack_multi kind 1).  Workspaces: ws_d B * nmajor * Np * H floats (D summed over the 4 key
- *   tiles of a major), ws_v like ws_q, ws_w as above (the [dWw | dbw] half is filled).  Np >= 16 ceil(N / 16) + 64.
- * keepbits: the dropout keep flags of spe_talking_flash_fwd, required when p_drop > 0.  Supported: H in {4, 8}, head dim <= 64; -2 otherwise. */
+ * spe_talking_bwdk_pass1 (KEY-major: a wave keeps one key tile's K / V records and 96 dV accumulators and streams the q-tiles): S, S', P recomputed
+ *   ONCE for Drows[b][q][h'] = sum_key dP[h'] P[h'] ([B][Np][H], rows >= N zero; D summed over the 4 key tiles of a major in ws_d), the dWw / dbw
+ *   partials, and dv[b, key, h, :] = sum_q P'd[b,h][q,key] dO[b, q, h, :] (P'd = dropout(proj_w(P)); element strides ob, on, oh; dv fp32 and /
+ *   or dv16 bf16, either may be NULL).  Qf, Kf fp16 records (the forward's), dOf, Vf bf16 records (kind 0), dO16 = bf16 dO in the 16-wide layout
+ *   (kind 1), c0 [B][Np][H] of spe_attn_merge_rows, Np >= 16 ceil(N / 16) + 64.
+ * spe_talking_bwdq_pass2 (QUERY-major): dS = proj_l^T (P (dP - D)) as bf16 16 x 16 blocks (the dK contraction reads them), dWl / dbl partials,
+ *   and dq[b, q, h, :] = scale * sum_key dS[b,h][q,key] k[b, key, h, :] accumulated in registers (element strides ob, on, oh; dq fp32 and / or
+ *   dq16 bf16 with the same addressing, either may be NULL).  K16 = bf16 k in the 16-wide layout (kind 1).
+ * keepbits: the dropout keep flags of spe_talking_flash_fwd, required when p_drop > 0.  Supported: H in {4, 8}, head dim <= 64 within the LDS
+ * bound (H = 8: head dim <= 48); -2 otherwise. */
 int spe_talking_bwdk_pass1(const void* Qf, const void* dOf, const void* dO16, const void* Kf, const void* Vf, const float* Wl, const float* Ww,
                            const float* bw, const float* c0, int Np, float* ws_d, float* ws_v, float* ws_w, float* Drows, float* dv, void* dv16,
                            long ob, long on, long oh, const void* keepbits, int B, int H, int N, int dh, int nwg, float p_drop, spe_stream_t stream);
 int spe_talking_bwdq_plan(int B, int N, int nwg, int* steps_per_wg, int* nwg_used, int* nmajor);
-int spe_talking_bwdq_pass1(const void* Qf, const void* dOf, const void* Kf, const void* Vf, const float* Wl, const float* Ww,
-                           const float* c0, int Np, float* ws_d, float* ws_w, float* Drows, const void* keepbits, int B, int H, int N, int dh,
-                           int nwg, float p_drop, spe_stream_t stream);
 int spe_talking_bwdq_pass2(const void* Qf, const void* dOf, const void* Kf, const void* Vf, const void* K16, const float* Wl, const float* Ww,
                            const float* c0, const float* Drows, int Np, float* ws_q, float* ws_w, void* dS, float* dq, void* dq16,
                            long ob, long on, long oh, float scale, const void* keepbits, int B, int H, int N, int dh, int nwg, float p_drop,
                            spe_stream_t stream);
 
-/* ---- streaming contractions of a blocked 16-bit score tensor T (written by spe_talking_fused modes 1/3):
+/* ---- streaming contractions of a blocked 16-bit score tensor T (dS of spe_talking_bwdq_pass2):
  *   trans = 0: out[b, q, h, :]   = alpha * sum_key T[b,h][q,key] x[b, key, h, :]   (`attn @ v`, cait.py:388; dQ)
  *   trans = 1: out[b, key, h, :] = alpha * sum_q   T[b,h][q,key] x[b, q, h, :]     (dV, dK of the same autograd)
  * X16 = spe_attn_pack16(x): bf16 [B,H,nt,ceil(dh/16)][64][4] = x[b, tile*16+4*(lane>>4)+i, h, dtile*16+(lane&15)]

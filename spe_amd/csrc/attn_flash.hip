@@ -1,33 +1,23 @@
-// Flash-style talking-heads attention (K4 of SURVEY.md section 2.2; reference models/cait.py:377-389 and its autograd): the
-// kernels of this file keep the N x N tensors out of HBM altogether.
+// Flash forward of the talking-heads attention (K4 of SURVEY.md section 2.2; reference models/cait.py:377-389): no N x N tensor in HBM.
 //
-//   forward  (spe_talking_flash_fwd):  O = dropout(Ww softmax_k(Wl S + bl) + bw) V, S = scale q k^T, with the row statistics of
-//            the statistics pass (spe_talking_fused mode 0 + spe_attn_merge) - the P'd tensor the materialising write pass stored
-//            (554 MB per block at cfg2) and the streaming P'd V contraction are gone: P' goes from the mix straight into the
-//            P' V matrix instructions, O accumulates in registers.
-//   backward (spe_talking_flash_bwd):  key-major.  A wave owns 16 keys and walks over the query tiles, recomputing S, P, P' and
-//            dP' = dO V^T, dP = Ww^T dP', dS' = P (dP - D), dS = Wl^T dS' per step and accumulating dV += P'd^T dO and
-//            dK += dS^T Q in registers; dWl / dbl partials as in attn_fused.hip.  Only dS leaves the kernel (bf16 blocks, transposed
-//            ownership: lane = (key, 4 queries)) for the one remaining streaming contraction dQ = scale dS K.
+//   spe_talking_flash_fwd:  O = dropout(Ww softmax_k(Wl S + bl) + bw) V, S = scale q k^T, with the row statistics of the statistics pass
+//            (attn_stats.hip: spe_talking_stats + spe_attn_merge_rows).  P' goes from the mix straight into the P' V matrix instructions, O accumulates
+//            in registers.  With dropout it also stores the keep flags of every tile (1 bit per element) for the backward kernels (attn_flash_bwd.hip).
 //
-// Both kernels run ONE wave per SIMD with the whole 512-entry register file (the accumulators live in its AccVGPR half) and stage
-// the streamed operand tiles of a step in LDS with global_load_lds_dwordx4, double-buffered: the DMA of step i + 1 is issued
-// right after the barrier that admits step i and has the whole step to land.  Work is split by a flattened (batch, major tile
-// group, streamed tile) numbering cut into equal ranges (attn_flash_common.h: fl_plan), so 260 tile groups on 256 CUs cost no
-// second round; a range's partial O / dV / dK go to slot workspaces that one small merge kernel sums in fixed order
-// (bitwise reproducible: no floating-point atomics anywhere).
+// Two waves per SIMD at <= 256 registers each (all ordinary VGPRs); the streamed operand tiles of a step are staged in LDS with
+// global_load_lds_dwordx4, multi-buffered: the DMA of step i + 1 is issued right after the barrier that admits step i and has the whole step to
+// land.  Work is split by a flattened (batch, major tile group, streamed tile) numbering cut into equal ranges (attn_flash_common.h: fl_plan), so 260
+// tile groups on 256 CUs cost no second round; a range's partial O goes to slot workspaces that one small merge kernel sums in fixed order (bitwise
+// reproducible: no floating-point atomics anywhere).  (Round 4 / 5 also ran the dV pass of the backward on this skeleton - template parameter KV,
+// spe_talking_flash_dv; the key-major backward kernel took it over: profiles/HISTORY_r05.md.)
 #include "attn_flash_common.h"
 
-// =====================================================================================================================
-// forward
-// =====================================================================================================================
 struct FlashFwdArgs {
-    // fragment records (DT * 512 B each).  forward: Qf = q (resident tiles, fp16), Kf = k (streamed, fp16), V16 = v (streamed, fp16);
-    // dV pass (KV): Qf = k (resident), Kf = q (streamed), V16 = dO in the 16-wide layout (streamed, bf16)
+    // fragment records (DT * 512 B each): Qf = q (resident tiles, fp16), Kf = k (streamed, fp16), V16 = v (streamed, fp16)
     const unsigned char* Qf; const unsigned char* Kf; const unsigned char* V16;
     const float* Wl; const float* Ww; const float* bw;
-    const float* c0;                     // [B][Np][H]: bl * log2(e) - m + log2(1 / l), rows >= N zero (spe_talking_flash_rows mode 0)
-    int Np;                              // rows per image of c0 (>= 16 nt + 64: the dV pass fetches whole 1-KB pieces of it)
+    const float* c0;                     // [B][Np][H]: bl * log2(e) - m + log2(1 / l), rows >= N zero (spe_attn_merge_rows)
+    int Np;                              // rows per image of c0
     float* ws_o;                         // partial O * 2^8: [B * nmaj][FL_MAXSLOT][NW waves][QS][H][DT][64 lanes][4]
     int B, N, nt, nmaj, spw; long total;
     float p_drop; uint64_t seed, offset;
@@ -37,70 +27,32 @@ struct FlashFwdArgs {
     unsigned* keepbits;
 };
 
-// Geometry: FLF_NW waves per workgroup, FLF_QS q-tiles per wave, 8 q-tiles = 128 queries per workgroup either way (the K / V
-// tiles a workgroup streams are 24 KB per step at cfg2 and a CU loads ~10 B / clk: fewer queries per workgroup would make the
-// kernel load-bound).
-//   (4, 2): ONE wave per SIMD with the 512-entry register file: the 2 x 96 O accumulators live in AccVGPRs, everything else must
-//           stay under 256 VGPRs (otherwise hipcc parks values in AccVGPRs around every matrix instruction) - so each q-tile's half
-//           steps are kept apart: H1(u) ends in 16 registers of packed fp16 probabilities, H2(u) starts from them.
-//           hipcc (ROCm 7.2) nevertheless gives every matrix result an AccVGPR and copies it out for the vector instructions
-//           (1060 v_accvgpr moves per step): built, not used.
-//   (8, 1): two waves per SIMD, <= 256 registers each, all of them ordinary VGPRs: clean code, 210 registers.  The default.
-// SKEW (8-wave geometry).  A step has a matrix-heavy half H1 (K Q^T, the fp32 Wl mix: ~1000 matrix cycles, few vector instructions)
+// Geometry: 8 waves per workgroup, one q-tile per wave: 8 q-tiles = 128 queries per workgroup (the K / V tiles a workgroup streams are 24 KB per
+// step at cfg2 and a CU loads ~10 B / clk: fewer queries per workgroup would make the kernel load-bound).  Two waves per SIMD, <= 256 registers
+// each, all of them ordinary VGPRs (a one-wave-per-SIMD variant with the accumulators in AccVGPRs was built in round 4: hipcc gives every matrix
+// result an AccVGPR then and copies it out for the vector instructions - 1060 moves per step; profiles/r04_flash_variants.txt).
+// SKEW.  A step has a matrix-heavy half H1 (K Q^T, the fp32 Wl mix: ~1000 matrix cycles, few vector instructions)
 // and a vector-heavy half H2 (the fp16 Ww mix, dropout, packs, P' V).  With every wave running H1, H2 between the same barriers the
 // two waves of a SIMD are in lock step: they queue on the matrix pipe in H1 and leave it idle in H2 (measured, rocprofv3 SQ
 // counters at cfg2: matrix pipe 53 % + vector 46 % busy = no overlap).  So the two wave groups place their ONE barrier per step at
 // different points of the same instruction stream - waves 0-3 in front of H1, waves 4-7 in front of H2 - which holds the groups
 // half a step apart: between two barriers group 0 runs H1(k), H2(k) and group 1 H2(k), H1(k + 1).  Three K buffers, two V buffers.
-#ifndef FLF_NW
 #define FLF_NW 8
-#endif
-#ifndef FLF_SKEW
-#define FLF_SKEW 1
-#endif
-#ifndef FLF_SCHED
-#define FLF_SCHED 1
-#endif
 #define FLF_MAJ 8                        // q-tiles per workgroup
-#ifndef FLF_MIXH
-#define FLF_MIXH 1
-#endif
-#ifndef FLF_TAILMIX
-#define FLF_TAILMIX 0
-#endif
-#ifndef FLF_HB
 #define FLF_HB 4                         // heads per operand-fragment batch of the K Q^T products
-#endif
-#ifndef SPE_ABLATE
-#undef FLF_DBG_NOS
-#undef FLF_DBG_NOMIX1
-#undef FLF_DBG_NOEXP
-#undef FLF_DBG_NOMIX2
-#undef FLF_DBG_NOPV
-#undef FLF_DBG_NODMA
-#undef FLF_DBG_NOBAR
-#undef FLF_DBG_Q1
-#undef FLF_DBG_K1
-#undef FLF_DBG_NOTAIL
-#endif
 #define FLF_QS (FLF_MAJ / FLF_NW)
 
-// KV = false: the forward pass (a wave keeps q-tiles, streams key tiles: O = P'd V).
-// KV = true : the dV pass of the backward - the SAME walk on the transposed problem: a wave keeps KEY tiles and streams q-tiles,
-//             S = Q K^T lands as lane = (key l & 15, queries 4 (l >> 4) + r), the addend c0 belongs to the streamed rows (fetched per
-//             step into LDS), and the last product is dV^T[d][key] += dO^T[d][q] P'd[q][key] on bf16 operands.  P'd is recomputed
-//             from the forward's own fp16 fragments and statistics: nothing N x N was saved for it.
-template <int H, int DSTEPS, bool TAIL16, bool DROP, bool KV>
+template <int H, int DSTEPS, bool TAIL16, bool DROP>
 __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_kernel(FlashFwdArgs a) {
     constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
     constexpr int NW = FLF_NW, QS = FLF_QS;
     constexpr int TILEB = H * REC;                 // one operand, one 16-row tile, all heads
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];           // [K 0][K 1][K 2][V 0][V 1][8 resident tiles x TILEB][KV: c0 rows 0 1 2, 1 KB each]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];           // [K 0][K 1][K 2][V 0][V 1][8 resident tiles x TILEB]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
     const unsigned char* sQ = smem + 5 * TILEB + wave * (QS * TILEB);
     const unsigned ldsQ = lds0 + 5 * TILEB + wave * (QS * TILEB);
-    const int grp = (FLF_SKEW && NW == 8) ? (wave >> 2) : 0;      // 1: this wave's barrier sits between H1 and H2
+    const int grp = wave >> 2;                     // 1: this wave's barrier sits between H1 and H2
     const int nt = a.nt, N = a.N;
 
     float Al4[H / 4][H];
@@ -152,29 +104,20 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
                 fl_glds16_s(tb, voff[i], dst + p * 1024);
             }
         };
-        // dV pass: the addend rows of streamed q-tile t (16 x H floats; the 1-KB piece reaches into the next tiles' rows / the padding)
-        auto issue_c0 = [&](int t, int buf) {
-            if constexpr (KV) {
-                if (wave == 0) fl_glds16_s(a.c0 + ((long)b * a.Np + t * 16) * H, (unsigned)(lane * 16), lds0 + (5 + FLF_MAJ) * TILEB + buf * 1024);
-            }
-        };
         issue_tile(a.Kf, kt0, lds0);
-        issue_c0(kt0, 0);
 
         // ---- row constants and accumulators
-        f32x4_t c0v[KV ? 1 : QS][H / 4];
+        f32x4_t c0v[QS][H / 4];
         int qrow[QS];
 #pragma unroll
         for (int u = 0; u < QS; ++u) {
-            qrow[u] = (qt0 + u) * 16 + (lane & 15);                         // forward: this lane's query ; dV pass: this lane's KEY
-            if constexpr (!KV) {
-                const float* cp = a.c0 + ((long)b * a.Np + (wvalid ? min(qrow[u], N - 1) : 0)) * H;
+            qrow[u] = (qt0 + u) * 16 + (lane & 15);                         // this lane's query
+            const float* cp = a.c0 + ((long)b * a.Np + (wvalid ? min(qrow[u], N - 1) : 0)) * H;
 #pragma unroll
-                for (int gh = 0; gh < H / 4; ++gh) {
-                    c0v[u][gh] = *reinterpret_cast<const f32x4_t*>(cp + 4 * gh);
+            for (int gh = 0; gh < H / 4; ++gh) {
+                c0v[u][gh] = *reinterpret_cast<const f32x4_t*>(cp + 4 * gh);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) c0v[u][gh][i] += 8.0f;       // exp2(. + 8) = P * 2^8
-                }
+                for (int i = 0; i < 4; ++i) c0v[u][gh][i] += 8.0f;       // exp2(. + 8) = P * 2^8
             }
         }
         f32x4_t O[QS][H][DT];
@@ -189,18 +132,10 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
         // step to land.  Group 0 passes barrier i + 1 in front of H1(i), group 1 between H1(i) and H2(i); barrier 0 is common.
         auto step_barrier = [&](int j) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMA pieces (and its Q records) have landed
-#ifdef FLF_DBG_NOBAR
-            if (j == 0)
-#endif
             __builtin_amdgcn_s_barrier();                                // everybody's have, and the buffers refilled below have been read
             asm volatile("" ::: "memory");
-#ifdef FLF_DBG_NODMA
-            if (j == 0)
-#endif
-            {
-            if (j + 1 < seg) { issue_tile(a.Kf, kt0 + j + 1, lds0 + ((j + 1) % 3) * TILEB); issue_c0(kt0 + j + 1, (j + 1) % 3); }
+            if (j + 1 < seg) issue_tile(a.Kf, kt0 + j + 1, lds0 + ((j + 1) % 3) * TILEB);
             if (j < seg) issue_tile(a.V16, kt0 + j, lds0 + (3 + (j & 1)) * TILEB);
-            }
         };
         step_barrier(0);
         for (int i = 0; i < seg; ++i) {
@@ -212,7 +147,6 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
             // ---- H1: S^T = K Q^T (M = keys, N = queries): lane = (query l & 15, keys 4 (l >> 4) + r) ; P * 2^8 = exp2(Wl S + c0 + 8)
 #pragma unroll
             for (int u = 0; u < QS; ++u) {
-#if FLF_MIXH
                 // head-outer order: as soon as the raw scores of head h exist, its 4 x H / 4 contributions to the fp32 Wl mix are issued -
                 // 8 independent 4x4x1 instructions per head that fill the matrix pipe while the next head's K Q^T products wait for
                 // their LDS operands; the mix accumulators (32 registers) replace the 32 registers of raw scores, which now live for
@@ -221,13 +155,7 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int gh = 0; gh < H / 4; ++gh) {
-                        if constexpr (KV) {     // the streamed row 4 (l >> 4) + r: broadcast LDS read
-                            sp[r][gh] = *reinterpret_cast<const f32x4_t*>(smem + (5 + FLF_MAJ) * TILEB + (i % 3) * 1024 + ((4 * (lane >> 4) + r) * H + 4 * gh) * 4);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) sp[r][gh][k] += 8.0f;
-                        } else sp[r][gh] = c0v[u][gh];
-                    }
+                    for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = c0v[u][gh];
 #pragma unroll
                 for (int h0 = 0; h0 < H; h0 += FLF_HB) {
                     flu32x4_t kf[FLF_HB][FULL ? FULL : 1], qf[FLF_HB][FULL ? FULL : 1];
@@ -253,14 +181,9 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
                         for (int st = 0; st < FULL; ++st) c = fl_mfma32<true>(kf[hb][st], qf[hb][st], c);
                         if constexpr (TAIL16) {
                             // the 16-wide tail step as a 16x16x16 instruction into its OWN accumulator (an accumulate chain never mixes two MFMA
-                            // shapes - attn_fused.hip); the mix is linear, so the two parts go into it one after the other: no vector add
+                            // shapes - attn_stats.hip), added on the vector pipe
                             const f32x4_t t = fl_mfma16<true>(kt16[hb], qt16[hb], (f32x4_t){0.f, 0.f, 0.f, 0.f});
-                            if constexpr (FULL > 0 && FLF_TAILMIX) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                                    for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = __builtin_amdgcn_mfma_f32_4x4x1f32(Al4[gh][h0 + hb], t[r], sp[r][gh], 0, 0, 0);
-                            } else c = (FULL > 0) ? c + t : t;
+                            c = (FULL > 0) ? c + t : t;
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
@@ -273,89 +196,7 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
 #pragma unroll
                     for (int hh = 0; hh < H / 4; ++hh)          // P * 2^8 <= 256: no saturation needed
                         bv[u][r][hh] = fl_pack4_f16(fl_exp2(sp[r][hh][0]), fl_exp2(sp[r][hh][1]), fl_exp2(sp[r][hh][2]), fl_exp2(sp[r][hh][3]));
-#else
-                f32x4_t acc[H];
-#ifndef FLF_DBG_NOS
-                // operand fragments of FLF_HB heads are requested together (one LDS round trip per batch, not per head); the 16-wide tail
-                // step runs as a 16x16x16 instruction on its 8-B operands into its OWN accumulator (no zero-extended copies, and an
-                // accumulate chain never mixes two MFMA shapes - see attn_fused.hip), added on the vector pipe
-#pragma unroll
-                for (int h0 = 0; h0 < H; h0 += FLF_HB) {
-                    flu32x4_t kf[FLF_HB][FULL ? FULL : 1], qf[FLF_HB][FULL ? FULL : 1];
-                    fls16x4_t kt16[FLF_HB], qt16[FLF_HB];
-#pragma unroll
-                    for (int hb = 0; hb < FLF_HB; ++hb) {
-#ifdef FLF_DBG_K1
-                        const unsigned char* kr = sK;
-#else
-                        const unsigned char* kr = sK + (h0 + hb) * REC;
-#endif
-#ifdef FLF_DBG_Q1
-                        const unsigned char* qr = sQ;
-#else
-                        const unsigned char* qr = sQ + (u * H + h0 + hb) * REC;
-#endif
-#pragma unroll
-                        for (int st = 0; st < FULL; ++st) {
-                            kf[hb][st] = *reinterpret_cast<const flu32x4_t*>(kr + st * 1024 + lane * 16);
-                            qf[hb][st] = *reinterpret_cast<const flu32x4_t*>(qr + st * 1024 + lane * 16);
-                        }
-                        if constexpr (TAIL16) {
-                            kt16[hb] = *reinterpret_cast<const fls16x4_t*>(kr + FULL * 1024 + lane * 8);
-                            qt16[hb] = *reinterpret_cast<const fls16x4_t*>(qr + FULL * 1024 + lane * 8);
-                        }
-                    }
-#pragma unroll
-                    for (int hb = 0; hb < FLF_HB; ++hb) {
-                        f32x4_t c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int st = 0; st < FULL; ++st) c = fl_mfma32<true>(kf[hb][st], qf[hb][st], c);
-#ifndef FLF_DBG_NOTAIL
-                        if constexpr (TAIL16)
-#else
-                        if constexpr (false)
-#endif
-                        {
-                            const f32x4_t t = fl_mfma16<true>(kt16[hb], qt16[hb], (f32x4_t){0.f, 0.f, 0.f, 0.f});
-                            c = (FULL > 0) ? c + t : t;
-                        }
-                        acc[h0 + hb] = c;
-                    }
-                }
-#else
-#pragma unroll
-                for (int h = 0; h < H; ++h) acc[h] = (f32x4_t){(float)(i + h), 0.f, 0.f, 0.f};
-#endif
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    f32x4_t sp[H / 4];
-#pragma unroll
-                    for (int gh = 0; gh < H / 4; ++gh) {
-                        f32x4_t d;
-                        if constexpr (KV) {     // the streamed row 4 (l >> 4) + r: broadcast LDS read
-                            d = *reinterpret_cast<const f32x4_t*>(smem + (5 + FLF_MAJ) * TILEB + (i % 3) * 1024 + ((4 * (lane >> 4) + r) * H + 4 * gh) * 4);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) d[k] += 8.0f;
-                        } else d = c0v[u][gh];
-#ifndef FLF_DBG_NOMIX1
-#pragma unroll
-                        for (int h = 0; h < H; ++h) d = __builtin_amdgcn_mfma_f32_4x4x1f32(Al4[gh][h], acc[h][r], d, 0, 0, 0);
-#else
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) d[k] += acc[4 * gh + k][r];
-#endif
-                        sp[gh] = d;
-                    }
-#pragma unroll
-                    for (int hh = 0; hh < H / 4; ++hh)          // P * 2^8 <= 256: no saturation needed
-#ifndef FLF_DBG_NOEXP
-                        bv[u][r][hh] = fl_pack4_f16(fl_exp2(sp[hh][0]), fl_exp2(sp[hh][1]), fl_exp2(sp[hh][2]), fl_exp2(sp[hh][3]));
-#else
-                        bv[u][r][hh] = fl_pack4_f16(sp[hh][0], sp[hh][1], sp[hh][2], sp[hh][3]);
-#endif
-                }
-#endif
-                if (FLF_SCHED) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (grp != 0) step_barrier(i + 1);
             // ---- H2: P' * 2^8 = Ww (P * 2^8) + bw * 2^8 ; dropout ; fp16 B operands ; O^T[d][q] += V^T[d][key] P'^T[key][q]
@@ -367,13 +208,9 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
 #pragma unroll
                     for (int gh = 0; gh < H / 4; ++gh) {
                         f32x4_t d = vbws[gh];
-#ifndef FLF_DBG_NOMIX2
 #pragma unroll
                         for (int hh = 0; hh < H / 4; ++hh)
                             d = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(flf16x4_t, Aw[gh][hh]), __builtin_bit_cast(flf16x4_t, bv[u][r][hh]), d, 0, 0, 0);
-#else
-                        { const flf16x4_t t = __builtin_bit_cast(flf16x4_t, bv[u][r][gh]); d[0] += (float)t[0]; d[1] += (float)t[1]; d[2] += (float)t[2]; d[3] += (float)t[3]; }
-#endif
                         pr[r][gh] = d;
                     }
                 if constexpr (DROP) {
@@ -383,57 +220,28 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
 #pragma unroll
                     for (int hp = 0; hp < H / 2; ++hp) {
                         const int g0 = 2 * hp, g1 = 2 * hp + 1;
-                        if constexpr (!KV) {        // lane = (query, 4 consecutive keys): one counter, lots r
-                            uint32_t o[4];
-                            fl_keep_lots<H>(a.seed, a.offset, b, hp, qrow[u], (kt0 + i) * 16 + 4 * (lane >> 4), N, o);
+                        // lane = (query, 4 consecutive keys): one counter, lots r
+                        uint32_t o[4];
+                        fl_keep_lots<H>(a.seed, a.offset, b, hp, qrow[u], (kt0 + i) * 16 + 4 * (lane >> 4), N, o);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const bool e0 = fl_lot(o, 0, r) >= thr, e1 = fl_lot(o, 1, r) >= thr;
-                                pr[r][g0 >> 2][g0 & 3] *= e0 ? inv : 0.f;
-                                pr[r][g1 >> 2][g1 & 3] *= e1 ? inv : 0.f;
-                                kbw |= ((e0 ? 1u : 0u) | (e1 ? 2u : 0u)) << (hp * 8 + 2 * r);
-                            }
-                        } else {
-                            // lane = (key, 4 consecutive queries 4 (l >> 4) + r): element (q, key) uses lot (key & 3) of the counter of
-                            // (q, key >> 2).  The 4 lanes of a quad hold the 4 keys of one key group, so lane (l & 3) = t evaluates the
-                            // counter of query 4 (l >> 4) + t ONCE, keeps its own key's two lots, and the quad exchanges them
-                            // (quad-permute DPP): one Philox call per lane and head pair, as in the forward
-                            uint32_t o[4];
-                            fl_keep_lots<H>(a.seed, a.offset, b, hp, (kt0 + i) * 16 + 4 * (lane >> 4) + (lane & 3), qrow[u] & ~3, N, o);
-                            // lots of query t for the 4 keys of the group, both heads: word w[k] = lot(head 0, k) | lot(head 1, k) << 16
-                            uint32_t w[4];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) w[k] = fl_lot(o, 0, k) | (fl_lot(o, 1, k) << 16);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                // from lane t = r of the quad: its w[my key & 3]
-                                uint32_t got = 0;
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    const uint32_t x = fl_quad_bcast(w[k], r);
-                                    got = ((lane & 3) == k) ? x : got;
-                                }
-                                pr[r][g0 >> 2][g0 & 3] *= ((got & 0xffffu) >= thr) ? inv : 0.f;
-                                pr[r][g1 >> 2][g1 & 3] *= ((got >> 16) >= thr) ? inv : 0.f;
-                            }
+                        for (int r = 0; r < 4; ++r) {
+                            const bool e0 = fl_lot(o, 0, r) >= thr, e1 = fl_lot(o, 1, r) >= thr;
+                            pr[r][g0 >> 2][g0 & 3] *= e0 ? inv : 0.f;
+                            pr[r][g1 >> 2][g1 & 3] *= e1 ? inv : 0.f;
+                            kbw |= ((e0 ? 1u : 0u) | (e1 ? 2u : 0u)) << (hp * 8 + 2 * r);
                         }
                     }
-                    if constexpr (!KV) {            // the q-major backward passes load this tile's flags instead of drawing them again
-                        if (a.keepbits && wvalid && qt0 + u < nt) a.keepbits[(((long)b * nt + (qt0 + u)) * nt + (kt0 + i)) * 64 + lane] = kbw;
-                    }
+                    // the backward kernels load this tile's flags instead of drawing them again
+                    if (a.keepbits && wvalid && qt0 + u < nt) a.keepbits[(((long)b * nt + (qt0 + u)) * nt + (kt0 + i)) * 64 + lane] = kbw;
                 }
 #pragma unroll
                 for (int g = 0; g < H; ++g) {
-                    const fls16x4_t pk = fl_pack4<!KV>(pr[0][g >> 2][g & 3], pr[1][g >> 2][g & 3], pr[2][g >> 2][g & 3], pr[3][g >> 2][g & 3]);
-#ifndef FLF_DBG_NOPV
+                    const fls16x4_t pk = fl_pack4<true>(pr[0][g >> 2][g & 3], pr[1][g >> 2][g & 3], pr[2][g >> 2][g & 3], pr[3][g >> 2][g & 3]);
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt)     // A = the V16 record (lane: d = dt*16 + (l & 15), keys 4 (l >> 4) + i), B = pk
-                        O[u][g][dt] = fl_mfma16<!KV>(*reinterpret_cast<const fls16x4_t*>(sV + g * REC + dt * 512 + lane * 8), pk, O[u][g][dt]);
-#else
-                    { const flf16x4_t t = __builtin_bit_cast(flf16x4_t, pk); O[u][g][0][0] += (float)t[0] + (float)t[1] + (float)t[2] + (float)t[3]; }
-#endif
+                        O[u][g][dt] = fl_mfma16<true>(*reinterpret_cast<const fls16x4_t*>(sV + g * REC + dt * 512 + lane * 8), pk, O[u][g][dt]);
                 }
-                if (FLF_SCHED) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __builtin_amdgcn_s_barrier();              // the last tiles have been read by everybody: the next segment may refill the buffers
@@ -456,9 +264,8 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
     }
 }
 
-// Sum of the partial result slots of each (major, wave, tile), times 2^-8 -> out[b, row, g, d] (element strides ob, on, oh; the
-// forward's O [B, N, H * dh], or the v slice of dqkv for the dV pass) fp32 (+ its bf16 copy / low part with the same addressing:
-// the operand of the output projection).  One thread per float4 of the fragment-ordered workspace; fixed summation order.
+// Sum of the partial result slots of each (major, wave, tile), times 2^-8 -> O[b, row, g, d] (element strides ob, on, oh) fp32 (+ its bf16 copy /
+// low part with the same addressing: the operand of the output projection).  One thread per float4 of the fragment-ordered workspace; fixed order.
 __global__ __launch_bounds__(256) void flash_merge_kernel(const float* __restrict__ ws, float* __restrict__ O, long ob, long on, long oh,
                                                           unsigned short* __restrict__ O16, unsigned short* __restrict__ O16lo,
                                                           int B, int H, int N, int nt, int dh, int DT, int nmaj, int spw, long nvec) {
@@ -513,37 +320,21 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(const float* __restric
     }
 }
 
-// =====================================================================================================================
-// row constants
-// =====================================================================================================================
-// out [B][Np][H], rows q >= N zero.
-// mode 0: out[b][q][g] = bl[g] * log2(e) - M[b][g][q] + log2(IL[b][g][q])     (the addend that turns Wl S into log2 P)
-// mode 1: out[b][q][g] = in0[b][g][q]                                            (D of backward pass 1, query-major)
-__global__ __launch_bounds__(256) void flash_rows_kernel(const float* __restrict__ in0, const float* __restrict__ in1, const float* __restrict__ bl,
-                                                         float* __restrict__ out, int B, int H, int N, int Np, int mode) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)B * Np * H) return;
-    const int g = (int)(i % H); const long bq = i / H; const int q = (int)(bq % Np), b = (int)(bq / Np);
-    if (q >= N) { out[i] = 0.f; return; }
-    const long si = ((long)b * H + g) * N + q;
-    out[i] = (mode == 0) ? bl[g] * FL_LOG2E - in0[si] + __builtin_amdgcn_logf(in1[si]) : in0[si];
-}
-
-template <int H, int DSTEPS, bool TAIL16, bool KV>
+template <int H, int DSTEPS, bool TAIL16>
 static int launch_flash_fwd(const FlashFwdArgs& a, int nwg, bool drop, hipStream_t st) {
     constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
-    constexpr int smem = (5 + FLF_MAJ) * H * REC + (KV ? 3 * 1024 : 0);
+    constexpr int smem = (5 + FLF_MAJ) * H * REC;
     if (smem > 160 * 1024) return -2;              // H * head dim too large for the resident tiles + the stage buffers: use the materialising path
     static bool attr_set[2] = {false, false};
-    const void* fn = drop ? reinterpret_cast<const void*>(&talking_flash_fwd_kernel<H, DSTEPS, TAIL16, true, KV>)
-                          : reinterpret_cast<const void*>(&talking_flash_fwd_kernel<H, DSTEPS, TAIL16, false, KV>);
+    const void* fn = drop ? reinterpret_cast<const void*>(&talking_flash_fwd_kernel<H, DSTEPS, TAIL16, true>)
+                          : reinterpret_cast<const void*>(&talking_flash_fwd_kernel<H, DSTEPS, TAIL16, false>);
     if (!attr_set[drop]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set[drop] = true;
     }
-    if (drop) hipLaunchKernelGGL((talking_flash_fwd_kernel<H, DSTEPS, TAIL16, true, KV>), dim3(nwg), dim3(64 * FLF_NW), smem, st, a);
-    else hipLaunchKernelGGL((talking_flash_fwd_kernel<H, DSTEPS, TAIL16, false, KV>), dim3(nwg), dim3(64 * FLF_NW), smem, st, a);
+    if (drop) hipLaunchKernelGGL((talking_flash_fwd_kernel<H, DSTEPS, TAIL16, true>), dim3(nwg), dim3(64 * FLF_NW), smem, st, a);
+    else hipLaunchKernelGGL((talking_flash_fwd_kernel<H, DSTEPS, TAIL16, false>), dim3(nwg), dim3(64 * FLF_NW), smem, st, a);
     SPE_CHECK_LAUNCH();
     return 0;
 }
@@ -563,59 +354,34 @@ extern "C" int spe_talking_flash_plan(int B, int N, int nwg, int* steps_per_wg, 
     return 0;
 }
 
-extern "C" int spe_talking_flash_rows(const float* in0, const float* in1, const float* bl, float* out, int B, int H, int N, int Np, int mode,
-                                      hipStream_t st) {
-    const long n = (long)B * Np * H;
-    if (n <= 0) return 0;
-    if (Np < N) return -2;
-    hipLaunchKernelGGL(flash_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in0, in1, bl, out, B, H, N, Np, mode);
-    SPE_CHECK_LAUNCH();
-    return 0;
-}
-
-// forward (kv = 0): R = Qf, S1 = Kf, S2 = V16, out = O.   dV pass (kv = 1): R = Kf, S1 = Qf, S2 = dO16 (bf16), out = dv.
-static int flash_run(int kv, const void* R, const void* S1, const void* S2, const float* Wl, const float* Ww, const float* bw, const float* c0,
-                     int Np, float* ws, float* out, long ob, long on, long oh, void* O16, void* O16lo, int B, int H, int N, int dh, int nwg,
-                     float p_drop, uint64_t seed, uint64_t offset, hipStream_t st, void* keepbits = nullptr) {
+// C-ABI: see include/spe_hip.h
+extern "C" int spe_talking_flash_fwd(const void* Qf, const void* Kf, const void* V16, const float* Wl, const float* Ww, const float* bw,
+                                     const float* c0, int Np, float* ws, float* O, void* O16, void* O16lo, void* keepbits, int B, int H, int N,
+                                     int dh, int nwg, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
     const int nt = (N + 15) / 16;
     if ((long)B * nt <= 0) return 0;
     if (dh < 1 || dh > 64 || nwg <= 0 || (O16lo && !O16) || Np < nt * 16 + 64) return -2;
     int tail; const int ds = flash_dsteps(dh, &tail);
     const FlashPlan p = fl_plan(B, nt, FLF_MAJ, nt, nwg);
     FlashFwdArgs a;
-    a.Qf = (const unsigned char*)R; a.Kf = (const unsigned char*)S1; a.V16 = (const unsigned char*)S2;
+    a.Qf = (const unsigned char*)Qf; a.Kf = (const unsigned char*)Kf; a.V16 = (const unsigned char*)V16;
     a.Wl = Wl; a.Ww = Ww; a.bw = bw; a.c0 = c0; a.Np = Np; a.ws_o = ws;
     a.B = B; a.N = N; a.nt = nt; a.nmaj = p.nmaj; a.spw = p.spw; a.total = p.total;
-    a.p_drop = p_drop; a.seed = seed; a.offset = offset; a.keepbits = reinterpret_cast<unsigned*>(keepbits);
+    a.p_drop = p_drop; a.seed = seed; a.offset = offset; a.keepbits = reinterpret_cast<unsigned*>(p_drop > 0.f ? keepbits : nullptr);
     const bool drop = p_drop > 0.f;
     int rc = -2;
-#define SPE_FLASH_FWD(HH, KVV)                                                                   \
-    if (H == HH && ds == 2 && tail) rc = launch_flash_fwd<HH, 2, true, KVV>(a, p.nwg, drop, st);       \
-    else if (H == HH && ds == 2 && !tail) rc = launch_flash_fwd<HH, 2, false, KVV>(a, p.nwg, drop, st); \
-    else if (H == HH && ds == 1 && tail) rc = launch_flash_fwd<HH, 1, true, KVV>(a, p.nwg, drop, st);  \
-    else if (H == HH && ds == 1 && !tail) rc = launch_flash_fwd<HH, 1, false, KVV>(a, p.nwg, drop, st);
-    if (kv) { SPE_FLASH_FWD(8, true) else SPE_FLASH_FWD(4, true) }
-    else { SPE_FLASH_FWD(8, false) else SPE_FLASH_FWD(4, false) }
+#define SPE_FLASH_FWD(HH)                                                                   \
+    if (H == HH && ds == 2 && tail) rc = launch_flash_fwd<HH, 2, true>(a, p.nwg, drop, st);       \
+    else if (H == HH && ds == 2 && !tail) rc = launch_flash_fwd<HH, 2, false>(a, p.nwg, drop, st); \
+    else if (H == HH && ds == 1 && tail) rc = launch_flash_fwd<HH, 1, true>(a, p.nwg, drop, st);  \
+    else if (H == HH && ds == 1 && !tail) rc = launch_flash_fwd<HH, 1, false>(a, p.nwg, drop, st);
+    SPE_FLASH_FWD(8) else SPE_FLASH_FWD(4)
 #undef SPE_FLASH_FWD
     if (rc != 0) return rc;
     const int DT = (dh + 15) / 16;
     const long nvec = (long)B * p.nmaj * FLF_MAJ * H * DT * 64;
-    hipLaunchKernelGGL(flash_merge_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, ws, out, ob, on, oh,
+    hipLaunchKernelGGL(flash_merge_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, ws, O, (long)N * H * dh, (long)H * dh, (long)dh,
                        reinterpret_cast<unsigned short*>(O16), reinterpret_cast<unsigned short*>(O16lo), B, H, N, nt, dh, DT, p.nmaj, p.spw, nvec);
     SPE_CHECK_LAUNCH();
     return 0;
-}
-
-extern "C" int spe_talking_flash_fwd(const void* Qf, const void* Kf, const void* V16, const float* Wl, const float* Ww, const float* bw,
-                                     const float* c0, int Np, float* ws, float* O, void* O16, void* O16lo, void* keepbits, int B, int H, int N,
-                                     int dh, int nwg, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
-    return flash_run(0, Qf, Kf, V16, Wl, Ww, bw, c0, Np, ws, O, (long)N * H * dh, (long)H * dh, dh, O16, O16lo, B, H, N, dh, nwg, p_drop, seed, offset, st,
-                     p_drop > 0.f ? keepbits : nullptr);
-}
-
-extern "C" int spe_talking_flash_dv(const void* Qf, const void* Kf, const void* dO16, const float* Wl, const float* Ww, const float* bw,
-                                    const float* c0, int Np, float* ws, float* dv, void* dv16, long ob, long on, long oh, int B, int H, int N, int dh,
-                                    int nwg, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
-    if (!dv && !dv16) return -2;
-    return flash_run(1, Kf, Qf, dO16, Wl, Ww, bw, c0, Np, ws, dv, ob, on, oh, dv16, nullptr, B, H, N, dh, nwg, p_drop, seed, offset, st);
 }

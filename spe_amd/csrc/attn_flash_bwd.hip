@@ -1,111 +1,67 @@
-// Query-major backward passes of the talking-heads attention on the flash skeleton (K4 of SURVEY.md section 2.2; reference
-// models/cait.py:377-389 and its autograd), built for ONE wave per SIMD and the whole 512-entry register file:
+// The two backward kernels of the talking-heads attention (K4 of SURVEY.md section 2.2; reference models/cait.py:377-389 and its autograd), built for
+// ONE wave per SIMD and the whole 512-entry register file:
 //
-//   pass 1 (spe_talking_bwdq_pass1):  D[h', q] = sum_k dP[h'] P[h'] (the softmax backward's row term), dWw, dbw
-//   pass 2 (spe_talking_bwdq_pass2):  dS' = P (dP - D), dWl, dbl, dS = Wl^T dS' -> bf16 16 x 16 blocks (read once more, by the dK
-//                                     contraction) AND dQ += dS K in registers: the streaming dQ contraction of attn_contract.hip and
-//                                     one of the two reads of the 554 MB (cfg2) dS tensor are gone.
+//   key-major   (spe_talking_bwdk_pass1): D[h', q] = sum_k dP[h'] P[h'] (the softmax backward's row term), dWw, dbw, dV += P'd^T dO in registers
+//   query-major (spe_talking_bwdq_pass2): dS' = P (dP - D), dWl, dbl, dS = Wl^T dS' -> bf16 16 x 16 blocks (read once more, by the dK contraction)
+//                                         AND dQ += dS K in registers
 //
-// with S = scale q k^T, S' = Wl S + bl, P = softmax_k(S'), P' = Ww P + bw, dP' = dropout-mask * (dO V^T), dP = Ww^T dP'.  Both passes
+// with S = scale q k^T, S' = Wl S + bl, P = softmax_k(S'), P' = Ww P + bw, dP' = dropout-mask * (dO V^T), dP = Ww^T dP'.  Both kernels
 // recompute S / S' / P from the forward's own fp16 fragments and statistics (P matches the forward exactly) and dP' from bf16 fragments.
 //
-// Register plan (why this file is compiled with -mllvm -amdgpu-mfma-vgpr-form=1, spe_amd/build.py).  A wave owns one 16-query tile for a
-// whole segment of key tiles.  Its Q and dO fragment records (2 x 48 registers at cfg2) and - pass 2 - the 96 dQ accumulators live in
-// the AccVGPR half of the register file: they are touched by matrix instructions only, as B operands resp. C / D, through inline
-// assembly with "a" constraints.  Everything else (the score tile of all heads, both head-mix accumulator sets, the mixing weights) stays
-// under 256 ordinary VGPRs, and with the VGPR form forced for the builtin matrix instructions hipcc moves nothing between the two halves
-// inside the key loop (without the flag every builtin result lands in an AccVGPR once a kernel may use them and is copied out for the
-// vector instructions: 4.4 moves per matrix instruction measured on the round-4 prototype of the forward kernel).
-// The q-side operands in registers instead of LDS is what makes the flash skeleton fit: 4 resident q-tiles x (Q + dO) would be 96 KB
-// next to 72 KB of stage buffers and 32 KB of transpose tiles.
+// Register plan (why this file is compiled with -mllvm -amdgpu-mfma-vgpr-form=1, spe_amd/build.py).  A wave owns one 16-row tile for a whole
+// segment of tiles of the other axis.  Its two fragment records (2 x 48 registers at cfg2) and the 96 accumulators live in the AccVGPR half of
+// the register file: they are touched by matrix instructions only, as B operands resp. C / D, through inline assembly with "a" constraints.
+// Everything else (the score tile of all heads, both head-mix accumulator sets, the mixing weights) stays under 256 ordinary VGPRs, and with
+// the VGPR form forced for the builtin matrix instructions hipcc moves nothing between the two halves inside the tile loop (without the flag every
+// builtin result lands in an AccVGPR once a kernel may use them and is copied out for the vector instructions: 4.4 moves per matrix instruction
+// measured on the round-4 prototype of the forward kernel).  The resident operands in registers instead of LDS is what makes the flash skeleton
+// fit: 4 resident tiles x 2 records would be 96 KB next to 72 KB of stage buffers and 32 KB of transpose tiles.
 //
-// LDS: two stages of the streamed key-side tiles - K fp16 fragments, V bf16 fragments, pass 2: K bf16 in the 16-wide layout - filled by
-// global_load_lds_dwordx4 one step ahead (one barrier per step), plus the wave-private transpose tiles of the weight-gradient outer
-// products (attn_fused.hip, GWM).  Work split: attn_flash_common.h (fl_plan) with 4 q-tiles per workgroup; partial D / dQ of a segment
-// go to slot workspaces summed in fixed order by the two small merge kernels below (bitwise reproducible, no atomics).
+// LDS: two stages of the streamed tiles (two 32-wide fragment sets + one 16-wide set in FLB_NK16 slots), filled by global_load_lds_dwordx4 one
+// step ahead (one barrier per step), plus the wave-private transpose tiles of the weight-gradient outer products.  Work split:
+// attn_flash_common.h (fl_plan) with 4 tiles per workgroup; partial D / dQ / dV of a segment go to slot workspaces summed in fixed order by the
+// small merge kernels below (bitwise reproducible, no atomics).
+//
+// What was tried on these loops and lost (exponentials inside an inline-assembly mix block, the reduce-scatter from DPP builtins,
+// sched_group_barrier interleave requests, the back half first in source order, a query-major pass 1): profiles/HISTORY_r05.md.
+// Timing ablations (-DSPE_ABLATE builds only, tools/ab.py): FLB_DBG_SAMETILE (every workgroup streams tile 0: all L2 hits), FLB_DBG_NOST (no dS store).
 #include "attn_flash_common.h"
 #include <type_traits>
 
-#define FLB_NW 4                         // waves per workgroup = q-tiles per workgroup (one wave per SIMD)
-#ifndef FLB_HB
+#define FLB_NW 4                         // waves per workgroup = resident tiles per workgroup (one wave per SIMD)
 #define FLB_HB 4                         // heads per operand batch of the score products
-#endif
-#ifndef FLB_PHASEFENCE
-#define FLB_PHASEFENCE 1
-#endif
 #define FLB_GWR 144                      // row pitch of the weight-gradient transpose tiles (bytes)
-#ifndef FLB_NK16
-#define FLB_NK16 3                       // slots of the 16-wide K tiles (pass 2): tile i is read by the back half of step i, one step after its K / V stage
-#endif
-#ifndef FLB_SGB
-#define FLB_SGB 0                        // 1: sched_group_barrier interleave request (FLB_SGB_N x {FLB_SGB_M matrix, FLB_SGB_V vector instructions})
-#endif
-#ifndef FLB_SGB_N
-#define FLB_SGB_N 120
-#endif
-#ifndef FLB_SGB_M
-#define FLB_SGB_M 1
-#endif
-#ifndef FLB_SGB_V
-#define FLB_SGB_V 2
-#endif
-#ifndef FLB_RSFUSE
+#define FLB_NK16 3                       // slots of the 16-wide tiles: tile i is read by the back half of step i, one step after its stage
 #define FLB_RSFUSE 1                     // key-major kernel: the D reduce-scatter of tile i inside the score-product blocks of tile i + 1 (head dim 33 .. 48, 8 heads)
-#endif
-#ifndef FLB_SGB2
-#define FLB_SGB2 0                       // key-major kernel: interleave request for the region of front_q (second chunk) + back_ds
-#endif
-#ifndef FLB_SGB2_N
-#define FLB_SGB2_N 32
-#endif
-#ifndef FLB_SGB2_V
-#define FLB_SGB2_V 3
-#endif
-#ifndef FLB_DQAHEAD
-#define FLB_DQAHEAD 2                    // heads the 16-wide K operand loads of the dQ products run ahead of their matrix instructions
-#endif
+#define FLB_DQAHEAD 2                    // heads the 16-wide operand loads of the accumulator products run ahead of their matrix instructions
 #define FLB_SB_NOMEM 0x00F               // sched_barrier mask: ALU / VALU / SALU / MFMA may cross, memory instructions (LDS reads) may not
-#ifndef FLB_PIPE
-#define FLB_PIPE 1                       // source order inside a pipelined step: 1 = front(i + 1) first, 0 = back(i) first
-#endif
-#if FLB_PHASEFENCE
 #define FLB_PHASE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define FLB_PHASE() do {} while (0)
-#endif
 #ifndef SPE_ABLATE
 #undef FLB_DBG_SAMETILE
-#undef FLB_DBG_NOGWM
-#undef FLB_DBG_NODQ
 #undef FLB_DBG_NOST
-#undef FLB_DBG_NOMIX1
-#undef FLB_DBG_NOEXP
-#undef FLB_DBG_NOMIX16
-#undef FLB_DBG_NODMA
 #endif
 
 struct FlashBwdArgs {
     const unsigned char* Qf; const unsigned char* dOf;            // q-side fragment records (fp16 q * scale * log2 e ; bf16 dO)
-    const unsigned char* Kf; const unsigned char* Vf; const unsigned char* K16;   // key-side records: fp16 k, bf16 v (32-wide layout), bf16 k (16-wide layout, pass 2)
+    const unsigned char* Kf; const unsigned char* Vf; const unsigned char* K16;   // key-side records: fp16 k, bf16 v (32-wide layout), bf16 k (16-wide layout)
     const float* Wl; const float* Ww;
     const float* c0;                     // [B][Np][H]: bl log2(e) - m + log2(1 / l), rows >= N zero
-    const float* Drows;                  // pass 2: [B][Np][H] D of pass 1, rows >= N zero
+    const float* Drows;                  // [B][Np][H] D of the key-major kernel, rows >= N zero
     int Np;
-    float* ws_d;                         // pass 1: partial D [B * nmaj][FL_MAXSLOT][FLB_NW][H][16]
-    float* ws_q;                         // pass 2: partial dQ [B * nmaj][FL_MAXSLOT][FLB_NW][H][DT][64 lanes][4]
-    float* ws_w;                         // weight-gradient partials [nwg * FLB_NW][2 * (H * H + H)], row = [dWl | dbl | dWw | dbw]: pass 2 fills the first half, pass 1 the second
-    unsigned short* dS;                  // pass 2: bf16 blocks [B, H, nt, nt][64 lanes][4], lane = (query l & 15, keys 4 (l >> 4) + i)
+    float* ws_q;                         // partial dQ [B * nmaj][FL_MAXSLOT][FLB_NW][H][DT][64 lanes][4]
+    float* ws_w;                         // weight-gradient partials [nwg * FLB_NW][2 * (H * H + H)], row = [dWl | dbl | dWw | dbw]: this kernel fills the first half, the key-major one the second
+    unsigned short* dS;                  // bf16 blocks [B, H, nt, nt][64 lanes][4], lane = (query l & 15, keys 4 (l >> 4) + i)
     const unsigned* keepbits;            // dropout keep flags of spe_talking_flash_fwd [B][nt][nt][64]
     int B, N, nt, nmaj, spw; long total;
     float p_drop;
 };
 
 // ---- score products with the B operand in AccVGPRs.  One statement per head: FULL chained 32-deep steps into c, the 16-deep tail step into
-// its OWN accumulator t (an accumulate chain never mixes two MFMA shapes: attn_fused.hip).  No wait states inside: the results are only
+// its OWN accumulator t (an accumulate chain never mixes two MFMA shapes: attn_stats.hip).  No wait states inside: the results are only
 // read behind flb_fence*, which follows the whole batch.
 // One statement per chunk of 4 heads: the FULL 32-deep steps of all four heads first, then (TAIL16) their 16-deep tail steps accumulating
 // onto the same registers - a head's two shapes are then three instructions apart, the first has long left the pipe when the second reads
-// its result (back to back, hipcc's placement in attn_fused.hip, the mixed-shape chain gave run-to-run different sums).  No wait states
+// its result (back to back, hipcc's placement in the round-2 kernels, the mixed-shape chain gave run-to-run different sums).  No wait states
 // inside: the results are only read behind flb_fence4, which follows the statement.
 #define FLB_SCORE_ASM(NAME, M32, M16)                                                                                                      \
     template <int FULL, bool TAIL16>                                                                                                       \
@@ -161,86 +117,15 @@ __device__ __forceinline__ void flb_dq_mfma(f32x4_t* acc, const fls16x4_t* ka, f
 // the accumulators become readable (segment end)
 __device__ __forceinline__ void flb_acc_fence(f32x4_t& a) { asm volatile("s_nop 7\n\ts_nop 4" : "+a"(a)); }
 
-// S' += Wl S for a chunk of 4 heads and 8 output heads (32 v_mfma_f32_4x4x1 on the 8 accumulators sp[r][gh]) with 16 v_exp_f32 of ANOTHER tile's exponents in
-// their shadow - one after every second matrix instruction.  The exponentials are quarter-rate vector instructions (16 cycles each): left to the compiler they sat
-// in runs of 8-32 behind the mixes (a single wave per SIMD overlaps its matrix and vector streams only where the instruction stream alternates).  The accumulate
-// chains reuse an accumulator every 12th instruction; s_nop 7 at the end: the 2-pass results and the exponentials are read by ordinary vector instructions next.
-// MEASURED SLOWER and off (round 5, isolated at cfg2: key-major pass 375 -> 398 us, pass 2 365 -> 360 ... 373 us): the compiler's own placement of these matrix
-// instructions between the packing instructions of the back half is worth more than the exponentials' shadow.  Kept as the record of the experiment.
-#ifndef FLB_MIXEXP
-#define FLB_MIXEXP 0
-#endif
-__device__ __forceinline__ void flb_mix4_exp8(const float (&A)[2][8], const int h0, const f32x4_t (&c)[4], f32x4_t (&sp)[4][2], f32x4_t (&e0)[4][2], const int eg) {
-    // e0[r][eg][k]: the 16 exponents ; A[gh][h0 + hb] ; c[hb][r]
-#define FLB_E(r, k) "+v"(e0[r][eg][k])
-    asm(
-            "v_mfma_f32_4x4x1_16b_f32 %0, %24, %32, %0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %1, %28, %32, %1\n\t"
-            "v_exp_f32 %8, %8\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %2, %24, %33, %2\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %3, %28, %33, %3\n\t"
-            "v_exp_f32 %9, %9\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %4, %24, %34, %4\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %5, %28, %34, %5\n\t"
-            "v_exp_f32 %10, %10\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %6, %24, %35, %6\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %7, %28, %35, %7\n\t"
-            "v_exp_f32 %11, %11\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %0, %25, %36, %0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %1, %29, %36, %1\n\t"
-            "v_exp_f32 %12, %12\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %2, %25, %37, %2\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %3, %29, %37, %3\n\t"
-            "v_exp_f32 %13, %13\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %4, %25, %38, %4\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %5, %29, %38, %5\n\t"
-            "v_exp_f32 %14, %14\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %6, %25, %39, %6\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %7, %29, %39, %7\n\t"
-            "v_exp_f32 %15, %15\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %0, %26, %40, %0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %1, %30, %40, %1\n\t"
-            "v_exp_f32 %16, %16\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %2, %26, %41, %2\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %3, %30, %41, %3\n\t"
-            "v_exp_f32 %17, %17\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %4, %26, %42, %4\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %5, %30, %42, %5\n\t"
-            "v_exp_f32 %18, %18\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %6, %26, %43, %6\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %7, %30, %43, %7\n\t"
-            "v_exp_f32 %19, %19\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %0, %27, %44, %0\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %1, %31, %44, %1\n\t"
-            "v_exp_f32 %20, %20\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %2, %27, %45, %2\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %3, %31, %45, %3\n\t"
-            "v_exp_f32 %21, %21\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %4, %27, %46, %4\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %5, %31, %46, %5\n\t"
-            "v_exp_f32 %22, %22\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %6, %27, %47, %6\n\t"
-            "v_mfma_f32_4x4x1_16b_f32 %7, %31, %47, %7\n\t"
-            "v_exp_f32 %23, %23\n\t"
-            "s_nop 7"
-        : "+v"(sp[0][0]), "+v"(sp[0][1]), "+v"(sp[1][0]), "+v"(sp[1][1]), "+v"(sp[2][0]), "+v"(sp[2][1]), "+v"(sp[3][0]), "+v"(sp[3][1]),
-          FLB_E(0, 0), FLB_E(0, 1), FLB_E(0, 2), FLB_E(0, 3), FLB_E(1, 0), FLB_E(1, 1), FLB_E(1, 2), FLB_E(1, 3),
-          FLB_E(2, 0), FLB_E(2, 1), FLB_E(2, 2), FLB_E(2, 3), FLB_E(3, 0), FLB_E(3, 1), FLB_E(3, 2), FLB_E(3, 3)
-        : "v"(A[0][h0]), "v"(A[0][h0 + 1]), "v"(A[0][h0 + 2]), "v"(A[0][h0 + 3]), "v"(A[1][h0]), "v"(A[1][h0 + 1]), "v"(A[1][h0 + 2]), "v"(A[1][h0 + 3]),
-          "v"(c[0][0]), "v"(c[0][1]), "v"(c[0][2]), "v"(c[0][3]), "v"(c[1][0]), "v"(c[1][1]), "v"(c[1][2]), "v"(c[1][3]),
-          "v"(c[2][0]), "v"(c[2][1]), "v"(c[2][2]), "v"(c[2][3]), "v"(c[3][0]), "v"(c[3][1]), "v"(c[3][2]), "v"(c[3][3]));
-#undef FLB_E
-}
-
-template <int H, int DSTEPS, bool TAIL16, bool DROP, int PASS>
+template <int H, int DSTEPS, bool TAIL16, bool DROP>
 __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdArgs a) {
     constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
     constexpr int NW = FLB_NW, HB = (H >= FLB_HB) ? FLB_HB : H;
     constexpr int TILEB = H * REC;                  // one operand, one 16-row tile, all heads
     constexpr int KVB = 2 * TILEB;                  // a K / V stage: K fragments, V fragments
-    constexpr int NK16 = (PASS == 2) ? FLB_NK16 : 0;
+    constexpr int NK16 = FLB_NK16;
     constexpr int F1 = FULL ? FULL : 1;
-    // LDS: [K / V stage 0][K / V stage 1][pass 2: FLB_NK16 slots of K in the 16-wide layout][constants 512 B][NW x 3 transpose tiles]
+    // LDS: [K / V stage 0][K / V stage 1][FLB_NK16 slots of K in the 16-wide layout][constants 512 B][NW x 3 transpose tiles]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
@@ -251,15 +136,18 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
     fl_mixA_f32<H, false>(a.Wl, lane, Al4);
     fls16x4_t Awt[H / 4][H / 4];                    // dP = Ww^T dP' (bf16, 4x4x4)
     fl_mixA_16<H, true, false>(a.Ww, lane, 1.0f, Awt);
-    fls16x4_t Alt[(PASS == 2) ? H / 4 : 1][(PASS == 2) ? H / 4 : 1];           // dS = Wl^T dS' (bf16, 4x4x4)
-    if constexpr (PASS == 2) fl_mixA_16<H, true, false>(a.Wl, lane, 1.0f, Alt);
+    fls16x4_t Alt[H / 4][H / 4];                    // dS = Wl^T dS' (bf16, 4x4x4)
+    fl_mixA_16<H, true, false>(a.Wl, lane, 1.0f, Alt);
 
-    // ---- weight-gradient outer products on the matrix pipe through a wave-private LDS transpose (see attn_fused.hip, GWM):
-    // pass 1: X = dP', Y = P -> dWw (+ dbw from the ones column) ; pass 2: X = dS', Y = S -> dWl (dbl stays an fp32 vector sum).
+    // ---- weight-gradient outer product on the matrix pipe through a wave-private LDS transpose: dW[g][h] = sum over (query, key) positions of x_g y_h is
+    // a contraction over POSITIONS, i.e. D[m = g][n = h] += A[g][pos] B[pos][h] with 16 positions per v_mfma_f32_16x16x16_bf16.  A lane owns ONE query and 4
+    // keys for all heads, the operands want one HEAD per lane (m = lane & 15) and 4 keys of query t for the t-th instruction: a (query x head) transpose inside
+    // each 16-lane group.  Rows m >= H read a block of zeros (the key-major kernel: row m = H of the B operand a block of ones - column H of D is the bias
+    // gradient).  Here: X = dS', Y = S -> dWl (dbl stays an fp32 vector sum) ; key-major kernel: X = dP', Y = P -> dWw, dbw.
     // Transpose tile: rows [key group 4][head H] of 16 packets (queries) x 8 B, row pitch FLB_GWR = 144 B - with the natural 128 B the 16-B
     // reads of 8 heads fall on 2 bank groups (4-way conflicts: SQ_LDS_BANK_CONFLICT was half of the LDS cycles of the round-3 passes); 144 B
     // spreads the 8 rows of a lane group over distinct banks, and the constant blocks sit on banks no row uses.  The operand the FRONT half
-    // of a tile writes (pass 1: X, pass 2: Y) is double-buffered by tile parity: the front half of tile j + 1 runs beside the back half of tile j.
+    // of a tile writes (here Y, in the key-major kernel X) is double-buffered by tile parity: the front half of tile j + 1 runs beside the back half of tile j.
     constexpr int GWR = FLB_GWR, GWT = 4 * H * GWR;
     unsigned char* gconst = smem + 2 * KVB + NK16 * TILEB;                  // 512 B: zeros at + 48 (128 B), bf16 ones at + 208 (128 B)
     unsigned char* sgw = gconst + 512 + wave * (3 * GWT);                   // [front operand, parity 0][front operand, parity 1][back operand]
@@ -268,13 +156,12 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
     unsigned char* gw_wr = sgw + (gk * H) * GWR + gm * 8;                   // + tile * GWT + h * GWR: packet of head h, query gm, key group gk
     const unsigned gw_rd = (unsigned)((gk * H + gm) * GWR);                 // + tile * GWT: 16 packets (queries 0..15) of head gm
     const unsigned char* gw_zero = gconst + 48;
-    const unsigned char* gw_ones = gconst + 208;
     f32x4_t gwacc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) gwacc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    float gb[(PASS == 2) ? H : 1];                  // dbl
+    float gb[H];                                    // dbl
 #pragma unroll
-    for (int g = 0; g < ((PASS == 2) ? H : 1); ++g) gb[g] = 0.f;
+    for (int g = 0; g < H; ++g) gb[g] = 0.f;
 
     constexpr int NP = TILEB / 1024, NPW = (NP + NW - 1) / NW;     // 1-KB pieces of an operand tile, pieces per wave
     unsigned voff[NPW];                                            // byte offset of this lane's 16 B of piece i * NW + wave inside a (b, tile) image
@@ -315,36 +202,30 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
             } else { qta[h] = (flu32x2_t){0u, 0u}; dta[h] = (flu32x2_t){0u, 0u}; }
         }
         // ---- row constants of this lane's query
-        f32x4_t c0v[H / 4], Dn[(PASS == 2) ? H / 4 : 1];           // Dn = -D
+        f32x4_t c0v[H / 4], Dn[H / 4];                 // Dn = -D
 #pragma unroll
         for (int gh = 0; gh < H / 4; ++gh) {
             c0v[gh] = *reinterpret_cast<const f32x4_t*>(a.c0 + ((long)b * a.Np + q) * H + 4 * gh);
-            if constexpr (PASS == 2) Dn[gh] = -*reinterpret_cast<const f32x4_t*>(a.Drows + ((long)b * a.Np + q) * H + 4 * gh);
+            Dn[gh] = -*reinterpret_cast<const f32x4_t*>(a.Drows + ((long)b * a.Np + q) * H + 4 * gh);
         }
-        float rD[(PASS == 1) ? H : 1];
+        f32x4_t dQ[H][DT];
 #pragma unroll
-        for (int g = 0; g < ((PASS == 1) ? H : 1); ++g) rD[g] = 0.f;
-        f32x4_t dQ[(PASS == 2) ? H : 1][(PASS == 2) ? DT : 1];
+        for (int g = 0; g < H; ++g)
 #pragma unroll
-        for (int g = 0; g < ((PASS == 2) ? H : 1); ++g)
-#pragma unroll
-            for (int dt = 0; dt < ((PASS == 2) ? DT : 1); ++dt) dQ[g][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int dt = 0; dt < DT; ++dt) dQ[g][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-        // the streamed operand tiles of key tile kt (local index i): K, V fragments -> K / V stage i & 1, (pass 2) 16-wide K -> slot i % NK16
+        // the streamed operand tiles of key tile kt (local index i): K, V fragments -> K / V stage i & 1, 16-wide K -> slot i % NK16
         auto issue_tiles = [&](int i) {
-#ifdef FLB_DBG_NODMA
-            if (i != 0) return;
-#endif
 #ifdef FLB_DBG_SAMETILE
             const int kt = 0;                 // timing experiment: every workgroup streams the same tile (all L2 hits)
 #else
             const int kt = kt0 + i;
 #endif
 #pragma unroll
-            for (int op = 0; op < ((PASS == 2) ? 3 : 2); ++op) {
+            for (int op = 0; op < 3; ++op) {
                 const unsigned char* base = (op == 0) ? a.Kf : ((op == 1) ? a.Vf : a.K16);
                 const unsigned char* tb = base + ((long)b * H * nt + kt) * REC;
-                const unsigned dst = (op < 2) ? lds0 + (i & 1) * KVB + op * TILEB : lds0 + 2 * KVB + (i % (NK16 ? NK16 : 1)) * TILEB;
+                const unsigned dst = (op < 2) ? lds0 + (i & 1) * KVB + op * TILEB : lds0 + 2 * KVB + (i % NK16) * TILEB;
 #pragma unroll
                 for (int ii = 0; ii < NPW; ++ii) {
                     const int p = ii * NW + wave;
@@ -356,7 +237,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
 
         // ---- FRONT half of key tile i (matrix-heavy), in chunks of FLB_HB heads:
         //   front_k: S^T = K Q^T (lane = (query l & 15, keys 4 (l >> 4) + r)) of the chunk's heads, S' += Wl S on the fly (head-outer,
-        //            attn_flash.hip FLF_MIXH) -> sp (the exponent of P; initialised with the row constants: MASK - the ragged last tile -
+        //            like the flash forward) -> sp (the exponent of P; initialised with the row constants: MASK - the ragged last tile -
         //            gives keys >= N the exponent -inf, i.e. P = 0)
         //   front_v: dP'^T = V dO^T (bf16) of the chunk's heads, dropout, dP += Ww^T dP' -> dp
         // operand fragments of a chunk: LDS -> registers (issued a whole chunk ahead of their use in the pipelined step: a single wave per SIMD
@@ -374,8 +255,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
         };
         auto load_k = [&](int i, int h0, Frags& o) { load_frags(smem + (i & 1) * KVB, h0, o); };
         auto load_v = [&](int i, int g0, Frags& o) { load_frags(smem + (i & 1) * KVB + TILEB, g0, o); };
-        // ex (pipelined step, 8 heads): the exponents of the PREVIOUS tile's head group h0 / HB, exponentiated in the shadow of this chunk's mix
-        auto front_k = [&](int i, auto h0_c, const Frags& kfr, f32x4_t (&sp)[4][H / 4], auto mask_c, f32x4_t (*ex)[H / 4] = nullptr) {
+        auto front_k = [&](int i, auto h0_c, const Frags& kfr, f32x4_t (&sp)[4][H / 4], auto mask_c) {
             constexpr bool MASK = decltype(mask_c)::value;
             constexpr int h0 = decltype(h0_c)::value;
             unsigned char* gwf = gw_wr + (i & 1) * GWT;         // this tile's front operand of the outer product
@@ -399,36 +279,21 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb) {
                 const f32x4_t cs = c[hb];
-#ifndef FLB_DBG_NOGWM
-                // pass 2: bf16(S) of this head is the Y operand of the dWl outer product - straight into the wave's transpose tile
-                if constexpr (PASS == 2) *reinterpret_cast<fls16x4_t*>(gwf + (h0 + hb) * GWR) = fl_pack4<false>(cs[0], cs[1], cs[2], cs[3]);
-#endif
-#ifndef FLB_DBG_NOMIX1
-                if constexpr (FLB_MIXEXP && H == 8) { if (ex) continue; }          // (mixed below, all four heads in one block)
+                // bf16(S) of this head is the Y operand of the dWl outer product - straight into the wave's transpose tile
+                *reinterpret_cast<fls16x4_t*>(gwf + (h0 + hb) * GWR) = fl_pack4<false>(cs[0], cs[1], cs[2], cs[3]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = __builtin_amdgcn_mfma_f32_4x4x1f32(Al4[gh][h0 + hb], cs[r], sp[r][gh], 0, 0, 0);
-#else
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sp[r][(h0 + hb) >> 2][(h0 + hb) & 3] += cs[r];
-#endif
             }
-#ifndef FLB_DBG_NOMIX1
-            if constexpr (FLB_MIXEXP && H == 8) { if (ex) flb_mix4_exp8(Al4, h0, c, sp, *reinterpret_cast<f32x4_t (*)[4][2]>(ex), h0 / HB); }
-#endif
         };
         auto front_v = [&](int i, auto g0_c, const Frags& vfr, f32x4_t (&dp)[4][H / 4], uint32_t kb) {
             constexpr int g0 = decltype(g0_c)::value;
-            unsigned char* gwf = gw_wr + (i & 1) * GWT;
             if constexpr (g0 == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int gh = 0; gh < H / 4; ++gh) {         // pass 2: the mix starts from -D, its result is dP - D
-                        if constexpr (PASS == 2) dp[r][gh] = Dn[gh];
-                        else dp[r][gh] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                    }
+                    for (int gh = 0; gh < H / 4; ++gh) dp[r][gh] = Dn[gh];         // the mix starts from -D, its result is dP - D
             }
             f32x4_t es[HB];
             flb_score_bf16<FULL, TAIL16>(vfr.f, vfr.t, &da[g0], &dta[g0], es);
@@ -440,23 +305,14 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
 #pragma unroll
                     for (int r = 0; r < 4; ++r) es[hb][r] *= ((kb >> ((g >> 1) * 8 + 2 * r + (g & 1))) & 1u) ? keep_inv : 0.f;
                 }
-#ifndef FLB_DBG_NOGWM
-                // pass 1: bf16(dP') of this head is the X operand of the dWw outer product
-                if constexpr (PASS == 1) *reinterpret_cast<fls16x4_t*>(gwf + (g0 + hb) * GWR) = fl_pack4<false>(es[hb][0], es[hb][1], es[hb][2], es[hb][3]);
-#endif
             }
 #pragma unroll
             for (int hq = 0; hq < HB / 4; ++hq)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-#ifndef FLB_DBG_NOMIX16
                     const fls16x4_t bv = fl_pack4<false>(es[4 * hq][r], es[4 * hq + 1][r], es[4 * hq + 2][r], es[4 * hq + 3][r]);
 #pragma unroll
                     for (int gh = 0; gh < H / 4; ++gh) dp[r][gh] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(Awt[gh][g0 / 4 + hq], bv, dp[r][gh], 0, 0, 0);
-#else
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) dp[r][g0 / 4 + hq][k] += es[4 * hq + k][r];
-#endif
                 }
         };
         auto load_kb = [&](int i) -> uint32_t {
@@ -466,50 +322,38 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
 
         // ---- BACK half of key tile i (vector-heavy), in four chunks:
         //   back_exp: P = exp2(sp)
-        //   back_ds : pass 1: D += dP . P, bf16(P) -> transpose tile ; pass 2: dS' = P (dP - D), dbl, bf16(dS') -> transpose tile
-        //   back_gw : the outer product (dWw / dbw resp. dWl) from the transpose tiles ; pass 2: dS = Wl^T dS' -> ds
-        //   back_dq : pass 2: bf16 block of dS -> HBM, dQ^T += K^T dS^T
+        //   back_ds : dS' = P (dP - D), dbl, bf16(dS') -> transpose tile
+        //   back_gw : the outer product dWl from the transpose tiles ; dS = Wl^T dS' -> ds
+        //   back_dq : bf16 block of dS -> HBM, dQ^T += K^T dS^T
         auto back_exp = [&](f32x4_t (&sp)[4][H / 4]) {
-#ifndef FLB_DBG_NOEXP
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int gh = 0; gh < H / 4; ++gh)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) sp[r][gh][k] = fl_exp2(sp[r][gh][k]);
-#endif
         };
         auto back_ds = [&](f32x4_t (&sp)[4][H / 4], f32x4_t (&dp)[4][H / 4]) {
             unsigned char* gwb = gw_wr + 2 * GWT;               // the back operand of the outer product
-            if constexpr (PASS == 1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int g = 0; g < H; ++g) rD[g] = fmaf(dp[r][g >> 2][g & 3], sp[r][g >> 2][g & 3], rD[g]);
-            } else {
+                for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = sp[r][gh] * dp[r][gh];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int gh = 0; gh < H / 4; ++gh) sp[r][gh] = sp[r][gh] * dp[r][gh];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int g = 0; g < H; ++g) gb[g] += sp[r][g >> 2][g & 3];
-            }
-#ifndef FLB_DBG_NOGWM
+                for (int g = 0; g < H; ++g) gb[g] += sp[r][g >> 2][g & 3];
 #pragma unroll
             for (int g = 0; g < H; ++g)
                 *reinterpret_cast<fls16x4_t*>(gwb + g * GWR) =
                     fl_pack4<false>(sp[0][g >> 2][g & 3], sp[1][g >> 2][g & 3], sp[2][g >> 2][g & 3], sp[3][g >> 2][g & 3]);
-#endif
         };
         auto back_gw = [&](int i, f32x4_t (&sp)[4][H / 4], f32x4_t (&ds)[4][H / 4]) {
-#ifndef FLB_DBG_NOGWM
             {
                 const unsigned rdf = gw_rd + (i & 1) * GWT, rdb = gw_rd + 2 * GWT;
-                // lanes >= H of a 16-lane group read zeros (X, Y) or ones (Y, lane H: the bias column)
-                const unsigned char* gw_xrd = (gm < H) ? sgw + ((PASS == 1) ? rdf : rdb) : gw_zero;
-                const unsigned char* gw_yrd = (gm < H) ? sgw + ((PASS == 1) ? rdb : rdf) : ((gm == H) ? gw_ones : gw_zero);
+                // lanes >= H of a 16-lane group read zeros
+                const unsigned char* gw_xrd = (gm < H) ? sgw + rdb : gw_zero;
+                const unsigned char* gw_yrd = (gm < H) ? sgw + rdf : gw_zero;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // wave-private tile: the other lanes' packets are read next
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
@@ -523,26 +367,18 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the back tile is rewritten by the next key tile
             }
-#endif
-            if constexpr (PASS == 2) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-#ifndef FLB_DBG_NOMIX16
-                    float x[H];
+            for (int r = 0; r < 4; ++r) {
+                float x[H];
 #pragma unroll
-                    for (int g = 0; g < H; ++g) x[g] = sp[r][g >> 2][g & 3];
-                    fl_mix_16<H, false>(x, Alt, nullptr, ds[r]);
-#else
-#pragma unroll
-                    for (int gh = 0; gh < H / 4; ++gh) ds[r][gh] = sp[r][gh];
-#endif
-                }
+                for (int g = 0; g < H; ++g) x[g] = sp[r][g >> 2][g & 3];
+                fl_mix_16<H, false>(x, Alt, nullptr, ds[r]);
             }
         };
         auto back_dq = [&](int i, f32x4_t (&ds)[4][H / 4]) {
-            if constexpr (PASS == 2) {
+            {
                 const int kt = kt0 + i;
-                const unsigned char* sK16 = smem + 2 * KVB + (i % (NK16 ? NK16 : 1)) * TILEB;
+                const unsigned char* sK16 = smem + 2 * KVB + (i % NK16) * TILEB;
                 fls16x4_t ka[H][DT];                // requested FLB_DQAHEAD heads ahead of the matrix instructions that consume them
 #pragma unroll
                 for (int h = 0; h < ((FLB_DQAHEAD < H) ? FLB_DQAHEAD : H); ++h)
@@ -560,11 +396,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
                     __builtin_nontemporal_store(__builtin_bit_cast(flu32x2_t, pk),
                                                 reinterpret_cast<flu32x2_t*>(a.dS + (((((long)b * H + h) * nt + qt) * nt + kt) * 64 + lane) * 4));
 #endif
-#ifndef FLB_DBG_NODQ
                     flb_dq_mfma<DT>(dQ[h], ka[h], pk);
-#else
-                    dQ[h][0][0] += __builtin_bit_cast(float, (unsigned)pk[0] << 16) + __builtin_bit_cast(float, (unsigned)ka[h][0][0] << 16);
-#endif
                 }
             }
         };
@@ -599,14 +431,13 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
             const uint32_t kb = load_kb(i + 1);
             if constexpr (H > HB) load_k(i + 1, HB, fr1); else load_v(i + 1, 0, fr1);
             __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
-            constexpr bool MXE = FLB_MIXEXP && H == 8;            // exp2 of tile i inside the mix blocks of tile i + 1
-            front_k(i + 1, std::integral_constant<int, 0>{}, fr0, spn, std::false_type{}, MXE ? sp : nullptr);
-            if constexpr (!MXE) back_exp(sp);
+            front_k(i + 1, std::integral_constant<int, 0>{}, fr0, spn, std::false_type{});
+            back_exp(sp);
             FLB_PHASE();
             if constexpr (H > HB) {
                 load_v(i + 1, 0, fr0);
                 __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
-                front_k(i + 1, std::integral_constant<int, HB>{}, fr1, spn, std::false_type{}, MXE ? sp : nullptr);
+                front_k(i + 1, std::integral_constant<int, HB>{}, fr1, spn, std::false_type{});
             }
             back_ds(sp, dp);
             FLB_PHASE();
@@ -647,14 +478,6 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
                 if (wvalid) {
                     load_k(i + 1, 0, frA);       // (the stage was admitted above)
                     step(i, spA, dpA, spB, dpB, frA, frB, false);
-#if FLB_SGB
-                    // interleave request for the step's region: FLB_SGB_M matrix instructions, then FLB_SGB_V vector instructions, repeated
-#pragma unroll
-                    for (int k = 0; k < FLB_SGB_N; ++k) {
-                        __builtin_amdgcn_sched_group_barrier(0x8, FLB_SGB_M, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x2, FLB_SGB_V, 0);
-                    }
-#endif
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -672,15 +495,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
         // ---- partial results of this segment -> the major's slot
         const int first_wg = (int)(((long)bm * nt) / a.spw);
         const int slot = (int)blockIdx.x - first_wg;
-        if constexpr (PASS == 1) {
-#pragma unroll
-            for (int g = 0; g < H; ++g) {
-                float d = rD[g];
-                d += __shfl_xor(d, 16, 64);
-                d += __shfl_xor(d, 32, 64);
-                if (lane < 16 && wvalid) a.ws_d[((((long)bm * FL_MAXSLOT + slot) * NW + wave) * H + g) * 16 + lane] = d;
-            }
-        } else {
+        {
 #pragma unroll
             for (int g = 0; g < H; ++g)
 #pragma unroll
@@ -699,41 +514,22 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
     // ---- weight-gradient partials of this wave -> its row of ws_w
     {
         constexpr int NWG = 2 * (H * H + H);
-        float* row = a.ws_w + ((long)blockIdx.x * NW + wave) * NWG + ((PASS == 1) ? (H * H + H) : 0);
-        // D[m = g][n]: lane holds rows 4 (lane >> 4) + r of column lane & 15; columns < H = dW[g][h], column H = the bias gradient (pass 1)
+        float* row = a.ws_w + ((long)blockIdx.x * NW + wave) * NWG;
+        // D[m = g][n]: lane holds rows 4 (lane >> 4) + r of column lane & 15; columns < H = dWl[g][h]
         const f32x4_t dsum = (gwacc[0] + gwacc[1]) + (gwacc[2] + gwacc[3]);
         const int nn = lane & 15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int g = 4 * (lane >> 4) + r;
-            // pass 2 accumulated dS' . (log2(e) S)^T: the weight gradient carries ln 2, the bias gradient does not
-            if (g < H && nn < H) row[g * H + nn] = (PASS == 2) ? FL_LN2 * dsum[r] : dsum[r];
-            if (PASS == 1 && g < H && nn == H) row[H * H + g] = dsum[r];
+            // accumulated dS' . (log2(e) S)^T: the weight gradient carries ln 2, the bias gradient does not
+            if (g < H && nn < H) row[g * H + nn] = FL_LN2 * dsum[r];
         }
-        if constexpr (PASS == 2) {
 #pragma unroll
-            for (int g = 0; g < H; ++g) {
-                const float v = spe_wave_sum(gb[g]);
-                if (lane == 0) row[H * H + g] = v;
-            }
+        for (int g = 0; g < H; ++g) {
+            const float v = spe_wave_sum(gb[g]);
+            if (lane == 0) row[H * H + g] = v;
         }
     }
-}
-
-// D rows [B][Np][H] = sum over the slots of each (major, wave) ; rows >= N zero.  One thread per element, fixed order.
-__global__ __launch_bounds__(256) void bwdq_rows_merge_kernel(const float* __restrict__ ws, float* __restrict__ out, int B, int H, int N, int nt, int Np,
-                                                              int nmaj, int spw) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)B * Np * H) return;
-    const int g = (int)(i % H); const long bq = i / H; const int q = (int)(bq % Np), b = (int)(bq / Np);
-    if (q >= N) { out[i] = 0.f; return; }
-    const int qt = q >> 4, mj = qt / FLB_NW, wave = qt % FLB_NW;
-    const long bm = (long)b * nmaj + mj;
-    const int first_wg = (int)((bm * nt) / spw), last_wg = (int)(((bm + 1) * nt - 1) / spw);
-    const float* src = ws + (((bm * FL_MAXSLOT) * FLB_NW + wave) * H + g) * 16 + (q & 15);
-    float acc = 0.f;
-    for (int sl = 0; sl <= last_wg - first_wg; ++sl) acc += src[(long)sl * FLB_NW * H * 16];
-    out[i] = acc;
 }
 
 // dq[b, q, g, d] = scale * sum over the slots (element strides ob, on, oh; fp32 and / or bf16 with the same addressing).  One thread per
@@ -787,8 +583,7 @@ __global__ __launch_bounds__(256) void bwdq_dq_merge_kernel(const float* __restr
 //   -> ws_d ; dWw / dbw outer products (the same transpose tiles as pass 1) ; P' = Ww P + bw in fp16 on P * 2^8 (the flash forward's
 //   arithmetic), dropout, bf16, dV += P'd^T dO.
 // No mask instance: a key >= N has K = V = 0 (zero-padded records), so dP' = dP = 0 there and its dV rows are dropped by the merge; a query
-// >= N has Q = dO = 0 and c0 = 0 (finite P, zero dO).  Replaces spe_talking_fused mode 2 + spe_attn_merge + spe_talking_flash_rows +
-// spe_talking_flash_dv + its merge: S, S', P are recomputed once for both results instead of twice.
+// >= N has Q = dO = 0 and c0 = 0 (finite P, zero dO).  S, S', P are recomputed once for D, dWw, dbw AND dV.
 struct FlashBwdKArgs {
     const unsigned char* Qf; const unsigned char* dOf; const unsigned char* dO16;     // streamed: fp16 q * scale * log2 e, bf16 dO (32-wide), bf16 dO (16-wide)
     const unsigned char* Kf; const unsigned char* Vf;                                 // resident: fp16 k, bf16 v (32-wide records)
@@ -908,29 +703,7 @@ __device__ __forceinline__ void flb_rowsum4(const f32x4_t (&t)[4], f32x4_t& o) {
 FLB_SCORE_RS_ASM(flb_score_rs_f16, "v_mfma_f32_16x16x32_f16", "v_mfma_f32_16x16x16_f16")
 FLB_SCORE_RS_ASM(flb_score_rs_bf16, "v_mfma_f32_16x16x32_bf16", "v_mfma_f32_16x16x16_bf16")
 
-// the same reduce-scatter from builtins (the scheduler can interleave them with matrix instructions; an inline-assembly block is one unit):
-// every stage adds the DPP-moved partner in all lanes and a select keeps the half each lane owns
-#ifndef FLB_DPP_BUILTIN
-#define FLB_DPP_BUILTIN 0
-#endif
-template <int CTRL>
-__device__ __forceinline__ float flb_dpp(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true)); }
-__device__ __forceinline__ void flb_rowsum4_b(const f32x4_t (&t)[4], f32x4_t& o, const bool hi8, const bool oddbank) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float s1[2];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const float lo = t[p][k] + flb_dpp<0x128>(t[p][k]), hi = t[p + 2][k] + flb_dpp<0x128>(t[p + 2][k]);
-            s1[p] = hi8 ? hi : lo;
-        }
-        const float u0 = s1[0] + flb_dpp<0x141>(s1[0]), u1 = s1[1] + flb_dpp<0x141>(s1[1]);
-        float s2 = oddbank ? u1 : u0;
-        s2 += flb_dpp<0xB1>(s2);
-        s2 += flb_dpp<0x4E>(s2);
-        o[k] = s2;
-    }
-}
+
 
 template <int H, int DSTEPS, bool TAIL16, bool DROP>
 __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKArgs a) {
@@ -1059,8 +832,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
         // ---- FRONT half of q-tile i (matrix-heavy), chunks of FLB_HB heads
         // rs_t / rs_o (both or neither): the terms of a 4-head row-sum reduce-scatter of the PREVIOUS tile's back half, run in the shadow of this chunk's score
         // products (head dim 33 .. 48 only), and its result
-        auto front_q = [&](int i, auto h0_c, const Frags& qfr, f32x4_t (&sp)[4][H / 4], const f32x4_t (*rs_t)[4] = nullptr, f32x4_t* rs_o = nullptr,
-                           f32x4_t (*ex)[H / 4] = nullptr) {
+        auto front_q = [&](int i, auto h0_c, const Frags& qfr, f32x4_t (&sp)[4][H / 4], const f32x4_t (*rs_t)[4] = nullptr, f32x4_t* rs_o = nullptr) {
             constexpr int h0 = decltype(h0_c)::value;
             if constexpr (h0 == 0) {        // the exponent starts from the row constants of query 4 (l >> 4) + r: broadcast LDS reads
                 const unsigned char* cr = smem + C0OFF + (i & 1) * 1024 + (4 * gk) * H * 4;
@@ -1076,9 +848,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
                 else flb_score_f16<FULL, TAIL16>(qfr.f, qfr.t, &ka[h0], &kta[h0], c);
             } else flb_score_f16<FULL, TAIL16>(qfr.f, qfr.t, &ka[h0], &kta[h0], c);
             flb_fence4(c[0], c[1], c[2], c[3]);
-            if constexpr (FLB_MIXEXP && H == 8) {
-                if (ex) { flb_mix4_exp8(Al4, h0, c, sp, *reinterpret_cast<f32x4_t (*)[4][2]>(ex), h0 / HB); return; }
-            }
+
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb) {
                 const f32x4_t cs = c[hb];
@@ -1162,11 +932,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
                 f32x4_t t[4], o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t[r] = dp[r][gh] * sp[r][gh];
-#if FLB_DPP_BUILTIN
-                flb_rowsum4_b(t, o, (gm & 8) != 0, (gm & 4) != 0);
-#else
                 flb_rowsum4(t, o);
-#endif
                 if ((gm & 3) == 0) *reinterpret_cast<f32x4_t*>(dx + 4 * gh) = o;
             }
 #pragma unroll
@@ -1269,9 +1035,8 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
             load_kb(i + 1, kbn);
             if constexpr (H > HB) load_q(i + 1, HB, fr1); else load_d(i + 1, 0, fr1);
             __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
-            constexpr bool MXE = FLB_MIXEXP && H == 8;            // exp2 of tile i inside the mix blocks of tile i + 1
-            front_q(i + 1, std::integral_constant<int, 0>{}, fr0, spn, nullptr, nullptr, MXE ? sp : nullptr);
-            if constexpr (!MXE) back_exp(sp);
+            front_q(i + 1, std::integral_constant<int, 0>{}, fr0, spn);
+            back_exp(sp);
             FLB_PHASE();
             constexpr bool RSF = FLB_RSFUSE && H == 2 * HB && FULL == 1 && TAIL16;      // the D reduce-scatters of tile i ride on two score-product blocks of tile i + 1
             f32x4_t rt[4], ro0, ro1;
@@ -1279,18 +1044,12 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
                 load_d(i + 1, 0, fr0);
                 if constexpr (RSF) d_terms(0, sp, dp, rt);
                 __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
-                if constexpr (RSF) front_q(i + 1, std::integral_constant<int, HB>{}, fr1, spn, &rt, &ro0, MXE ? sp : nullptr);
-                else front_q(i + 1, std::integral_constant<int, HB>{}, fr1, spn, nullptr, nullptr, MXE ? sp : nullptr);
+                if constexpr (RSF) front_q(i + 1, std::integral_constant<int, HB>{}, fr1, spn, &rt, &ro0);
+                else front_q(i + 1, std::integral_constant<int, HB>{}, fr1, spn);
             }
             if constexpr (RSF) { d_store(i, 0, ro0); back_ds(i, sp, dp, false); d_terms(1, sp, dp, rt); }
             else back_ds(i, sp, dp);
-#if FLB_SGB2
-#pragma unroll
-            for (int k = 0; k < FLB_SGB2_N; ++k) {          // interleave request: one matrix instruction, then FLB_SGB2_V vector instructions
-                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x2, FLB_SGB2_V, 0);
-            }
-#endif
+
             FLB_PHASE();
             if constexpr (H > HB) {
                 load_d(i + 1, HB, fr1);
@@ -1394,40 +1153,35 @@ static inline int flb_dsteps(int dh, int* tail) {
     return full + *tail;
 }
 
-template <int H, int DSTEPS, bool TAIL16, int PASS>
+template <int H, int DSTEPS, bool TAIL16>
 static int launch_bwdq(const FlashBwdArgs& a, int nwg, bool drop, hipStream_t st) {
     constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
-    constexpr int smem = 4 * H * REC + ((PASS == 2) ? FLB_NK16 : 0) * H * REC + 512 + FLB_NW * 3 * 4 * H * FLB_GWR;
+    constexpr int smem = 4 * H * REC + FLB_NK16 * H * REC + 512 + FLB_NW * 3 * 4 * H * FLB_GWR;
     if (smem > 160 * 1024) return -2;
     static bool attr_set[2] = {false, false};
-    const void* fn = drop ? reinterpret_cast<const void*>(&talking_bwdq_kernel<H, DSTEPS, TAIL16, true, PASS>)
-                          : reinterpret_cast<const void*>(&talking_bwdq_kernel<H, DSTEPS, TAIL16, false, PASS>);
+    const void* fn = drop ? reinterpret_cast<const void*>(&talking_bwdq_kernel<H, DSTEPS, TAIL16, true>)
+                          : reinterpret_cast<const void*>(&talking_bwdq_kernel<H, DSTEPS, TAIL16, false>);
     if (!attr_set[drop]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set[drop] = true;
     }
-    if (drop) hipLaunchKernelGGL((talking_bwdq_kernel<H, DSTEPS, TAIL16, true, PASS>), dim3(nwg), dim3(64 * FLB_NW), smem, st, a);
-    else hipLaunchKernelGGL((talking_bwdq_kernel<H, DSTEPS, TAIL16, false, PASS>), dim3(nwg), dim3(64 * FLB_NW), smem, st, a);
+    if (drop) hipLaunchKernelGGL((talking_bwdq_kernel<H, DSTEPS, TAIL16, true>), dim3(nwg), dim3(64 * FLB_NW), smem, st, a);
+    else hipLaunchKernelGGL((talking_bwdq_kernel<H, DSTEPS, TAIL16, false>), dim3(nwg), dim3(64 * FLB_NW), smem, st, a);
     SPE_CHECK_LAUNCH();
     return 0;
 }
 
-template <int PASS>
 static int dispatch_bwdq(const FlashBwdArgs& a, int H, int dh, int nwg, hipStream_t st) {
     int tail; const int ds = flb_dsteps(dh, &tail);
     const bool drop = a.p_drop > 0.f;
-#define SPE_BWDQ(HH)                                                                             \
-    if (H == HH && ds == 2 && tail) return launch_bwdq<HH, 2, true, PASS>(a, nwg, drop, st);     \
-    if (H == HH && ds == 2 && !tail) return launch_bwdq<HH, 2, false, PASS>(a, nwg, drop, st);   \
-    if (H == HH && ds == 1 && tail) return launch_bwdq<HH, 1, true, PASS>(a, nwg, drop, st);     \
-    if (H == HH && ds == 1 && !tail) return launch_bwdq<HH, 1, false, PASS>(a, nwg, drop, st);
-#ifdef FLB_ONLY_CFG2          // register audits: only the cfg2 instance
-    if (H == 8 && ds == 2 && tail) return launch_bwdq<8, 2, true, PASS>(a, nwg, drop, st);
-#else
+#define SPE_BWDQ(HH)                                                                       \
+    if (H == HH && ds == 2 && tail) return launch_bwdq<HH, 2, true>(a, nwg, drop, st);     \
+    if (H == HH && ds == 2 && !tail) return launch_bwdq<HH, 2, false>(a, nwg, drop, st);   \
+    if (H == HH && ds == 1 && tail) return launch_bwdq<HH, 1, true>(a, nwg, drop, st);     \
+    if (H == HH && ds == 1 && !tail) return launch_bwdq<HH, 1, false>(a, nwg, drop, st);
     SPE_BWDQ(8)
     SPE_BWDQ(4)
-#endif
 #undef SPE_BWDQ
     return -2;
 }
@@ -1448,28 +1202,12 @@ static int bwdq_fill(FlashBwdArgs& a, FlashPlan& p, const void* Qf, const void* 
     p = fl_plan(B, nt, FLB_NW, nt, nwg);
     a.Qf = (const unsigned char*)Qf; a.dOf = (const unsigned char*)dOf; a.Kf = (const unsigned char*)Kf; a.Vf = (const unsigned char*)Vf;
     a.K16 = (const unsigned char*)K16; a.Wl = Wl; a.Ww = Ww; a.c0 = c0; a.Np = Np; a.Drows = nullptr;
-    a.ws_d = nullptr; a.ws_q = nullptr; a.ws_w = nullptr; a.dS = nullptr;
+    a.ws_q = nullptr; a.ws_w = nullptr; a.dS = nullptr;
     a.keepbits = (p_drop > 0.f) ? reinterpret_cast<const unsigned*>(keepbits) : nullptr;
     a.B = B; a.N = N; a.nt = nt; a.nmaj = p.nmaj; a.spw = p.spw; a.total = p.total; a.p_drop = p_drop;
     return 0;
 }
 
-extern "C" int spe_talking_bwdq_pass1(const void* Qf, const void* dOf, const void* Kf, const void* Vf, const float* Wl, const float* Ww,
-                                      const float* c0, int Np, float* ws_d, float* ws_w, float* Drows, const void* keepbits, int B, int H, int N, int dh,
-                                      int nwg, float p_drop, hipStream_t st) {
-    if ((long)B * ((N + 15) / 16) <= 0) return 0;
-    FlashBwdArgs a; FlashPlan p;
-    int rc = bwdq_fill(a, p, Qf, dOf, Kf, Vf, nullptr, Wl, Ww, c0, Np, keepbits, B, H, N, dh, nwg, p_drop);
-    if (rc != 0) return rc;
-    if (!ws_d || !ws_w || !Drows) return -2;
-    a.ws_d = ws_d; a.ws_w = ws_w;
-    rc = dispatch_bwdq<1>(a, H, dh, p.nwg, st);
-    if (rc != 0) return rc;
-    const long n = (long)B * Np * H;
-    hipLaunchKernelGGL(bwdq_rows_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws_d, Drows, B, H, N, a.nt, Np, p.nmaj, p.spw);
-    SPE_CHECK_LAUNCH();
-    return 0;
-}
 
 extern "C" int spe_talking_bwdq_pass2(const void* Qf, const void* dOf, const void* Kf, const void* Vf, const void* K16, const float* Wl, const float* Ww,
                                       const float* c0, const float* Drows, int Np, float* ws_q, float* ws_w, void* dS, float* dq, void* dq16,
@@ -1481,7 +1219,7 @@ extern "C" int spe_talking_bwdq_pass2(const void* Qf, const void* dOf, const voi
     if (rc != 0) return rc;
     if (!ws_q || !ws_w || !dS || !Drows || !K16 || (!dq && !dq16)) return -2;
     a.ws_q = ws_q; a.ws_w = ws_w; a.dS = reinterpret_cast<unsigned short*>(dS); a.Drows = Drows;
-    rc = dispatch_bwdq<2>(a, H, dh, p.nwg, st);
+    rc = dispatch_bwdq(a, H, dh, p.nwg, st);
     if (rc != 0) return rc;
     const int DT = (dh + 15) / 16;
     const long nvec = (long)B * p.nmaj * FLB_NW * H * DT * 64;
@@ -1519,12 +1257,8 @@ static int dispatch_bwdk(const FlashBwdKArgs& a, int H, int dh, int nwg, hipStre
     if (H == HH && ds == 2 && !tail) return launch_bwdk<HH, 2, false>(a, nwg, drop, st);   \
     if (H == HH && ds == 1 && tail) return launch_bwdk<HH, 1, true>(a, nwg, drop, st);     \
     if (H == HH && ds == 1 && !tail) return launch_bwdk<HH, 1, false>(a, nwg, drop, st);
-#ifdef FLB_ONLY_CFG2
-    if (H == 8 && ds == 2 && tail) return launch_bwdk<8, 2, true>(a, nwg, drop, st);
-#else
     SPE_BWDK(8)
     SPE_BWDK(4)
-#endif
 #undef SPE_BWDK
     return -2;
 }

@@ -290,7 +290,7 @@ extern "C" int spe_reduce_defer_ranges(const void* const* ptrs, const size_t* by
 extern "C" int spe_reduce_flush(hipStream_t st) { return defer_flush(st); }
 extern "C" int spe_reduce_pending(void) { return g_dt.n; }
 
-extern "C" int spe_abi_version(void) { return 6; }    // 2: round 2 (signatures of spe_hungarian, spe_adamw_flat, spe_layernorm_fwd, spe_attn_contract, spe_talking_fused_plan changed; new entry points)
+extern "C" int spe_abi_version(void) { return 7; }    // 2: round 2 (signatures of spe_hungarian, spe_adamw_flat, spe_layernorm_fwd, spe_attn_contract, spe_talking_fused_plan changed; new entry points)
 
 
 // ------------------------------------------------------------------------------------------

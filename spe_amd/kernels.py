@@ -207,8 +207,6 @@ def _call(name, *args):
         ev = _TIMED.get("%s:%d,%d,%d" % (name, args[i], args[j], args[k]))
     if ev is None:
         return lib.call(name, *args)
-    if name == "spe_talking_fused":          # time the four modes separately
-        ev = _TIMED.setdefault(name + ":" + str(args[0]), [])
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     lib.call(name, *args)
@@ -333,7 +331,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None,
 # fp32-operand kernel.
 LINEAR16 = True              # module attributes (tools/error_budget.py and the tests flip them), not environment knobs
 LINEAR16_MIN_ROWS = 128
-_W16 = {}        # id(W) -> (weakref, version, data_ptr, epoch, W16 [N,K], W16T [K,N])
+_W16 = {}        # id(W) -> (weakref, version, epoch, W16 [N,K], W16T [K,N], W16lo (bf16 low part or IEEE fp16 copy, or None))
 _W16_EPOCH = 0   # bumped by writers that bypass autograd's version counters (spe_amd.optim.FlatAdamW)
 
 
@@ -670,6 +668,8 @@ def linear_res_bwd(dout2, saved, W, gamma, need_dx=True, grad_bufs=(None, None, 
                                                         drop=drop, sscale=sscale, rps=rps)
         dW = _dw16_tn(dy16, xs, N, K, R, gW)
     else:
+        if pre is not None:         # the sums are already in db / dgamma: running the LayerScale backward again would count them twice
+            raise RuntimeError("spe_amd.kernels.linear_res_bwd: a LayerNorm backward took this node's LayerScale part, but its save is not row-major")
         Rp = xs.shape[1]
         dy16, dy16T, db, dg = layerscale_residual_bwd16(dout2, y, gamma, Rp, db_out=gb, dg_out=gg, want_rowmajor=need_dx,
                                                         drop=drop, sscale=sscale, rps=rps)
@@ -698,7 +698,9 @@ MLP_F16 = True
 
 
 def mlp_f16_ok(R, K, Hd, N):
-    return MLP_F16 and split_fwd() and R >= 2048 and K % 64 == 0 and Hd % 64 == 0 and N % 8 == 0
+    # mirrors spe_nt2_dispatch (csrc/gemm_nt2.hip): the fp16-operand extended epilogue exists only there - M >= 2048, contraction % 64 == 0 and
+    # >= 128, >= 64 output columns, for BOTH products (fc1: K -> Hd, fc2: Hd -> N); anything else takes the split-bf16 path
+    return (MLP_F16 and split_fwd() and R >= 2048 and K % 64 == 0 and K >= 128 and Hd % 64 == 0 and Hd >= 128 and N % 8 == 0 and N >= 64)
 
 
 def mlp_gelu_fwd(x2, W1, b1, W2, b2, res=None, gamma=None, save=True, src=None, drop1=None, drop2=None, sscale=None, rps=1):
@@ -795,6 +797,8 @@ def mlp_gelu_bwd(dy2, saved, W1, W2, need_dx=True, grad_bufs=(None, None, None, 
     dev = dy2.device
     gW1, gb1, gW2, gb2 = grad_bufs
     dg = None
+    if ls_pre is not None and (gamma is None or not tn):      # never fall through: the LayerNorm backward already added this node's sums
+        raise RuntimeError("spe_amd.kernels.mlp_gelu_bwd: a LayerNorm backward took this node's LayerScale part, but the node cannot consume it")
     if gamma is not None and ls_pre is not None and tn:      # the LayerScale part came with the LayerNorm backward that produced dy2 (layernorm_bwd ls=)
         dy16, db2, dg = ls_pre
         dy16T = None
@@ -1227,11 +1231,10 @@ def box_loss_bwd(srow_i64, lidx_i32, g1, g2, c1, c2, shape):
 
 
 # ---- fused talking-heads attention (bf16 mode) ----------------------------------------------
-# workgroups per fused pass (256 CUs): every pass runs at 2 waves per SIMD (239-256 registers), i.e. 512 resident workgroups -
-# more only adds a partial second round (statistics / write pass 0.188 -> 0.180 ms at cfg2 with 512 instead of 768).  Modes 2
-# and 3 share ws_w rows, so they use the same count.
-FUSED_NWG = {0: 512, 1: 512, 2: 512, 3: 512}
-_FUSED_NWG_SOLO = dict(FUSED_NWG)
+# workgroups of the statistics pass (256 CUs): it runs at 2 waves per SIMD (244 registers), i.e. 512 resident workgroups - more only adds a
+# partial second round (0.188 -> 0.180 ms at cfg2 with 512 instead of 768)
+STATS_NWG = 512
+_STATS_NWG_SOLO = STATS_NWG
 
 
 def set_cu_reserve(n):
@@ -1241,10 +1244,9 @@ def set_cu_reserve(n):
     a 512-workgroup launch would need a second, nearly empty round (measured with tools/dp_proxy.py: +8 % per step for ANY
     number of foreign workgroups from 8 to 64).  With the grids cut to 512 - n the launches stay single-round.
     spe_amd.dp.GradAllReducer calls this with its channel budget when world > 1; 0 restores the solo grids."""
-    global _CU_RESERVE
+    global _CU_RESERVE, STATS_NWG
     _CU_RESERVE = int(n)
-    for m in FUSED_NWG:
-        FUSED_NWG[m] = max(8, (_FUSED_NWG_SOLO[m] - int(n)) & ~7) if n > 0 else _FUSED_NWG_SOLO[m]
+    STATS_NWG = max(8, (_STATS_NWG_SOLO - int(n)) & ~7) if n > 0 else _STATS_NWG_SOLO
 
 
 _CU_RESERVE = 0
@@ -1255,7 +1257,10 @@ def get_cu_reserve():
 
 
 def fused_supported(H, dh):
-    return H in (4, 8) and dh <= 64
+    """The fused attention path = statistics pass + flash forward + the two backward kernels: all of them must fit (LDS: the 8 resident tiles + 5
+    stage buffers of the forward, the stage buffers + transpose tiles of the backward kernels).  H = 8 with head dim 49 .. 64 does not (no model
+    of the reference has it: every CaiT variant uses head dim 48); it takes the materialised path."""
+    return flash_supported(H, dh) and bwdq_supported(H, dh) and bwdk_supported(H, dh)
 
 
 LOG2E = 1.4426950408889634
@@ -1274,33 +1279,26 @@ def attn_pack(x4, scale=1.0):
 _PLANS = {}          # work splits are pure functions of (shape, workgroup budget): asked once per shape, not once per block and step
 
 
-def fused_plan(B, N, mode):
-    """(steps per workgroup, workgroups) the launcher uses for pass `mode` (sizes ws_w, parametrises attn_merge)."""
-    key = ("fused", B, N, mode, FUSED_NWG[mode])
+def fused_plan(B, N, mode=0):
+    """(steps per workgroup, workgroups) the statistics pass uses (parametrises attn_merge_rows)."""
+    assert mode == 0
+    key = ("stats", B, N, STATS_NWG)
     r = _PLANS.get(key)
     if r is None:
         spw, nwg = ctypes.c_int(0), ctypes.c_int(0)
-        lib.call("spe_talking_fused_plan", B, N, FUSED_NWG[mode], int(mode), ctypes.byref(spw), ctypes.byref(nwg))
+        lib.call("spe_talking_stats_plan", B, N, STATS_NWG, ctypes.byref(spw), ctypes.byref(nwg))
         r = _PLANS[key] = (spw.value, nwg.value)
     return r
 
 
-def talking_fused(mode, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, ws_stats, ws_w, outT, B, H, N, dh, p_drop, seed, offset, keepbits=None):
-    """keepbits (modes 2, 3 with dropout): the keep flags stored by talking_flash_fwd - loaded instead of regenerated."""
-    if keepbits is not None:
-        _call("spe_talking_fused_bits", mode, _p(Qf), _p(Kf), _p(Vf), _p(dOf), _p(Wl), _p(bl), _p(Ww), _p(bw), _p(M), _p(IL), _p(D),
-              _p(ws_stats), _p(ws_w), _p(outT), _p(keepbits), B, H, N, dh, FUSED_NWG[mode], float(p_drop), seed, offset, _st())
-        return
-    _call("spe_talking_fused", mode, _p(Qf), _p(Kf), _p(Vf), _p(dOf), _p(Wl), _p(bl), _p(Ww), _p(bw), _p(M), _p(IL), _p(D),
-          _p(ws_stats), _p(ws_w), _p(outT), B, H, N, dh, FUSED_NWG[mode], float(p_drop), seed, offset, _st())
-
-
-PD_SCALE = 256.0       # spe_talking_fused mode 1 stores fp16(P'd * 2^8) (csrc/attn_fused.hip: SPE_PD_SCALE)
+def talking_stats(Qf, Kf, Wl, bl, ws_stats, B, H, N, dh):
+    """Statistics pass: partial (max, sum) of softmax_k(Wl S + bl) per (b, head, query) -> ws_stats (B * nt * 8 * H * 32 floats); merged by
+    attn_merge_rows with fused_plan(B, N)[0]."""
+    _call("spe_talking_stats", _p(Qf), _p(Kf), _p(Wl), _p(bl), _p(ws_stats), B, H, N, dh, STATS_NWG, _st())
 
 
 def score_blocks(B, H, N, device, dtype=torch.bfloat16):
-    """Uninitialised blocked score tensor [B,H,nt,nt,64,4] (16x16 blocks; see csrc/attn_contract.hip): fp16 for the forward
-    P'd (written scaled by PD_SCALE), bf16 for the backward dS."""
+    """Uninitialised blocked score tensor [B,H,nt,nt,64,4] (16x16 blocks; see csrc/attn_contract.hip): the backward's dS (bf16)."""
     nt = (N + 15) // 16
     return torch.empty((B, H, nt, nt, 64, 4), device=device, dtype=dtype)
 
@@ -1317,7 +1315,7 @@ def attn_pack16(x4):
 
 def frag_record_elems(dh):
     """bf16 elements of one (b, h, 16-row tile) fragment record of the score kernels: full 32-wide d-steps of 64 x 8
-    plus a 16-wide tail step of 64 x 4 when dh % 32 is in 1..16 (csrc/attn_fused.hip: frag_load)."""
+    plus a 16-wide tail step of 64 x 4 when dh % 32 is in 1..16 (csrc/attn_stats.hip: frag_load)."""
     rem = dh % 32
     full = dh // 32 + (1 if rem > 16 else 0)
     return full * 512 + (256 if 0 < rem <= 16 else 0)
@@ -1443,14 +1441,6 @@ def flash_plan(B, N):
     return r
 
 
-def flash_rows(in0, in1, bl, B, H, N, mode):
-    """mode 0: c0 [B,Np,H] = bl log2(e) - M + log2(IL) ; mode 1: the [B,H,N] rows of in0 as [B,Np,H]; rows >= N zero."""
-    Np = flash_plan(B, N)[3]
-    out = torch.empty((B, Np, H), device=in0.device, dtype=torch.float32)
-    _call("spe_talking_flash_rows", _p(in0), _p(in1), _p(bl), _p(out), B, H, N, Np, int(mode), _st())
-    return out
-
-
 _FLASH_WS = {}         # device -> partial-result workspace shared by every flash launch of the stream (all blocks reuse one)
 
 
@@ -1460,9 +1450,6 @@ def _flash_ws(device, floats):
         ent = torch.empty((floats,), device=device, dtype=torch.float32)
         _FLASH_WS[device] = ent
     return ent
-
-
-FLASH_KEEPBITS = True      # module attribute (tests/test_round4_gpu.py runs both settings), not an environment knob
 
 
 def talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, offset, want16=False, want16lo=False, want_bits=False):
@@ -1476,7 +1463,7 @@ def talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, of
     O16 = torch.empty((B * N, C), device=dev, dtype=torch.bfloat16) if want16 else None
     O16lo = torch.empty((B * N, C), device=dev, dtype=torch.bfloat16) if (want16 and want16lo) else None
     nt = (N + 15) // 16
-    bits = torch.empty((B, nt, nt, 64), device=dev, dtype=torch.int32) if (want_bits and p_drop > 0 and FLASH_KEEPBITS) else None
+    bits = torch.empty((B, nt, nt, 64), device=dev, dtype=torch.int32) if (want_bits and p_drop > 0) else None
     _call("spe_talking_flash_fwd", _p(Qf), _p(Kf), _p(V16), _p(Wl), _p(Ww), _p(bw), _p(c0), c0.shape[1], _p(ws), _p(O), _p(O16), _p(O16lo),
           _p(bits), B, H, N, dh, FLASH_NWG, float(p_drop), seed, offset, _st())
     if want_bits:
@@ -1484,20 +1471,7 @@ def talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, of
     return O, O16, O16lo
 
 
-def talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, c0, dv4, p_drop, seed, offset, dv16=None):
-    """dv4 [B,N,H,dh] (fp32 view, unit last stride) = P'd^T dO with P'd recomputed from the forward's fragments and statistics.
-    dv16: bf16 view with the same element strides (then dv4 may be None: only the 16-bit result is written)."""
-    ref = dv4 if dv4 is not None else dv16
-    B, N, H, dh = ref.shape
-    assert ref.stride(3) == 1 and (dv4 is None or dv16 is None or dv4.stride() == dv16.stride())
-    nmaj = flash_plan(B, N)[2]
-    ws = _flash_ws(ref.device, B * nmaj * FLASH_SLOTS * 128 * H * 16 * ((dh + 15) // 16))
-    _call("spe_talking_flash_dv", _p(Qf), _p(Kf), _p(dO16), _p(Wl), _p(Ww), _p(bw), _p(c0), c0.shape[1], _p(ws), _p(dv4), _p(dv16),
-          ref.stride(0), ref.stride(1), ref.stride(2), B, H, N, dh, FLASH_NWG, float(p_drop), seed, offset, _st())
-    return ref
-
-
-# ---- query-major backward passes on the flash skeleton (csrc/attn_flash_bwd.hip): 4-wave workgroups, one wave per SIMD, one per CU
+# ---- the two backward kernels (csrc/attn_flash_bwd.hip): 4-wave workgroups, one wave per SIMD, one workgroup per CU
 def bwdq_supported(H, dh):
     DT = (dh + 15) // 16
     return H in (4, 8) and dh <= 64 and 7 * H * DT * 512 + 512 + 4 * 3 * 4 * H * 144 <= 160 * 1024
@@ -1515,18 +1489,6 @@ def bwdq_plan(B, N):
             _PLANS.clear()
         r = _PLANS[key] = (spw.value, nwg.value, nmaj.value)
     return r
-
-
-def talking_bwdq_pass1(Qf, dOf, Kf, Vf, Wl, Ww, c0, keepbits, B, H, N, dh, p_drop):
-    """-> (Drows [B, Np, H]: D = sum_key dP P, query-major; ws_w [4 nwg, 2 (H H + H)]: its dWw / dbw half filled)."""
-    dev = Qf.device
-    _, nwg, nmaj = bwdq_plan(B, N)
-    ws_d = _flash_ws(dev, B * nmaj * FLASH_SLOTS * 4 * H * 16)
-    ws_w = torch.empty((4 * nwg, 2 * (H * H + H)), device=dev, dtype=torch.float32)
-    Drows = torch.empty((B, c0.shape[1], H), device=dev, dtype=torch.float32)
-    _call("spe_talking_bwdq_pass1", _p(Qf), _p(dOf), _p(Kf), _p(Vf), _p(Wl), _p(Ww), _p(c0), c0.shape[1], _p(ws_d), _p(ws_w), _p(Drows),
-          _p(keepbits), B, H, N, dh, max(8, FLASH_NWG - _CU_RESERVE), float(p_drop), _st())
-    return Drows, ws_w
 
 
 def bwdk_supported(H, dh):
@@ -1564,15 +1526,8 @@ def talking_bwdq_pass2(Qf, dOf, Kf, Vf, K16, Wl, Ww, c0, Drows, ws_w, dS, dq4, d
           max(8, FLASH_NWG - _CU_RESERVE), float(p_drop), _st())
 
 
-def attn_merge(ws_stats, B, H, N, spw, mode):
-    out0 = torch.empty((B, H, N), device=ws_stats.device, dtype=torch.float32)
-    out1 = torch.empty_like(out0) if mode == 0 else None
-    _call("spe_attn_merge", _p(ws_stats), _p(out0), _p(out1), B, H, N, spw, mode, _st())
-    return out0, out1
-
-
 def attn_merge_rows(ws_stats, bl, B, H, N, spw):
-    """Mode-0 merge -> (M, IL [B,H,N], c0 [B,Np,H]: the flash kernels' row constants) in one launch."""
+    """Merge of the statistics pass -> (M, IL [B,H,N], c0 [B,Np,H]: the row constants of the flash forward and the backward kernels)."""
     Np = flash_plan(B, N)[3]
     M = torch.empty((B, H, N), device=ws_stats.device, dtype=torch.float32)
     IL = torch.empty_like(M)
@@ -1592,28 +1547,14 @@ def jitter_pick(box, scale, ratio):
 
 def talking_wgrad_reduce(ws_w, H, params):
     """Column sums of the weight-gradient partials [nwg, 2*(H*H+H)] as (dWl [H,H], dbl [H], dWw [H,H], dbw [H]), written
-    into the parameters' all-reduce bucket views when those are still unclaimed this step (params = Wl, bl, Ww, bw)."""
+    into the parameters' all-reduce bucket views when those are still unclaimed this step (params = Wl, bl, Ww, bw; a None entry: a fresh tensor).
+    The kernel STORES its sums (no accumulation)."""
     shapes = ((H, H), (H,), (H, H), (H,))
     outs = []
     for prm, shp in zip(params, shapes):
-        buf = grad_buffer(prm)
+        buf = grad_buffer(prm) if prm is not None else None
         outs.append(buf.view(shp) if buf is not None else torch.empty(shp, device=ws_w.device, dtype=torch.float32))
     _call("spe_talking_wgrad_reduce", _p(ws_w), ws_w.shape[0], H, _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), _st())
-    return outs
-
-
-def talking_wgrad_reduce2(ws_l, ws_w, H, params):
-    """The same with the two halves of the partial rows in different workspaces: (dWl, dbl) from ws_l's first half, (dWw, dbw) from ws_w's
-    second half (pass 2 and pass 1 run on kernels with different grids)."""
-    shapes = ((H, H), (H,), (H, H), (H,))
-    outs = []
-    for prm, shp in zip(params, shapes):
-        buf = grad_buffer(prm)
-        outs.append(buf.view(shp) if buf is not None else torch.empty(shp, device=ws_l.device, dtype=torch.float32))
-    scratch = torch.empty((2 * (H * H + H),), device=ws_l.device, dtype=torch.float32)
-    hh = H * H
-    _call("spe_talking_wgrad_reduce", _p(ws_l), ws_l.shape[0], H, _p(outs[0]), _p(outs[1]), _p(scratch), _p(scratch[hh:]), _st())
-    _call("spe_talking_wgrad_reduce", _p(ws_w), ws_w.shape[0], H, _p(scratch), _p(scratch[hh:]), _p(outs[2]), _p(outs[3]), _st())
     return outs
 
 

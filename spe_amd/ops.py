@@ -272,7 +272,10 @@ class _LayerNormSkip(Function):
         ctx.params = (g, b)
         # the node that produced x, when it is a LayerScale-residual Linear / MLP node whose output feeds ONLY this norm (its caller said so: `single`):
         # this norm's backward then also takes that node's LayerScale backward - gamma * dx as bf16, the bias and gamma column sums - from the dx it is
-        # writing anyway (kernels.layernorm_bwd ls=), instead of that node re-reading dx in a launch of its own
+        # writing anyway (kernels.layernorm_bwd ls=), instead of that node re-reading dx in a launch of its own.
+        # CONTRACT of `single`: the producer's backward runs in the same backward pass as this norm's (always true for loss.backward() of the
+        # model; NOT for torch.autograd.grad(..., inputs=<the block output>) that stops between the two nodes - its bias / gamma bucket views
+        # would then hold this norm's partial sums only).  A producer that cannot consume what was taken raises (kernels.linear_res_bwd / mlp_gelu_bwd)
         prod = x.grad_fn if (K.LN_LS_FUSE and x.requires_grad) else None
         ctx.prod = prod if (prod is not None and getattr(prod, "ls_single", False) and x2.shape[1] <= 512) else None
         ctx.save_for_backward(x2, g, mean, rstd)
@@ -427,20 +430,14 @@ class _TalkingHeadsAttention(Function):
         return dqkv, dWl, dbl, dWw, dbw, None, None, None
 
 
-# developer knob (A/B): 0 = round-3 backward passes 1 / 2 + the streaming dQ contraction ; 1 = both passes on the flash skeleton
-# (csrc/attn_flash_bwd.hip) ; 2 = pass 1 on the round-3 kernel (two waves per SIMD: faster for the pass without dQ accumulators),
-# pass 2 + dQ on the flash skeleton ; 3 = KEY-major pass 1 + dV in one launch (spe_talking_bwdk_pass1), pass 2 + dQ on the flash skeleton.
-# Measured in the cfg2 step, same box: 53.4 / 53.5 ms (0), 52.6 (1), 52.0 / 52.9 (2); 52.8 / 52.6 (2) against 50.8 / 50.5 (3, the default).
-BWDQ_MODE = int(os.environ.get("SPE_BWDQ", "3"))
-BWDQ = BWDQ_MODE != 0
-
-
 class _TalkingHeadsAttentionFused(Function):
-    """Same operator on the fused score kernels (csrc/attn_fused.hip): no fp32 N x N tensor in HBM.
-    forward : pack q*scale*log2e, k, v (fp16) -> statistics pass -> write pass (P'd * 2^8, blocked fp16) -> O = P'd V (streaming contraction)
-    backward: dV = P'd^T dO ; pass 1 (D, dWw, dbw) ; pass 2 (dS blocked bf16, dWl, dbl) ; dQ, dK contractions.
-    Saved for backward: the packed q / k fragments (fp16 for the score recompute, bf16 for the gradient contractions), the bf16 v
-    fragments, P'd (fp16) and the row statistics - not qkv itself."""
+    """Same operator on the fused kernels: no N x N tensor in HBM in the forward, only the bf16 dS in the backward.  ONE composition:
+    forward : pack q * scale * log2 e, k, v (fp16 fragment records) -> statistics pass (csrc/attn_stats.hip) -> merge (row constants c0) -> flash
+              forward (csrc/attn_flash.hip: S, S', P, P', dropout, O += P'd V in registers; with dropout it stores the 1-bit keep flags)
+    backward: pack dO -> key-major kernel (D, dWw, dbw, dV) -> query-major kernel (dS blocks, dWl, dbl, dQ) -> weight-gradient reduce -> dK
+              contraction (csrc/attn_flash_bwd.hip, csrc/attn_contract.hip)
+    Saved for backward: the packed q / k fragments (fp16 for the score recompute, bf16 for the gradient contractions), the bf16 v fragments, the
+    row constants and - with dropout - the keep flags; not qkv itself."""
 
     @staticmethod
     @K.forward_scope
@@ -461,7 +458,7 @@ class _TalkingHeadsAttentionFused(Function):
         v5 = qkv.view(B, N, 3, H, dh)
         q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
         nt = (N + 15) // 16
-        spw0, _ = K.fused_plan(B, N, 0)
+        spw0, _ = K.fused_plan(B, N)
         # the fused kernels work in the log2 domain: scale * log2(e) is folded into the Q fragments
         # forward operands in fp16 (O(1) values: 3 more mantissa bits than bf16 at the same size and MFMA rate)
         # ... and, when a backward will follow, its bf16 fragments of q / k / v from the same read of qkv (one launch; the fp32
@@ -474,34 +471,19 @@ class _TalkingHeadsAttentionFused(Function):
         Wl, bl, Ww, bw = Wl.contiguous(), bl.contiguous(), Ww.contiguous(), bw.contiguous()
         ws_stats = torch.empty((B * nt * 8 * H * 32,), device=qkv.device, dtype=torch.float32)
         seed, off = K.next_rng() if p_drop > 0 else (0, 0)
-        K.talking_fused(0, Qf, Kf, None, None, Wl, bl, Ww, bw, None, None, None, ws_stats, None, None, B, H, N, dh, 0.0, 0, 0)
+        K.talking_stats(Qf, Kf, Wl, bl, ws_stats, B, H, N, dh)
         want16 = K.produces16(B * N, C)
-        flash = K.flash_supported(H, dh)
-        if flash:
-            M, IL, c0 = K.attn_merge_rows(ws_stats, bl, B, H, N, spw0)
-        else:
-            M, IL = K.attn_merge(ws_stats, B, H, N, spw0, 0)
-        if flash:
-            # P' goes from the head mix straight into the P' V products (csrc/attn_flash.hip): the 554 MB (cfg2) P'd tensor of the
-            # write pass is neither stored, streamed back nor saved - the backward recomputes it inside its dV pass
-            O, O16, O16lo, bits = K.talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, off, want16, K.split_fwd(),
-                                                      want_bits=True)
-            Pd = c0                                                        # what the backward needs instead of P'd
-        else:
-            Pd = K.score_blocks(B, H, N, qkv.device, torch.float16)          # fp16(P'd * PD_SCALE)
-            K.talking_fused(1, Qf, Kf, None, None, Wl, bl, Ww, bw, M, IL, None, None, None, Pd, B, H, N, dh, p_drop, seed, off)
-            O = torch.empty((B, N, C), device=qkv.device, dtype=torch.float32)
-            O16 = torch.empty((B * N, C), device=qkv.device, dtype=torch.bfloat16) if want16 else None
-            O16lo = torch.empty((B * N, C), device=qkv.device, dtype=torch.bfloat16) if (O16 is not None and K.split_fwd()) else None
-            K.attn_contract(Pd, V16, O.view(B, N, H, dh), False, alpha=1.0 / K.PD_SCALE, out16=O16, out16lo=O16lo)
+        _, _, c0 = K.attn_merge_rows(ws_stats, bl, B, H, N, spw0)
+        # P' goes from the head mix straight into the P' V products: nothing N x N is stored or saved - the backward recomputes it
+        O, O16, O16lo, bits = K.talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, c0, B, H, N, dh, p_drop, seed, off, want16, K.split_fwd(),
+                                                  want_bits=True)
         if O16 is not None:
-            K.attach16(O, O16, O16lo)        # the output projection's operand, written by the contraction's epilogue
-        ctx.meta = (B, N, C, H, dh, nt, scale, p_drop, seed, off, flash)
+            K.attach16(O, O16, O16lo)        # the output projection's operand, written by the merge's epilogue
+        ctx.meta = (B, N, C, H, dh, nt, scale, p_drop)
         ctx.wparams = (Wl, bl, Ww, bw)      # leaves: looked up in backward for their gradient buckets
-        # with dropout the flash forward leaves the keep flags of every tile behind (1 bit per element): backward passes 1 and 2 load them
-        kb = bits if (flash and train and bits is not None) else None
-        ctx.has_bits = kb is not None
-        saved = (packed[3], packed[4], packed[5], Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw) + ((kb,) if kb is not None else ()) if train else ()
+        # with dropout the flash forward leaves the keep flags of every tile behind (1 bit per element): the backward kernels load them
+        ctx.has_bits = train and bits is not None
+        saved = (packed[3], packed[4], packed[5], Qf, Kf, c0, Wl, Ww, bw) + ((bits,) if ctx.has_bits else ()) if train else ()
         return O, saved
 
     @staticmethod
@@ -513,10 +495,9 @@ class _TalkingHeadsAttentionFused(Function):
     def _bwd(ctx, saved, dO, out16):
         """-> (dqkv, dWl, dbl, dWw, dbw).  out16: dqkv comes back as the bf16 [B, N, 3C] operand of the qkv Linear's backward GEMMs
         (written by the contraction / merge epilogues); no fp32 copy exists then."""
-        Vf, K16, Q16, Qf, Kf, Pd, M, IL, Wl, bl, Ww, bw = saved[:12]
-        kbits = saved[12] if ctx.has_bits else None
-        B, N, C, H, dh, nt, scale, p_drop, seed, off, flash = ctx.meta
-        spw, nwg = K.fused_plan(B, N, 2)
+        Vf, K16, Q16, Qf, Kf, c0, Wl, Ww, bw = saved[:9]
+        kbits = saved[9] if ctx.has_bits else None
+        B, N, C, H, dh, nt, scale, p_drop = ctx.meta
         dO = dO.contiguous()
         dqkv = torch.empty((B, N, 3 * C), device=dO.device, dtype=torch.bfloat16 if out16 else torch.float32)
         d5 = dqkv.view(B, N, 3, H, dh)
@@ -525,49 +506,12 @@ class _TalkingHeadsAttentionFused(Function):
         b16 = (lambda t: t) if out16 else (lambda t: None)
         dO4 = dO.view(B, N, H, dh)
         dOf, dO16 = K.attn_pack_multi([(dO4, 1.0, 32), (dO4, 1.0, 16)])
-        nw = 2 * (H * H + H)
         dS = K.score_blocks(B, H, N, dO.device)
-        # q-major passes on the flash skeleton (csrc/attn_flash_bwd.hip): pass 2 also accumulates dQ in registers - the streaming dQ
-        # contraction and one of the two reads of dS are gone
-        bwdq = flash and BWDQ and K.bwdq_supported(H, dh) and (p_drop <= 0 or kbits is not None)
-        bwdk = bwdq and BWDQ_MODE == 3 and K.bwdk_supported(H, dh)
-        if bwdk:
-            # KEY-major pass 1 + dV in one walk (S, S', P recomputed once for D, dWw, dbw AND dV), then pass 2 + dQ on the flash skeleton
-            Drows, ws_w = K.talking_bwdk_pass1(Qf, dOf, dO16, Kf, Vf, Wl, Ww, bw, Pd, kbits, f32(dv), b16(dv), B, H, N, dh, p_drop)
-            K.talking_bwdq_pass2(Qf, dOf, Kf, Vf, K16, Wl, Ww, Pd, Drows, ws_w, dS, f32(dq), b16(dq), scale, kbits, B, H, N, dh, p_drop)
-        elif bwdq and BWDQ_MODE == 2:
-            # pass 1 on the round-3 kernel (two waves per SIMD: faster for the pass that has no dQ accumulators), pass 2 + dQ on the flash skeleton
-            ws_stats = torch.empty((B * nt * 8 * H * 32,), device=dO.device, dtype=torch.float32)
-            ws_w1 = torch.empty((nwg, nw), device=dO.device, dtype=torch.float32)
-            K.talking_fused(2, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, None, ws_stats, ws_w1, None, B, H, N, dh, p_drop, seed, off, keepbits=kbits)
-            D, _ = K.attn_merge(ws_stats, B, H, N, spw, 2)
-            Drows = K.flash_rows(D, None, None, B, H, N, 1)
-            ws_w = torch.empty((4 * K.bwdq_plan(B, N)[1], nw), device=dO.device, dtype=torch.float32)
-            K.talking_bwdq_pass2(Qf, dOf, Kf, Vf, K16, Wl, Ww, Pd, Drows, ws_w, dS, f32(dq), b16(dq), scale, kbits, B, H, N, dh, p_drop)
-        elif bwdq:
-            Drows, ws_w = K.talking_bwdq_pass1(Qf, dOf, Kf, Vf, Wl, Ww, Pd, kbits, B, H, N, dh, p_drop)
-            K.talking_bwdq_pass2(Qf, dOf, Kf, Vf, K16, Wl, Ww, Pd, Drows, ws_w, dS, f32(dq), b16(dq), scale, kbits, B, H, N, dh, p_drop)
-        else:
-            ws_stats = torch.empty((B * nt * 8 * H * 32,), device=dO.device, dtype=torch.float32)
-            ws_w = torch.empty((nwg, nw), device=dO.device, dtype=torch.float32)
-            K.talking_fused(2, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, None, ws_stats, ws_w, None, B, H, N, dh, p_drop, seed, off, keepbits=kbits)
-            D, _ = K.attn_merge(ws_stats, B, H, N, spw, 2)
-            K.talking_fused(3, Qf, Kf, Vf, dOf, Wl, bl, Ww, bw, M, IL, D, None, ws_w, dS, B, H, N, dh, p_drop, seed, off, keepbits=kbits)
-        # dV[key,d] = sum_q P'd[q,key] dO[q,d] - issued here, between backward pass 2 and the contractions that re-read
-        # its 554 MB of dS: a streaming read right after a pass that wrote that much runs ~20 % slower (measured)
-        if bwdk:
-            pass
-        elif flash:       # Pd holds the row constants c0: P'd is recomputed tile by tile inside the dV pass
-            K.talking_flash_dv(Qf, Kf, dO16, Wl, Ww, bw, Pd, f32(dv), p_drop, seed, off, dv16=b16(dv))
-        else:
-            K.attn_contract(Pd, dO16, f32(dv), True, alpha=1.0 / K.PD_SCALE, out16=b16(dv))
-        if bwdq and BWDQ_MODE == 2:
-            dWl, dbl, dWw, dbw = K.talking_wgrad_reduce2(ws_w, ws_w1, H, ctx.wparams)
-        else:
-            dWl, dbl, dWw, dbw = K.talking_wgrad_reduce(ws_w, H, ctx.wparams)
-        # dQ[q,d] = scale * sum_key dS[q,key] K[key,d] ; dK[key,d] = scale * sum_q dS[q,key] Q[q,d]
-        if not bwdq:
-            K.attn_contract(dS, K16, f32(dq), False, alpha=scale, out16=b16(dq))
+        # KEY-major kernel: S, S', P recomputed once for D, dWw, dbw AND dV ; then the QUERY-major kernel: dS blocks, dWl, dbl and dQ in registers
+        Drows, ws_w = K.talking_bwdk_pass1(Qf, dOf, dO16, Kf, Vf, Wl, Ww, bw, c0, kbits, f32(dv), b16(dv), B, H, N, dh, p_drop)
+        K.talking_bwdq_pass2(Qf, dOf, Kf, Vf, K16, Wl, Ww, c0, Drows, ws_w, dS, f32(dq), b16(dq), scale, kbits, B, H, N, dh, p_drop)
+        dWl, dbl, dWw, dbw = K.talking_wgrad_reduce(ws_w, H, ctx.wparams)
+        # dK[key,d] = scale * sum_q dS[q,key] Q[q,d]: the one streaming read of dS
         K.attn_contract(dS, Q16, f32(dk), True, alpha=scale, out16=b16(dk))
         return dqkv, dWl, dbl, dWw, dbw
 

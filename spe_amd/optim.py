@@ -99,8 +99,15 @@ class FlatAdamW(torch.optim.Optimizer):
         return loss
 
     def state_dict(self):
-        """torch's format (a per-parameter `step` entry: here every parameter's entry is the one shared, always current step tensor)."""
-        return super().state_dict()
+        """torch's format.  Inside this optimizer every parameter's `step` entry is the one shared, always current tensor; the EXPORTED
+        dict gives each parameter its own copy: pickle / torch.save keep aliasing, and torch.optim.AdamW (the reference's optimizer,
+        main.py:189-191 and its resume path :224-232) bumps every entry of the list it is handed - one shared tensor would advance by
+        the parameter count per step after such a resume."""
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            if "step" in st:
+                st["step"] = self._step_t.clone()
+        return sd
 
     def zero_grad(self, set_to_none=True):
         """The reference loop calls optimizer.zero_grad() before backward (engine.py:161): the gradients live in the

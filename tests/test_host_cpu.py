@@ -20,7 +20,11 @@ def test_library_exports_every_header_symbol():
     for name, sig in protos.items():
         fn = getattr(l, name)            # AttributeError == missing export
         assert fn.restype is ctypes.c_int and len(fn.argtypes) == len(sig)
-    assert l.spe_abi_version() == 6
+    assert l.spe_abi_version() == 7
+    # ONE attention backward composition (ABI 7): the retired entries are neither declared nor exported
+    for gone in ("spe_talking_fused", "spe_talking_fused_bits", "spe_talking_fused_plan", "spe_attn_merge", "spe_talking_flash_rows",
+                 "spe_talking_flash_dv", "spe_talking_bwdq_pass1"):
+        assert gone not in protos and not hasattr(l, gone), gone
 
 
 def test_comm_library_exports_every_header_symbol():

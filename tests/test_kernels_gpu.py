@@ -862,6 +862,17 @@ def test_flat_adamw_matches_torch(dev):
         assert rel(opt.state[y]["exp_avg"], ref.state[x]["exp_avg"]) < 2e-6
         # v accumulates (clip * g)^2: twice the relative rounding difference of the two global-norm reductions
         assert rel(opt.state[y]["exp_avg_sq"], ref.state[x]["exp_avg_sq"]) < 5e-5
+    # resume into the REFERENCE's optimizer (main.py:189-191, 224-232): the exported `step` entries are independent tensors - a shared one would be
+    # bumped once per parameter by torch.optim.AdamW's foreach step
+    steps = [st["step"] for st in sd["state"].values()]
+    assert len({id(s) for s in steps}) == len(steps) and all(float(s) == 3.0 for s in steps)
+    pc = mk()
+    fresh = torch.optim.AdamW(groups(pc), betas=(0.9, 0.999), eps=1e-8)
+    fresh.load_state_dict(sd)
+    for p in pc:
+        p.grad = torch.zeros_like(p)
+    fresh.step()
+    assert all(float(fresh.state[p]["step"]) == 4.0 for p in pc), [float(fresh.state[p]["step"]) for p in pc]
 
 
 def test_per_class_nms_and_flip_merge_vs_oracle(dev):

@@ -77,7 +77,7 @@ def test_forward_and_losses_match_reference(dev, name, prec):
             logging_only = ("class_error", "cardinality_error")
             for l, ref in ((l0, ev["loss0"]), (l1, ev["loss1"])):
                 for k, v in ref.items():
-                    tol = LOSS_TOL[prec] * max(1.0, abs(float(v)))
+                    tol = LOSS_TOL[prec] * max(1.0 if k.startswith(logging_only) else 1e-2, abs(float(v)))     # loss keys: truly relative
                     if k.startswith(logging_only) and prec == "bf16":
                         continue      # argmax-derived counters may flip under bf16 rounding
                     assert abs(float(l[k]) - float(v)) <= tol, (k, float(l[k]), float(v))
@@ -138,7 +138,7 @@ def test_train_step_grads_match_reference(dev, name, prec):
         for l, ref in ((l0, tr["loss0"]), (l1, tr["loss1"])):
             for k, v in ref.items():
                 if k in wd:
-                    assert abs(float(l[k].detach()) - float(v)) <= LOSS_TOL[prec] * max(1.0, abs(float(v))), (k, float(l[k].detach()), float(v))
+                    assert abs(float(l[k].detach()) - float(v)) <= LOSS_TOL[prec] * max(1e-2, abs(float(v))), (k, float(l[k].detach()), float(v))
         total = sum(l0[k] * wd[k] for k in l0 if k in wd) + sum(l1[k] * wd[k] for k in l1 if k in wd)
         assert abs(float(total.detach()) - float(tr["total"])) <= LOSS_TOL[prec] * abs(float(tr["total"]))
         total.backward()

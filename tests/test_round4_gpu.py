@@ -203,42 +203,6 @@ def test_block_with_training_rates_fused_equals_composite(dev):
         assert (blk(x0) - res[True][0][0]).norm() > 1e-2 * res[True][0][0].norm()
 
 
-def test_attention_dropout_keep_flags_equal_regenerated_masks(dev):
-    """With attn_drop > 0 the flash forward stores the keep flags of every tile (1 bit per element, lane layout of the q-major passes);
-    backward passes 1 and 2 load them instead of regenerating the masks from Philox.  Same masks: the gradients are bitwise those of the
-    regenerating path (reference models/cait.py:387 attn_drop and its autograd)."""
-    from spe_amd import kernels as K, ops
-    K.set_precision("bf16s")
-    g = torch.Generator().manual_seed(9)
-    for B, H, N, dh in ((2, 8, 1100, 48), (1, 4, 333, 32)):
-        C = H * dh
-        qkv0 = torch.randn(B, N, 3 * C, generator=g).to(dev)
-        Wl = (torch.eye(H) + 0.2 * torch.randn(H, H, generator=g)).to(dev).requires_grad_(True)
-        Ww = (torch.eye(H) + 0.2 * torch.randn(H, H, generator=g)).to(dev).requires_grad_(True)
-        bl = (0.1 * torch.randn(H, generator=g)).to(dev).requires_grad_(True)
-        bw = (0.1 * torch.randn(H, generator=g)).to(dev).requires_grad_(True)
-        w = torch.randn(B, N, C, generator=g).to(dev)
-        res = []
-        for keep in (True, False):
-            K.FLASH_KEEPBITS = keep
-            bwdq = ops.BWDQ
-            ops.BWDQ = False            # the property of the q-major round-3 passes (the flash-skeleton passes always load the flags: test_round5_gpu.py)
-            try:
-                K.manual_seed(31)
-                qkv = qkv0.clone().requires_grad_(True)
-                for t in (Wl, Ww, bl, bw):
-                    t.grad = None
-                O = ops.talking_heads_attention(qkv, Wl, bl, Ww, bw, H, dh ** -0.5, 0.1)
-                (O * w).sum().backward()
-                res.append((O.detach().clone(), qkv.grad.clone(), Wl.grad.clone(), Ww.grad.clone(), bl.grad.clone(), bw.grad.clone()))
-            finally:
-                K.FLASH_KEEPBITS = True
-                ops.BWDQ = bwdq
-        for a, b in zip(*res):
-            assert torch.equal(a, b)
-        assert res[0][1].abs().sum() > 0
-
-
 def test_jitter_pick_kernel_equals_elementwise_composition(dev):
     """One-to-many target jitter (reference models/conditional_detr.py:409-431): the one-launch pick kernel against the elementwise
     torch composition on the SAME uniform draws - identical boxes (the arithmetic is written without contraction), incl. boxes for which

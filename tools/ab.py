@@ -4,7 +4,7 @@
 
 writes build_ab/<name>.so (git-ignored, travels with gpurun), built with -DSPE_ABLATE - the only builds in which the timing-experiment
 switches (SPE_DBG_*, SPE_ABL_*) of csrc/ exist (csrc/common.h); run a tool against one with
-  SPE_HIP_LIB=build_ab/<name>.so python tools/time_fused.py
+  SPE_HIP_LIB=build_ab/<name>.so python tools/debug/attn_time.py
 """
 import os
 import subprocess

@@ -1,0 +1,79 @@
+"""The five attention kernels of one backbone block in isolation at cfg2 (B = 2, H = 8, N = 4150, dh = 48) or another shape, timed with HIP events on the
+launch stream (kernel + its merges per entry point):
+
+    python tools/debug/attn_time.py [B N H dh [p_drop]]                         # the shipped library
+    SPE_HIP_LIB=build_ab/<name>.so python tools/debug/attn_time.py ...          # a -DSPE_ABLATE variant built by tools/ab.py
+
+Reference: models/cait.py:377-389 and its autograd."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from spe_amd import kernels as K  # noqa: E402
+
+a = [float(x) for x in sys.argv[1:]]
+B, N, H, dh = (int(a[0]), int(a[1]), int(a[2]), int(a[3])) if len(a) >= 4 else (2, 4150, 8, 48)
+p_drop = a[4] if len(a) >= 5 else 0.0
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(1)
+C = H * dh
+qkv = torch.randn(B, N, 3 * C, generator=g).to(dev)
+Wl = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g)).to(dev); bl = (0.1 * torch.randn(H, generator=g)).to(dev)
+Ww = (torch.eye(H) + 0.3 * torch.randn(H, H, generator=g)).to(dev); bw = (0.1 * torch.randn(H, generator=g) / N).to(dev)
+dO = torch.randn(B, N, C, generator=g).to(dev)
+scale = dh ** -0.5
+v5 = qkv.view(B, N, 3, H, dh)
+q, k, v = v5[:, :, 0], v5[:, :, 1], v5[:, :, 2]
+Qf, Kf, V16, Vf, K16, Q16 = K.attn_pack_multi([(q, scale * K.LOG2E, 32 + K.F16), (k, 1.0, 32 + K.F16), (v, 1.0, 16 + K.F16), (v, 1.0, 32), (k, 1.0, 16), (q, 1.0, 16)])
+dO4 = dO.view(B, N, H, dh)
+dOf, dO16 = K.attn_pack_multi([(dO4, 1.0, 32), (dO4, 1.0, 16)])
+nt = (N + 15) // 16
+spw0, _ = K.fused_plan(B, N)
+ws = torch.zeros(B * nt * 8 * H * 32, device=dev)
+dqkv = torch.empty(B, N, 3 * C, device=dev, dtype=torch.bfloat16)
+d5 = dqkv.view(B, N, 3, H, dh)
+dS = K.score_blocks(B, H, N, dev)
+state = {}
+
+
+def stats():
+    K.talking_stats(Qf, Kf, Wl, bl, ws, B, H, N, dh)
+    state["c0"] = K.attn_merge_rows(ws, bl, B, H, N, spw0)[2]
+
+
+def fwd():
+    state["bits"] = K.talking_flash_fwd(Qf, Kf, V16, Wl, Ww, bw, state["c0"], B, H, N, dh, p_drop, 7, 3, True, True, want_bits=True)[3]
+
+
+def bwdk():
+    state["D"], state["ws_w"] = K.talking_bwdk_pass1(Qf, dOf, dO16, Kf, Vf, Wl, Ww, bw, state["c0"], state["bits"], None, d5[:, :, 2], B, H, N, dh, p_drop)
+
+
+def bwdq():
+    K.talking_bwdq_pass2(Qf, dOf, Kf, Vf, K16, Wl, Ww, state["c0"], state["D"], state["ws_w"], dS, None, d5[:, :, 0], scale, state["bits"], B, H, N, dh, p_drop)
+
+
+def dk():
+    K.attn_contract(dS, Q16, None, True, alpha=scale, out16=d5[:, :, 1])
+
+
+steps = [("statistics + merge", stats), ("flash forward + merge", fwd), ("key-major backward (D, dWw, dbw, dV) + merges", bwdk),
+         ("query-major backward (dS, dWl, dbl, dQ) + merge", bwdq), ("dK contraction", dk)]
+for _, f in steps:
+    f()
+torch.cuda.synchronize()
+REP = 10
+tot = 0.0
+print(f"library {K.lib.LIBPATH}; B={B} N={N} H={H} dh={dh} p_drop={p_drop}")
+for name, f in steps:
+    e = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(REP)]
+    for a_, b_ in e:
+        a_.record(); f(); b_.record()
+    torch.cuda.synchronize()
+    ms = sorted(x.elapsed_time(y) for x, y in e)
+    tot += ms[REP // 2]
+    print(f"  {name:52s} median {ms[REP // 2] * 1e3:8.1f} us   min {ms[0] * 1e3:8.1f} us")
+print(f"  {'sum of medians':52s}        {tot * 1e3:8.1f} us")

@@ -17,18 +17,13 @@ import sys
 from collections import defaultdict
 
 KERNELS = {
-    "talking_fused_mode0": "talking_fused_kernel<8, 2, true, 0,",
-    "talking_fused_mode1": "talking_fused_kernel<8, 2, true, 1,",
-    "talking_fused_mode2": "talking_fused_kernel<8, 2, true, 2,",
-    "talking_fused_mode3": "talking_fused_kernel<8, 2, true, 3,",
-    "attn_contract": "attn_contract_kernel<3, false",
+    "talking_stats": "talking_stats_kernel<8, 2, true,",
     "attn_contract_T": "attn_contract_kernel<3, true",
-    "flash_fwd": "talking_flash_fwd_kernel<8, 2, true, false, false>",
-    "flash_dv": "talking_flash_fwd_kernel<8, 2, true, false, true>",
+    "flash_fwd": "talking_flash_fwd_kernel<8, 2, true, false>",
     "flash_merge": "flash_merge_kernel",
-    "talking_bwdq_pass1": "talking_bwdq_kernel<8, 2, true, false, 1>",
-    "talking_bwdq_pass2": "talking_bwdq_kernel<8, 2, true, false, 2>",
+    "talking_bwdq_pass2": "talking_bwdq_kernel<8, 2, true, false>",
     "talking_bwdk_pass1": "talking_bwdk_kernel<8, 2, true, false>",
+    "gemm_nt": "gemm_nt",
 }
 
 

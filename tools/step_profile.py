@@ -72,8 +72,6 @@ def main():
         elif name == "spe_cvt_bf16":
             d = dict(zip(names[name], args))
             key = "cvt R=%d C=%d T=%d cs=%d aux=%d" % (d["R"], d["C"], int(bool(d["outT"])), int(bool(d["colsum"])), int(bool(d["aux"])))
-        elif name == "spe_talking_fused":
-            key = name + ":" + str(args[0])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         r = orig(name, *args)
