@@ -71,47 +71,113 @@ extern "C" int spe_matcher_cost(const float* logits, const float* boxes, const i
 //   srow = (l*B + b)*Q + q        (row of the flattened [L*B*Q] predictions)
 //   gidx = toff[b] + j            (index into the concatenated targets)
 //   lidx = l
+//
+// The search is ONE serial chain of (rows x path length) steps - 300 x 300 costs ~45 000 of them - so what matters is the latency of a step.
+// Everything a step touches lives in registers: lane t owns the columns t + 1 + 64 c, c < CPL, with their v, minv, way, p, used AND the row
+// potential of the row matched to the column (u travels with p: the row potentials are only ever read through a column); the problem's cost
+// matrix is staged once in LDS (transposed: a row's costs lie along the lanes) when it fits.  The wave-wide argmin - the bulk of a step in
+// round 4's kernel, whose butterfly of 64-bit __shfl_xor pairs cost six dependent LDS-crossbar round trips - is two 32-bit unsigned minima
+// over an order-preserving integer image of the doubles, each four DPP stages + four v_readlane, and the lowest column among the ties comes
+// from one ballot per column slot.  No LDS traffic but the cost row, no barrier inside the search.  Same fp64 arithmetic in the same order and
+// the same tie rule (lowest column index) as rounds 2-5: the pairs equal SciPy's at every tested size.
 #define HUNG_QMAX 1024
+#define HUNG_LDS_FLOATS (36 * 1024)
+
+template <int CTRL>
+__device__ __forceinline__ unsigned hung_dpp(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false); }
+// minimum over the 64 lanes (all active), returned uniform: xor 1, xor 2 inside the quads, the mirrored quad of the half row, the mirrored half
+// row - 16 lanes agree - then the four rows through the scalar unit
+__device__ __forceinline__ unsigned hung_wave_umin(unsigned x) {
+    x = min(x, hung_dpp<0xB1>(x));          // quad_perm [1,0,3,2]
+    x = min(x, hung_dpp<0x4E>(x));          // quad_perm [2,3,0,1]
+    x = min(x, hung_dpp<0x141>(x));         // row_half_mirror
+    x = min(x, hung_dpp<0x140>(x));         // row_mirror
+    const unsigned a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16), c = __builtin_amdgcn_readlane(x, 32),
+                   d = __builtin_amdgcn_readlane(x, 48);
+    return min(min(a, b), min(c, d));
+}
+// order-preserving map double -> uint64 (and back): a < b  <=>  key(a) < key(b) for all non-NaN values
+__device__ __forceinline__ unsigned long long hung_key(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double hung_unkey(unsigned long long k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+
+template <int CPL>
 __global__ __launch_bounds__(64) void hungarian_kernel(const float* __restrict__ cost, const int* __restrict__ toff,
                                                        long* __restrict__ srow, long* __restrict__ gidx, int* __restrict__ lidx,
                                                        int* __restrict__ err, int B, int Q) {
-    __shared__ double u[HUNG_QMAX + 1], v[HUNG_QMAX + 1], minv[HUNG_QMAX + 1];
-    __shared__ int p[HUNG_QMAX + 1], way[HUNG_QMAX + 1];
-    __shared__ unsigned char used[HUNG_QMAX + 1];
+    extern __shared__ float a_t[];                       // [n][m] when n * m <= HUNG_LDS_FLOATS
     const int lane = threadIdx.x;
     const int b = blockIdx.x, l = blockIdx.y;
     const int total = toff[B];
     const int n = toff[b + 1] - toff[b], m = Q;          // n targets (rows, 1-based i), m queries (columns, 1-based j)
     if (n <= 0) return;
     const float* a = cost + (long)l * Q * total + (long)Q * toff[b];      // a(i, j) = a[(j-1)*n + (i-1)]
-    for (int j = lane; j <= m; j += 64) { v[j] = 0.0; p[j] = 0; }
-    for (int i = lane; i <= n; i += 64) u[i] = 0.0;
-    __syncthreads();
-    for (int i = 1; i <= n; ++i) {
-        if (lane == 0) p[0] = i;
-        for (int j = lane; j <= m; j += 64) { minv[j] = INFINITY; used[j] = 0; }
-        __syncthreads();
-        int j0 = 0;
-        do {
-            if (lane == 0) used[j0] = 1;
-            __syncthreads();
-            const int i0 = p[j0];
-            const double ui0 = u[i0];
-            double best = INFINITY; int bj = 0x7fffffff;
-            for (int j = lane + 1; j <= m; j += 64) {
-                if (used[j]) continue;
-                const double cur = (double)a[(long)(j - 1) * n + (i0 - 1)] - ui0 - v[j];
-                double mv = minv[j];
-                if (cur < mv) { mv = cur; minv[j] = cur; way[j] = j0; }
-                if (mv < best) { best = mv; bj = j; }
-            }
+    const bool staged = (long)n * m <= HUNG_LDS_FLOATS;
+    if (staged)
+        for (int e = lane; e < n * m; e += 64) { const int j = e / n, i = e - j * n; a_t[i * m + j] = a[e]; }
+    double v[CPL], minv[CPL], ucol[CPL]; int p[CPL], way[CPL]; bool used[CPL];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ob = __shfl_xor(best, o, 64); const int oj = __shfl_xor(bj, o, 64);
-                if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+    for (int c = 0; c < CPL; ++c) { v[c] = 0.0; ucol[c] = 0.0; p[c] = 0; way[c] = 0; }
+    // value of a per-column register of column j (1-based; wave-uniform j) as a uniform value: a select over the slots + one v_readlane
+    auto col_i = [&](const int (&r)[CPL], int j) {
+        const int slot = (j - 1) >> 6, own = __builtin_amdgcn_readfirstlane((j - 1) & 63);
+        int x = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) if (c == slot) x = r[c];
+        return __builtin_amdgcn_readlane(x, own);
+    };
+    auto col_d = [&](const double (&r)[CPL], int j) {
+        const int slot = (j - 1) >> 6, own = __builtin_amdgcn_readfirstlane((j - 1) & 63);
+        double x = 0.0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) if (c == slot) x = r[c];
+        const long long bits = __double_as_longlong(x);
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)bits, own), hi = __builtin_amdgcn_readlane((unsigned)(bits >> 32), own);
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    __syncthreads();                                     // the staged costs are in place
+    for (int i = 1; i <= n; ++i) {
+        const int p0 = i;                                 // the virtual column 0 holds the row being inserted ...
+        double u0 = 0.0;                                  // ... and its potential (a fresh row starts at 0)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { minv[c] = INFINITY; used[c] = false; }
+        int j0 = 0, i0 = p0;
+        double ui0 = 0.0;
+        do {
+            if (j0 != 0) {
+                const int slot = (j0 - 1) >> 6, own = (j0 - 1) & 63;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) if (c == slot && lane == own) used[c] = true;
             }
-            const double delta = best; const int j1 = bj;
-            if (j1 == 0x7fffffff || !(fabs(delta) <= 1.7e308)) {
+            unsigned long long bk = ~0ull;                // this lane's best key over its free columns
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int j = lane + 64 * c + 1;
+                if (j > m || used[c]) continue;
+                const float av = staged ? a_t[(i0 - 1) * m + (j - 1)] : a[(long)(j - 1) * n + (i0 - 1)];
+                const double cur = (double)av - ui0 - v[c];
+                if (cur < minv[c]) { minv[c] = cur; way[c] = j0; }
+                const unsigned long long k = hung_key(minv[c]);
+                bk = (k < bk) ? k : bk;
+            }
+            // wave minimum of the 64-bit keys: high words first, then the low words of the lanes that hold the minimal high word
+            const unsigned hi = hung_wave_umin((unsigned)(bk >> 32));
+            const unsigned lo = hung_wave_umin(((unsigned)(bk >> 32) == hi) ? (unsigned)bk : 0xffffffffu);
+            const unsigned long long best = ((unsigned long long)hi << 32) | lo;
+            const double delta = hung_unkey(best);
+            // lowest column index among the free columns whose minv equals the minimum (SciPy's tie rule)
+            int j1 = 0x7fffffff;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int j = lane + 64 * c + 1;
+                const unsigned long long mask = __ballot(j <= m && !used[c] && hung_key(minv[c]) == best);
+                if (j1 == 0x7fffffff && mask != 0ull) j1 = 64 * c + __builtin_ctzll(mask) + 1;
+            }
+            if (best == ~0ull || j1 == 0x7fffffff || !(fabs(delta) <= 1.7e308)) {
                 // every remaining cost of this row is NaN / +-inf (diverged logits or boxes): the augmenting-path search
                 // has no column to move to.  SciPy raises ValueError here (matcher.py:86); the device path raises flag
                 // bit 1 (inspected by the host without a stall) and emits the identity assignment so that nothing
@@ -125,132 +191,30 @@ __global__ __launch_bounds__(64) void hungarian_kernel(const float* __restrict__
                 }
                 return;
             }
-            __syncthreads();
-            for (int j = lane; j <= m; j += 64) {
-                if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
-                else minv[j] -= delta;
-            }
-            j0 = j1;
-            __syncthreads();
-        } while (p[j0] != 0);
-        if (lane == 0) {
-            do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0);
-        }
-        __syncthreads();
-    }
-    // emit the pairs in ascending query order
-    const long obase = (long)l * total + toff[b];
-    int base = 0;
-    for (int jc = 1; jc <= m; jc += 64) {
-        const int j = jc + lane;
-        const bool has = j <= m && p[j] != 0;
-        const unsigned long long mask = __ballot(has);
-        if (has) {
-            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-            srow[obase + pos] = ((long)l * B + b) * Q + (j - 1);
-            gidx[obase + pos] = toff[b] + (p[j] - 1);
-            lidx[obase + pos] = l;
-        }
-        base += __popcll(mask);
-    }
-}
-
-// The same algorithm with the per-column state (v, minv, way, p, used) in REGISTERS - lane t owns the columns t + 1 + 64 c, c < CPL - and
-// the problem's cost matrix staged once in LDS (transposed: a row's costs lie along the lanes) when it fits.  The LDS kernel above pays a
-// global-memory round trip for the cost row and several LDS round trips for the column state in EVERY step of the augmenting-path search,
-// and the search is one serial chain (round 3: 245 us per launch at 100 x 35, the GPU otherwise idle).  Identical arithmetic (fp64 potentials,
-// lowest column index on ties, same update order per value): the pairs are the same.  Row potentials u stay in LDS (indexed by row).
-#define HUNG_LDS_FLOATS (36 * 1024)
-template <int CPL>
-__global__ __launch_bounds__(64) void hungarian_reg_kernel(const float* __restrict__ cost, const int* __restrict__ toff,
-                                                           long* __restrict__ srow, long* __restrict__ gidx, int* __restrict__ lidx,
-                                                           int* __restrict__ err, int B, int Q) {
-    extern __shared__ float a_t[];                       // [n][m] when n * m <= HUNG_LDS_FLOATS
-    __shared__ double u[HUNG_QMAX + 1];
-    const int lane = threadIdx.x;
-    const int b = blockIdx.x, l = blockIdx.y;
-    const int total = toff[B];
-    const int n = toff[b + 1] - toff[b], m = Q;
-    if (n <= 0) return;
-    const float* a = cost + (long)l * Q * total + (long)Q * toff[b];      // a(i, j) = a[(j-1)*n + (i-1)]
-    const bool staged = (long)n * m <= HUNG_LDS_FLOATS;
-    if (staged)
-        for (int e = lane; e < n * m; e += 64) { const int j = e / n, i = e - j * n; a_t[i * m + j] = a[e]; }
-    for (int i = lane; i <= n; i += 64) u[i] = 0.0;
-    double v[CPL], minv[CPL]; int p[CPL], way[CPL]; bool used[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) { v[c] = 0.0; p[c] = 0; way[c] = 0; }
-    // value of a per-column register of column j (1-based; uniform j) broadcast to the wave
-    auto col_i = [&](const int (&r)[CPL], int j) {
-        const int slot = (j - 1) >> 6, own = (j - 1) & 63;
-        int x = 0;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) if (c == slot) x = r[c];
-        return __shfl(x, own, 64);
-    };
-    __syncthreads();
-    for (int i = 1; i <= n; ++i) {
-        const int p0 = i;                                 // the virtual column 0 holds the row being inserted
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) { minv[c] = INFINITY; used[c] = false; }
-        int j0 = 0, pj0 = p0;
-        do {
-            if (j0 != 0) {
-                const int slot = (j0 - 1) >> 6, own = (j0 - 1) & 63;
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) if (c == slot && lane == own) used[c] = true;
-            }
-            const int i0 = pj0;
-            const double ui0 = u[i0];
-            double best = INFINITY; int bj = 0x7fffffff;
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                const int j = lane + 64 * c + 1;
-                if (j > m || used[c]) continue;
-                const float av = staged ? a_t[(i0 - 1) * m + (j - 1)] : a[(long)(j - 1) * n + (i0 - 1)];
-                const double cur = (double)av - ui0 - v[c];
-                if (cur < minv[c]) { minv[c] = cur; way[c] = j0; }
-                if (minv[c] < best) { best = minv[c]; bj = j; }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ob = __shfl_xor(best, o, 64); const int oj = __shfl_xor(bj, o, 64);
-                if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
-            }
-            const double delta = best; const int j1 = bj;
-            if (j1 == 0x7fffffff || !(fabs(delta) <= 1.7e308)) {         // see hungarian_kernel: flag + identity assignment
-                if (err && lane == 0) atomicOr(err, 2);
-                const long ob = (long)l * total + toff[b];
-                for (int i2 = lane; i2 < n; i2 += 64) {
-                    srow[ob + i2] = ((long)l * B + b) * Q + i2;
-                    gidx[ob + i2] = toff[b] + i2;
-                    lidx[ob + i2] = l;
-                }
-                return;
-            }
-            __syncthreads();                              // every lane has read u[i0]
-            if (lane == 0) u[p0] += delta;                // column 0 is always in the tree
+            u0 += delta;                                  // column 0 is always in the tree
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const int j = lane + 64 * c + 1;
                 if (j > m) continue;
-                if (used[c]) { u[p[c]] += delta; v[c] -= delta; }
+                if (used[c]) { ucol[c] += delta; v[c] -= delta; }
                 else minv[c] -= delta;
             }
             j0 = j1;
-            pj0 = col_i(p, j0);
-            __syncthreads();
-        } while (pj0 != 0);
-        // augment along the alternating path (uniform walk; the owner of a column rewrites its p)
+            i0 = col_i(p, j0);
+            ui0 = col_d(ucol, j0);
+        } while (i0 != 0);
+        // augment along the alternating path (uniform walk; the owner of a column rewrites its row and that row's potential)
         do {
             const int j1 = col_i(way, j0);
             const int pj1 = (j1 == 0) ? p0 : col_i(p, j1);
+            const double uj1 = (j1 == 0) ? u0 : col_d(ucol, j1);
             const int slot = (j0 - 1) >> 6, own = (j0 - 1) & 63;
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) if (c == slot && lane == own) p[c] = pj1;
+            for (int c = 0; c < CPL; ++c) if (c == slot && lane == own) { p[c] = pj1; ucol[c] = uj1; }
             j0 = j1;
         } while (j0);
     }
+    // emit the pairs in ascending query order
     const long obase = (long)l * total + toff[b];
     int base = 0;
 #pragma unroll
@@ -269,15 +233,15 @@ __global__ __launch_bounds__(64) void hungarian_reg_kernel(const float* __restri
 }
 
 template <int CPL>
-static int launch_hungarian_reg(const float* cost, const int* toff, long* srow, long* gidx, int* lidx, int* err, int L, int B, int Q, hipStream_t st) {
+static int launch_hungarian(const float* cost, const int* toff, long* srow, long* gidx, int* lidx, int* err, int L, int B, int Q, hipStream_t st) {
     constexpr int smem = HUNG_LDS_FLOATS * (int)sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hungarian_reg_kernel<CPL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hungarian_kernel<CPL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(hungarian_reg_kernel<CPL>, dim3(B, L), dim3(64), smem, st, cost, toff, srow, gidx, lidx, err, B, Q);
+    hipLaunchKernelGGL(hungarian_kernel<CPL>, dim3(B, L), dim3(64), smem, st, cost, toff, srow, gidx, lidx, err, B, Q);
     SPE_CHECK_LAUNCH();
     return 0;
 }
@@ -287,12 +251,10 @@ extern "C" int spe_hungarian(const float* cost, const int* toff, long* srow, lon
                              int Q, hipStream_t st) {
     if (L <= 0 || B <= 0 || Q <= 0) return 0;
     if (Q > HUNG_QMAX) return -2;
-    static const bool reg_path = !SPE_KNOB("SPE_HUNGARIAN_LDS", 0);      // (-DSPE_ABLATE builds: 1 = the LDS-state kernel)
-    if (reg_path && Q <= 128) return launch_hungarian_reg<2>(cost, toff, srow, gidx, lidx, err, L, B, Q, st);
-    if (reg_path && Q <= 320) return launch_hungarian_reg<5>(cost, toff, srow, gidx, lidx, err, L, B, Q, st);
-    hipLaunchKernelGGL(hungarian_kernel, dim3(B, L), dim3(64), 0, st, cost, toff, srow, gidx, lidx, err, B, Q);
-    SPE_CHECK_LAUNCH();
-    return 0;
+    if (Q <= 128) return launch_hungarian<2>(cost, toff, srow, gidx, lidx, err, L, B, Q, st);
+    if (Q <= 320) return launch_hungarian<5>(cost, toff, srow, gidx, lidx, err, L, B, Q, st);
+    if (Q <= 512) return launch_hungarian<8>(cost, toff, srow, gidx, lidx, err, L, B, Q, st);
+    return launch_hungarian<16>(cost, toff, srow, gidx, lidx, err, L, B, Q, st);
 }
 
 // Weighted sigmoid focal loss, forward value + d(sum)/d(logit) in one pass (one wave per

@@ -30,6 +30,11 @@ CASES = {
     "cfg2_enc3_small": dict(backbone="TSCAM_cait_S24_depth2", width=384, depth=2, heads=8, init_scale=1e-5, layer_to_det=1,
                             enc=3, dec=6, Q=100, dataset="coco", K=90, sizes_hw=[(512, 640), (480, 608)], n_tgt=[7, 4], seed=203,
                             gamma=0.5),
+    # ... and at configs[1]'s REAL token count (round 6): 2 x 3 x 800 x 1333 with a padded second image - the encoder's flash MHA self-attention
+    # over S = 4150 keys with a key-padding mask (reference models/transformer.py:253-288), 2 of the 24 backbone blocks
+    "cfg2_enc3_depth2": dict(backbone="TSCAM_cait_S24_depth2", width=384, depth=2, heads=8, init_scale=1e-5, layer_to_det=1,
+                             enc=3, dec=6, Q=100, dataset="coco", K=90, sizes_hw=[(800, 1333), (768, 1280)], n_tgt=[7, 5], seed=204,
+                             gamma=0.5),
     # configs[4] dims (S36: models/cait.py:1882-1888), 1x3x1000x1600 -> N = 6200 tokens; 2 of the 36 blocks
     "cfg5_depth2": dict(backbone="TSCAM_cait_S36_depth2", width=384, depth=2, heads=8, init_scale=1e-6, layer_to_det=1, enc=0,
                         dec=6, Q=100, dataset="coco", K=90, sizes_hw=[(1000, 1600)], n_tgt=[7], seed=505, gamma=0.5),

@@ -109,7 +109,7 @@ def compare_grads(named_grads, blob, norm_errs=None):
 
 
 # -------------------------------------------------------------------------------------------------- CPU: oracle
-@pytest.mark.parametrize("name", ["cfg1", "cfg2_enc3_small", "cfg2_depth2", "script_voc"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2_enc3_small", "cfg2_depth2", "cfg2_enc3_depth2", "script_voc"])
 def test_oracle_matches_reference_at_config_dims(name):
     from oracle import spe_oracle as O
     blob = torch.load(os.path.join(GOLD, f"cfg_{name}.pt"), weights_only=False)

@@ -229,8 +229,8 @@ def test_dropout_streams_have_the_reference_semantics_at_script_rates(dev):
         assert torch.equal(K.dropout(x, p, seed, off), y)
     # attention dropout: the keep flags of the flash forward (one bit per (head, query, key)) at attn_drop = 0.05
     B, H, N, dh, p = 1, 8, 1024, 48, 0.05
-    x_ = _inputs(B, H, N, dh, p, dev)
-    bits = x_["bits"]                                                   # [B, nt, nt, 64] dwords, 32 flags each (4 keys x 8 heads of one query)
+    from test_round6_gpu import _run_kernels
+    bits = _run_kernels(B, H, N, dh, p, dev)["bits"]                    # [B, nt, nt, 64] dwords, 32 flags each (4 keys x 8 heads of one query)
     assert bits is not None
     cnt = 0
     b32 = bits.view(-1).to(torch.int64) & 0xFFFFFFFF
