@@ -328,8 +328,7 @@ def main():
     S_rows, d_model = a.batch * (a.height // 16) * (a.width // 16), body.embed_dim
     n_dec = args.dec_layers
     CAG_N = 2 * n_dec * d_model          # ca_kcontent + ca_v of all decoder layers in one launch (ops.multi_linear)
-    CAG_WIDE = K.gemm_f16_wide_ok(S_rows, CAG_N // 2, d_model) and a.precision != "bf16x3"
-    CAG = (f"spe_gemm_f16nt_wide:{S_rows},{CAG_N},{d_model}" if CAG_WIDE else f"spe_gemm_bf16nt:{S_rows},{CAG_N},{d_model}")
+    CAG = f"spe_gemm_bf16nt:{S_rows},{CAG_N},{d_model}"
     K.enable_timing([DOMQ, HBMK, CAG, FLF, STATS, BWDK])
     reducer.measure = True
     sync()

@@ -34,7 +34,7 @@ typedef struct ihipStream_t* spe_stream_t; /* == hipStream_t */
  * before any entry point that sums across workgroups, spe_box_loss takes L, spe_linear_small_fwd / _bwd are new; 5 (round 4):
  * the flash-style talking-heads entry points spe_talking_flash_* are new; 6 (round 5): spe_talking_bwdq_* are new; 7 (round 6): ONE attention
  * backward composition - spe_talking_fused(_bits / _plan), spe_attn_merge, spe_talking_flash_rows, spe_talking_flash_dv, spe_talking_bwdq_pass1 removed,
- * spe_talking_stats(_plan) new (the statistics pass alone), spe_gemm_f16nt_wide new */
+ * spe_talking_stats(_plan) new (the statistics pass alone) */
 int spe_abi_version(void);
 
 /* ---- reduction workspace --------------------------------------------------------------------
@@ -142,15 +142,6 @@ int spe_cvt_f16(const float* x, long ldx, int R, int C, void* out, long ldo, spe
 int spe_gemm_bf16nt(const void* A16, const void* B16, const void* A16lo, const void* B16lo, float* C, const float* bias,
                     float* C2, int M, int N, int K, long lda, long ldb, long ldc, float alpha, int act, int splitk,
                     spe_stream_t stream);
-/* ---- north_star's decoder cross-attention GEMM (reference models/transformer.py:389-396: ca_kcontent_proj / ca_v_proj of `memory`, ca_kpos_proj of
- * `pos`, evaluated per layer and decoder pass there; here stacked over all layers): C[m][n] = fp16(alpha * sum_k A[m][k] B[n][k] + bias[n]) for a SHORT
- * contraction against a wide weight - A [M, K], B [N, K] IEEE fp16 (k-contiguous), C [c_rows, N] IEEE fp16.  A-resident persistent kernel
- * (csrc/gemm_ares.hip): a workgroup keeps a 256-row panel of A in registers and streams the weight tiles.  Supported: K in {192, 384}, N a multiple of
- * 128 and >= 512, M >= 2048, 16-B aligned pointers, leading dimensions multiples of 8; C must have c_rows >= 256 ceil(M / 256) ALLOCATED rows - the rows
- * M .. c_rows-1 receive unspecified finite values (every store of the kernel is unconditional).  -2 otherwise (use spe_gemm_bf16nt with act bits 8 + 9). */
-int spe_gemm_f16nt_wide(const void* A16, const void* B16, void* C16, const float* bias, int M, int N, int K, long lda, long ldb, long ldc,
-                        long c_rows, float alpha, spe_stream_t stream);
-
 /* nn.Linear on a few hundred rows (the decoder / encoder / head side: reference models/transformer.py:21-33, 206-250, 355-427,
  * models/conditional_detr.py:68-116) as ONE launch each way - these products are bound by dependent launches, not by throughput.
  * spe_linear_small_fwd: y[R][ldc] = act(x W^T + bias) from the fp32 activations x [R][ldx] and the cached bf16 weight W16 [N][K]

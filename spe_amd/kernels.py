@@ -125,7 +125,7 @@ def timing_results():
 
 # entry point -> positions of (M, N, K) in its argument list: GEMM launches can be timed per problem shape, e.g.
 # enable_timing(["spe_gemm_bf16nt:8300,384,384"])
-_GEMM_DIMS = {"spe_gemm_bf16nt": (7, 8, 9), "spe_gemm_bf16nt_ex": (16, 17, 18), "spe_gemm_f16nt_wide": (4, 5, 6)}
+_GEMM_DIMS = {"spe_gemm_bf16nt": (7, 8, 9), "spe_gemm_bf16nt_ex": (16, 17, 18)}
 
 
 # Reduction workspace of the deterministic cross-workgroup sums (include/spe_hip.h: spe_set_reduce_workspace; csrc/det_reduce.h):
@@ -519,20 +519,6 @@ def gemm16(A16, B16, C, M, N, K, lda, ldb, ldc, bias=None, C2=None, alpha=1.0, a
     _call("spe_gemm_bf16nt", _p(A16), _p(B16), _p(Alo), _p(Blo), _p(C), _p(bias), _p(C2), M, N, K, lda, ldb, ldc, float(alpha), int(act),
           int(splitk), _st())
     return C
-
-
-def gemm_f16_wide_ok(M, N, K):
-    """Shapes of the A-resident persistent fp16 GEMM (csrc/gemm_ares.hip: spe_gemm_f16nt_wide)."""
-    return K in (192, 384) and N % 128 == 0 and N >= 512 and M >= 2048
-
-
-def gemm_f16_wide(A16, B16, M, N, K, bias=None, alpha=1.0):
-    """fp16 [M, N] = alpha * A16 @ B16.T + bias for fp16 A16 [M, K], B16 [N, K] (contiguous) - north_star's decoder cross-attention GEMM.  The
-    result is a view of the first M rows of a buffer padded to a multiple of 256 rows (the kernel stores whole 256-row panels unconditionally)."""
-    Mp = ((M + 255) // 256) * 256
-    full = torch.empty((Mp, N), device=A16.device, dtype=torch.float16)
-    _call("spe_gemm_f16nt_wide", _p(A16), _p(B16), _p(full), _p(bias), M, N, K, A16.stride(0), B16.stride(0), N, Mp, float(alpha), _st())
-    return full[:M]
 
 
 def cvt_f16(x2, out=None):

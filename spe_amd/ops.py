@@ -915,16 +915,10 @@ class _MemorySideKV(Function):
         train = any(ctx.needs_input_grad) or bool(getattr(holder, "want_bwd", False))
         Wmh, bmc = K.weightcat_f16(Wm, bm)
         Wph, bpc = K.weightcat_f16(Wp, bp)
-        R = B * S
-        if K.gemm_f16_wide_ok(R, L * d, d):
-            # the A-resident persistent kernel (csrc/gemm_ares.hip): a 256-row panel of the memory stays in registers, only the weights stream
-            ym = K.gemm_f16_wide(K.cvt_f16(m2), Wmh, R, 2 * L * d, d, bias=bmc)
-            yp = K.gemm_f16_wide(K.cvt_f16(p2), Wph, R, L * d, d, bias=bpc)
-        else:
-            ym = torch.empty((R, 2 * L * d), device=memory.device, dtype=torch.float16)
-            yp = torch.empty((R, L * d), device=memory.device, dtype=torch.float16)
-            K.gemm16(K.cvt_f16(m2), Wmh, ym, R, 2 * L * d, d, d, d, 2 * L * d, bias=bmc, act=0x300)
-            K.gemm16(K.cvt_f16(p2), Wph, yp, R, L * d, d, d, d, L * d, bias=bpc, act=0x300)
+        ym = torch.empty((B * S, 2 * L * d), device=memory.device, dtype=torch.float16)
+        yp = torch.empty((B * S, L * d), device=memory.device, dtype=torch.float16)
+        K.gemm16(K.cvt_f16(m2), Wmh, ym, B * S, 2 * L * d, d, d, d, 2 * L * d, bias=bmc, act=0x300)
+        K.gemm16(K.cvt_f16(p2), Wph, yp, B * S, L * d, d, d, d, L * d, bias=bpc, act=0x300)
         holder.Kf, holder.V16, holder.K16, holder.Vf = K.kv_frags(ym, yp, L, B, S, H, dh, train)
         holder.dims = (L, B, S, H, dh)
         holder.ztok = torch.zeros((1,), device=memory.device, dtype=torch.float32)

@@ -313,33 +313,3 @@ def test_dp_world2_deferred_sums_two_processes_one_gpu(dev):
     out = mgr.dict()
     mp.spawn(_dp2_defer_worker, args=(2, port, out), nprocs=2, join=True)
     assert out.get(0) and out.get(1)
-
-
-# ------------------------------------------------------------------------------------------------ north_star's decoder cross-attention GEMM
-@pytest.mark.parametrize("M,N,Kd,bias", [(8300, 4608, 384, True), (8300, 2304, 384, True), (4150, 1152, 192, True), (2048, 512, 384, False),
-                                          (2049, 640, 192, True), (6200, 4608, 384, True)])
-def test_a_resident_fp16_gemm_vs_fp64(dev, M, N, Kd, bias):
-    """spe_gemm_f16nt_wide (csrc/gemm_ares.hip: A panel in registers, weight tiles streamed, persistent over (panel, column tile) units) against the
-    fp64 product of the SAME fp16 operands - the memory-side projections of the decoder's cross attention (reference models/transformer.py:389-396) at
-    cfg2 (8300 x 384 x 4608 / 2304), cfg5, the XXS width (K = 192) and ragged row counts (partial last panel, a workgroup range that crosses a panel
-    boundary): the only rounding left is the fp32 accumulation and the fp16 result; bitwise reproducible; padding rows beyond M are never read back."""
-    from spe_amd import kernels as K
-    assert K.gemm_f16_wide_ok(M, N, Kd)
-    g = torch.Generator().manual_seed(M + N)
-    A = torch.randn(M, Kd, generator=g).to(dev).half()
-    W = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).to(dev).half()
-    b = torch.randn(N, generator=g).to(dev) if bias else None
-    C = K.gemm_f16_wide(A, W, M, N, Kd, bias=b)
-    C2 = K.gemm_f16_wide(A, W, M, N, Kd, bias=b)
-    torch.cuda.synchronize()
-    assert C.shape == (M, N) and C.dtype == torch.float16 and torch.isfinite(C.float()).all()
-    assert torch.equal(C, C2)
-    ref = A.double() @ W.double().t() + (b.double() if bias else 0.0)
-    err = rel(C, ref)
-    worst = float((C.double() - ref).abs().max() / ref.abs().max())
-    print(f"[a-resident fp16 gemm {M}x{N}x{Kd}] rel {err:.2e}, worst element {worst:.2e}")
-    assert err < 4e-4 and worst < 2e-3, (err, worst)          # fp16 result: 2^-11 per element
-    # and the generic tile kernel it replaces gives the same values to fp32 summation order
-    Cg = torch.empty((M, N), device=dev, dtype=torch.float16)
-    K.gemm16(A, W, Cg, M, N, Kd, Kd, Kd, N, bias=b, act=0x300)
-    assert rel(C, Cg.double()) < 3e-4
