@@ -34,7 +34,7 @@ typedef struct ihipStream_t* spe_stream_t; /* == hipStream_t */
  * before any entry point that sums across workgroups, spe_box_loss takes L, spe_linear_small_fwd / _bwd are new; 5 (round 4):
  * the flash-style talking-heads entry points spe_talking_flash_* are new; 6 (round 5): spe_talking_bwdq_* are new; 7 (round 6): ONE attention
  * backward composition - spe_talking_fused(_bits / _plan), spe_attn_merge, spe_talking_flash_rows, spe_talking_flash_dv, spe_talking_bwdq_pass1 removed,
- * spe_talking_stats(_plan) new (the statistics pass alone) */
+ * spe_talking_stats(_plan) new (the statistics pass alone), spe_rowdot new */
 int spe_abi_version(void);
 
 /* ---- reduction workspace --------------------------------------------------------------------
@@ -378,6 +378,10 @@ int spe_dropout(const float* x, float* y, long n, float p, uint64_t seed, uint64
 /* ---- patch gather for the 16x16 stride-16 patch-embed conv (reference models/cait.py:518-528):
  * img[B,Cin,Hi,Wi] -> cols[B*(Hi/P)*(Wi/P), Cin*P*P] in conv-weight column order. */
 int spe_patchify(const float* img, float* cols, int B, int Cin, int Hi, int Wi, int P, spe_stream_t stream);
+
+/* ---- D[b][h][q] = sum_d x[b][q][h][d] y[b][q][h][d] for contiguous fp32 [B, L, H, dh] tensors (16-B aligned when dh % 4 == 0): the row term
+ * rowsum(dO . O) of the softmax backward of the decoder's cross attention (autograd of reference models/attention.py:277-383). */
+int spe_rowdot(const float* x, const float* y, float* D, int B, int L, int H, int dh, spe_stream_t stream);
 
 /* ---- out = a + b[(i mod period)] (adds the interpolated pos-embed table, cait.py:623-624). */
 int spe_add_rows(const float* a, const float* b, float* out, long n, long period, spe_stream_t stream);

@@ -22,8 +22,6 @@ struct Gemm16Args {
     int splitk; long slab; int kt_per_split;
     int xcd_bind;              // 0: plain tile order, 1: M-panels bound to XCDs, 2: N-panels bound to XCDs
     int stagger;               // gemm_nt2.hip: start delay of the second-slot workgroups (units of ~4 us)
-    int mpan;                  // gemm_nt2.hip: > 0: mpan full-height row panels spread evenly over [0, M) (neighbours overlap by a few rows,
-                               // which both compute and store identically) - one workgroup per CU and no partial round (set by launch_nt2)
     // extended epilogue (spe_gemm_bf16nt_ex): bf16 copies of the result for the NEXT GEMMs, column sums, and the
     // derivative of a fused activation applied from its saved argument
     unsigned short* out16; long ld16;      // [M][ld16]  bf16(v)

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(Gemm16Args p) {
     constexpr int STE = NP * 512;                 // bf16 elements per stage
     static_assert(NP % 4 == 0 && BM % 32 == 0 && BN % 32 == 0 && (BK == 32 || BK == 64) && NST >= 2, "tile geometry");
 
-    const int tiles_m = p.mpan > 0 ? p.mpan : (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     int tm, tn;
     if (p.xcd_bind == 0) { tm = blockIdx.x % tiles_m; tn = blockIdx.x / tiles_m; }
     else {      // the panels of the operand with more rows are bound to XCDs (workgroup b runs on XCD b % 8): see gemm_bf16.hip
@@ -60,8 +60,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(Gemm16Args p) {
         tm = (p.xcd_bind == 1) ? tb : to; tn = (p.xcd_bind == 1) ? to : tb;
         if (tm >= tiles_m || tn >= tiles_n) return;
     }
-    // balanced panels: panel tm starts at floor(tm (M - BM) / (mpan - 1)) - the last one ends exactly at M, every panel is BM rows of valid data
-    const int m0 = p.mpan > 1 ? (int)(((long)tm * (p.M - BM)) / (p.mpan - 1)) : tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BN;
     // Phase stagger: the two workgroups of a CU start together and would run their main loops (operand loads + MFMA) and then their
     // epilogues (tens of MB of stores) in lockstep - neither overlaps the other's.  The workgroups that fill the second slot
     // of the CUs (grid indices 256-511 of the first round) start `stagger` x ~4 us late, so one's epilogue meets the other's loop;
@@ -172,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(Gemm16Args p) {
 }
 
 template <int BM, int BN, int BK, int NST, bool SPLIT, bool EX, bool F16 = false>
-static int launch_nt2(const Gemm16Args& p, hipStream_t stream, int mpan = 0) {
+static int launch_nt2(const Gemm16Args& p, hipStream_t stream) {
     constexpr int ring = NST * ((BM + BN) / (64 / (BK / 8))) * (SPLIT ? 2 : 1) * 1024;
     constexpr int epi = EX ? BM * (BN + 8) * 2 * ((SPLIT || F16) ? 2 : 1) : 0;
     constexpr int smem = ring > epi ? ring : epi;
@@ -183,9 +182,8 @@ static int launch_nt2(const Gemm16Args& p, hipStream_t stream, int mpan = 0) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int tiles_m = mpan > 0 ? mpan : (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     Gemm16Args q = p;
-    q.mpan = mpan;
     static const int stagger = SPE_KNOB("SPE_NT2_STAGGER", 0);
     q.stagger = stagger;
     q.xcd_bind = 0;
@@ -198,7 +196,7 @@ static int launch_nt2(const Gemm16Args& p, hipStream_t stream, int mpan = 0) {
     if (q.xcd_bind == 2) tiles = 8 * ((tiles_n + 7) / 8) * tiles_m;
     // column sums of the extended epilogue (a bias gradient): deferred when the caller said so - sets = column tiles, members = row tiles
     const DetDeferSeg sg[1] = {{q.colsum, q.N}};
-    float* region = (EX && q.colsum && mpan == 0) ? det_defer_try(tiles_n, tiles_m, BN, 1, sg, stream) : nullptr;
+    float* region = (EX && q.colsum) ? det_defer_try(tiles_n, tiles_m, BN, 1, sg, stream) : nullptr;
     if (region) q.ws.defer = region;
     hipLaunchKernelGGL((gemm_nt2_kernel<BM, BN, BK, NST, SPLIT, EX, F16>), dim3(tiles), dim3(256), smem, stream, q);
     if (region) det_defer_commit(region, tiles_n, tiles_m, BN, 1, sg, 1);
@@ -252,38 +250,8 @@ int spe_nt2_dispatch(const Gemm16Args& p, bool ex, hipStream_t stream) {
         const long c128 = ((t128 + 511) / 512) * 128, c160 = ((t160 + 511) / 512) * 160;
         if (c160 < c128) return split ? launch_nt2<160, 128, 32, 2, true, false>(p, stream) : launch_nt2<160, 128, 64, 2, false, false>(p, stream);
     }
-    // Balanced single round for narrow outputs (N = 384 at cfg2: proj / fc2 forward, the three input-gradient products): 8300 x 384 is 390
-    // tiles of 128 x 64 = 1.52 workgroups per CU - the kernel ends when the CUs that got two are done, and those move 2 x (128 + 64) rows
-    // of operands per contraction step.  52 panels of 160 rows spread evenly over the rows (neighbours overlap by a row or two, stored twice
-    // with identical values: no padded tail tile) x 4 column tiles of 96 = 208 workgroups, at most one per CU, (160 + 96) operand rows per
-    // step on every CU that works, a 3-stage ring instead of a second workgroup.  Not with column sums in the epilogue (rows would count twice).
-    // MEASURED SLOWER (profiles/r04_bench_nt.txt: proj fwd 23.9 -> 30.9 us, fc2 fwd 64.4 -> 78.0, qkv dx 17.5 -> 26.2, fc1 dx 22.3 -> 31.9; step
-    // 55.7 -> 56.5 ms): one workgroup per CU moves its operands at a lower rate than two smaller ones, whatever the ring depth - the
-    // imbalance of 1.52 workgroups per CU costs less than the lost overlap.  Kept for the record in the -DSPE_ABLATE builds only.
-#ifdef SPE_ABLATE
-    static const int bal = SPE_KNOB("SPE_NT2_BALANCED", 0);      // developer knob (A/B)
-#else
-    constexpr int bal = 0;
-#endif
-    if (bal && !wide && cfg == 0 && p.N % 96 == 0 && !(ex && p.colsum)) {
-        const int tn96 = p.N / 96, P = 256 / tn96;
-        int BMsel = 0, mp = 0;
-        if (P >= 2 && p.M >= 128 && (long)P * 128 >= p.M) BMsel = 128;
-        else if (P >= 2 && p.M >= 160 && (long)P * 160 >= p.M) BMsel = 160;
-        if (BMsel) mp = (p.M + BMsel - 1) / BMsel;          // <= P panels of BMsel rows: the last one is shifted up to end at row M
-#ifdef SPE_ABLATE
-        if (BMsel == 160) {
-            if (ex && split) return launch_nt2<160, 96, 32, 3, true, true>(p, stream, mp);
-            if (!ex && split) return launch_nt2<160, 96, 32, 3, true, false>(p, stream, mp);
-            if (!ex && !split) return launch_nt2<160, 96, 64, 3, false, false>(p, stream, mp);
-        } else if (BMsel == 128) {
-            if (ex && split) return launch_nt2<128, 96, 32, 3, true, true>(p, stream, mp);
-            if (!ex && split) return launch_nt2<128, 96, 32, 3, true, false>(p, stream, mp);
-            if (!ex && !split) return launch_nt2<128, 96, 64, 3, false, false>(p, stream, mp);
-        }
-#endif
-        (void)mp;
-    }
+    // (A balanced single round for narrow outputs - 52 evenly spread 160-row panels x 4 column tiles of 96, one workgroup per CU, 3-stage ring - was
+    // measured slower in round 4 and is gone: profiles/r04_bench_nt.txt, profiles/HISTORY_r05.md.)
     // Narrow outputs (N = 384: the input-gradient products, proj / fc2 forward): 8300 x 384 is 390 tiles of 128 x 64 - 1.5 workgroups
     // per CU.  64 x 64 tiles (780 workgroups, three to four per CU) hide each other's load latency: qkv dx 19.4 -> 17.0 us, fc1 dx
     // 24.0 -> 21.5, the stacked decoder dx (K = 4608) 59.3 -> 53.1.  SPE_NT2_SHORT: bit 0 single-term plain, bit 1 split plain,

@@ -53,6 +53,33 @@ extern "C" int spe_add_rows(const float* a, const float* b, float* out, long n, 
     return 0;
 }
 
+// D[b][h][q] = sum_d x[b][q][h][d] * y[b][q][h][d] for contiguous [B, L, H, dh] tensors - the row term rowsum(dO . O) of a softmax backward
+// (reference: the autograd of models/attention.py:277-383's softmax), one thread per (b, q, h); replaces an ATen mul + sum + permuted copy.
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ D, int B, int L, int H, int dh) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;          // over B * L * H, h fastest (the inputs' order)
+    if (i >= (long)B * L * H) return;
+    const int h = (int)(i % H); const long bq = i / H; const int q = (int)(bq % L), b = (int)(bq / L);
+    const float* xp = x + i * dh; const float* yp = y + i * dh;
+    float acc = 0.f;
+    if ((dh & 3) == 0) {
+        for (int d = 0; d < dh; d += 4) {
+            const float4 u = *reinterpret_cast<const float4*>(xp + d), v = *reinterpret_cast<const float4*>(yp + d);
+            acc = fmaf(u.x, v.x, acc); acc = fmaf(u.y, v.y, acc); acc = fmaf(u.z, v.z, acc); acc = fmaf(u.w, v.w, acc);
+        }
+    } else {
+        for (int d = 0; d < dh; ++d) acc = fmaf(xp[d], yp[d], acc);
+    }
+    D[((long)b * H + h) * L + q] = acc;
+}
+extern "C" int spe_rowdot(const float* x, const float* y, float* D, int B, int L, int H, int dh, hipStream_t st) {
+    const long n = (long)B * L * H;
+    if (n <= 0) return 0;
+    if (dh <= 0 || ((dh & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15))) return -2;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, D, B, L, H, dh);
+    SPE_CHECK_LAUNCH();
+    return 0;
+}
+
 // Bicubic (A = -0.75, align_corners = false) resize of the learned position-embedding grid, token-major:
 // in[gh*gw][C] -> out[h*w][C]  (reference models/cait.py:598-613, F.interpolate(mode='bicubic')).
 __device__ __forceinline__ void cubic_w(float t, float w[4]) {

@@ -1386,9 +1386,17 @@ def mha_bwd(Qf, Kf, Vf, dOf, K16, Q16, dO16, mask_u8, lse, D, keep, B, H, Lq, Lk
     _call("spe_mha_bwd", _p(Qf), _p(Kf), _p(Vf), _p(dOf), _p(K16), _p(Q16), _p(dO16), _p(mask_u8), _p(lse), _p(D), _p(keep), _p(dq),
           _p(ws), _p(dk_), _p(dv_), B, H, Lq, Lk, dk, dv, nch, float(scale), float(p_drop), _st())
     if ws is not None:
-        dq.zero_()
-        colsum(ws, out=dq.view(-1))
+        colsum(ws, out=dq.view(-1), accumulate=False)          # overwrites: no zero fill in front of it
     return dq, dk_, dv_
+
+
+def rowdot(x4, y4):
+    """D [B,H,L] = sum_d x4 * y4 for contiguous fp32 [B,L,H,dh] tensors (the softmax backward's row term rowsum(dO . O)) in one launch."""
+    _chk(x4, y4)
+    B, L, H, dh = x4.shape
+    D = torch.empty((B, H, L), device=x4.device, dtype=torch.float32)
+    _call("spe_rowdot", _p(x4), _p(y4), _p(D), B, L, H, dh, _st())
+    return D
 
 
 _CONTRACT_WS = {}      # device -> (scratch floats, zeroed counters) shared by every contraction launch of the stream

@@ -7,7 +7,6 @@ reference main.py / engine.py drive it unchanged.  Device arithmetic is libspe_h
 all decoder layers' matching costs in one launch + one D2H copy (reference: 2*dec_layers round
 trips), all layers' focal losses in one launch, all layers' matched-box L1/GIoU in one launch.
 """
-import copy
 import math
 
 import torch
@@ -119,7 +118,9 @@ def jitter_targets(targets, ratio, jitter):
     and scores repeated.  Vectorised over ALL boxes of the batch and over the ratio-1 picks (the reference loops over
     images, boxes and attempts): a dozen small launches per call whatever the number of images; RNG = torch's generator
     on the device."""
-    out = copy.deepcopy(targets)
+    # (the reference deep-copies the target dicts, conditional_detr.py:409: ten tiny device copies per call; nothing below writes INTO a tensor - every key
+    # that changes is rebound to a new tensor - so new dicts over the same tensors are equivalent)
+    out = [dict(t) for t in targets]
     counts = [t["boxes"].shape[0] for t in out]
     if sum(counts) > 0:
         box = torch.cat([t["boxes"] for t in out if t["boxes"].shape[0] > 0])
@@ -218,7 +219,7 @@ class SetCriterion(nn.Module):
             if self.training:
                 targets_cp = jitter_targets(targets, self.hung_match_ratio, self.box_jitter)
             else:
-                targets_cp = copy.deepcopy(targets)
+                targets_cp = [dict(t) for t in targets]              # (no tensor is written in place: see jitter_targets)
         sizes = [int(len(t["labels"])) for t in targets_cp]
         # normaliser: a host number on one GPU; across ranks it stays a device scalar (no .item() stall per step)
         if is_dist_avail_and_initialized() and (get_world_size() > 1 or FORCE_NUM_BOXES_ALLREDUCE):

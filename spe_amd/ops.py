@@ -874,7 +874,7 @@ class _AttentionFlash(Function):
         B, Lq, Lk, H, dk, dv, nch, scale, p_drop = ctx.meta
         dO = dO.contiguous()
         dO4 = dO.view(B, Lq, H, dv)
-        D = (dO4 * O.view(B, Lq, H, dv)).sum(-1).permute(0, 2, 1).contiguous()          # [B,H,Lq] = rowsum(dO . O)
+        D = K.rowdot(dO4, O.contiguous().view(B, Lq, H, dv))                             # [B,H,Lq] = rowsum(dO . O)
         dOf, dO16 = K.attn_pack_multi([(dO4, 1.0, 322), (dO4, 1.0, 16)])
         dq, dk_, dv_ = K.mha_bwd(Qf, Kf, Vf, dOf, K16, Q16, dO16, mask_u8, lse, D, keep, B, H, Lq, Lk, dk, dv, nch, scale, p_drop)
         return dq, dk_, dv_, None, None, None
@@ -1006,7 +1006,7 @@ class _CrossAttentionKV(Function):
         d = H * dh
         dO = dO.contiguous()
         dO4 = dO.view(B, Lq, H, dh)
-        D = (dO4 * O.view(B, Lq, H, dh)).sum(-1).permute(0, 2, 1).contiguous()          # [B,H,Lq] = rowsum(dO . O)
+        D = K.rowdot(dO4, O.contiguous().view(B, Lq, H, dh))                             # [B,H,Lq] = rowsum(dO . O)
         dOf, dO16 = K.attn_pack_multi([(dO4, 1.0, 322), (dO4, 1.0, 16)])
         dq, dk_, dv_ = K.mha_bwd(Qf, h.Kf[layer], h.Vf[layer], dOf, h.K16[layer], Q16, dO16, mask_u8, lse, D, keep, B, H, Lq, S, dk, dh, nch,
                                  scale, p_drop)
@@ -1043,7 +1043,13 @@ def memory_side_kv(memory, pos, H, Wm, Wp, bm, bp):
 
 
 def cross_attention_kv(q, tok, holder, layer, key_padding_mask, scale, p_drop):
-    m = key_padding_mask.to(torch.uint8).contiguous() if key_padding_mask is not None else None
+    # the uint8 image of the padding mask is the same for every layer of a decoder pass: converted once, kept on the holder
+    m = None
+    if key_padding_mask is not None:
+        ent = getattr(holder, "mask_u8", None)
+        if ent is None or ent[0] is not key_padding_mask:
+            ent = holder.mask_u8 = (key_padding_mask, key_padding_mask.to(torch.uint8).contiguous())
+        m = ent[1]
     return _CrossAttentionKV.apply(q, tok, holder, layer, m, float(scale), float(p_drop))
 
 

@@ -1,4 +1,4 @@
-"""gpurun_out/parity_<case>_<precision>.json (written by tests/test_config_golden.py on the GPU box) -> profiles/parity_r05.json:
+"""gpurun_out/parity_<case>_<precision>.json (written by tests/test_config_golden.py on the GPU box) -> profiles/parity_r06.json:
 per precision mode the worst measured error over the cases at BASELINE.json's own dimensions, against the REFERENCE.
 bench.py copies the entry of the precision it runs into its JSON line ("precision_contract")."""
 import glob
@@ -11,26 +11,29 @@ out = {}
 for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "parity_*.json"))):
     r = json.load(open(f))
     e = out.setdefault(r["precision"], {"verified_against": "reference outputs/losses/gradients at cfg1, cfg2 (N=4150; 2 blocks and FULL depth 24 at "
-                                                            "batch 2), cfg2+enc3, cfg5 (N=6200; 2 blocks and FULL depth 36) dimensions: "
+                                                            "batch 2), cfg2 + 3 encoder layers (N=1280 and N=4150), cfg5 (N=6200; 2 blocks and FULL depth 36), the launch-"
+                                                            "script configuration (XXS36 two-branch): "
                                                             "tests/test_config_golden.py, fixtures tests/golden/cfg_*.pt",
                                         "cases": {}, "worst": {}})
     rec = {"tokens": r["tokens"], "pred_logits": r["pred_logits"], "pred_boxes": r["pred_boxes"], "x_patch": r["x_patch"],
-           "worst_output": r["worst_output"][1], "worst_loss_key": r["worst_loss"][1], "total_loss": r["total_loss_rel_err"],
+           "worst_output": r["worst_output"][1], "worst_loss_key": r["worst_loss"][1], "worst_loss_key_name": r["worst_loss"][0],
+           "loss_metric": r.get("loss_metric"), "stage1_box_keys_rel": {k: v[1] for k, v in (r.get("stage1_box_keys") or {}).items()},
+           "total_loss": r["total_loss_rel_err"],
            "median_grad": r["median_grad"], "p90_grad": r.get("p90_grad"), "worst_grad_64_samples": r["worst_grad"][1],
            "worst_grad_norm_err": (r.get("worst_grad_norm_err") or [None, None])[1]}
     e["cases"][r["case"]] = rec
     for k, v in rec.items():
-        if k != "tokens" and v is not None:
+        if k not in ("tokens", "worst_loss_key_name", "loss_metric", "stage1_box_keys_rel") and v is not None:
             e["worst"][k] = max(e["worst"].get(k, 0.0), v)
-tol = {"bf16s": "asserted: every output 1e-3, every loss key 1e-3, total loss 1e-3 (north_star's bound); gradients: median 1.5e-2, p90 4e-2 "
+tol = {"bf16s": "asserted: every output 1e-3 (norm-relative), every loss key 1e-3 TRULY RELATIVE (|err| / max(|ref|, 1e-2); round 6), total loss 1e-3 (north_star's bound); gradients: median 1.5e-2, p90 4e-2 "
                 "(64 samples per tensor), worst full-tensor norm 5e-2",
-       "bf16x3": "asserted: outputs 1e-3, every loss key 1e-3, total loss 1e-3 (north_star's bound), median gradient 1e-2",
+       "bf16x3": "asserted: outputs 1e-3, every loss key 1e-3 (relative), total loss 1e-3 (north_star's bound), median gradient 1e-2",
        "bf16": "asserted: outputs 1.2e-2, every loss key 1.5e-2, total loss 3e-3, median gradient 8e-2 (single bf16 operand rounding, 2^-9 per "
                "operand): NOT within north_star's 1e-3"}
 for k in out:
     out[k]["asserted_tolerances"] = tol.get(k)
 out["label"] = (sys.argv[1] if len(sys.argv) > 1 else "round 4") + ": tests/test_config_golden.py on the GPU box, product vs reference fixtures"
-path = os.path.join(ROOT, "profiles", "parity_r05.json")
+path = os.path.join(ROOT, "profiles", "parity_r06.json")
 json.dump(out, open(path, "w"), indent=1, sort_keys=True)
 for k, v in out.items():
     if isinstance(v, dict):
