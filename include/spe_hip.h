@@ -34,7 +34,7 @@ typedef struct ihipStream_t* spe_stream_t; /* == hipStream_t */
  * before any entry point that sums across workgroups, spe_box_loss takes L, spe_linear_small_fwd / _bwd are new; 5 (round 4):
  * the flash-style talking-heads entry points spe_talking_flash_* are new; 6 (round 5): spe_talking_bwdq_* are new; 7 (round 6): ONE attention
  * backward composition - spe_talking_fused(_bits / _plan), spe_attn_merge, spe_talking_flash_rows, spe_talking_flash_dv, spe_talking_bwdq_pass1 removed,
- * spe_talking_stats(_plan) new (the statistics pass alone), spe_rowdot new */
+ * spe_talking_stats(_plan) new (the statistics pass alone), spe_rowdot new, spe_layernorm_res_bwd takes dy2 */
 int spe_abi_version(void);
 
 /* ---- reduction workspace --------------------------------------------------------------------
@@ -159,12 +159,14 @@ int spe_linear_small_bwd(const float* dy, const float* aux, int act, const void*
  * (reference models/transformer.py:368-372: sa_qcontent / sa_kcontent / sa_v of tgt; 369-371, 399: sa_qpos / sa_kpos of every layer and
  * ca_qpos of the first on query_pos) - as one launch each way; every Linear keeps its own cached weight copies, output and gradient
  * buffers: the arguments are HOST arrays of nblk device pointers, nothing is stacked.  nblk <= 16.
- * spe_linear_small_group_fwd: y[i] [R][N] = x W_i^T + bias[i] (W16lo != NULL: split operands, every element non-NULL); N % 32 == 0.
+ * spe_linear_small_group_fwd: y[i] [R][N] = x W_i^T + bias[i] (+ add[i], a contiguous fp32 [R][N]; `add` or single elements may be NULL - the
+ *   decoder's q = sa_qcontent_proj(tgt) + sa_qpos_proj(query_pos), transformer.py:373-374, without an add launch) (W16lo != NULL: split operands, every
+ *   element non-NULL); N % 32 == 0.
  * spe_linear_small_group_bwd: dx [R][K] = sum_i dy[i] W_i (WT16[i] = bf16 W_i^T [K][N]), dW[i] [N][K] = dy[i]^T x16, db[i] [N] =
  *   colsum(dy[i]), overwritten, fixed summation order; dy[i] == NULL: output i received no gradient - it adds nothing to dx and its
  *   dW[i] / db[i] are not written.  dx, dW, db (or single elements of dW / db) may be NULL.  N % 128 == 0. */
 int spe_linear_small_group_fwd(const float* x, long ldx, const void* const* W16, const void* const* W16lo, const float* const* bias,
-                               float* const* y, void* x16_out, int R, int nblk, int N, int K, spe_stream_t stream);
+                               const float* const* add, float* const* y, void* x16_out, int R, int nblk, int N, int K, spe_stream_t stream);
 int spe_linear_small_group_bwd(const float* const* dy, const void* x16, const void* const* WT16, float* dx, float* const* dW,
                                float* const* db, int R, int nblk, int N, int K, spe_stream_t stream);
 /* spe_gemm_bf16tn: C[m][n] = alpha * sum_r A16[r][m] * B16[r][n] - the weight gradient dW = dy^T x of a Linear (autograd of
@@ -363,11 +365,12 @@ int spe_act_bwd(const float* dy, const float* aux, float* dx, long n, int mode, 
 /* ---- norm(x + dropout(z)): the post-norm residual sites of the DETR encoder / decoder layers (reference
  * models/transformer.py:279-287, 384-386, 420-421, 426-427) in one pass each way.  fwd: sum = x + z*keepscale(row*C+c) (kept:
  * it is LayerNorm's input), y / mean / rstd as spe_layernorm_fwd.  bwd: ds = LayerNorm backward (gradient of x and of the sum),
- * dz = ds*keepscale with the same mask (not written when p == 0: the branch gradient is ds); dgamma / dbeta pre-zeroed. */
+ * dz = ds*keepscale with the same mask (not written when p == 0: the branch gradient is ds); dgamma / dbeta pre-zeroed; dy2 (optional): the
+ * gradient of a second consumer of y - a post-norm layer's output feeds a Linear AND the next residual - added to dy while the row is loaded. */
 int spe_layernorm_res_fwd(const float* x, const float* z, const float* gamma, const float* beta, float* sum, float* y,
                           float* mean, float* rstd, long R, int C, float eps, float p, uint64_t seed, uint64_t offset,
                           spe_stream_t stream);
-int spe_layernorm_res_bwd(const float* dy, const float* sum, const float* gamma, const float* mean, const float* rstd,
+int spe_layernorm_res_bwd(const float* dy, const float* dy2, const float* sum, const float* gamma, const float* mean, const float* rstd,
                           float* ds, float* dz, float* dgamma, float* dbeta, long R, int C, float p, uint64_t seed,
                           uint64_t offset, spe_stream_t stream);
 

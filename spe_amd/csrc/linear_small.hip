@@ -47,6 +47,7 @@ struct LinSmallArgs {
     // weight / bias / output (forward) and dy / W^T / dW / db (backward) pointers: no stacked copies of anything
     int nblk, Nblk;
     const unsigned short* Wb[LS_MAXBLK]; const unsigned short* Wlob[LS_MAXBLK]; const float* biasb[LS_MAXBLK]; float* yb[LS_MAXBLK];
+    const float* addb[LS_MAXBLK];   // forward, optional: y[i] += add[i] ([R, Nblk] fp32) - q = sa_qcontent_proj(tgt) + sa_qpos_proj(query_pos) without an add launch
     const float* dyb[LS_MAXBLK]; const unsigned short* WTb[LS_MAXBLK]; float* dWb[LS_MAXBLK]; float* dbb[LS_MAXBLK];
 };
 
@@ -167,6 +168,14 @@ __global__ __launch_bounds__(256) void linear_small_fwd_kernel(LinSmallArgs p) {
                                  p.x16 != nullptr && tn == 0, ls_smem, acc1);
         Gemm16Args g = p.g;
         g.C = p.yb[blk]; g.bias = p.biasb[blk]; g.N = p.Nblk; g.ldc = p.Nblk;
+        if (p.addb[blk]) {          // the lane's 4 columns of its row (the epilogue's ownership: gemm16_epilogue.h), alpha = 1
+            const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+            const int m = tr * LS_T + (w >> 1) * 16 + (lane & 15), n = tl * LS_T + (w & 1) * 16 + (lane >> 4) * 4;
+            if (m < p.g.M && n + 3 < p.Nblk) {
+                const float4 a4 = *reinterpret_cast<const float4*>(p.addb[blk] + (long)m * p.Nblk + n);
+                acc1[0] += a4.x; acc1[1] += a4.y; acc1[2] += a4.z; acc1[3] += a4.w;
+            }
+        }
         f32x4_t accg[1][1] = {{acc1}};
         gemm16_epilogue_plain<LS_T, LS_T>(g, accg, g.C, tr * LS_T, tl * LS_T);
         return;
@@ -367,7 +376,7 @@ extern "C" int spe_linear_small_bwd(const float* dy, const float* aux, int act, 
 // for all of them, every Linear keeping its own weight copies, output and gradient buffers (pointer tables, nothing is stacked).
 static bool ls_group_kc_wide(int N) { return N % 384 == 0; }
 extern "C" int spe_linear_small_group_fwd(const float* x, long ldx, const void* const* W16, const void* const* W16lo, const float* const* bias,
-                                          float* const* y, void* x16_out, int R, int nblk, int N, int K, hipStream_t stream) {
+                                          const float* const* add, float* const* y, void* x16_out, int R, int nblk, int N, int K, hipStream_t stream) {
     if (R <= 0 || N <= 0 || nblk <= 0) return 0;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if (nblk > LS_MAXBLK || K <= 0 || (K & 7) || (N % LS_T) || (ldx & 3) || !al16(x) || !al16(x16_out)) return -2;
@@ -377,6 +386,8 @@ extern "C" int spe_linear_small_group_fwd(const float* x, long ldx, const void* 
         if (!W16[i] || !y[i] || !al16(W16[i]) || !al16(y[i]) || (split && (!W16lo[i] || !al16(W16lo[i])))) return -2;
         p.Wb[i] = reinterpret_cast<const unsigned short*>(W16[i]); p.Wlob[i] = split ? reinterpret_cast<const unsigned short*>(W16lo[i]) : nullptr;
         p.biasb[i] = bias ? bias[i] : nullptr; p.yb[i] = y[i];
+        p.addb[i] = add ? add[i] : nullptr;
+        if (p.addb[i] && (!al16(p.addb[i]) || (N & 3))) return -2;
     }
     p.nblk = nblk; p.Nblk = N;
     p.g.M = R; p.g.N = nblk * N; p.g.K = K; p.g.ldc = N; p.g.alpha = 1.f; p.g.act = 0; p.g.splitk = 1;

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      long R, int C, const float* __restrict__ add, float* __restrict__ dz,
-                                                     float p, uint64_t seed, uint64_t offset, DetWs ws,
+                                                     float p, uint64_t seed, uint64_t offset, DetWs ws, const float* __restrict__ dy2,
                                                      const float* __restrict__ ls_y, const float* __restrict__ ls_gamma,
                                                      unsigned short* __restrict__ ls_dy16, float* __restrict__ ls_db, float* __restrict__ ls_dg) {
     extern __shared__ float red_raw[];                 // [2 (LS: 4)][NW][C + 4]
@@ -97,6 +97,9 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict
     for (long row = (long)blockIdx.x * NW + w; row < R; row += (long)gridDim.x * NW) {
         const float4* xr = reinterpret_cast<const float4*>(x + row * C);
         const float4* dr = reinterpret_cast<const float4*>(dy + row * C);
+        // dy2 (optional): the gradient of a SECOND consumer of the norm's output (post-norm layers: the output feeds a Linear and the next residual) - the
+        // sum autograd would take in a launch of its own happens while the row is loaded
+        const float4* dr2 = dy2 ? reinterpret_cast<const float4*>(dy2 + row * C) : nullptr;
         const float mu = mean[row], rs = rstd[row];
         float4 xh[MAXV], dg[MAXV];
         float s1 = 0.f, s2 = 0.f;
@@ -104,7 +107,9 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict
         for (int i = 0; i < MAXV; ++i) {
             const int c = lane + 64 * i;
             if (c < C4) {
-                const float4 xv = xr[c], dv = dr[c], g = g4[c];
+                const float4 xv = xr[c], g = g4[c];
+                float4 dv = dr[c];
+                if (dr2) { const float4 d2 = dr2[c]; dv.x += d2.x; dv.y += d2.y; dv.z += d2.z; dv.w += d2.w; }
                 xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs; xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
                 dg[i].x = dv.x * g.x; dg[i].y = dv.y * g.y; dg[i].z = dv.z * g.z; dg[i].w = dv.w * g.w;
                 s1 += dg[i].x + dg[i].y + dg[i].z + dg[i].w;
@@ -362,7 +367,7 @@ extern "C" int spe_layernorm_fwd_h(const float* x, const float* gamma, const flo
 static int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
                          float* dgamma, float* dbeta, long R, int C, const float* add, float* dz, float p, uint64_t seed,
                          uint64_t offset, hipStream_t st, const float* ls_y = nullptr, const float* ls_gamma = nullptr, void* ls_dy16 = nullptr,
-                         float* ls_db = nullptr, float* ls_dg = nullptr) {
+                         float* ls_db = nullptr, float* ls_dg = nullptr, const float* dy2 = nullptr) {
     if (R <= 0) return 0;
     if ((C & 3) || C > 256 * LN_MAXV) return -2;
     const bool ls = ls_y != nullptr;
@@ -388,11 +393,11 @@ static int ln_bwd_launch(const float* dy, const float* x, const float* gamma, co
     float* region = det_defer_try(1, nb, nk * C, nk, sg, st);
     if (region) ws.defer = region; else DET_CHECK(ws, 1, nb, nk * C);
     if (ls) hipLaunchKernelGGL((ln_bwd_kernel<NW, true, 2>), dim3((unsigned)nb), dim3(NW * 64), 4 * NW * (C + 4) * (int)sizeof(float), st, dy, x, gamma, mean,
-                               rstd, dx, dgamma, dbeta, R, C, add, dz, p, seed, offset, ws, ls_y, ls_gamma, reinterpret_cast<unsigned short*>(ls_dy16), ls_db, ls_dg);
+                               rstd, dx, dgamma, dbeta, R, C, add, dz, p, seed, offset, ws, dy2, ls_y, ls_gamma, reinterpret_cast<unsigned short*>(ls_dy16), ls_db, ls_dg);
     else if (C <= 512) hipLaunchKernelGGL((ln_bwd_kernel<NW, false, 2>), dim3((unsigned)nb), dim3(NW * 64), 2 * NW * (C + 4) * (int)sizeof(float), st, dy, x, gamma, mean,
-                                          rstd, dx, dgamma, dbeta, R, C, add, dz, p, seed, offset, ws, nullptr, nullptr, nullptr, nullptr, nullptr);
+                                          rstd, dx, dgamma, dbeta, R, C, add, dz, p, seed, offset, ws, dy2, nullptr, nullptr, nullptr, nullptr, nullptr);
     else hipLaunchKernelGGL((ln_bwd_kernel<NW, false, LN_MAXV>), dim3((unsigned)nb), dim3(NW * 64), 2 * NW * (C + 4) * (int)sizeof(float), st, dy, x, gamma, mean,
-                            rstd, dx, dgamma, dbeta, R, C, add, dz, p, seed, offset, ws, nullptr, nullptr, nullptr, nullptr, nullptr);
+                            rstd, dx, dgamma, dbeta, R, C, add, dz, p, seed, offset, ws, dy2, nullptr, nullptr, nullptr, nullptr, nullptr);
     if (region) det_defer_commit(region, 1, nb, nk * C, nk, sg, 1);
     SPE_CHECK_LAUNCH();
     return 0;
@@ -410,11 +415,12 @@ extern "C" int spe_layernorm_bwd(const float* dy, const float* x, const float* g
     return ln_bwd_launch(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, add, nullptr, 0.f, 0, 0, st);
 }
 // C-ABI: see include/spe_hip.h (spe_layernorm_res_bwd): backward of spe_layernorm_res_fwd; ds = gradient of the sum (= of x),
-// dz = ds * keepscale (null when p == 0: the branch gradient is ds itself).
-extern "C" int spe_layernorm_res_bwd(const float* dy, const float* sum, const float* gamma, const float* mean, const float* rstd,
+// dz = ds * keepscale (null when p == 0: the branch gradient is ds itself); dy2 (optional): a second gradient of the output, added to dy on load.
+extern "C" int spe_layernorm_res_bwd(const float* dy, const float* dy2, const float* sum, const float* gamma, const float* mean, const float* rstd,
                                      float* ds, float* dz, float* dgamma, float* dbeta, long R, int C, float p, uint64_t seed,
                                      uint64_t offset, hipStream_t st) {
-    return ln_bwd_launch(dy, sum, gamma, mean, rstd, ds, dgamma, dbeta, R, C, nullptr, (p > 0.f) ? dz : nullptr, p, seed, offset, st);
+    return ln_bwd_launch(dy, sum, gamma, mean, rstd, ds, dgamma, dbeta, R, C, nullptr, (p > 0.f) ? dz : nullptr, p, seed, offset, st,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, dy2);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -890,8 +890,9 @@ def _ptr_array(ptrs):
     return (ctypes.c_void_p * len(ptrs))(*[(p if p else None) for p in ptrs])
 
 
-def linear_group_fwd(x2, Ws, bs, src=None):
-    """[x2 W_i^T + b_i] as n separate contiguous [R, N] tensors from ONE launch; -> (ys, x16 save for the backward)."""
+def linear_group_fwd(x2, Ws, bs, src=None, adds=None):
+    """[x2 W_i^T + b_i (+ adds[i])] as n separate contiguous [R, N] tensors from ONE launch; -> (ys, x16 save for the backward).  adds: list of
+    contiguous fp32 [R, N] tensors or None entries."""
     _chk(x2, *Ws)
     R, K = x2.shape
     N = Ws[0].shape[0]
@@ -907,6 +908,7 @@ def linear_group_fwd(x2, Ws, bs, src=None):
     ys = [torch.empty((R, N), device=x2.device, dtype=torch.float32) for _ in Ws]
     _call("spe_linear_small_group_fwd", _p(x2), x2.stride(0), _ptr_array([t_[0].data_ptr() for t_ in trip]),
           _ptr_array([t_[2].data_ptr() for t_ in trip]) if sp else None, _ptr_array([b.data_ptr() for b in bs]),
+          _ptr_array([0 if a is None else a.data_ptr() for a in adds]) if adds is not None else None,
           _ptr_array([y.data_ptr() for y in ys]), _p(x16_out), R, len(Ws), N, K, _st())
     return ys, x16
 
@@ -1082,14 +1084,14 @@ def layernorm_res_fwd(x2, z2, g, b, eps, p, seed, offset):
     return y, sm, mean, rstd
 
 
-def layernorm_res_bwd(dy2, sm, g, mean, rstd, p, seed, offset, dg_out=None, db_out=None):
-    """-> (ds, dz, dgamma, dbeta); dz is ds itself when p == 0."""
+def layernorm_res_bwd(dy2, sm, g, mean, rstd, p, seed, offset, dg_out=None, db_out=None, dy_b=None):
+    """-> (ds, dz, dgamma, dbeta); dz is ds itself when p == 0.  dy_b: the gradient of a second consumer of the output (added to dy2 on load)."""
     R, C = sm.shape
     ds = torch.empty_like(sm)
     dz = torch.empty_like(sm) if p > 0 else None
     dg = _zeros_or(dg_out, C, sm.device)
     db = _zeros_or(db_out, C, sm.device)
-    _call("spe_layernorm_res_bwd", _p(dy2), _p(sm), _p(g), _p(mean), _p(rstd), _p(ds), _p(dz), _p(dg), _p(db), R, C, float(p), seed,
+    _call("spe_layernorm_res_bwd", _p(dy2), _p(dy_b), _p(sm), _p(g), _p(mean), _p(rstd), _p(ds), _p(dz), _p(dg), _p(db), R, C, float(p), seed,
           offset, _st())
     return ds, (dz if dz is not None else ds), dg, db
 

@@ -21,6 +21,10 @@ class LayerNorm(nn.LayerNorm):
         """norm(x + drop(z)) as one kernel (drop: the layer's Dropout module)."""
         return ops.res_drop_layer_norm(x, z, self.weight, self.bias, self.eps, drop.p, drop.training)
 
+    def residual2(self, x, z, drop):
+        """(y, y_skip) with y = norm(x + drop(z)): the same values twice, for an output with two consumers (ops._ResDropLayerNorm2)."""
+        return ops.res_drop_layer_norm2(x, z, self.weight, self.bias, self.eps, drop.p, drop.training)
+
     def skip(self, x, f16=False):
         """(LN(x), x) for a pre-norm residual branch: pass the second result to the residual add (ops._LayerNormSkip).  f16: the branch
         starts with a single-term fp16 product (the backbone MLP in precision mode bf16s)."""

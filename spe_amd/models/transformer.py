@@ -77,9 +77,9 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, src, src_key_padding_mask=None, pos=None):
         qk = src if pos is None else ops.add(src, pos)
         src2 = self.self_attn(qk, src, src_key_padding_mask)
-        src = self.norm1.residual(src, src2, self.dropout1)
+        src, src_skip = self.norm1.residual2(src, src2, self.dropout1)       # two consumers: linear1 and the next residual site
         src2 = self.linear2(self.dropout(self.linear1(src, ops.ACT_RELU)))
-        return self.norm2.residual(src, src2, self.dropout2)
+        return self.norm2.residual(src_skip, src2, self.dropout2)
 
 
 class TransformerEncoder(nn.Module):
@@ -147,15 +147,17 @@ class TransformerDecoderLayer(nn.Module):
         # qp: this layer's projections of query_pos (sa_qpos, sa_kpos, ca_qpos or None), evaluated for all layers at once by the decoder
         q_pos, k_pos, ca_pos = qp if qp is not None else (self.sa_qpos_proj(query_pos), self.sa_kpos_proj(query_pos), None)
         content = (self.sa_qcontent_proj, self.sa_kcontent_proj, self.sa_v_proj)
-        if ops.group_linear_ok(tgt, content):       # the three projections of tgt: one launch each way
-            q, k, v = ops.group_linear(tgt, content)
+        if ops.group_linear_ok(tgt, content):       # the three projections of tgt AND q + q_pos, k + k_pos: one launch each way
+            q, k, v = ops.group_linear(tgt, content, adds=(q_pos, k_pos, None))
         else:
             q, k, v = (m(tgt) for m in content)
-        q = q + q_pos
-        k = k + k_pos
+            q = q + q_pos
+            k = k + k_pos
         sa = lambda t: t.view(B * n_stages, Q, d)
         tgt2 = self.self_attn(sa(q), sa(k), sa(v))[0].view(B, RQ, d)
-        tgt = self.norm1.residual(tgt, tgt2, self.dropout1)
+        # (post-norm: the norm's output feeds the next projection AND the next residual site - two results of one node, so that their gradients are
+        # added inside its backward kernel)
+        tgt, tgt_skip = self.norm1.residual2(tgt, tgt2, self.dropout1)
         # ---- conditional cross attention
         q = self.ca_qcontent_proj(tgt)
         if is_first:
@@ -177,10 +179,10 @@ class TransformerDecoderLayer(nn.Module):
             q = torch.cat([q.view(B, RQ, H, dh), qs.view(B, RQ, H, dh)], dim=3).view(B, RQ, 2 * d)
             k, v = mem_kv
             tgt2 = self.cross_attn(q, k, v, key_padding_mask=memory_key_padding_mask)[0]
-        tgt = self.norm2.residual(tgt, tgt2, self.dropout2)
+        tgt, tgt_skip = self.norm2.residual2(tgt_skip, tgt2, self.dropout2)
         # ---- FFN
         tgt2 = self.linear2(self.dropout(self.linear1(tgt, ops.ACT_RELU)))
-        return self.norm3.residual(tgt, tgt2, self.dropout3)
+        return self.norm3.residual(tgt_skip, tgt2, self.dropout3)
 
 
 class TransformerDecoder(nn.Module):

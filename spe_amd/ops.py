@@ -134,22 +134,28 @@ class _GroupLinear(Function):
     conditional-DETR decoder layer (reference models/transformer.py:368-372: sa_qcontent_proj / sa_kcontent_proj / sa_v_proj of tgt;
     369-371, 399: sa_qpos_proj / sa_kpos_proj of every layer and the first layer's ca_qpos_proj of query_pos) - as ONE launch each way
     (csrc/linear_small.hip group entries) instead of n forward launches, n backward launches and n - 1 gradient-accumulation adds;
-    same arithmetic per output as ops.linear on that path."""
+    same arithmetic per output as ops.linear on that path.  Optional addends (n_add = n, entries may be None): output i + adds[i] from the same launch
+    (transformer.py:373-374: q = q_content + q_pos, k = k_content + k_pos); an addend's gradient is the output's gradient itself."""
 
     @staticmethod
     @K.forward_scope
-    def forward(ctx, x, *wb):
+    def forward(ctx, x, n_add, *rest):
+        adds, wb = rest[:n_add], rest[n_add:]
         n = len(wb) // 2
         Ws, bs = wb[:n], wb[n:]
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        ys, x16 = K.linear_group_fwd(x2, Ws, bs, src=x)
+        N = Ws[0].shape[0]
+        a2 = None
+        if n_add:
+            a2 = [None if a is None else (lambda u: u if u.is_contiguous() else u.contiguous())(a.reshape(-1, N)) for a in adds]
+        ys, x16 = K.linear_group_fwd(x2, Ws, bs, src=x, adds=a2)
         ctx.set_materialize_grads(False)          # an output outside the loss arrives as None, not as a zero tensor
         ctx.params = (Ws, bs)
+        ctx.add_shapes = tuple(None if a is None else a.shape for a in adds)
         ctx.save_for_backward(x16)
-        N = Ws[0].shape[0]
         return tuple(y.view(*shp[:-1], N) for y in ys)
 
     @staticmethod
@@ -172,7 +178,8 @@ class _GroupLinear(Function):
         if dx is not None:
             ref = next(d for d in dys if d is not None)
             dx = dx.view(*ref.shape[:-1], Ws[0].shape[1])
-        return (dx, *dWs, *[None if b is None else b.view_as(p) for b, p in zip(dbs, bs)])
+        dadds = tuple(None if (shp is None or d is None) else d.reshape(shp) for shp, d in zip(ctx.add_shapes, dys))
+        return (dx, None, *dadds, *dWs, *[None if b is None else b.view_as(p) for b, p in zip(dbs, bs)])
 
 
 def group_linear_ok(x, mods):
@@ -183,8 +190,11 @@ def group_linear_ok(x, mods):
     return K.linear_group_ok(R, [m.weight for m in mods], [m.bias for m in mods])
 
 
-def group_linear(x, mods):
-    return _GroupLinear.apply(x, *[m.weight for m in mods], *[m.bias for m in mods])
+def group_linear(x, mods, adds=None):
+    """adds (optional): one entry per module - a tensor of the output's shape that is added to that output in the same launch, or None."""
+    adds = tuple(adds) if adds is not None else ()
+    assert len(adds) in (0, len(mods))
+    return _GroupLinear.apply(x, len(adds), *adds, *[m.weight for m in mods], *[m.bias for m in mods])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -248,6 +258,46 @@ class _ResDropLayerNorm(Function):
 
 def res_drop_layer_norm(x, z, g, b, eps, p, training):
     return _ResDropLayerNorm.apply(x, z, g, b, eps, p if training else 0.0)
+
+
+class _ResDropLayerNorm2(Function):
+    """(y, y) with y = norm(x + dropout(z)) for a post-norm layer whose output has TWO consumers - a Linear and the next residual site (reference
+    models/transformer.py:384-427: tgt = norm1(...); q = ca_qcontent_proj(tgt); ...; tgt = norm2(tgt + ...)): the two gradients of y meet in THIS node and
+    are added while the LayerNorm backward loads its rows (spe_layernorm_res_bwd dy2), instead of by an autograd accumulation launch."""
+
+    @staticmethod
+    @K.forward_scope
+    def forward(ctx, x, z, g, b, eps, p):
+        x2 = x.reshape(-1, x.shape[-1])
+        z2 = z.reshape(-1, z.shape[-1])
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        z2 = z2 if z2.is_contiguous() else z2.contiguous()
+        seed, off = K.next_rng() if p > 0 else (0, 0)
+        y, sm, mean, rstd = K.layernorm_res_fwd(x2, z2, g, b, eps, p, seed, off)
+        ctx.params = (g, b)
+        ctx.drop = (p, seed, off)
+        ctx.save_for_backward(sm, g, mean, rstd)
+        yv = y.view(x.shape)
+        return yv, yv.view_as(yv)
+
+    @staticmethod
+    @K.backward_scope
+    def backward(ctx, dy, dy_b):
+        sm, g, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            dy, dy_b = dy_b, None
+        if dy is None:
+            return None, None, None, None, None, None
+        c2 = lambda t: None if t is None else (lambda u: u if u.is_contiguous() else u.contiguous())(t.reshape(-1, t.shape[-1]))
+        gp, bp = ctx.params
+        p, seed, off = ctx.drop
+        ds, dz, dg, db = K.layernorm_res_bwd(c2(dy), sm, g, mean, rstd, p, seed, off, dg_out=K.grad_buffer(gp), db_out=K.grad_buffer(bp), dy_b=c2(dy_b))
+        return ds.view(dy.shape), dz.view(dy.shape), dg.view_as(gp), db.view_as(bp), None, None
+
+
+def res_drop_layer_norm2(x, z, g, b, eps, p, training):
+    """-> (y, y_skip): use the first for the layer's next Linear, the second as the skip operand of the next residual site."""
+    return _ResDropLayerNorm2.apply(x, z, g, b, eps, p if training else 0.0)
 
 
 class _LayerNormSkip(Function):

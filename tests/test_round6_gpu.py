@@ -313,3 +313,91 @@ def test_dp_world2_deferred_sums_two_processes_one_gpu(dev):
     out = mgr.dict()
     mp.spawn(_dp2_defer_worker, args=(2, port, out), nprocs=2, join=True)
     assert out.get(0) and out.get(1)
+
+
+# ------------------------------------------------------------------------------------------------ glue diet
+@pytest.mark.parametrize("R,C,p", [(400, 384, 0.1), (8300, 384, 0.0), (77, 64, 0.3)])
+def test_two_output_residual_layer_norm(dev, R, C, p):
+    """ops.res_drop_layer_norm2 - (y, y) of norm(x + dropout(z)) for a post-norm layer whose output feeds a Linear AND the next residual site
+    (reference models/transformer.py:384-427, 279-287); the two gradients are added inside the LayerNorm backward kernel (spe_layernorm_res_bwd dy2) -
+    against the one-output node with the SUM of the gradients (same Philox stream: same mask): bitwise the same y, gradients to fp32 rounding; one
+    consumer only (the other gradient None) in both positions; p = 0 against fp64."""
+    from spe_amd import kernels as K, ops
+    g_ = torch.Generator().manual_seed(R + C + 1)
+    x = torch.randn(1, R, C, generator=g_).to(dev)
+    z = torch.randn(x.shape, generator=g_).to(dev)
+    w = (1 + 0.2 * torch.randn(C, generator=g_)).to(dev); b = (0.1 * torch.randn(C, generator=g_)).to(dev)
+    ga = torch.randn(x.shape, generator=g_).to(dev); gb = torch.randn(x.shape, generator=g_).to(dev)
+
+    def run(two, g1, g2):
+        xs, zs, ws, bs = (t.clone().requires_grad_() for t in (x, z, w, b))
+        K.manual_seed(99)
+        if two:
+            y1, y2 = ops.res_drop_layer_norm2(xs, zs, ws, bs, 1e-5, p, True)
+            assert y1.data_ptr() == y2.data_ptr()
+            outs = [(y1, g1), (y2, g2)]
+            loss = sum((y * g).sum() for y, g in outs if g is not None)
+            y = y1
+        else:
+            y = ops.res_drop_layer_norm(xs, zs, ws, bs, 1e-5, p, True)
+            loss = (y * ((g1 if g1 is not None else 0) + (g2 if g2 is not None else 0))).sum()
+        return (y.detach(),) + torch.autograd.grad(loss, (xs, zs, ws, bs))
+
+    for g1, g2 in ((ga, gb), (ga, None), (None, gb)):
+        r2, r1 = run(True, g1, g2), run(False, g1, g2)
+        assert torch.equal(r2[0], r1[0])
+        for a, c in zip(r2[1:], r1[1:]):
+            assert rel(a, c) < 2e-6, rel(a, c)
+    if p == 0.0:
+        xd, zd, wd_, bd = (t.double().requires_grad_() for t in (x, z, w, b))
+        yd = torch.nn.functional.layer_norm(xd + zd, (C,), wd_, bd, 1e-5)
+        gd = torch.autograd.grad(yd, (xd, zd, wd_, bd), (ga + gb).double())
+        for a, c in zip(run(True, ga, gb), (yd,) + gd):
+            assert rel(a, c) < 1e-5
+
+
+def test_rowdot_kernel(dev):
+    """spe_rowdot: D[b][h][q] = sum_d dO[b][q][h][d] O[b][q][h][d] (the softmax backward's row term of the decoder's cross attention) against torch."""
+    from spe_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    for B, L, H, dh in ((2, 200, 8, 48), (1, 7, 4, 10), (3, 4150, 8, 32)):
+        x = torch.randn(B, L, H, dh, generator=g).to(dev); y = torch.randn(B, L, H, dh, generator=g).to(dev)
+        D = K.rowdot(x, y)
+        ref = (x.double() * y.double()).sum(-1).permute(0, 2, 1)
+        assert D.shape == (B, H, L) and rel(D, ref) < 1e-6
+
+
+def test_group_linear_with_addends(dev):
+    """ops.group_linear(x, mods, adds=...): output i + adds[i] from the same launch (the decoder's q = sa_qcontent_proj(tgt) + sa_qpos_proj(query_pos),
+    k likewise, reference models/transformer.py:368-374) against the group launch followed by torch adds: outputs to fp32 rounding (the addend joins the
+    accumulator before the bias instead of after it), every gradient - input, weights, biases, addends - bitwise."""
+    from spe_amd import kernels as K, ops
+    from spe_amd.models.layers import Linear
+    K.set_precision("bf16s")
+    torch.manual_seed(5)
+    R, d = 400, 384
+    mods = [Linear(d, d).to(dev) for _ in range(3)]
+    x0 = torch.randn(2, R // 2, d, device=dev)
+    a0 = [torch.randn(2, R // 2, d, device=dev), torch.randn(2, R // 2, d, device=dev), None]
+    ws = [torch.randn(2, R // 2, d, device=dev) for _ in range(3)]
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        adds = [None if a is None else a.clone().requires_grad_(True) for a in a0]
+        for m in mods:
+            m.weight.grad = m.bias.grad = None
+        if fused:
+            ys = ops.group_linear(x, mods, adds=adds)
+        else:
+            ys = [y if a is None else y + a for y, a in zip(ops.group_linear(x, mods), adds)]
+        sum((y * w).sum() for y, w in zip(ys, ws)).backward()
+        return ([y.detach() for y in ys], x.grad, [m.weight.grad.clone() for m in mods], [m.bias.grad.clone() for m in mods],
+                [None if a is None else a.grad for a in adds])
+
+    f, c = run(True), run(False)
+    for yf, yc in zip(f[0], c[0]):
+        assert rel(yf, yc) < 1e-6
+    assert torch.equal(f[1], c[1])
+    for i in range(3):
+        assert torch.equal(f[2][i], c[2][i]) and torch.equal(f[3][i], c[3][i])
+    assert torch.equal(f[4][0], c[4][0]) and torch.equal(f[4][1], c[4][1]) and f[4][2] is None
