@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
     fl_mixA_16<H, true, false>(a.Wl, lane, 1.0f, Alt);
 
     // ---- weight-gradient outer product on the matrix pipe through a wave-private LDS transpose: dW[g][h] = sum over (query, key) positions of x_g y_h is
-    // a contraction over POSITIONS, i.e. D[m = g][n = h] += A[g][pos] B[pos][h] with 16 positions per v_mfma_f32_16x16x16_bf16.  A lane owns ONE query and 4
+    // a contraction over POSITIONS, i.e. D[m = g][n = h] += A[g][pos] B[pos][h] with 32 positions per v_mfma_f32_16x16x32_bf16 (round 6; rounds 4-5 issued two 16-deep instructions per packet pair, each as dear as this one).  A lane owns ONE query and 4
     // keys for all heads, the operands want one HEAD per lane (m = lane & 15) and 4 keys of query t for the t-th instruction: a (query x head) transpose inside
     // each 16-lane group.  Rows m >= H read a block of zeros (the key-major kernel: row m = H of the B operand a block of ones - column H of D is the bias
     // gradient).  Here: X = dS', Y = S -> dWl (dbl stays an fp32 vector sum) ; key-major kernel: X = dP', Y = P -> dWw, dbw.
@@ -360,10 +360,9 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
                 for (int c = 0; c < 8; ++c) {
                     const flu32x4_t xa = *reinterpret_cast<const flu32x4_t*>(gw_xrd + c * 16);
                     const flu32x4_t yb = *reinterpret_cast<const flu32x4_t*>(gw_yrd + c * 16);
-                    gwacc[(2 * c) & 3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(fls16x4_t, (flu32x2_t){xa[0], xa[1]}),
-                                                                                     __builtin_bit_cast(fls16x4_t, (flu32x2_t){yb[0], yb[1]}), gwacc[(2 * c) & 3], 0, 0, 0);
-                    gwacc[(2 * c + 1) & 3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(fls16x4_t, (flu32x2_t){xa[2], xa[3]}),
-                                                                                         __builtin_bit_cast(fls16x4_t, (flu32x2_t){yb[2], yb[3]}), gwacc[(2 * c + 1) & 3], 0, 0, 0);
+                    // one 32-deep instruction per 16-B packet pair: a contraction over positions does not care which 8 positions a lane group brings
+                    // (the 16-deep form costs the same issue slot for half the positions: profiles/r05_mfma_form.txt)
+                    gwacc[c & 3] = fl_mfma32<false>(xa, yb, gwacc[c & 3]);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the back tile is rewritten by the next key tile
             }
@@ -951,10 +950,9 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
                 for (int c = 0; c < 8; ++c) {
                     const flu32x4_t xa = *reinterpret_cast<const flu32x4_t*>(gw_xrd + c * 16);
                     const flu32x4_t yb = *reinterpret_cast<const flu32x4_t*>(gw_yrd + c * 16);
-                    gwacc[(2 * c) & 3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(fls16x4_t, (flu32x2_t){xa[0], xa[1]}),
-                                                                                     __builtin_bit_cast(fls16x4_t, (flu32x2_t){yb[0], yb[1]}), gwacc[(2 * c) & 3], 0, 0, 0);
-                    gwacc[(2 * c + 1) & 3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(fls16x4_t, (flu32x2_t){xa[2], xa[3]}),
-                                                                                         __builtin_bit_cast(fls16x4_t, (flu32x2_t){yb[2], yb[3]}), gwacc[(2 * c + 1) & 3], 0, 0, 0);
+                    // one 32-deep instruction per 16-B packet pair: a contraction over positions does not care which 8 positions a lane group brings
+                    // (the 16-deep form costs the same issue slot for half the positions: profiles/r05_mfma_form.txt)
+                    gwacc[c & 3] = fl_mfma32<false>(xa, yb, gwacc[c & 3]);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             }
