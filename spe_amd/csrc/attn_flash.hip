@@ -97,11 +97,14 @@ __global__ __launch_bounds__(64 * FLF_NW, FLF_NW / 4) void talking_flash_fwd_ker
         // (uniform base of the (b, tile)) + (per-lane 32-bit offset of the piece, computed once): no 64-bit vector arithmetic per piece
         auto issue_tile = [&](const unsigned char* base, int kt, unsigned dst) {
             const unsigned char* tb = base + ((long)b * H * nt + kt) * REC;
+            if constexpr (NP % NW == 0 && NPW <= 4) fl_glds16_run<NPW, NW * 1024>(tb, voff, dst + wave * 1024);
+            else {
 #pragma unroll
-            for (int i = 0; i < NPW; ++i) {
-                const int p = i * NW + wave;
-                if (NP % NW != 0 && p >= NP) break;
-                fl_glds16_s(tb, voff[i], dst + p * 1024);
+                for (int i = 0; i < NPW; ++i) {
+                    const int p = i * NW + wave;
+                    if (NP % NW != 0 && p >= NP) break;
+                    fl_glds16_s(tb, voff[i], dst + p * 1024);
+                }
             }
         };
         issue_tile(a.Kf, kt0, lds0);

@@ -39,6 +39,17 @@
 #ifndef SPE_ABLATE
 #undef FLB_DBG_SAMETILE
 #undef FLB_DBG_NOST
+#undef FLB_DBG_STAMP
+#endif
+// FLB_DBG_STAMP (timing experiment, query-major kernel): s_memtime at the boundaries of a pipelined step's scheduling regions, summed over the steps of
+// workgroup 0 / wave 0 and left in the first bytes of the dS tensor (tools/debug/attn_time.py --stamps; profiles/r06_bwdq_stamps.txt)
+#ifdef FLB_DBG_STAMP
+#define FLB_STAMP(k) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[k]))     /* the wait: hipcc may copy the pair before it lands otherwise */
+#else
+#define FLB_STAMP(k)
+#endif
+#ifndef FLB_STAGGER
+#define FLB_STAGGER 1                    // query-major kernel: waves 2, 3 issue their share of the next tile's loads one scheduling region later than waves 0, 1
 #endif
 
 struct FlashBwdArgs {
@@ -170,6 +181,9 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
         const int o = (i * NW + wave) * 1024 + lane * 16;
         voff[i] = (unsigned)((o / REC) * nt * REC + o % REC);
     }
+#ifdef FLB_DBG_STAMP
+    unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0}, stacc[5] = {0, 0, 0, 0, 0}, stn = 0;
+#endif
     const float keep_inv = DROP ? 1.0f / (1.0f - a.p_drop) : 1.0f;
 
     const long s_begin = (long)blockIdx.x * a.spw;
@@ -226,11 +240,14 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
                 const unsigned char* base = (op == 0) ? a.Kf : ((op == 1) ? a.Vf : a.K16);
                 const unsigned char* tb = base + ((long)b * H * nt + kt) * REC;
                 const unsigned dst = (op < 2) ? lds0 + (i & 1) * KVB + op * TILEB : lds0 + 2 * KVB + (i % NK16) * TILEB;
+                if constexpr (NP % NW == 0 && NPW <= 4) fl_glds16_run<NPW, NW * 1024>(tb, voff, dst + wave * 1024);
+                else {
 #pragma unroll
-                for (int ii = 0; ii < NPW; ++ii) {
-                    const int p = ii * NW + wave;
-                    if (NP % NW != 0 && p >= NP) break;
-                    fl_glds16_s(tb, voff[ii], dst + p * 1024);
+                    for (int ii = 0; ii < NPW; ++ii) {
+                        const int p = ii * NW + wave;
+                        if (NP % NW != 0 && p >= NP) break;
+                        fl_glds16_s(tb, voff[ii], dst + p * 1024);
+                    }
                 }
             }
         };
@@ -433,6 +450,9 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
             front_k(i + 1, std::integral_constant<int, 0>{}, fr0, spn, std::false_type{});
             back_exp(sp);
             FLB_PHASE();
+            FLB_STAMP(2);
+            // the late half of the workgroup's tile loads (see admit)
+            if (FLB_STAGGER && more && wave >= NW / 2) issue_tiles(i + 2);
             if constexpr (H > HB) {
                 load_v(i + 1, 0, fr0);
                 __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
@@ -440,6 +460,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
             }
             back_ds(sp, dp);
             FLB_PHASE();
+            FLB_STAMP(3);
             if constexpr (H > HB) {
                 load_v(i + 1, HB, fr1);
                 __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
@@ -447,18 +468,22 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
             } else front_v(i + 1, std::integral_constant<int, 0>{}, fr1, dpn, kb);
             back_gw(i, sp, ds);
             FLB_PHASE();
+            FLB_STAMP(4);
             if constexpr (H > HB) front_v(i + 1, std::integral_constant<int, HB>{}, fr1, dpn, kb);
             back_dq(i, ds);
-            (void)more;
         };
 
         // step i + 1 is admitted: this wave's pieces have landed, a barrier (everybody's have, and everybody is done with the buffers refilled
         // next), then the tiles of step i + 2 go out with a whole step to land
-        auto admit = [&](int nxt) {
+        // The 36 LDS-DMA instructions of a tile (9 per wave) are worth 576 cycles of the CU's one vector-memory pipeline (1 KB each at 64 B / clk); issued by all
+        // four waves at once they hold every wave for that long (measured: 570 of a step's 5100 cycles - profiles/r06_bwdq_stamps.txt - a single wave per SIMD issues
+        // nothing else meanwhile), a wave issuing alone or in a pair pays ~39 cycles apiece for its own 9.  `late`: inside the pipelined loop waves 2, 3 therefore
+        // issue theirs at the first region boundary of the step (step()), while waves 0, 1 compute.
+        auto admit = [&](int nxt, bool late) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (nxt + 1 < seg) issue_tiles(nxt + 1);
+            if (nxt + 1 < seg && !(late && wave >= NW / 2)) issue_tiles(nxt + 1);
         };
 
         // Software pipeline over the segment's key tiles: the matrix-heavy front half of tile i + 1 runs in ONE scheduling region with the
@@ -469,21 +494,29 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
         f32x4_t spA[4][H / 4], dpA[4][H / 4], spB[4][H / 4], dpB[4][H / 4];
         Frags frA, frB;
         issue_tiles(0);
-        admit(0);
+        admit(0, false);
         if (nfull > 0) {
             if (wvalid) front(0, spA, dpA, std::false_type{});
             for (int i = 0; i + 1 < nfull; ++i) {
-                admit(i + 1);
+                FLB_STAMP(0);
+                admit(i + 1, FLB_STAGGER && wvalid);
+                FLB_STAMP(1);
                 if (wvalid) {
                     load_k(i + 1, 0, frA);       // (the stage was admitted above)
-                    step(i, spA, dpA, spB, dpB, frA, frB, false);
+                    step(i, spA, dpA, spB, dpB, frA, frB, i + 2 < seg);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int gh = 0; gh < H / 4; ++gh) { spA[r][gh] = spB[r][gh]; dpA[r][gh] = dpB[r][gh]; }
                 }
+#ifdef FLB_DBG_STAMP
+                FLB_STAMP(5);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(stamp[0]), "+s"(stamp[1]), "+s"(stamp[2]), "+s"(stamp[3]), "+s"(stamp[4]), "+s"(stamp[5]));
+                for (int k = 0; k < 5; ++k) stacc[k] += stamp[k + 1] - stamp[k];
+                ++stn;
+#endif
             }
-            if (nfull < seg) admit(nfull);
+            if (nfull < seg) admit(nfull, false);
             if (wvalid) back(nfull - 1, spA, dpA);
         }
         if (nfull < seg) {
@@ -510,6 +543,13 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
         s += seg;
     }
 
+#ifdef FLB_DBG_STAMP
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.dS);
+        for (int k = 0; k < 5; ++k) o[k] = stacc[k];
+        o[5] = stn;
+    }
+#endif
     // ---- weight-gradient partials of this wave -> its row of ws_w
     {
         constexpr int NWG = 2 * (H * H + H);
@@ -805,11 +845,14 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
                 const unsigned char* base = (op == 0) ? a.Qf : ((op == 1) ? a.dOf : a.dO16);
                 const unsigned char* tb = base + ((long)b * H * nt + qt) * REC;
                 const unsigned dst = (op < 2) ? lds0 + (i & 1) * STG + op * TILEB : lds0 + 2 * STG + (i % NK16) * TILEB;
+                if constexpr (NP % NW == 0 && NPW <= 4) fl_glds16_run<NPW, NW * 1024>(tb, voff, dst + wave * 1024);
+                else {
 #pragma unroll
-                for (int ii = 0; ii < NPW; ++ii) {
-                    const int p = ii * NW + wave;
-                    if (NP % NW != 0 && p >= NP) break;
-                    fl_glds16_s(tb, voff[ii], dst + p * 1024);
+                    for (int ii = 0; ii < NPW; ++ii) {
+                        const int p = ii * NW + wave;
+                        if (NP % NW != 0 && p >= NP) break;
+                        fl_glds16_s(tb, voff[ii], dst + p * 1024);
+                    }
                 }
             }
             if (wave == NW - 1) fl_glds16_s(a.c0 + ((long)b * a.Np + qt * 16) * H, (unsigned)(lane * 16), lds0 + C0OFF + (i & 1) * 1024);

@@ -121,6 +121,28 @@ __device__ __forceinline__ void fl_glds16_s(const void* sbase, unsigned voff, un
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
+// CNT pieces of one tile image, `stride` bytes apart in LDS (a wave's share of a tile: pieces wave, wave + NW, ...): three instructions per piece (m0, the
+// wait state behind its write, the load) instead of seven - the issuing wave is the one wave of its SIMD, every scalar instruction of the admission is
+// ~4.5 cycles nothing hides (profiles/r06_bwdq_stamps.txt).  m0 is not restored: nothing hipcc generates in these kernels reads it (no LDS instruction of this
+// target needs it), every LDS-DMA sets it itself.
+template <int CNT, int STRIDE>
+__device__ __forceinline__ void fl_glds16_run(const void* sbase, const unsigned* voff, unsigned lds_dst) {
+    static_assert(CNT >= 1 && CNT <= 4, "pieces per wave and tile");
+    if constexpr (CNT == 1)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0"
+                     :: "s"(sbase), "s"(lds_dst), "v"(voff[0]) : "memory");
+    else if constexpr (CNT == 2)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0\n\ts_add_u32 m0, m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %0"
+                     :: "s"(sbase), "s"(lds_dst), "v"(voff[0]), "v"(voff[1]), "n"(STRIDE) : "memory", "scc");
+    else if constexpr (CNT == 3)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0\n\ts_add_u32 m0, m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %0\n\t"
+                     "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %0"
+                     :: "s"(sbase), "s"(lds_dst), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "n"(STRIDE) : "memory", "scc");
+    else
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0\n\ts_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %0\n\t"
+                     "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %0\n\ts_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %0"
+                     :: "s"(sbase), "s"(lds_dst), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "n"(STRIDE) : "memory", "scc");
+}
 
 // ---- fragment records (spe_attn_pack_multi): per (b, h, 16-row tile) FULL steps of 64 lanes x 16 B (32 head dims each) and, when
 // TAIL16, one step of 64 lanes x 8 B (16 head dims); the 16-wide "X16" records are DT = 2 FULL + TAIL16 steps of 64 x 8 B.  Both are

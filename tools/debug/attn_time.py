@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from spe_amd import kernels as K  # noqa: E402
 
-a = [float(x) for x in sys.argv[1:]]
+STAMPS = "--stamps" in sys.argv
+a = [float(x) for x in sys.argv[1:] if not x.startswith("--")]
 B, N, H, dh = (int(a[0]), int(a[1]), int(a[2]), int(a[3])) if len(a) >= 4 else (2, 4150, 8, 48)
 p_drop = a[4] if len(a) >= 5 else 0.0
 dev = torch.device("cuda:0")
@@ -77,3 +78,13 @@ for name, f in steps:
     tot += ms[REP // 2]
     print(f"  {name:52s} median {ms[REP // 2] * 1e3:8.1f} us   min {ms[0] * 1e3:8.1f} us")
 print(f"  {'sum of medians':52s}        {tot * 1e3:8.1f} us")
+if STAMPS:          # a -DFLB_DBG_STAMP build (tools/ab.py) leaves the region sums of workgroup 0 / wave 0 in the first bytes of dS
+    bwdq(); torch.cuda.synchronize()
+    st = dS.view(-1)[:24].view(torch.int64).tolist()
+    n = max(st[5], 1)
+    names = ["admission (vmcnt + barrier + next tile loads)", "region 1: S + fp32 mix of heads 0-3 | exp2", "region 2: S + mix of heads 4-7 | dS' = P (dP - D), dbl, packs",
+             "region 3: dP' + dP mix of heads 0-3 | outer product, dS mix", "region 4: dP' + dP mix of heads 4-7 | dS store, dQ product"]
+    print(f"  query-major kernel, s_memtime ticks per pipelined step of workgroup 0 / wave 0 ({n} steps; 100 MHz ticks x 10 ns or core cycles: compare with the total):")
+    for k in range(5):
+        print(f"    {names[k]:64s} {st[k] / n:9.1f}")
+    print(f"    {'total':64s} {sum(st[:5]) / n:9.1f}")
