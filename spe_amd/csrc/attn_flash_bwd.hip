@@ -49,7 +49,7 @@
 #define FLB_STAMP(k)
 #endif
 #ifndef FLB_STAGGER
-#define FLB_STAGGER 1                    // query-major kernel: waves 2, 3 issue their share of the next tile's loads one scheduling region later than waves 0, 1
+#define FLB_STAGGER 1                    // waves 2, 3 issue their share of the next tile's loads one scheduling region later than waves 0, 1
 #endif
 
 struct FlashBwdArgs {
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
         };
         // one pipelined step: the front half of q-tile i + 1 beside the back half of q-tile i (see talking_bwdq_kernel)
         auto step = [&](int i, f32x4_t (&sp)[4][H / 4], f32x4_t (&dp)[4][H / 4], f32x4_t (&spn)[4][H / 4], f32x4_t (&dpn)[4][H / 4], Frags& fr0, Frags& fr1,
-                        const uint32_t (&kb)[4], uint32_t (&kbn)[4]) {
+                        const uint32_t (&kb)[4], uint32_t (&kbn)[4], bool more) {
             f32x4_t pp[4][H / 4];
             load_kb(i + 1, kbn);
             if constexpr (H > HB) load_q(i + 1, HB, fr1); else load_d(i + 1, 0, fr1);
@@ -1079,6 +1079,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
             front_q(i + 1, std::integral_constant<int, 0>{}, fr0, spn);
             back_exp(sp);
             FLB_PHASE();
+            if (FLB_STAGGER && more && wave >= NW / 2) issue_tiles(i + 2);       // the late half of the workgroup's tile loads (talking_bwdq_kernel: admit)
             constexpr bool RSF = FLB_RSFUSE && H == 2 * HB && FULL == 1 && TAIL16;      // the D reduce-scatters of tile i ride on two score-product blocks of tile i + 1
             f32x4_t rt[4], ro0, ro1;
             if constexpr (H > HB) {
@@ -1103,25 +1104,25 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
             if constexpr (H > HB) front_d(i + 1, std::integral_constant<int, HB>{}, fr1, dpn, kbn);
             back_dv(i, pp, kb);
         };
-        auto admit = [&](int nxt) {
+        auto admit = [&](int nxt, bool late) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (nxt + 1 < seg) issue_tiles(nxt + 1);
+            if (nxt + 1 < seg && !(late && wave >= NW / 2)) issue_tiles(nxt + 1);
         };
 
         f32x4_t spA[4][H / 4], dpA[4][H / 4], spB[4][H / 4], dpB[4][H / 4];
         uint32_t kbA[4], kbB[4];
         Frags frA, frB;
         issue_tiles(0);
-        admit(0);
+        admit(0, false);
         if (wvalid) front(0, spA, dpA, kbA);
         for (int i = 0; i + 1 < seg; ++i) {
-            admit(i + 1);
+            admit(i + 1, FLB_STAGGER && wvalid);
             if (i > 0) d_flush(i - 1);           // written during step i - 1, one barrier ago
             if (wvalid) {
                 load_q(i + 1, 0, frA);
-                step(i, spA, dpA, spB, dpB, frA, frB, kbA, kbB);
+                step(i, spA, dpA, spB, dpB, frA, frB, kbA, kbB, i + 2 < seg);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     kbA[r] = kbB[r];
