@@ -161,6 +161,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
     // of a tile writes (here Y, in the key-major kernel X) is double-buffered by tile parity: the front half of tile j + 1 runs beside the back half of tile j.
     constexpr int GWR = FLB_GWR, GWT = 4 * H * GWR;
     unsigned char* gconst = smem + 2 * KVB + NK16 * TILEB;                  // 512 B: zeros at + 48 (128 B), bf16 ones at + 208 (128 B)
+    constexpr int KBOFF = 2 * KVB + NK16 * TILEB + 512 + NW * 3 * GWT;     // dropout: 2 x 1 KB of keep-flag records (the four waves' 256 B of a key tile each), behind the transpose tiles
     unsigned char* sgw = gconst + 512 + wave * (3 * GWT);                   // [front operand, parity 0][front operand, parity 1][back operand]
     if (threadIdx.x < 64) reinterpret_cast<uint2*>(gconst)[threadIdx.x] = (threadIdx.x >= 26 && threadIdx.x < 42) ? make_uint2(0x3F803F80u, 0x3F803F80u) : make_uint2(0u, 0u);
     const int gm = lane & 15, gk = lane >> 4;
@@ -197,6 +198,14 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
         const bool wvalid = qt < nt;
         const int qtc = wvalid ? qt : nt - 1;
         const int q = qtc * 16 + (lane & 15);
+        // keep flags (dropout): the (q-tile, key tile) records of the four waves are nt * 256 B apart; one LDS-DMA instruction (wave 1) gathers them - lanes
+        // 16 w .. 16 w + 15 fetch wave w's 256 B - beside the tile's fragments, so no load the compiler can see (and would wait for with vmcnt(0), draining the
+        // tile loads in flight) is left in the loop
+        unsigned kb_voff = 0u;
+        if constexpr (DROP) {
+            const int w = lane >> 4, qw = (mj * NW + w < nt) ? w : 0;
+            kb_voff = (unsigned)(qw * nt * 256 + (lane & 15) * 16);
+        }
 
         // ---- this wave's Q and dO records -> registers (AccVGPR operands of the score products)
         flu32x4_t qa[H][F1], da[H][F1];
@@ -250,6 +259,8 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
                     }
                 }
             }
+            if constexpr (DROP)
+                if (wave == 1) fl_glds16_s(a.keepbits + (((long)b * nt + mj * NW) * nt + kt) * 64, kb_voff, lds0 + KBOFF + (i & 1) * 1024);
         };
 
         // ---- FRONT half of key tile i (matrix-heavy), in chunks of FLB_HB heads:
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdq_kernel(FlashBwdAr
                 }
         };
         auto load_kb = [&](int i) -> uint32_t {
-            if constexpr (DROP) return a.keepbits[(((long)b * nt + qt) * nt + (kt0 + i)) * 64 + lane];
+            if constexpr (DROP) return *reinterpret_cast<const uint32_t*>(smem + KBOFF + (i & 1) * 1024 + wave * 256 + lane * 4);
             else return 0u;
         };
 
@@ -758,6 +769,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
     const int nt = a.nt;
     constexpr int C0OFF = 2 * STG + NK16 * TILEB, DXB = 16 * H * 4, DXOFF = C0OFF + 2048, GCOFF = DXOFF + 2 * NW * DXB;
+    constexpr int KBOFF = GCOFF + 512 + NW * 3 * (4 * H * FLB_GWR);       // dropout: 2 x 1 KB of keep-flag records behind the transpose tiles (talking_bwdq_kernel)
 
     float Al4[H / 4][H];                            // S' = Wl S (fp32, 4x4x1)
     fl_mixA_f32<H, false>(a.Wl, lane, Al4);
@@ -809,6 +821,11 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
         const bool wvalid = kt < nt;
         const int ktc = wvalid ? kt : nt - 1;
         const int nvw = (nt - mj * NW < NW) ? nt - mj * NW : NW;   // waves of this major that own a key tile
+        unsigned kb_voff = 0u;              // keep flags: the four waves' records of a q-tile are consecutive (256 B each)
+        if constexpr (DROP) {
+            const int w = lane >> 4, kw = (mj * NW + w < nt) ? w : 0;
+            kb_voff = (unsigned)(kw * 256 + (lane & 15) * 16);
+        }
 
         // ---- this wave's K and V records -> registers (AccVGPR B operands of the score products)
         flu32x4_t ka[H][F1], va[H][F1];
@@ -856,6 +873,8 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
                 }
             }
             if (wave == NW - 1) fl_glds16_s(a.c0 + ((long)b * a.Np + qt * 16) * H, (unsigned)(lane * 16), lds0 + C0OFF + (i & 1) * 1024);
+            if constexpr (DROP)
+                if (wave == 1) fl_glds16_s(a.keepbits + (((long)b * nt + qt) * nt + mj * NW) * 64, kb_voff, lds0 + KBOFF + (i & 1) * 1024);
         };
 
         struct Frags { flu32x4_t f[HB][F1]; flu32x2_t t[HB]; };
@@ -937,9 +956,9 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
         };
         auto load_kb = [&](int i, uint32_t (&kb)[4]) {
             if constexpr (DROP) {
-                const unsigned* base = a.keepbits + (((long)b * nt + (qt0 + i)) * nt + ktc) * 64 + kbln + 4 * gk;
+                const flu32x4_t w4 = *reinterpret_cast<const flu32x4_t*>(smem + KBOFF + (i & 1) * 1024 + (wvalid ? wave : 0) * 256 + (kbln + 4 * gk) * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) kb[r] = base[r];
+                for (int r = 0; r < 4; ++r) kb[r] = w4[r];
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) kb[r] = 0u;
@@ -1198,7 +1217,8 @@ static inline int flb_dsteps(int dh, int* tail) {
 template <int H, int DSTEPS, bool TAIL16>
 static int launch_bwdq(const FlashBwdArgs& a, int nwg, bool drop, hipStream_t st) {
     constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
-    constexpr int smem = 4 * H * REC + FLB_NK16 * H * REC + 512 + FLB_NW * 3 * 4 * H * FLB_GWR;
+    constexpr int smem0 = 4 * H * REC + FLB_NK16 * H * REC + 512 + FLB_NW * 3 * 4 * H * FLB_GWR;
+    const int smem = smem0 + (drop ? 2048 : 0);          // + the keep-flag records
     if (smem > 160 * 1024) return -2;
     static bool attr_set[2] = {false, false};
     const void* fn = drop ? reinterpret_cast<const void*>(&talking_bwdq_kernel<H, DSTEPS, TAIL16, true>)
@@ -1275,7 +1295,8 @@ extern "C" int spe_talking_bwdq_pass2(const void* Qf, const void* dOf, const voi
 template <int H, int DSTEPS, bool TAIL16>
 static int launch_bwdk(const FlashBwdKArgs& a, int nwg, bool drop, hipStream_t st) {
     constexpr int FULL = DSTEPS - (TAIL16 ? 1 : 0), DT = 2 * FULL + (TAIL16 ? 1 : 0), REC = DT * 512;
-    constexpr int smem = 4 * H * REC + FLB_NK16 * H * REC + 2048 + 2 * FLB_NW * 16 * H * 4 + 512 + FLB_NW * 3 * 4 * H * FLB_GWR;
+    constexpr int smem0 = 4 * H * REC + FLB_NK16 * H * REC + 2048 + 2 * FLB_NW * 16 * H * 4 + 512 + FLB_NW * 3 * 4 * H * FLB_GWR;
+    const int smem = smem0 + (drop ? 2048 : 0);          // + the keep-flag records
     if (smem > 160 * 1024) return -2;
     static bool attr_set[2] = {false, false};
     const void* fn = drop ? reinterpret_cast<const void*>(&talking_bwdk_kernel<H, DSTEPS, TAIL16, true>)
