@@ -808,6 +808,9 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
     }
     const float keep_inv = DROP ? 1.0f / (1.0f - a.p_drop) : 1.0f;
     const int kbsh = 2 * (gm & 3);                                 // keep flag of (query row, this lane's key), head g: bit (g >> 1) * 8 + kbsh + (g & 1) ...
+#ifdef FLB_DBG_STAMP
+    unsigned long long stamp[7] = {0, 0, 0, 0, 0, 0, 0}, stacc[6] = {0, 0, 0, 0, 0, 0}, stn = 0;
+#endif
     const int kbln = (gm >> 2) << 4;                               // ... of the word of lane (query row) | kbln of the (q-tile, key tile) block
 
     const long s_begin = (long)blockIdx.x * a.spw;
@@ -1098,6 +1101,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
             front_q(i + 1, std::integral_constant<int, 0>{}, fr0, spn);
             back_exp(sp);
             FLB_PHASE();
+            FLB_STAMP(3);
             if (FLB_STAGGER && more && wave >= NW / 2) issue_tiles(i + 2);       // the late half of the workgroup's tile loads (talking_bwdq_kernel: admit)
             constexpr bool RSF = FLB_RSFUSE && H == 2 * HB && FULL == 1 && TAIL16;      // the D reduce-scatters of tile i ride on two score-product blocks of tile i + 1
             f32x4_t rt[4], ro0, ro1;
@@ -1112,6 +1116,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
             else back_ds(i, sp, dp);
 
             FLB_PHASE();
+            FLB_STAMP(4);
             if constexpr (H > HB) {
                 load_d(i + 1, HB, fr1);
                 __builtin_amdgcn_sched_barrier(FLB_SB_NOMEM);
@@ -1120,6 +1125,7 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
             } else front_d(i + 1, std::integral_constant<int, 0>{}, fr1, dpn, kbn);
             back_gw(i, sp, pp);
             FLB_PHASE();
+            FLB_STAMP(5);
             if constexpr (H > HB) front_d(i + 1, std::integral_constant<int, HB>{}, fr1, dpn, kbn);
             back_dv(i, pp, kb);
         };
@@ -1137,8 +1143,11 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
         admit(0, false);
         if (wvalid) front(0, spA, dpA, kbA);
         for (int i = 0; i + 1 < seg; ++i) {
+            FLB_STAMP(0);
             admit(i + 1, FLB_STAGGER && wvalid);
-            if (i > 0) d_flush(i - 1);           // written during step i - 1, one barrier ago
+            FLB_STAMP(1);
+            if (i > 0) d_flush(i - 1);           // written during step i - 1, one barrier ago (tried INSIDE the step's first region: slower, profiles/r06_bwdq_stamps.txt)
+            FLB_STAMP(2);
             if (wvalid) {
                 load_q(i + 1, 0, frA);
                 step(i, spA, dpA, spB, dpB, frA, frB, kbA, kbB, i + 2 < seg);
@@ -1149,6 +1158,12 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
                     for (int gh = 0; gh < H / 4; ++gh) { spA[r][gh] = spB[r][gh]; dpA[r][gh] = dpB[r][gh]; }
                 }
             }
+#ifdef FLB_DBG_STAMP
+            FLB_STAMP(6);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(stamp[0]), "+s"(stamp[1]), "+s"(stamp[2]), "+s"(stamp[3]), "+s"(stamp[4]), "+s"(stamp[5]), "+s"(stamp[6]));
+            for (int k = 0; k < 6; ++k) stacc[k] += stamp[k + 1] - stamp[k];
+            ++stn;
+#endif
         }
         if (wvalid) back(seg - 1, spA, dpA, kbA);
         __builtin_amdgcn_s_barrier();              // the last buffers have been read, the last D blocks written by everybody
@@ -1172,6 +1187,13 @@ __global__ __launch_bounds__(64 * FLB_NW, 1) void talking_bwdk_kernel(FlashBwdKA
         s += seg;
     }
 
+#ifdef FLB_DBG_STAMP
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.ws_w);       // (row 0, the half the query-major kernel fills later)
+        for (int k = 0; k < 6; ++k) o[k] = stacc[k];
+        o[6] = stn;
+    }
+#endif
     // ---- weight-gradient partials of this wave -> the [dWw | dbw] half of its row of ws_w
     {
         constexpr int NWG = 2 * (H * H + H);

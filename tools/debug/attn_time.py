@@ -78,6 +78,16 @@ for name, f in steps:
     tot += ms[REP // 2]
     print(f"  {name:52s} median {ms[REP // 2] * 1e3:8.1f} us   min {ms[0] * 1e3:8.1f} us")
 print(f"  {'sum of medians':52s}        {tot * 1e3:8.1f} us")
+if STAMPS:          # key-major kernel: region sums in row 0 of the weight-gradient workspace
+    bwdk(); torch.cuda.synchronize()
+    st = state["ws_w"].view(-1)[:14].view(torch.int64).tolist()
+    n = max(st[6], 1)
+    names = ["admission (vmcnt + barrier + next tile loads of waves 0, 1)", "D flush of the previous q-tile", "region 1: S + fp32 mix of heads 0-3 | exp2 (+ tile loads of waves 2, 3)",
+             "region 2: S + mix of heads 4-7 | D terms, P' mix", "region 3: dP' of heads 0-3 | outer product", "region 4: dP' of heads 4-7 | dV product"]
+    print(f"  key-major kernel, s_memtime ticks per pipelined step of workgroup 0 / wave 0 ({n} steps):")
+    for k in range(6):
+        print(f"    {names[k]:72s} {st[k] / n:9.1f}")
+    print(f"    {'total':72s} {sum(st[:6]) / n:9.1f}")
 if STAMPS:          # a -DFLB_DBG_STAMP build (tools/ab.py) leaves the region sums of workgroup 0 / wave 0 in the first bytes of dS
     bwdq(); torch.cuda.synchronize()
     st = dS.view(-1)[:24].view(torch.int64).tolist()
