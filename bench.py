@@ -451,8 +451,9 @@ def main():
                          "traffic_provenance": rin_prov,
                          "limiter": "instruction issue + exposed waits of ONE wave per SIMD",
                          "note": ("priced against the MFMA roofline (its arithmetic is matrix work), bound by something else: one wave per SIMD (512 registers: Q / dO "
-                                  "fragments and the 96 dQ accumulators in AccVGPRs) issues in order; per 16x16 tile of all heads 545 instructions of which 168 are matrix "
-                                  "instructions = 2352 matrix-pipe cycles of ~6000 (profiles/r06_bwd_isa_hist.txt, profiles/r05_fused_pmc.txt, DESIGN.md 4.1)"),
+                                  "fragments and the 96 dQ accumulators in AccVGPRs) issues in order; per 16x16 tile of all heads ~540 instructions of which 160 are matrix "
+                                  "instructions: the wave issues during ~2600 and keeps the matrix pipe busy ~1800 of the ~5100 cycles a tile takes (SQ counters: "
+                                  "profiles/r06_attn_pmc.txt; region stamps: profiles/r06_bwdq_stamps.txt; DESIGN.md 4.1)"),
                          "valu_achieved": valu, "valu_peak": 157.3,
                          "valu_frac": valu / 157.3,
                          "hbm_kernel": {"bound": "hbm", "kernel": "attn_contract_kernel<3,true,*> (dK = scale dS^T Q: the one streaming read of the blocked bf16 dS)",
@@ -466,8 +467,9 @@ def main():
                                                        f"[{d_model}x{d_model}] GEMMs per decoder pass)",
                                              "launches": g_launch, "avg_us": g_ms * 1e3, "flop": g_flop, "executed_flop": g_exec, "bytes": g_bytes,
                                              "achieved_tflops": g_tf, "mfma_frac": g_tf / 2500.0, "executed_mfma_frac": g_exec / max(g_ms, 1e-9) / 1e9 / 2500.0,
-                                             "achieved_gbs": g_bw, "hbm_frac": g_bw / 8000.0, "bound": "operand traffic per CU + stores", "floor_us": g_floor_us,
-                                             "note": "north_star's 60 % target is not met: at K = 384 the product is bound by the bytes a CU moves, not by the "
+                                             "achieved_gbs": g_bw, "hbm_frac": g_bw / 8000.0, "bound": "epilogue + launch phases beside a 12-step main loop", "floor_us": g_floor_us,
+                                             "note": "north_star's 60 % target is not met (the vendor GEMM: 48-52 us = 23-24 % for this product, tools/debug/mm_peak.py; an A-resident "
+                                                     "persistent kernel measured 55-60 us, profiles/r06_gemm_ares.txt): at K = 384 epilogue and launch phases weigh as much as the "
                                                      "matrix pipe.  Round 4: IEEE fp16 single-term operands (11 significand bits at bf16's bytes and MFMA rate: "
                                                      "the keys / values are packed to fp16 MFMA operands by their consumer anyway) and an LDS-staged fp16 output "
                                                      "(76 MB instead of 153 MB of fp32) - isolated 155 -> 58 us = 503 TFLOP/s = 20 % of the bf16 peak "
