@@ -23,6 +23,7 @@ print(os.environ.get("SPE_HIP_LIB", "default"))
 print("layernorm_bwd       %6.1f us" % timeit(lambda: K.layernorm_bwd(dy, x, gam, mean, rstd, add=add)))
 yb = torch.randn(R, C, generator=g).to(dev)
 Rp = ((R + 63) // 64) * 64
+print("layernorm_bwd + LS  %6.1f us" % timeit(lambda: K.layernorm_bwd(dy, x, gam, mean, rstd, add=add, ls=(yb, gam, None, None))))
 print("lsres_bwd16         %6.1f us" % timeit(lambda: K.layerscale_residual_bwd16(dy, yb, gam, Rp, want_rowmajor=True, want_T=False)))
 x16 = torch.empty(R, C, device=dev, dtype=torch.bfloat16); cs = torch.zeros(C, device=dev)
 print("cvt_bf16 + colsum   %6.1f us" % timeit(lambda: K.cvt_bf16(dy, True, False, colsum_out=cs, out=x16)))
