@@ -44,3 +44,5 @@ for _ in range(3):
 pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(35)
+if "--cum" in sys.argv:
+    st.sort_stats("cumtime").print_stats(70)
